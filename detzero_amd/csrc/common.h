@@ -1,0 +1,106 @@
+// Shared host/device helpers for libdetzero_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/detzero_hip.h"
+
+namespace dz {
+
+void set_error(const char *fmt, ...);
+
+#define DZ_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            dz::set_error(__VA_ARGS__);         \
+            return DZ_ERR_INVALID;              \
+        }                                       \
+    } while (0)
+
+#define DZ_HIP(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dz::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DZ_ERR_HIP;                                                           \
+        }                                                                                \
+    } while (0)
+
+#define DZ_LAUNCH_CHECK()                                                                \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            dz::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DZ_ERR_HIP;                                                           \
+        }                                                                                \
+    } while (0)
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// persistent-grid size for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
+static inline int stream_grid(long work_items, int block) {
+    long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+
+// ---- bitmap index lookups -------------------------------------------------------------------
+// rank of an ACTIVE cell `key` = number of active cells with a smaller key
+__device__ __forceinline__ int bitmap_rank(const uint32_t *__restrict__ bitmap,
+                                           const uint32_t *__restrict__ prefix, uint32_t key) {
+    const uint32_t w = key >> 5, bit = key & 31u;
+    const uint32_t word = bitmap[w];
+    return (int)(prefix[w] + __popc(word & ((1u << bit) - 1u)));
+}
+// rank or -1 when the cell is not active
+__device__ __forceinline__ int bitmap_find(const uint32_t *__restrict__ bitmap,
+                                           const uint32_t *__restrict__ prefix, uint32_t key) {
+    const uint32_t w = key >> 5, bit = key & 31u;
+    const uint32_t word = bitmap[w];
+    if (!((word >> bit) & 1u)) return -1;
+    return (int)(prefix[w] + __popc(word & ((1u << bit) - 1u)));
+}
+
+// Exclusive scan of one value per thread across a 256-thread block (4 waves of 64).
+// lds: >= 4 uint32.  Returns the exclusive prefix of `v`; `total` = block sum.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *lds, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) lds[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = lds[w];
+        if (w < wid) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + incl - v;
+}
+
+// Bitmap scan (3 launches): prefix[w] = #set bits in words < w ; *d_total = popcount of all.
+// Optionally emits the coordinates of every set bit at its rank:
+//   mode 0: key = ((b*D+z)*H+y)*W+x  -> coords [b,z,y,x]   (dims = D,H,W)
+//   mode 1: key = ((b*GX+x)*GY+y)*GZ+z -> coords [b,z,y,x] (dims = GX,GY,GZ)   (DynamicMeanVFE order)
+//   mode -1: no coordinates
+struct ScanDims { int d0, d1, d2; };
+constexpr int SCAN_WORDS_PER_THREAD = 8;
+constexpr int SCAN_CHUNK = 256 * SCAN_WORDS_PER_THREAD;
+size_t bitmap_scan_workspace_bytes(size_t nwords);
+int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
+                ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
+                hipStream_t stream);
+
+}  // namespace dz

@@ -1,0 +1,174 @@
+// Dense BEV convolutions (Conv2d 3x3 / 1x1, ConvTranspose2d with kernel == stride) with fused
+// BatchNorm/bias + ReLU, channel-last implicit GEMM on the fp32 matrix cores (gfx950).
+//
+// Reference: detection/detzero_det/models/centerpoint_modules/backbone2d.py:33-120 (BaseBEVBackbone),
+// center_head.py:14-48 (SeparateHead), :81-102 (shared_conv).  The reference runs these through
+// cuDNN/MIOpen in NCHW with separate BN and ReLU passes; here the activations stay channel-last in
+// zero-bordered images (the border is the conv padding, so the kernel has no bounds tests), BN is
+// folded into a per-channel scale/shift epilogue, and every layer writes straight into the buffer
+// (and channel offset) its consumer reads - the concat of backbone2d.py:107-108 is free.
+#include <string.h>
+
+#include "igemm.h"
+
+namespace dz {
+
+template <class T>
+__global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) {
+    __shared__ __attribute__((aligned(16))) float As[T::AS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[T::BS_FLOATS];
+    __shared__ int in_pix[T::BM];    // input pixel index of the (0,0) tap, -1 past the end
+    __shared__ int out_pix[T::BM];   // output pixel index
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / T::WN, wn = wid % T::WN;
+    const int ntn = p.cout_pad / T::BN;           // N tiles per group
+    const int grp = blockIdx.y / ntn;
+    const int n0 = (blockIdx.y % ntn) * T::BN;
+    const long row0 = (long)blockIdx.x * T::BM;
+
+    for (int r = tid; r < T::BM; r += 256) {
+        const long mrow = row0 + r;
+        int ip = -1, op = -1;
+        if (mrow < m_total) {
+            const int x = (int)(mrow % p.wo);
+            const long t = mrow / p.wo;
+            const int y = (int)(t % p.ho);
+            const int b = (int)(t / p.ho);
+            ip = (b * p.in_hp + y * p.stride + p.in_off) * p.in_wp + x * p.stride + p.in_off;
+            op = (b * p.out_hp + y * p.out_sy + p.out_dy) * p.out_wp + x * p.out_sx + p.out_dx;
+        }
+        in_pix[r] = ip;
+        out_pix[r] = op;
+    }
+    __syncthreads();
+
+    f32x4 acc[T::MT][T::NT];
+#pragma unroll
+    for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int taps = p.kh * p.kw;
+    const int kchunks = p.cin / T::KC;
+    const int nchunks = taps * kchunks;
+    const float *wg = p.w + (size_t)grp * taps * p.cin * p.cout_pad;
+    const long cbase = p.in_coff + (long)grp * p.cin;
+
+    Stage<T> st;
+    int tap = 0, kc = 0;
+    {
+        const long add = (long)((tap / p.kw) * p.in_wp + (tap % p.kw)) * p.in_cstride + cbase + (long)kc * T::KC;
+        load_a<T>(st, p.in, in_pix, p.in_cstride, add, tid);
+        load_b<T>(st, wg + ((size_t)tap * p.cin + (size_t)kc * T::KC) * p.cout_pad, p.cout_pad, n0, tid);
+    }
+    store_stage<T>(st, As, Bs, tid);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1 < nchunks);
+        if (more) {
+            if (++kc == kchunks) { kc = 0; ++tap; }
+            const long add = (long)((tap / p.kw) * p.in_wp + (tap % p.kw)) * p.in_cstride + cbase + (long)kc * T::KC;
+            load_a<T>(st, p.in, in_pix, p.in_cstride, add, tid);
+            load_b<T>(st, wg + ((size_t)tap * p.cin + (size_t)kc * T::KC) * p.cout_pad, p.cout_pad, n0, tid);
+        }
+        mma_chunk<T>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+        if (more) {
+            store_stage<T>(st, As, Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    const int r = lane & 15, g = lane >> 4;
+    const int gcout = p.g_cout[grp];
+    const int ooff = p.out_coff + p.g_ooff[grp];
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) {
+        const int col = n0 + wn * T::NT * 16 + nt * 16 + r;
+        if (col >= gcout) continue;
+        const float sc = p.scale ? p.scale[grp * p.cout_pad + col] : 1.f;
+        const float sh = p.shift ? p.shift[grp * p.cout_pad + col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int op = out_pix[wm * T::MT * 16 + mt * 16 + g * 4 + e];
+                if (op >= 0) {
+                    float v = fmaf(acc[mt][nt][e], sc, sh);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[(size_t)op * p.out_cstride + ooff + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+static int launch_conv(const dz_conv2d_desc &p, hipStream_t stream) {
+    const long m_total = (long)p.batch * p.ho * p.wo;
+    dim3 grid(ceil_div(m_total, T::BM), (p.cout_pad / T::BN) * p.groups);
+    hipLaunchKernelGGL(k_conv2d<T>, grid, dim3(256), 0, stream, p, m_total);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+static int conv2d_dispatch(const dz_conv2d_desc &p, hipStream_t stream) {
+    const long m_total = (long)p.batch * p.ho * p.wo;
+    if (m_total == 0) return DZ_OK;
+    if (p.cin % 32 != 0 && p.cin % 16 == 0) {
+        if (p.cout_pad % 64 == 0) return launch_conv<TileCfg<64, 64, 16, 2, 2>>(p, stream);
+        if (p.cout_pad % 16 == 0) return launch_conv<TileCfg<128, 16, 16, 4, 1>>(p, stream);
+    }
+    if (p.cin % 32 == 0) {
+        if (p.cout_pad % 64 == 0) {
+            // pick the M tile so that the grid has at least ~2 workgroups per CU (256 CUs)
+            const long blocks128 = (long)ceil_div(m_total, 128) * (p.cout_pad / 64) * p.groups;
+            if (blocks128 >= 512) return launch_conv<TileCfg<128, 64, 32, 2, 2>>(p, stream);
+            return launch_conv<TileCfg<64, 64, 32, 2, 2>>(p, stream);
+        }
+        if (p.cout_pad % 32 == 0) return launch_conv<TileCfg<128, 32, 32, 4, 1>>(p, stream);
+        if (p.cout_pad % 16 == 0) return launch_conv<TileCfg<128, 16, 32, 4, 1>>(p, stream);
+    }
+    set_error("dz_conv2d_forward: unsupported channels cin=%d cout_pad=%d", p.cin, p.cout_pad);
+    return DZ_ERR_UNSUPPORTED;
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward: null pointer");
+    DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward: groups %d not in [1,8]", d->groups);
+    DZ_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->cin >= 16, "dz_conv2d_forward: bad kernel/cin");
+    DZ_CHECK_ARG(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0 && d->cout_pad % 16 == 0,
+                 "dz_conv2d_forward: channel strides must keep 16-byte alignment");
+    for (int g = 0; g < d->groups; ++g)
+        DZ_CHECK_ARG(d->g_cout[g] >= 1 && d->g_cout[g] <= d->cout_pad, "dz_conv2d_forward: bad g_cout[%d]", g);
+    // the last tap of the last enumerated pixel must stay inside the input image
+    DZ_CHECK_ARG((d->ho - 1) * d->stride + d->in_off + d->kh - 1 < d->in_hp &&
+                 (d->wo - 1) * d->stride + d->in_off + d->kw - 1 < d->in_wp && d->in_off >= 0,
+                 "dz_conv2d_forward: taps leave the input image");
+    DZ_CHECK_ARG((d->ho - 1) * d->out_sy + d->out_dy < d->out_hp && (d->wo - 1) * d->out_sx + d->out_dx < d->out_wp,
+                 "dz_conv2d_forward: output leaves the output image");
+    return conv2d_dispatch(*d, stream);
+}
+
+int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
+                      const float *scale, const float *shift, int relu, float *y, int y_stride, void *stream_) {
+    dz_conv2d_desc d = {};
+    d.in = x; d.out = y; d.w = w; d.scale = scale; d.shift = shift;
+    d.batch = 1; d.ho = 1; d.wo = rows;
+    d.in_hp = 1; d.in_wp = rows; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin;
+    d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
+    d.out_hp = 1; d.out_wp = rows; d.out_cstride = y_stride; d.out_coff = 0;
+    d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
+    d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
+    return dz_conv2d_forward(&d, stream_);
+}
+
+}  // extern "C"

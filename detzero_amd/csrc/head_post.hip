@@ -1,0 +1,511 @@
+// CenterHead post-processing on the device (gfx950): score map, exact top-K, box decode with
+// range / score masks, rotated BEV IoU, rotated NMS with the suppression sweep on the GPU, and the
+// refiner's points-in-boxes test.
+//
+// Reference:
+//   detection/detzero_det/models/centerpoint_modules/center_head.py:315-368
+//   detection/detzero_det/utils/centernet_utils.py:138-230 (_topk, decode_bbox_from_heatmap)
+//   detection/detzero_det/utils/model_nms_utils.py:6-25
+//   utils/detzero_utils/ops/iou3d_nms/src/iou3d_nms_kernel.cu:15-232,328-335,386-430 (geometry)
+//   utils/detzero_utils/ops/iou3d_nms/src/iou3d_nms.cpp:114-160 (host sweep, D2H copy -> removed)
+//   utils/detzero_utils/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-36,352-374
+//
+// Parity notes: all geometry is evaluated with the reference's formula sequence in fp32 and with
+// FMA contraction disabled, so that discrete decisions (IoU > thr, inside/outside) agree with the
+// CPU restatement wherever libm and ocml agree on sin/cos/atan2.
+#include <string.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace dz {
+
+// ------------------------------------------------------------------------------------------
+// rotated rectangle overlap
+// ------------------------------------------------------------------------------------------
+struct P2 { float x, y; };
+constexpr float GEO_EPS = 1e-8f;
+
+__device__ __forceinline__ float cr2(P2 a, P2 b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ float cr3(P2 p1, P2 p2, P2 p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+__device__ __forceinline__ bool bbox_cross(P2 p1, P2 p2, P2 q1, P2 q2) {
+    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+__device__ __forceinline__ bool corner_in_box(const float *box, P2 p) {
+    const float MARGIN = 1e-2f;
+    const float cx = box[0], cy = box[1];
+    const float ac = cosf(-box[6]), as = sinf(-box[6]);
+    const float rx = (p.x - cx) * ac + (p.y - cy) * (-as);
+    const float ry = (p.x - cx) * as + (p.y - cy) * ac;
+    return fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN;
+}
+__device__ __forceinline__ bool edge_cross(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans) {
+    if (!bbox_cross(p0, p1, q0, q1)) return false;
+    const float s1 = cr3(q0, p1, p0);
+    const float s2 = cr3(p1, q1, p0);
+    const float s3 = cr3(p0, q1, q0);
+    const float s4 = cr3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = cr3(q1, p1, p0);
+    if (fabsf(s5 - s1) > GEO_EPS) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+__device__ __forceinline__ void spin(P2 c, float ac, float as, P2 &p) {
+    const float nx = (p.x - c.x) * ac + (p.y - c.y) * (-as) + c.x;
+    const float ny = (p.x - c.x) * as + (p.y - c.y) * ac + c.y;
+    p.x = nx; p.y = ny;
+}
+
+__device__ float rect_overlap(const float *A, const float *B) {
+    const float adx = A[3] / 2, bdx = B[3] / 2, ady = A[4] / 2, bdy = B[4] / 2;
+    const P2 ca{A[0], A[1]}, cb{B[0], B[1]};
+    P2 ac[5], bc[5];
+    ac[0] = P2{A[0] - adx, A[1] - ady}; ac[1] = P2{A[0] + adx, A[1] - ady};
+    ac[2] = P2{A[0] + adx, A[1] + ady}; ac[3] = P2{A[0] - adx, A[1] + ady};
+    bc[0] = P2{B[0] - bdx, B[1] - bdy}; bc[1] = P2{B[0] + bdx, B[1] - bdy};
+    bc[2] = P2{B[0] + bdx, B[1] + bdy}; bc[3] = P2{B[0] - bdx, B[1] + bdy};
+    const float acs = cosf(A[6]), asn = sinf(A[6]), bcs = cosf(B[6]), bsn = sinf(B[6]);
+    for (int k = 0; k < 4; ++k) { spin(ca, acs, asn, ac[k]); spin(cb, bcs, bsn, bc[k]); }
+    ac[4] = ac[0]; bc[4] = bc[0];
+
+    P2 cp[16];
+    P2 pc{0.f, 0.f};
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            P2 t;
+            if (edge_cross(ac[i + 1], ac[i], bc[j + 1], bc[j], t)) {
+                cp[cnt] = t; pc.x = pc.x + t.x; pc.y = pc.y + t.y; ++cnt;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (corner_in_box(A, bc[k])) { pc.x = pc.x + bc[k].x; pc.y = pc.y + bc[k].y; cp[cnt++] = bc[k]; }
+        if (corner_in_box(B, ac[k])) { pc.x = pc.x + ac[k].x; pc.y = pc.y + ac[k].y; cp[cnt++] = ac[k]; }
+    }
+    pc.x /= cnt; pc.y /= cnt;   // cnt == 0 gives NaN exactly as the reference; the loops below do not run
+    // bubble sort by polar angle around the centroid (angles cached; comparisons identical)
+    float ang[16];
+    for (int i = 0; i < cnt; ++i) ang[i] = atan2f(cp[i].y - pc.y, cp[i].x - pc.x);
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                const P2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const P2 u{cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+        const P2 v{cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        area += cr2(u, v);
+    }
+    return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float rect_iou(const float *A, const float *B) {
+    const float sa = A[3] * A[4], sb = B[3] * B[4];
+    const float so = rect_overlap(A, B);
+    return so / fmaxf(sa + sb - so, GEO_EPS);
+}
+
+template <bool IOU>
+__global__ void k_pairwise(const float *__restrict__ a, int na, const float *__restrict__ b, int nb,
+                           float *__restrict__ out) {
+    const long total = (long)na * nb;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / nb), j = (int)(idx % nb);
+        float A[7], B[7];
+        for (int q = 0; q < 7; ++q) { A[q] = a[i * 7 + q]; B[q] = b[j * 7 + q]; }
+        out[idx] = IOU ? rect_iou(A, B) : rect_overlap(A, B);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rotated NMS
+// ------------------------------------------------------------------------------------------
+// mask[i][cb] bit j: iou(box i, box cb*64+j) > thr, only for j > i (upper triangle)
+__global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, const int *__restrict__ d_n, int n_cap,
+                                                 float thr, unsigned long long *__restrict__ mask, int col_blocks) {
+    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (rb * 64 >= n) return;
+    __shared__ float cbx[64 * 7];
+    const int col_size = min(n - cb * 64, 64);
+    const int t = threadIdx.x;
+    const int i = rb * 64 + t;
+    if (cb < rb || col_size <= 0) {       // lower triangle / beyond n: nothing can be suppressed there
+        if (i < n) mask[(size_t)i * col_blocks + cb] = 0ull;
+        return;
+    }
+    if (t < col_size)
+        for (int q = 0; q < 7; ++q) cbx[t * 7 + q] = boxes[(cb * 64 + t) * 7 + q];
+    __syncthreads();
+    if (i < n) {
+        float A[7];
+        for (int q = 0; q < 7; ++q) A[q] = boxes[i * 7 + q];
+        unsigned long long bits = 0ull;
+        const int start = (rb == cb) ? t + 1 : 0;
+        for (int j = start; j < col_size; ++j)
+            if (rect_iou(A, cbx + j * 7) > thr) bits |= 1ull << j;
+        mask[(size_t)i * col_blocks + cb] = bits;
+    }
+}
+
+// sequential suppression, one workgroup: 64 mask rows at a time are staged in LDS, wave 0 sweeps.
+__global__ __launch_bounds__(256) void k_nms_sweep(const unsigned long long *__restrict__ mask, const int *__restrict__ d_n,
+                                                   int n_cap, int col_blocks, int post_max, int *__restrict__ keep,
+                                                   int *__restrict__ d_num_keep) {
+    extern __shared__ unsigned long long rows[];   // 64 x col_blocks
+    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned long long remv = 0ull;   // lane l of wave 0 owns column block l
+    int nk = 0;
+    const int nrb = (n + 63) / 64;
+    for (int rb = 0; rb < nrb; ++rb) {
+        const int rows_here = min(64, n - rb * 64);
+        for (int idx = threadIdx.x; idx < rows_here * col_blocks; idx += 256)
+            rows[idx] = mask[(size_t)rb * 64 * col_blocks + idx];
+        __syncthreads();
+        if (wid == 0) {
+            for (int r = 0; r < rows_here; ++r) {
+                const unsigned long long own = __shfl(remv, rb, 64);
+                if (!((own >> r) & 1ull) && nk < post_max) {
+                    if (lane == 0) keep[nk] = rb * 64 + r;
+                    ++nk;
+                    if (lane < col_blocks) remv |= rows[r * col_blocks + lane];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *d_num_keep = nk;
+}
+
+// ------------------------------------------------------------------------------------------
+// score map + top-K + decode
+// ------------------------------------------------------------------------------------------
+constexpr int HEAD_COLS = 12;  // center 0:2 | center_z 2 | dim 3:6 | rot 6:8 | iou 8 | hm 9:12
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// keys[b][cls*HW + pix] = bits of score (>= 0, so uint order == float order)
+__global__ void k_score_keys(const float *__restrict__ head, int batch, int hw, int ncls, int use_iou,
+                             uint32_t *__restrict__ keys) {
+    const long total = (long)batch * hw;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw), pix = (int)(idx % hw);
+        const float *row = head + idx * HEAD_COLS;
+        float w = 1.f;
+        if (use_iou) {
+            const float iou = fminf(fmaxf(row[8], 0.f), 1.f);
+            w = iou * iou;
+        }
+        for (int c = 0; c < ncls; ++c) {
+            float s = sigmoidf_(row[9 + c]);
+            if (use_iou) s = s * w;
+            keys[((size_t)b * ncls + c) * hw + pix] = __float_as_uint(s);
+        }
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) lds[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < NW; ++w) {
+        uint32_t s = lds[w];
+        if (w < wid) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + incl - v;
+}
+
+struct DecodeArgs {
+    const float *head;
+    const uint32_t *keys;
+    float *boxes, *scores;
+    int *labels, *counts;
+    int hw, w, ncls, k, stride;
+    float score_thresh;
+    float lim[6], lo[3], vs[3];
+};
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_MAXK = 1024;
+
+// one workgroup per batch item: exact radix select of the K largest keys (ties -> smaller flat
+// index first), bitonic sort (score desc, index asc), decode, masks, ordered compaction.
+__global__ __launch_bounds__(TOPK_THREADS) void k_topk_decode(DecodeArgs a) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t scan_lds[TOPK_THREADS / 64];
+    __shared__ unsigned long long cand[TOPK_MAXK];
+    __shared__ uint32_t s_prefix, s_need, s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.ncls * a.hw;
+    const uint32_t *keys = a.keys + (size_t)b * n;
+    const int K = min(a.k, n);
+
+    // ---- radix select: find T = K-th largest key
+    if (tid == 0) { s_prefix = 0u; s_need = (uint32_t)K; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int i = tid; i < n; i += TOPK_THREADS) {
+            const uint32_t kv = keys[i];
+            if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t need = s_need, acc = 0u;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + hist[d] >= need) break;
+                acc += hist[d];
+            }
+            s_need = need - acc;                 // still needed among keys with this digit
+            s_prefix = prefix | ((uint32_t)d << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;
+    const uint32_t need_eq = s_need;             // number of keys == T to take (in index order)
+
+    // ---- collect: all keys > T (any order), then the first need_eq keys == T in index order
+    if (tid == 0) s_cnt = 0u;
+    for (int i = tid; i < TOPK_MAXK; i += TOPK_THREADS) cand[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += TOPK_THREADS) {
+        const uint32_t kv = keys[i];
+        if (kv > T) {
+            const uint32_t pos = atomicAdd(&s_cnt, 1u);
+            if (pos < TOPK_MAXK) cand[pos] = ((unsigned long long)kv << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_gt = s_cnt;
+    uint32_t taken = 0u;
+    for (int base = 0; base < n && taken < need_eq; base += TOPK_THREADS) {
+        const int i = base + tid;
+        const uint32_t flag = (i < n && keys[i] == T) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<TOPK_THREADS / 64>(flag, scan_lds, tot);
+        if (flag && taken + ex < need_eq) {
+            const uint32_t pos = n_gt + taken + ex;
+            if (pos < TOPK_MAXK) cand[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+        }
+        taken += tot;
+    }
+    __syncthreads();
+
+    // ---- bitonic sort of TOPK_MAXK 64-bit keys, descending (unused slots are 0 -> sink to the end)
+    for (int size = 2; size <= TOPK_MAXK; size <<= 1) {
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+            const int i = tid;
+            const int j = i ^ strd;
+            if (j > i) {
+                const unsigned long long x = cand[i], y = cand[j];
+                const bool desc = ((i & size) == 0);
+                if (desc ? (x < y) : (x > y)) { cand[i] = y; cand[j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- decode + masks + ordered compaction
+    float box[7];
+    float score = 0.f;
+    int label = 0;
+    uint32_t pass = 0u;
+    if (tid < K) {
+        const unsigned long long e = cand[tid];
+        const uint32_t kv = (uint32_t)(e >> 32);
+        const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
+        score = __uint_as_float(kv);
+        label = (int)(flat / (uint32_t)a.hw);
+        const int pix = (int)(flat % (uint32_t)a.hw);
+        const float ys = (float)(pix / a.w), xs = (float)(pix % a.w);
+        const float *row = a.head + ((size_t)b * a.hw + pix) * HEAD_COLS;
+        const float fx = xs + row[0], fy = ys + row[1];
+        box[0] = fx * (float)a.stride * a.vs[0] + a.lo[0];
+        box[1] = fy * (float)a.stride * a.vs[1] + a.lo[1];
+        box[2] = row[2];
+        box[3] = expf(row[3]); box[4] = expf(row[4]); box[5] = expf(row[5]);
+        box[6] = atan2f(row[7], row[6]);    // rot[:,1] = sin, rot[:,0] = cos (center_head.py:330-331)
+        bool ok = box[0] >= a.lim[0] && box[1] >= a.lim[1] && box[2] >= a.lim[2] && box[0] <= a.lim[3] &&
+                  box[1] <= a.lim[4] && box[2] <= a.lim[5];
+        ok = ok && (score > a.score_thresh);
+        pass = ok ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t pos = block_excl_scan<TOPK_THREADS / 64>(pass, scan_lds, tot);
+    if (pass) {
+        float *bo = a.boxes + ((size_t)b * a.k + pos) * 7;
+        for (int q = 0; q < 7; ++q) bo[q] = box[q];
+        a.scores[(size_t)b * a.k + pos] = score;
+        a.labels[(size_t)b * a.k + pos] = label;
+    }
+    if (tid == 0) a.counts[b] = (int)tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// points in boxes (refiner crop)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_points_in_boxes(const float *__restrict__ boxes, const float *__restrict__ pts,
+                                                         int t, int m, int *__restrict__ mask) {
+    // block = 256 points of one batch item; boxes staged in LDS in chunks of 64 with cos/sin hoisted
+    __shared__ float sb[64 * 9];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *bx = boxes + (size_t)b * t * 7;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < m) {
+        const float *p = pts + ((size_t)b * m + i) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+    }
+    for (int base = 0; base < t; base += 64) {
+        const int nb = min(64, t - base);
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const float *q = bx + (size_t)(base + threadIdx.x) * 7;
+            float *d = sb + threadIdx.x * 9;
+            for (int j = 0; j < 7; ++j) d[j] = q[j];
+            d[7] = cosf(-q[6]);
+            d[8] = sinf(-q[6]);
+        }
+        __syncthreads();
+        if (i < m) {
+            for (int k = 0; k < nb; ++k) {
+                const float *q = sb + k * 9;
+                int in = 0;
+                if (!((double)fabsf(z - q[2]) > (double)q[5] / 2.0)) {
+                    const float sx = x - q[0], sy = y - q[1];
+                    const float lx = sx * q[7] + sy * (-q[8]);
+                    const float ly = sx * q[8] + sy * q[7];
+                    const bool inx = (double)fabsf(lx) < (double)q[3] / 2.0 + (double)1e-5f;
+                    const bool iny = (double)fabsf(ly) < (double)q[4] / 2.0 + (double)1e-5f;
+                    in = (inx && iny) ? 1 : 0;
+                }
+                mask[((size_t)b * t + base + k) * m + i] = in;
+            }
+        }
+    }
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(na >= 0 && nb >= 0, "dz_boxes_overlap_bev: negative size");
+    if (na == 0 || nb == 0) return DZ_OK;
+    DZ_CHECK_ARG(a && b && out, "dz_boxes_overlap_bev: null pointer");
+    hipLaunchKernelGGL(k_pairwise<false>, dim3(stream_grid((long)na * nb, 128)), dim3(128), 0, stream, a, na, b, nb, out);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(na >= 0 && nb >= 0, "dz_boxes_iou_bev: negative size");
+    if (na == 0 || nb == 0) return DZ_OK;
+    DZ_CHECK_ARG(a && b && out, "dz_boxes_iou_bev: null pointer");
+    hipLaunchKernelGGL(k_pairwise<true>, dim3(stream_grid((long)na * nb, 128)), dim3(128), 0, stream, a, na, b, nb, out);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+size_t dz_nms_workspace_bytes(int n_cap) {
+    const size_t cb = (size_t)(n_cap + 63) / 64;
+    return align_up((size_t)(n_cap > 0 ? n_cap : 1) * (cb > 0 ? cb : 1) * sizeof(unsigned long long), 256);
+}
+
+int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, int post_max, int *keep, int *d_num_keep,
+                   void *ws, size_t ws_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(keep && d_num_keep && n_cap >= 0 && post_max >= 0, "dz_nms_rotated: bad argument");
+    if (n_cap == 0) { DZ_HIP(hipMemsetAsync(d_num_keep, 0, sizeof(int), stream)); return DZ_OK; }
+    DZ_CHECK_ARG(boxes && ws, "dz_nms_rotated: null pointer");
+    DZ_CHECK_ARG(n_cap <= 4096, "dz_nms_rotated: n_cap %d > 4096 (NMS_PRE_MAXSIZE of the reference configs)", n_cap);
+    if (ws_bytes < dz_nms_workspace_bytes(n_cap)) { set_error("dz_nms_rotated: workspace too small"); return DZ_ERR_WORKSPACE; }
+    const int cb = (n_cap + 63) / 64;
+    unsigned long long *mask = (unsigned long long *)ws;
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, stream, boxes, d_n, n_cap, thresh, mask, cb);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(256), (size_t)64 * cb * sizeof(unsigned long long), stream, mask, d_n,
+                       n_cap, cb, post_max, keep, d_num_keep);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+size_t dz_centerhead_decode_workspace_bytes(int batch, int hw, int ncls, int k) {
+    (void)k;
+    return align_up((size_t)batch * hw * ncls * sizeof(uint32_t), 256);
+}
+
+int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, int k, float score_thresh,
+                         const float *h_limit6, const float *h_range6, const float *h_vsize3, int stride, int use_iou,
+                         float *boxes, float *scores, int *labels, int *d_counts, void *ws, size_t ws_bytes,
+                         void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(head && boxes && scores && labels && d_counts && ws, "dz_centerhead_decode: null pointer");
+    DZ_CHECK_ARG(batch >= 1 && h >= 1 && w >= 1 && ncls >= 1 && ncls <= 3, "dz_centerhead_decode: bad sizes (ncls<=3)");
+    DZ_CHECK_ARG(k >= 1 && k <= TOPK_MAXK, "dz_centerhead_decode: K %d not in [1,%d]", k, TOPK_MAXK);
+    const int hw = h * w;
+    if (ws_bytes < dz_centerhead_decode_workspace_bytes(batch, hw, ncls, k)) {
+        set_error("dz_centerhead_decode: workspace too small");
+        return DZ_ERR_WORKSPACE;
+    }
+    uint32_t *keys = (uint32_t *)ws;
+    hipLaunchKernelGGL(k_score_keys, dim3(stream_grid((long)batch * hw, 256)), dim3(256), 0, stream, head, batch, hw, ncls,
+                       use_iou, keys);
+    DecodeArgs a;
+    a.head = head; a.keys = keys; a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = d_counts;
+    a.hw = hw; a.w = w; a.ncls = ncls; a.k = k; a.stride = stride; a.score_thresh = score_thresh;
+    for (int i = 0; i < 6; ++i) a.lim[i] = h_limit6[i];
+    for (int i = 0; i < 3; ++i) { a.lo[i] = h_range6[i]; a.vs[i] = h_vsize3[i]; }
+    hipLaunchKernelGGL(k_topk_decode, dim3(batch), dim3(TOPK_THREADS), 0, stream, a);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_points_in_boxes_v2(const float *boxes, const float *pts, int batch, int t, int m, int *mask, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(batch >= 0 && t >= 0 && m >= 0, "dz_points_in_boxes_v2: negative size");
+    if (batch == 0 || t == 0 || m == 0) return DZ_OK;
+    DZ_CHECK_ARG(boxes && pts && mask, "dz_points_in_boxes_v2: null pointer");
+    hipLaunchKernelGGL(k_points_in_boxes, dim3(ceil_div(m, 256), batch), dim3(256), 0, stream, boxes, pts, t, m, mask);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// Fused multi-head attention core for the refining module (GRM / PRM), fp32 MFMA, gfx950.
+//
+// Reference: refining/detzero_refine/models/transformer/multi_head_attention.py:207-288
+//   q = q * scaling; attn = bmm(q, k^T); masked_fill(key_padding_mask, -inf); softmax; bmm(attn, v)
+// The reference materialises the (B*heads, Lq, Lk) score tensor (PRM: 200 x 9600 per head) and a
+// head-averaged copy of it; here one wavefront owns 16 queries of one (batch, head) and streams the
+// keys once with an online softmax - scores never leave registers.
+//
+// Register-only dataflow (no LDS, no barriers).  With v_mfma_f32_16x16x4_f32:
+//   S^T (16 keys x 16 queries) = K_tile (16 x 32) . Q^T (32 x 16)
+//       A = K rows straight from global memory (one 16-byte load per lane per 16-d slice),
+//       B = Q^T, pre-scaled, resident in 8 VGPRs for the whole key loop.
+//     C layout: lane (g = l>>4, r = l&15) holds keys 4g..4g+3 of query r -> the softmax reduction
+//     over keys is 3 in-lane ops + 2 cross-lane shuffles, and each lane's running max / sum /
+//     rescale factor belong to ITS query column.
+//   O^T (32 x 16 queries) += V^T (32 x 16 keys) . P^T (16 keys x 16 queries)
+//       B = P^T: MFMA number e takes k-slot g' <-> key 4g'+e, which is exactly register e of
+//       lane (g', r): the probabilities feed the second GEMM without leaving their lane.
+//       A = V[key 4g+e][d] loaded per lane (16 lanes read 64 contiguous bytes).
+#include "igemm.h"
+
+namespace dz {
+
+constexpr int HD = 32;  // head dim of every DetZero refiner config (256 / 8 heads)
+
+__global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, const float *__restrict__ k,
+                                                  const float *__restrict__ v, const uint8_t *__restrict__ kpm,
+                                                  int batch, int lq, int lk, int heads, float scale,
+                                                  float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int qtiles = (lq + 15) / 16;
+    const long item = (long)blockIdx.x * 4 + wid;
+    const long nitems = (long)batch * heads * qtiles;
+    if (item >= nitems) return;
+    const int qt = (int)(item % qtiles);
+    const int h = (int)((item / qtiles) % heads);
+    const int b = (int)(item / ((long)qtiles * heads));
+    const int e_dim = heads * HD;
+
+    // B operand of S^T: Q[query r][d = 16*s + 4g + e] * scale
+    const int qi = qt * 16 + r;
+    float qreg[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi < lq) t = *reinterpret_cast<const float4 *>(q + ((size_t)b * lq + qi) * e_dim + h * HD + s * 16 + g * 4);
+        qreg[s][0] = t.x * scale; qreg[s][1] = t.y * scale; qreg[s][2] = t.z * scale; qreg[s][3] = t.w * scale;
+    }
+
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float m_run = -INFINITY, l_run = 0.f;   // per query column r (replicated over g)
+    const float *kb = k + (size_t)b * lk * e_dim + h * HD;
+    const float *vb = v + (size_t)b * lk * e_dim + h * HD;
+    const uint8_t *mb = kpm ? kpm + (size_t)b * lk : nullptr;
+
+    for (int key0 = 0; key0 < lk; key0 += 16) {
+        // ---- S^T tile
+        const int krow = key0 + r;                      // A operand row = key
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (krow < lk) kv = *reinterpret_cast<const float4 *>(kb + (size_t)krow * e_dim + sl * 16 + g * 4);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qreg[sl][0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qreg[sl][1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qreg[sl][2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qreg[sl][3], s, 0, 0, 0);
+        }
+        // lane (g,r): s[e] = score(query r, key key0 + 4g + e)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = key0 + g * 4 + e;
+            const bool dead = (key >= lk) || (mb && mb[key]);
+            if (dead) s[e] = -INFINITY;
+            tmax = fmaxf(tmax, s[e]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        float alpha = 1.f;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m_new != -INFINITY) {
+            alpha = expf(m_run - m_new);               // m_run = -inf -> 0
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = expf(s[e] - m_new);
+        }
+        l_run = l_run * alpha + (p[0] + p[1] + p[2] + p[3]);   // in-lane partial; reduced over g at the end
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = key0 + g * 4 + e;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float vv = (key < lk) ? vb[(size_t)key * e_dim + dt * 16 + r] : 0.f;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p[e], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    // row sums: every lane of column r holds the partial over its own keys
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // o[dt][e] = O^T[d = dt*16 + 4g + e][query r]
+    if (qi < lq) {
+        const float inv = 1.f / l_run;               // fully masked row -> NaN, as torch.softmax gives
+        float *dst = out + ((size_t)b * lq + qi) * e_dim + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            float4 w = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<float4 *>(dst + dt * 16 + g * 4) = w;
+        }
+    }
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *key_padding_mask, int batch, int lq,
+                int lk, int heads, float scale, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(batch >= 0 && lq >= 0 && lk >= 1 && heads >= 1, "dz_mha_core: bad sizes");
+    if (batch == 0 || lq == 0) return DZ_OK;
+    DZ_CHECK_ARG(q && k && v && out, "dz_mha_core: null pointer");
+    const long items = (long)batch * heads * ((lq + 15) / 16);
+    hipLaunchKernelGGL(k_mha_core, dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, key_padding_mask, batch, lq,
+                       lk, heads, scale, out);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+}  // extern "C"

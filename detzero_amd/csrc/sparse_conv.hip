@@ -1,0 +1,187 @@
+// Sparse 3-D convolution forward (SubMConv3d / SparseConv3d) with fused BatchNorm + bias +
+// residual + ReLU epilogue, and the sparse->dense BEV scatter.  gfx950, fp32 MFMA.
+//
+// Reference call sites: detection/detzero_det/models/centerpoint_modules/backbone3d.py:64-121
+// (post_act_block, SparseBasicBlock), :243-280 (layer list), height_compression.py:20-24.
+//
+// Output-stationary gather -> implicit GEMM -> direct store (no atomics, no scatter):
+//   * a workgroup owns BM consecutive output rows (rows are spatially sorted, sparse_index.hip);
+//   * it stages the tile's neighbour lists (kvol x BM int32) in LDS once and derives a bitmask of
+//     kernel taps that have at least one neighbour in the tile; empty taps are skipped entirely;
+//   * per (tap, channel chunk) the BM gathered input rows and the KC x Cout weight slice are
+//     register-staged into LDS and multiplied on the matrix cores (igemm.h);
+//   * the epilogue applies scale/shift (folded BN + bias), the residual and ReLU and writes the
+//     output row-major, each 16-lane group storing 64 contiguous bytes.
+#include "igemm.h"
+
+namespace dz {
+
+constexpr int KVOL_MAX = 27;
+
+struct SpConvArgs {
+    const float *in;
+    const int *nbr;
+    const int *d_m_out;
+    const float *w;
+    const float *scale;
+    const float *shift;
+    const float *residual;
+    float *out;
+    int cin, cout, kvol, cap, relu;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[T::AS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[T::BS_FLOATS];
+    __shared__ int nbr_s[KVOL_MAX * T::BM];
+    __shared__ unsigned int mask_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / T::WN, wn = wid % T::WN;
+    const int m = min(*a.d_m_out, a.cap);
+    const int ntiles = (m + T::BM - 1) / T::BM;
+    const int kchunks = a.cin / T::KC;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * T::BM;
+        if (tid == 0) mask_s = 0u;
+        __syncthreads();
+        unsigned int local = 0u;
+        for (int idx = tid; idx < a.kvol * T::BM; idx += 256) {
+            const int k = idx / T::BM, r = idx % T::BM;
+            const int row = row0 + r;
+            const int v = (row < m) ? a.nbr[(size_t)k * a.cap + row] : -1;
+            nbr_s[idx] = v;
+            if (v >= 0) local |= 1u << k;
+        }
+        if (local) atomicOr(&mask_s, local);
+        __syncthreads();
+        unsigned int taps = mask_s;
+
+        f32x4 acc[T::MT][T::NT];
+#pragma unroll
+        for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const int nchunks = __popc(taps) * kchunks;
+        if (nchunks > 0) {
+            Stage<T> st;
+            // chunk iterator: (current tap = lowest set bit of `rem`, channel chunk kc)
+            unsigned int rem = taps;
+            int tap = __ffs((int)rem) - 1, kc = 0;
+            load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
+            load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, 0, tid);
+            store_stage<T>(st, As, Bs, tid);
+            __syncthreads();
+            for (int c = 0; c < nchunks; ++c) {
+                const bool more = (c + 1 < nchunks);
+                if (more) {
+                    if (++kc == kchunks) {
+                        kc = 0;
+                        rem &= rem - 1;
+                        tap = __ffs((int)rem) - 1;
+                    }
+                    load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
+                    load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, 0, tid);
+                }
+                mma_chunk<T>(As, Bs, acc, wm, wn, lane);
+                __syncthreads();
+                if (more) {
+                    store_stage<T>(st, As, Bs, tid);
+                    __syncthreads();
+                }
+            }
+        }
+
+        // epilogue: C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < T::NT; ++nt) {
+            const int col = wn * T::NT * 16 + nt * 16 + r;
+            const float sc = a.scale ? a.scale[col] : 1.f;
+            const float sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < T::MT; ++mt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = row0 + wm * T::MT * 16 + mt * 16 + g * 4 + e;
+                    if (row < m) {
+                        float v = fmaf(acc[mt][nt][e], sc, sh);
+                        if (a.residual) v += a.residual[(size_t)row * a.cout + col];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.out[(size_t)row * a.cout + col] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // nbr_s / mask_s are rewritten by the next tile
+    }
+}
+
+__global__ void k_sparse_to_bev(const float *__restrict__ feats, const int *__restrict__ coords,
+                                const int *__restrict__ d_m, int cap, int c, int d, int h, int w, int pad,
+                                float *__restrict__ bev) {
+    const int m = min(*d_m, cap);
+    const long total = (long)m * c;
+    const int hp = h + 2 * pad, wp = w + 2 * pad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx / c), ch = (int)(idx % c);
+        const int4 cc = reinterpret_cast<const int4 *>(coords)[o];  // [b,z,y,x]
+        const size_t pix = ((size_t)cc.x * hp + (cc.z + pad)) * wp + (cc.w + pad);
+        bev[pix * ((size_t)c * d) + (size_t)ch * d + cc.y] = feats[idx];
+    }
+}
+
+template <class T>
+static int launch_spconv(const SpConvArgs &a, hipStream_t stream) {
+    // persistent grid: enough workgroups to cover every CU several times; tiles are strided
+    int grid = ceil_div(a.cap, T::BM);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_spconv<T>, dim3(grid), dim3(256), 0, stream, a);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+                      const float *w, const float *scale, const float *shift, const float *residual, int relu,
+                      float *out, int cout, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(in && nbr && d_m_out && w && out, "dz_spconv_forward: null pointer");
+    DZ_CHECK_ARG(kvol >= 1 && kvol <= KVOL_MAX, "dz_spconv_forward: kvol %d not in [1,27]", kvol);
+    if (cap_out == 0) return DZ_OK;
+    SpConvArgs a{in, nbr, d_m_out, w, scale, shift, residual, out, cin, cout, kvol, cap_out, relu};
+    // tile shapes: BM x BN=cout, KC = min(cin,32); small BM for the deep, small levels so that
+    // a level of ~20-40k sites still yields >= 2 workgroups per CU
+    if (cin == 16 && cout == 16) return launch_spconv<TileCfg<128, 16, 16, 4, 1>>(a, stream);
+    if (cin == 16 && cout == 32) return launch_spconv<TileCfg<128, 32, 16, 4, 1>>(a, stream);
+    if (cin == 32 && cout == 32) return launch_spconv<TileCfg<128, 32, 32, 4, 1>>(a, stream);
+    if (cin == 32 && cout == 64) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
+    if (cin == 64 && cout == 64) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
+    if (cin == 64 && cout == 128) return launch_spconv<TileCfg<64, 128, 32, 2, 2>>(a, stream);
+    if (cin == 128 && cout == 128) return launch_spconv<TileCfg<64, 128, 32, 2, 2>>(a, stream);
+    set_error("dz_spconv_forward: unsupported channels cin=%d cout=%d", cin, cout);
+    return DZ_ERR_UNSUPPORTED;
+}
+
+int dz_sparse_to_bev(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h, int w,
+                     int pad, float *bev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(feats && coords && d_m && bev && c > 0 && d > 0 && pad >= 0, "dz_sparse_to_bev: bad argument");
+    if (cap == 0) return DZ_OK;
+    hipLaunchKernelGGL(k_sparse_to_bev, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream, feats, coords, d_m,
+                       cap, c, d, h, w, pad, bev);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+}  // extern "C"

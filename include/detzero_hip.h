@@ -1,0 +1,194 @@
+/*
+ * libdetzero_hip — C ABI of the MI355X (gfx950) implementation of DetZero's per-frame detection
+ * hot path.  Plain pointers and sizes only (no torch types); every pointer is a caller-owned
+ * DEVICE pointer unless the name starts with `h_`; every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*), allocates nothing, never exits the process and returns
+ * DZ_OK (0) or a negative error code (message via dz_last_error()).
+ *
+ * Counts that are only known on the device (number of voxels, of active sites, of kept boxes)
+ * live in device int32 words (`d_*`); kernels read them, so a whole frame can be enqueued — or
+ * captured in a hipGraph — without a host round trip.  `cap` arguments are the row capacities
+ * of the caller's buffers (upper bounds).
+ *
+ * Each entry point names the reference interface it stands in for (paths relative to the
+ * reference repository root).  spconv / cumm / torch_scatter are un-vendored pip dependencies
+ * of the reference; their Python call sites are cited instead.
+ */
+#ifndef DETZERO_HIP_H
+#define DETZERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZ_OK 0
+#define DZ_ERR_INVALID (-1)     /* bad argument */
+#define DZ_ERR_WORKSPACE (-2)   /* workspace too small */
+#define DZ_ERR_HIP (-3)         /* HIP runtime error */
+#define DZ_ERR_UNSUPPORTED (-4) /* shape not supported by this build */
+
+const char *dz_version(void);
+const char *dz_last_error(void);
+/* number of compute units of the current device (used by callers to size persistent grids) */
+int dz_device_cu_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Points -> voxels
+ * ------------------------------------------------------------------------------------------- */
+
+/* Hard voxelization == spconv.utils.Point2VoxelCPU3d(...).point_to_voxel(points)
+ * as called from detection/detzero_det/datasets/processor/data_processor.py:69-83.
+ *   points (n,c) f32; h_range6 = [x0,y0,z0,x1,y1,z1]; h_vsize3; h_grid3 = (gx,gy,gz)
+ *   voxels (max_voxels,max_points,c) f32 zero padded; coords_zyx (max_voxels,3) i32;
+ *   num_points (max_voxels) i32; d_num_voxels: device i32, number of voxels produced.
+ * Voxel order = first appearance in the input, points per voxel = first max_points in input order. */
+size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_points);
+int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
+                     const int *h_grid3, int max_points, int max_voxels, float *voxels,
+                     int *coords_zyx, int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes,
+                     void *stream);
+
+/* MeanVFE.forward — detection/detzero_det/models/centerpoint_modules/vfe.py:66-83.
+ * out (m, c_out_stride) f32: columns [0,c) = sum over slots / max(num_points,1); columns
+ * [c, c_out_stride) are written as 0 (channel padding used by the sparse backbone). */
+int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int cap, int max_points,
+                int c, float *out, int c_out_stride, void *stream);
+
+/* DynamicMeanVFE.forward — vfe.py:109-147 (torch.unique + torch_scatter.scatter_mean).
+ *   points_b (n,1+c) f32 rows [b,x,y,z,...]; feats (cap,c) f32; coords_bzyx (cap,4) i32 in
+ *   ascending merge-key order (key = b*gx*gy*gz + cx*gy*gz + cy*gz + cz). */
+size_t dz_voxelize_dynamic_workspace_bytes(int n, int batch, int gx, int gy, int gz, int c, int cap);
+int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h_range6,
+                             const float *h_vsize3, const int *h_grid3, int batch, float *feats,
+                             int *coords_bzyx, int *d_num_voxels, int cap, void *ws, size_t ws_bytes,
+                             void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse tensor index ("indice" machinery of spconv.pytorch.SparseConvTensor / SubMConv3d /
+ * SparseConv3d — call sites detection/detzero_det/models/centerpoint_modules/backbone3d.py:
+ * 243-280, 302-307).  A level is a bit per cell of the (B,D,H,W) grid plus an exclusive
+ * popcount prefix per 32-bit word; active sites are numbered in ascending linear key
+ * ((b*D+z)*H+y)*W+x, which is also their row in the feature matrix.
+ * ------------------------------------------------------------------------------------------- */
+size_t dz_index_words(int b, int d, int h, int w);            /* uint32 words in bitmap / prefix */
+size_t dz_index_workspace_bytes(int b, int d, int h, int w);
+
+/* Build a level from (n,4) i32 [b,z,y,x] coordinates in any order (duplicates allowed).
+ * d_n may be NULL (then n_cap rows are all valid).  Writes bitmap, prefix, canonical coords and
+ * *d_m; rank_of_input (n_cap) receives the canonical row of each input row (may be NULL). */
+int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, int d, int h, int w,
+                         uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap_out,
+                         int *rank_of_input, void *ws, size_t ws_bytes, void *stream);
+
+/* Output level of a regular sparse convolution (SparseConv3d, backbone3d.py:256-277):
+ * out dims = floor((in + 2p - k)/s) + 1; a site is active iff >=1 active input in its window. */
+int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int b, int d, int h,
+                        int w, const int *h_k3, const int *h_s3, const int *h_p3, uint32_t *bitmap_out,
+                        uint32_t *prefix_out, int *coords_out, int *d_m_out, int cap_out, void *ws,
+                        size_t ws_bytes, void *stream);
+
+/* Rulebook in output-stationary form: nbr[t*cap_out + o] = input row feeding output row o
+ * through kernel tap t = (tz*kH+ty)*kW+tx (input coordinate = o*s - p + t), or -1.
+ * SubMConv3d = (k=3,s=1,p=1) with the output level equal to the input level. */
+int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
+                       const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3,
+                       const int *h_s3, const int *h_p3, int *nbr, void *stream);
+
+/* dst[rank[i]][0:c_src] = src[i][0:c_src]; dst[rank[i]][c_src:c_dst] = 0 (rows with rank<0 skipped) */
+int dz_scatter_rows(const float *src, const int *rank, const int *d_n, int n_cap, int c_src, float *dst,
+                    int c_dst, void *stream);
+
+/* Sparse convolution forward with fused epilogue
+ *   out[o] = relu?( (sum_t in[nbr[t][o]] . W[t]) * scale + shift (+ residual[o]) )
+ * == SubMConv3d/SparseConv3d + BatchNorm1d(eval, folded into scale/shift together with the conv
+ * bias) + residual add + ReLU of backbone3d.py:77-81,105-121.  fp32 in, fp32 MFMA accumulate.
+ *   in (m_in, cin) f32, cin in {16,32,64,128}; w (kvol,cin,cout) f32; cout in {16,32,64,128}. */
+int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+                      const float *w, const float *scale, const float *shift, const float *residual,
+                      int relu, float *out, int cout, void *stream);
+
+/* spconv SparseConvTensor.dense() + HeightCompression reshape (height_compression.py:20-24),
+ * written channel-last into a zero-bordered BEV image: bev[b][y+pad][x+pad][c*D + z] = feats[o][c].
+ * The caller zero-fills `bev` (hipMemsetAsync) before the call. */
+int dz_sparse_to_bev(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
+                     int w, int pad, float *bev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense BEV network (torch.nn.Conv2d / ConvTranspose2d / BatchNorm2d / ReLU of
+ * backbone2d.py:33-120 and center_head.py:14-48,81-102), channel-last implicit GEMM on fp32 MFMA.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dz_conv2d_desc {
+    const float *in;      /* (B, in_hp, in_wp, in_cstride) channel-last, zero border included   */
+    float *out;           /* (B, out_hp, out_wp, out_cstride)                                  */
+    const float *w;       /* (groups, kh*kw, cin, cout_pad)                                    */
+    const float *scale;   /* (groups*cout_pad) or NULL (=1)                                    */
+    const float *shift;   /* (groups*cout_pad) or NULL (=0)                                    */
+    int batch, ho, wo;    /* logical output extent enumerated by the kernel                    */
+    int in_hp, in_wp, in_cstride, in_coff, cin;
+    int kh, kw, stride, in_off; /* input pixel = (y*stride + ky + in_off, x*stride + kx + in_off) */
+    int out_hp, out_wp, out_cstride, out_coff;
+    int out_sy, out_sx, out_dy, out_dx; /* output pixel = (y*out_sy + out_dy, x*out_sx + out_dx) (pad included) */
+    int groups, cout_pad;
+    int g_cout[8];        /* valid output channels of each group                               */
+    int g_ooff[8];        /* output channel offset of each group (added to out_coff)           */
+    int relu;
+} dz_conv2d_desc;
+int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CenterHead decode + NMS (center_head.py:315-368, centernet_utils.py:138-230,
+ * model_nms_utils.py:6-25, utils/detzero_utils/ops/iou3d_nms/)
+ * ------------------------------------------------------------------------------------------- */
+/* head (B, HW, 12) channel-last, columns [center 0:2 | center_z 2 | dim 3:6 | rot 6:8 | iou 8 | hm 9:12].
+ * Produces, per batch item, the top-K (score = sigmoid(hm)*clamp(iou,0,1)^2) candidates in
+ * descending score order that pass the score threshold and the centre range test:
+ *   boxes (B,K,7) [x,y,z,dx,dy,dz,heading], scores (B,K), labels (B,K) i32 0-based, d_counts (B). */
+size_t dz_centerhead_decode_workspace_bytes(int batch, int hw, int ncls, int k);
+int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, int k, float score_thresh,
+                         const float *h_limit6, const float *h_range6, const float *h_vsize3, int stride,
+                         int use_iou, float *boxes, float *scores, int *labels, int *d_counts, void *ws,
+                         size_t ws_bytes, void *stream);
+
+/* iou3d_nms_cuda.nms_gpu (iou3d_nms.cpp:114-160 + nms_kernel iou3d_nms_kernel.cu:386-430), with the
+ * suppression sweep done on the device.  boxes (n_cap,7) already in descending score order;
+ * *d_n of them valid (d_n may be NULL).  keep (n_cap) i32 receives kept indices in order,
+ * *d_num_keep their number (limited to post_max). */
+size_t dz_nms_workspace_bytes(int n_cap);
+int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, int post_max, int *keep,
+                   int *d_num_keep, void *ws, size_t ws_bytes, void *stream);
+
+/* iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d_nms.cpp:60-111) : (na,nb) f32 */
+int dz_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out, void *stream);
+int dz_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out, void *stream);
+
+/* gather rows: out[i] = src[idx[i]] for i < *d_n (used to apply the NMS keep list on device) */
+int dz_gather_rows(const float *src, const int *idx, const int *d_n, int n_cap, int c, float *out,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Refining module, secondary kernel set
+ * ------------------------------------------------------------------------------------------- */
+/* roiaware_pool3d_cuda.points_in_boxes_gpu_v2 (roiaware_pool3d.cpp:135-155,
+ * roiaware_pool3d_kernel.cu:352-374): mask (B,T,M) i32, 1 where point m is inside box t. */
+int dz_points_in_boxes_v2(const float *boxes, const float *pts, int batch, int t, int m, int *mask,
+                          void *stream);
+
+/* multi_head_attention_forward core (refining/detzero_refine/models/transformer/
+ * multi_head_attention.py:207-288): q (B,Lq,E), k,v (B,Lk,E) already projected, E = heads*32;
+ * key_padding_mask (B,Lk) u8 (1 = ignore) or NULL; out (B,Lq,E).  softmax(q*scale . k^T) . v */
+int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *key_padding_mask, int batch,
+                int lq, int lk, int heads, float scale, float *out, void *stream);
+
+/* y (rows, cout) = relu?( x (rows, cin) . W (cin, cout_pad) * scale + shift ) — the 1x1 Conv1d/Conv2d
+ * + BatchNorm + ReLU stacks of the GRM/PRM PointNet encoders
+ * (refining/detzero_refine/models/modules/geometry_transformer.py:34-67), same MFMA engine. */
+int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
+                      const float *scale, const float *shift, int relu, float *y, int y_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETZERO_HIP_H */
