@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: LiDAR frames/sec of the per-frame detection path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the whole hot path over one synthetic 160k-point frame (BASELINE.json
+configs[1]: 0.1 m voxels, grid 1504x1504x40, full VoxelResBackBone8x + BaseBEVBackbone + CenterHead +
+decode + rotated NMS), frame already resident in HBM when the timed region starts, fp32 throughout
+(fp32 MFMA = exact fp32).  One process per GPU, frames sharded one-per-GPU (weak scaling); with N>1 the
+per-frame boxes are gathered to rank 0 with one RCCL all-gather at the end of the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA peak (dense)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--points', type=int, default=160000)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
+    ap.add_argument('--profile-frames', type=int, default=3)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if args.gpus != world:
+        if rank == 0:
+            print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from detzero_amd import ops
+    from detzero_amd.centerpoint import FramePipeline, synth_detector
+    from detzero_amd.synth import VOXEL_SIZE_01, synth_waymo_frame
+    from detzero_amd import frame_parallel as fp
+
+    model, cfg, info = synth_detector(VOXEL_SIZE_01, seed=0)
+    model = model.to(dev)
+    pipe = FramePipeline(model, info)
+    n_distinct = 4
+    frames = [torch.from_numpy(synth_waymo_frame(1000 * rank + i, args.points)).to(dev) for i in range(n_distinct)]
+    static_in = frames[0].clone()
+    K, W = args.steps, args.warmup
+    post_max = pipe.post_max
+    results = torch.zeros((K, post_max, 9), dtype=torch.float32, device=dev)
+    counts = torch.zeros((K,), dtype=torch.int32, device=dev)
+
+    # warm-up (also primes the caching allocator and builds the kernel-layout weights)
+    use_graph = not args.no_graph
+    graph = None
+    g_out = g_n = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(max(W, 3)):
+            static_in.copy_(frames[i % n_distinct])
+            g_out, g_n = pipe(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph_note = 'hipGraph replay'
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_out, g_n = pipe(static_in)
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture is an optimisation, not a requirement
+            graph = None
+            graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
+            torch.cuda.synchronize()
+    else:
+        graph_note = 'eager launches'
+
+    def step(i):
+        nonlocal g_out, g_n
+        static_in.copy_(frames[i % n_distinct], non_blocking=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            g_out, g_n = pipe(static_in)
+        results[i].copy_(g_out, non_blocking=True)
+        counts[i:i + 1].copy_(g_n, non_blocking=True)
+
+    for i in range(W):
+        step(i % K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    if world > 1:
+        all_b, all_c = fp.gather_frame_boxes(results, counts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_boxes = counts.float().mean().item()
+
+    out = None
+    if rank == 0:
+        value = world * K / dt
+        out = {
+            'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(value, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: single %d-pt synthetic Waymo frame per step, 0.1 m voxels '
+                                   '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
+                                   '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
+                       'frames_per_step_per_gpu': 1, 'parallelism': 'frame-parallel x%d' % world,
+                       'launch': graph_note, 'weights': 'seeded random init (no checkpoints offline)',
+                       'mean_boxes_per_frame': round(n_boxes, 1)},
+        }
+
+    # ---- roofline of the dominant kernel: HIP events around every conv launch, on the launch stream
+    if rank == 0:
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+        stage_ms = {}
+        try:
+            for i in range(args.profile_frames):
+                static_in.copy_(frames[i % n_distinct])
+                pipe(static_in)
+            agg = prof.summary()
+        finally:
+            ops.PROFILER = None
+        kern = []
+        for name, a in agg.items():
+            per = a['ms'] / a['launches']
+            kern.append({'kernel': name, 'launches_per_frame': a['launches'] / args.profile_frames,
+                         'avg_us': round(1000.0 * per, 2), 'ms_per_frame': round(a['ms'] / args.profile_frames, 4),
+                         'tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
+                         'algorithmic_gbs': round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)})
+        kern.sort(key=lambda r: -r['ms_per_frame'])
+        if kern:
+            top = kern[0]
+            a = agg[top['kernel']]
+            achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
+                               'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                               'traffic': None,
+                               'flop_per_launch': round(a['flops'] / a['launches'], 1),
+                               'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
+                               'note': 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; '
+                                       'algorithmic FLOP = 2*pixels*taps*Cin*Cout'}
+        out['kernels'] = kern
+        out['conv_ms_per_frame'] = round(sum(r['ms_per_frame'] for r in kern), 4)
+
+    # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests.util import cpu_state_dict, oracle_detect       # oracle = checker/baseline only
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd = cpu_state_dict(model)
+        pts = [f.cpu().numpy() for f in frames]
+        from oracle.voxelize import mask_points_by_range
+        done, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_baseline_seconds and done < 8:
+            p = pts[done % n_distinct]
+            p = p[mask_points_by_range(p, info.point_cloud_range)]
+            t1 = time.perf_counter()
+            oracle_detect(sd, p, info)
+            t_cpu += time.perf_counter() - t1
+            done += 1
+        out['cpu_baseline'] = {'value': round(done / t_cpu, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+                               'sample': '%d frames of the same 160k-pt workload through oracle/ (numpy + CPU torch '
+                                         'restatement of the spconv/PyTorch path; spconv itself is not installable), '
+                                         '%.1f s' % (done, t_cpu)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

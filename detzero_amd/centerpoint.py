@@ -1,0 +1,223 @@
+"""CenterPoint detector (plugin surface of the reference) and the sync-free per-frame pipeline.
+
+``CenterPoint`` mirrors /root/reference/detection/detzero_det/models/centerpoint.py:15-129,210-352 and
+``build_network`` / ``load_data_to_gpu`` mirror detzero_det/models/__init__.py:13-29, so
+detection/tools/test.py's ``eval_one_epoch`` drives it unchanged: ``model(batch_dict)`` returns
+``(pred_dicts, recall_dict)`` in eval mode.
+
+``FramePipeline`` is the same computation arranged for throughput: points already resident in HBM ->
+voxelize -> VFE -> sparse backbone -> BEV -> head -> decode -> NMS, every size-dependent quantity kept
+in device counters, so one frame is ~110 kernel launches with no host synchronisation; results are
+padded (500, 9) boxes + a count, which is also the payload of the RCCL gather.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import det_modules as cp_modules
+from . import iou3d_nms_utils, ops
+from .lib import DetZeroHipError
+
+
+class CenterPoint(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.dataset = dataset
+        self.tta = getattr(self.dataset, 'tta', False)
+        if self.tta:
+            raise DetZeroHipError('TTA / weighted box fusion is out of scope of the HIP backend (SURVEY.md §8f)')
+        self.class_names = dataset.class_names
+        self.register_buffer('global_step', torch.LongTensor(1).zero_())
+        self.second_stage = model_cfg.SECOND_STAGE
+        if self.second_stage:
+            raise DetZeroHipError('PDV second stage (ROI_HEAD) is out of scope of the HIP backend (SURVEY.md §8f)')
+        self.module_list = self.build_networks()
+
+    def build_networks(self):
+        """centerpoint.py:59-129."""
+        info = {
+            'num_point_features': self.dataset.point_feature_encoder.num_point_features,
+            'grid_size': self.dataset.grid_size,
+            'point_cloud_range': self.dataset.point_cloud_range,
+            'voxel_size': self.dataset.voxel_size,
+        }
+        vfe = cp_modules.__all__[self.model_cfg.VFE.NAME](
+            model_cfg=self.model_cfg.VFE, num_point_features=info['num_point_features'],
+            point_cloud_range=info['point_cloud_range'], voxel_size=info['voxel_size'], grid_size=info['grid_size'])
+        info['num_point_features'] = vfe.get_output_feature_dim()
+        backbone3d = cp_modules.__all__[self.model_cfg.BACKBONE_3D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_3D, input_channels=info['num_point_features'],
+            grid_size=info['grid_size'], voxel_size=info['voxel_size'], point_cloud_range=info['point_cloud_range'])
+        map_to_bev = cp_modules.__all__[self.model_cfg.MAP_TO_BEV.NAME](
+            model_cfg=self.model_cfg.MAP_TO_BEV, grid_size=info['grid_size'])
+        backbone2d = cp_modules.__all__[self.model_cfg.BACKBONE_2D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_2D, input_channels=map_to_bev.num_bev_features)
+        dense_head = cp_modules.__all__[self.model_cfg.DENSE_HEAD.NAME](
+            model_cfg=self.model_cfg.DENSE_HEAD, input_channels=backbone2d.num_bev_features,
+            num_class=self.num_class if not self.model_cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1,
+            class_names=self.class_names, grid_size=info['grid_size'], voxel_size=info['voxel_size'],
+            point_cloud_range=info['point_cloud_range'], tta=self.tta, predict_boxes_when_training=self.second_stage)
+        self.add_module('vfe', vfe)
+        self.add_module('backbone3d', backbone3d)
+        self.add_module('map_to_bev', map_to_bev)
+        self.add_module('backbone2d', backbone2d)
+        self.add_module('dense_head', dense_head)
+        return [vfe, backbone3d, map_to_bev, backbone2d, dense_head]
+
+    @property
+    def mode(self):
+        return 'TRAIN' if self.training else 'TEST'
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def forward(self, batch_dict):
+        if self.training:
+            raise DetZeroHipError('CenterPoint: training is out of scope of the HIP backend; call .eval()')
+        for cur_module in self.module_list:
+            batch_dict = cur_module(batch_dict)
+        return self.post_processing(batch_dict)
+
+    def post_processing(self, batch_dict):
+        """centerpoint.py:283-296 (one-stage branch)."""
+        post_process_cfg = self.model_cfg.POST_PROCESSING
+        pred_dicts = batch_dict['final_box_dicts']
+        recall_dict = {}
+        for index in range(batch_dict['batch_size']):
+            recall_dict = self.generate_recall_record(
+                box_preds=pred_dicts[index]['pred_boxes'], recall_dict=recall_dict, batch_index=index,
+                data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+        return pred_dicts, recall_dict
+
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """centerpoint.py:310-352."""
+        if 'gt_boxes' not in data_dict:
+            return recall_dict
+        gt_boxes = data_dict['gt_boxes'][batch_index]
+        if len(recall_dict) == 0:
+            recall_dict = {'gt': 0}
+            for t in thresh_list:
+                recall_dict['roi_%s' % str(t)] = 0
+                recall_dict['rcnn_%s' % str(t)] = 0
+        cur_gt = gt_boxes
+        k = len(cur_gt) - 1
+        while k > 0 and cur_gt[k].sum() == 0:
+            k -= 1
+        cur_gt = cur_gt[:k + 1]
+        if cur_gt.shape[0] > 0:
+            if box_preds.shape[0] > 0:
+                iou3d = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7].contiguous(), cur_gt[:, 0:7].contiguous())
+            else:
+                iou3d = torch.zeros((0, cur_gt.shape[0]))
+            for t in thresh_list:
+                if iou3d.shape[0] > 0:
+                    recall_dict['rcnn_%s' % str(t)] += (iou3d.max(dim=0)[0] > t).sum().item()
+            recall_dict['gt'] += cur_gt.shape[0]
+        return recall_dict
+
+
+__all__ = {'CenterPoint': CenterPoint}
+
+
+def build_network(model_cfg, num_class, dataset):
+    return __all__[model_cfg.NAME](model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+
+
+def load_data_to_gpu(batch_dict):
+    """models/__init__.py:21-29 (every ndarray -> float32 device tensor)."""
+    for key, val in batch_dict.items():
+        if key in ['frame_id', 'metadata', 'sequence_name', 'pose', 'tta_ops', 'aug_matrix_inv']:
+            continue
+        elif isinstance(val, np.ndarray):
+            batch_dict[key] = torch.from_numpy(val).float().cuda()
+
+
+class SyntheticDatasetInfo:
+    """The attributes build_networks reads from a DatasetTemplate (dataset.py:22-53)."""
+
+    class _PFE:
+        def __init__(self, n):
+            self.num_point_features = n
+
+    def __init__(self, cfg, num_point_features=5):
+        dcfg = cfg.DATA_CONFIG
+        self.class_names = list(cfg.CLASS_NAMES)
+        self.point_cloud_range = np.array(dcfg.POINT_CLOUD_RANGE, dtype=np.float32)
+        vox = [p for p in dcfg.DATA_PROCESSOR if p.NAME.startswith('transform_points_to_voxels')][0]
+        self.voxel_size = list(vox.VOXEL_SIZE)
+        self.max_points_per_voxel = vox.get('MAX_POINTS_PER_VOXEL', 5)
+        self.max_voxels = vox.get('MAX_NUMBER_OF_VOXELS', {'test': 200000})
+        self.grid_size = ops.grid_size_of(self.point_cloud_range, self.voxel_size)
+        self.point_feature_encoder = self._PFE(num_point_features)
+        self.tta = False
+
+
+class FramePipeline:
+    """Sync-free single-frame detector step on one GPU (batch = 1 frame per call).
+
+    ``__call__(points)``: points (N,C) float32 device tensor (already range-masked or not - the xy
+    mask of data_processor.py:24-37 is applied on the device) -> (boxes9 (K,9), count (1,) i32) where
+    rows [0,count) are ``[x,y,z,dx,dy,dz,heading,score,label(1-based)]`` after NMS.
+    """
+
+    def __init__(self, model, dataset_info, mode='test', dynamic=False):
+        self.model = model.eval()
+        self.info = dataset_info
+        self.mode = mode
+        self.dynamic = dynamic
+        self.head = model.dense_head
+        post = self.head.model_cfg.POST_PROCESSING
+        self.k = post.MAX_OBJ_PER_SAMPLE
+        self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
+
+    @torch.no_grad()
+    def __call__(self, points):
+        info, m = self.info, self.model
+        rng = info.point_cloud_range
+        if self.dynamic:
+            pb = torch.cat([points.new_zeros((points.shape[0], 1)), points], dim=1).contiguous()
+            feats, coords, d_n = ops.voxelize_dynamic_nosync(pb, rng, info.voxel_size, 1, xy_range_mask=True)
+        else:
+            # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
+            voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(points, rng, info.voxel_size,
+                                                              info.max_points_per_voxel, info.max_voxels[self.mode],
+                                                              xy_range_mask=True)
+            feats = ops.mean_vfe(voxels, nump, d_m=d_n)
+            coords = torch.cat([zyx.new_zeros((zyx.shape[0], 1)), zyx], dim=1).contiguous()
+        res = m.backbone3d.run(feats, coords, 1, d_n)
+        x, lvl = res['encoded']
+        bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1)
+        concat = m.backbone2d.run(bev, 1)
+        head, h, w = self.head.run_convs(concat, 1)
+        boxes, scores, labels, keep, d_nk = self.head.decode_nosync(head, h, w)[0]
+        packed = torch.cat([boxes, scores[:, None], (labels + 1).float()[:, None]], dim=1).contiguous()
+        out = ops.gather_rows(packed, keep, d_nk, self.post_max)
+        return out, d_nk
+
+
+def synth_detector(voxel_size, seed=0):
+    """Seeded random-init CenterPoint of the reference architecture (there are no checkpoints offline):
+    default inits, BatchNorm running statistics randomised so BN folding is exercised, final-conv biases
+    of hm / dim / iou spread so that a few hundred boxes pass SCORE_THRESH and NMS has work to do
+    (SURVEY.md §8d).  Returns (model on CPU in eval mode, cfg, dataset_info)."""
+    from .config import centerpoint_1sweep_cfg
+    cfg = centerpoint_1sweep_cfg(tuple(voxel_size))
+    info = SyntheticDatasetInfo(cfg)
+    torch.manual_seed(seed)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), info).eval()
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+                m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+        hl = model.dense_head.heads_list[0]
+        hl.hm[1].bias.fill_(-0.5)
+        hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4]))
+        hl.iou[1].bias.fill_(0.6)
+    return model, cfg, info

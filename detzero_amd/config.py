@@ -1,0 +1,113 @@
+"""Minimal EasyDict-compatible config tree (easydict is not installed here).
+
+Mirrors what the hot path needs of /root/reference/utils/detzero_utils/config_utils.py:59-94:
+attribute access, ``.get``, yaml loading with ``_BASE_CONFIG_`` includes.
+"""
+import os
+
+import yaml
+
+
+class AttrDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}, **kw)
+        for k, v in d.items():
+            self[k] = v
+
+    @staticmethod
+    def _wrap(v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            return AttrDict(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(AttrDict._wrap(x) for x in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, AttrDict._wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def merge_new_config(config, new_config, base_dir='.'):
+    """config_utils.py:59-76 (include path resolved against base_dir instead of the CWD)."""
+    if '_BASE_CONFIG_' in new_config:
+        path = new_config['_BASE_CONFIG_']
+        if not os.path.isabs(path):
+            path = os.path.join(base_dir, path)
+        with open(path, 'r') as f:
+            config.update(AttrDict(yaml.safe_load(f)))
+    for key, val in new_config.items():
+        if not isinstance(val, dict):
+            config[key] = val
+            continue
+        if key not in config:
+            config[key] = AttrDict()
+        merge_new_config(config[key], val, base_dir)
+    return config
+
+
+def cfg_from_yaml_file(cfg_file, config=None, base_dir=None):
+    config = AttrDict() if config is None else config
+    base_dir = base_dir if base_dir is not None else os.path.dirname(os.path.dirname(os.path.abspath(cfg_file)))
+    with open(cfg_file, 'r') as f:
+        new_config = yaml.safe_load(f)
+    merge_new_config(config, new_config, base_dir)
+    return config
+
+
+def centerpoint_1sweep_cfg(voxel_size=(0.1, 0.1, 0.15), max_voxels_test=200000):
+    """In-code copy of the VALUES of tools/cfgs/det_model_cfgs/centerpoint_1sweep.yaml and
+    det_dataset_cfgs/waymo_1sweep.yaml that the inference path reads."""
+    return AttrDict({
+        'CLASS_NAMES': ['Vehicle', 'Pedestrian', 'Cyclist'],
+        'DATA_CONFIG': {
+            'POINT_CLOUD_RANGE': [-75.2, -75.2, -2, 75.2, 75.2, 4.0],
+            'DATA_PROCESSOR': [
+                {'NAME': 'mask_points_and_boxes_outside_range', 'REMOVE_OUTSIDE_BOXES': True},
+                {'NAME': 'shuffle_points', 'SHUFFLE_ENABLED': {'train': True, 'test': False}},
+                {'NAME': 'transform_points_to_voxels', 'VOXEL_SIZE': list(voxel_size), 'MAX_POINTS_PER_VOXEL': 5,
+                 'MAX_NUMBER_OF_VOXELS': {'train': 150000, 'test': max_voxels_test}},
+            ],
+        },
+        'MODEL': {
+            'NAME': 'CenterPoint',
+            'SECOND_STAGE': False,
+            'VFE': {'NAME': 'MeanVFE'},
+            'BACKBONE_3D': {'NAME': 'VoxelResBackBone8x'},
+            'MAP_TO_BEV': {'NAME': 'HeightCompression', 'NUM_BEV_FEATURES': 256},
+            'BACKBONE_2D': {'NAME': 'BaseBEVBackbone', 'LAYER_NUMS': [5, 5], 'LAYER_STRIDES': [1, 2],
+                            'NUM_FILTERS': [128, 256], 'UPSAMPLE_STRIDES': [1, 2],
+                            'NUM_UPSAMPLE_FILTERS': [256, 256]},
+            'DENSE_HEAD': {
+                'NAME': 'CenterHead', 'CLASS_AGNOSTIC': False,
+                'CLASS_NAMES_EACH_HEAD': [['Vehicle', 'Pedestrian', 'Cyclist']],
+                'SHARED_CONV_CHANNEL': 64, 'USE_BIAS_BEFORE_NORM': True, 'NUM_HM_CONV': 2, 'IOU_WEIGHT': 1,
+                'SEPARATE_HEAD_CFG': {
+                    'HEAD_ORDER': ['center', 'center_z', 'dim', 'rot', 'iou'],
+                    'HEAD_DICT': {'center': {'out_channels': 2, 'num_conv': 2},
+                                  'center_z': {'out_channels': 1, 'num_conv': 2},
+                                  'dim': {'out_channels': 3, 'num_conv': 2},
+                                  'rot': {'out_channels': 2, 'num_conv': 2},
+                                  'iou': {'out_channels': 1, 'num_conv': 2}},
+                },
+                'TARGET_ASSIGNER_CONFIG': {'FEATURE_MAP_STRIDE': 8, 'NUM_MAX_OBJS': 500, 'GAUSSIAN_OVERLAP': 0.1,
+                                           'MIN_RADIUS': 2},
+                'POST_PROCESSING': {
+                    'SCORE_THRESH': 0.03, 'POST_CENTER_LIMIT_RANGE': [-80, -80, -10.0, 80, 80, 10.0],
+                    'MAX_OBJ_PER_SAMPLE': 500,
+                    'NMS_CONFIG': {'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096,
+                                   'NMS_POST_MAXSIZE': 500},
+                },
+            },
+            'POST_PROCESSING': {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.03,
+                                'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'waymo'},
+        },
+    })

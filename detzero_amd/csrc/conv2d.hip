@@ -113,22 +113,40 @@ static int launch_conv(const dz_conv2d_desc &p, hipStream_t stream) {
     return DZ_OK;
 }
 
-static int conv2d_dispatch(const dz_conv2d_desc &p, hipStream_t stream) {
+// variant ids: tile BM x BN x KC
+enum ConvVariant { CV_NONE = 0, CV_64_64_16, CV_128_16_16, CV_128_64_32, CV_64_64_32, CV_128_32_32, CV_128_16_32 };
+static const char *kConvVariantName[] = {"none", "k_conv2d<64x64x16>", "k_conv2d<128x16x16>", "k_conv2d<128x64x32>",
+                                         "k_conv2d<64x64x32>", "k_conv2d<128x32x32>", "k_conv2d<128x16x32>"};
+
+static ConvVariant conv2d_select(const dz_conv2d_desc &p) {
     const long m_total = (long)p.batch * p.ho * p.wo;
-    if (m_total == 0) return DZ_OK;
     if (p.cin % 32 != 0 && p.cin % 16 == 0) {
-        if (p.cout_pad % 64 == 0) return launch_conv<TileCfg<64, 64, 16, 2, 2>>(p, stream);
-        if (p.cout_pad % 16 == 0) return launch_conv<TileCfg<128, 16, 16, 4, 1>>(p, stream);
+        if (p.cout_pad % 64 == 0) return CV_64_64_16;
+        if (p.cout_pad % 16 == 0) return CV_128_16_16;
     }
     if (p.cin % 32 == 0) {
         if (p.cout_pad % 64 == 0) {
             // pick the M tile so that the grid has at least ~2 workgroups per CU (256 CUs)
             const long blocks128 = (long)ceil_div(m_total, 128) * (p.cout_pad / 64) * p.groups;
-            if (blocks128 >= 512) return launch_conv<TileCfg<128, 64, 32, 2, 2>>(p, stream);
-            return launch_conv<TileCfg<64, 64, 32, 2, 2>>(p, stream);
+            return blocks128 >= 512 ? CV_128_64_32 : CV_64_64_32;
         }
-        if (p.cout_pad % 32 == 0) return launch_conv<TileCfg<128, 32, 32, 4, 1>>(p, stream);
-        if (p.cout_pad % 16 == 0) return launch_conv<TileCfg<128, 16, 32, 4, 1>>(p, stream);
+        if (p.cout_pad % 32 == 0) return CV_128_32_32;
+        if (p.cout_pad % 16 == 0) return CV_128_16_32;
+    }
+    return CV_NONE;
+}
+
+static int conv2d_dispatch(const dz_conv2d_desc &p, hipStream_t stream) {
+    const long m_total = (long)p.batch * p.ho * p.wo;
+    if (m_total == 0) return DZ_OK;
+    switch (conv2d_select(p)) {
+        case CV_64_64_16: return launch_conv<TileCfg<64, 64, 16, 2, 2>>(p, stream);
+        case CV_128_16_16: return launch_conv<TileCfg<128, 16, 16, 4, 1>>(p, stream);
+        case CV_128_64_32: return launch_conv<TileCfg<128, 64, 32, 2, 2>>(p, stream);
+        case CV_64_64_32: return launch_conv<TileCfg<64, 64, 32, 2, 2>>(p, stream);
+        case CV_128_32_32: return launch_conv<TileCfg<128, 32, 32, 4, 1>>(p, stream);
+        case CV_128_16_32: return launch_conv<TileCfg<128, 16, 32, 4, 1>>(p, stream);
+        default: break;
     }
     set_error("dz_conv2d_forward: unsupported channels cin=%d cout_pad=%d", p.cin, p.cout_pad);
     return DZ_ERR_UNSUPPORTED;
@@ -157,6 +175,8 @@ int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
                  "dz_conv2d_forward: output leaves the output image");
     return conv2d_dispatch(*d, stream);
 }
+
+const char *dz_conv2d_variant(const dz_conv2d_desc *d) { return d ? kConvVariantName[conv2d_select(*d)] : "none"; }
 
 int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
                       const float *scale, const float *shift, int relu, float *y, int y_stride, void *stream_) {

@@ -1,6 +1,6 @@
 // Fused multi-head attention core for the refining module (GRM / PRM), fp32 MFMA, gfx950.
 //
-// Reference: refining/detzero_refine/models/transformer/multi_head_attention.py:207-288
+// Reference: refining/detzero_refine/models/modules/transformer/multi_head_attention.py:207-288
 //   q = q * scaling; attn = bmm(q, k^T); masked_fill(key_padding_mask, -inf); softmax; bmm(attn, v)
 // The reference materialises the (B*heads, Lq, Lk) score tensor (PRM: 200 x 9600 per head) and a
 // head-averaged copy of it; here one wavefront owns 16 queries of one (batch, head) and streams the

@@ -173,6 +173,15 @@ int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int ca
     return DZ_ERR_UNSUPPORTED;
 }
 
+const char *dz_spconv_variant(int cin, int cout) {
+    if (cin == 16 && cout == 16) return "k_spconv<128x16x16>";
+    if (cin == 16 && cout == 32) return "k_spconv<128x32x16>";
+    if (cin == 32 && cout == 32) return "k_spconv<128x32x32>";
+    if ((cin == 32 || cin == 64) && cout == 64) return "k_spconv<64x64x32>";
+    if ((cin == 64 || cin == 128) && cout == 128) return "k_spconv<64x128x32>";
+    return "none";
+}
+
 int dz_sparse_to_bev(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h, int w,
                      int pad, float *bev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;

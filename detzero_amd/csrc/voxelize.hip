@@ -16,13 +16,15 @@
 namespace dz {
 
 struct VoxGeom {
-    float lo[3], vs[3];
-    int g[3];  // gx, gy, gz
+    float lo[3], vs[3], hi[3];
+    int g[3];      // gx, gy, gz
+    int xy_mask;   // also apply mask_points_by_range (lo <= x,y <= hi, inclusive; common_utils.py:247-250)
 };
 
 // c_j = floor((p_j - lo_j) / vs_j) with one IEEE rounding per operation (no FMA contraction, no
 // reciprocal): identical to numpy/torch fp32 and to spconv's CPU loop.
 __device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &g, int &cx, int &cy, int &cz) {
+    if (g.xy_mask && !(p[0] >= g.lo[0] && p[0] <= g.hi[0] && p[1] >= g.lo[1] && p[1] <= g.hi[1])) return false;
     const float fx = floorf(__fdiv_rn(__fsub_rn(p[0], g.lo[0]), g.vs[0]));
     const float fy = floorf(__fdiv_rn(__fsub_rn(p[1], g.lo[1]), g.vs[1]));
     const float fz = floorf(__fdiv_rn(__fsub_rn(p[2], g.lo[2]), g.vs[2]));
@@ -172,9 +174,10 @@ __global__ void k_dyn_divide(float *__restrict__ sums, const int *__restrict__ c
     }
 }
 
-static bool make_geom(const float *r6, const float *vs3, const int *g3, VoxGeom &g) {
+static bool make_geom(const float *r6, const float *vs3, const int *g3, int xy_mask, VoxGeom &g) {
+    g.xy_mask = xy_mask;
     for (int i = 0; i < 3; ++i) {
-        g.lo[i] = r6[i]; g.vs[i] = vs3[i]; g.g[i] = g3[i];
+        g.lo[i] = r6[i]; g.hi[i] = r6[3 + i]; g.vs[i] = vs3[i]; g.g[i] = g3[i];
         if (!(g.vs[i] > 0.f) || g.g[i] < 1) return false;
     }
     return true;
@@ -219,13 +222,13 @@ size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_p
 }
 
 int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
-                     const int *h_grid3, int max_points, int max_voxels, float *voxels, int *coords_zyx,
+                     const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels, int *coords_zyx,
                      int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1, "dz_voxelize_hard: bad sizes");
     DZ_CHECK_ARG(voxels && coords_zyx && num_points && d_num_voxels && ws, "dz_voxelize_hard: null pointer");
     VoxGeom g;
-    DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, g), "dz_voxelize_hard: bad geometry");
+    DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_hard: bad geometry");
     const size_t cells = (size_t)g.g[0] * g.g[1] * g.g[2];
     if (cells >= 0xFFFFFFFFull) { set_error("dz_voxelize_hard: grid too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
     if (n == 0) { DZ_HIP(hipMemsetAsync(d_num_voxels, 0, sizeof(int), stream)); return DZ_OK; }
@@ -291,13 +294,14 @@ size_t dz_voxelize_dynamic_workspace_bytes(int n, int batch, int gx, int gy, int
 }
 
 int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h_range6, const float *h_vsize3,
-                             const int *h_grid3, int batch, float *feats, int *coords_bzyx, int *d_num_voxels, int cap,
+                             const int *h_grid3, int xy_range_mask, int batch, float *feats, int *coords_bzyx,
+                             int *d_num_voxels, int cap,
                              void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(n >= 0 && c >= 3 && batch >= 1 && cap >= 0, "dz_voxelize_dynamic_mean: bad sizes");
     DZ_CHECK_ARG(feats && coords_bzyx && d_num_voxels && ws, "dz_voxelize_dynamic_mean: null pointer");
     VoxGeom g;
-    DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, g), "dz_voxelize_dynamic_mean: bad geometry");
+    DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_dynamic_mean: bad geometry");
     const size_t cells = (size_t)batch * g.g[0] * g.g[1] * g.g[2];
     // the reference's int32 merge key overflows for b >= 24 on the Waymo grid (vfe.py:128-131); we refuse instead
     if (cells >= 0x7FFFFFFFull) { set_error("dz_voxelize_dynamic_mean: batch*grid exceeds int32 merge keys"); return DZ_ERR_UNSUPPORTED; }

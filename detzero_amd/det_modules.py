@@ -1,0 +1,681 @@
+"""CenterPoint modules under the reference's registry names, backed by libdetzero_hip.
+
+Mirror of /root/reference/detection/detzero_det/models/centerpoint_modules/ (``__init__.py:8-17``):
+same class names, constructor kwargs, ``forward(batch_dict) -> batch_dict`` contract, batch_dict
+keys and ``state_dict()`` layout, so checkpoints of the reference load unchanged.
+Underneath there is no spconv / cuDNN / torch_scatter: every module drives the HIP kernels through
+``detzero_amd.ops``.  Inference only (the reference's training path - autograd through spconv,
+target assignment, losses - is out of scope).
+
+Internal data layout (differs from the reference on purpose):
+  * sparse features: rows sorted by linear voxel key, 16-channel padded input;
+  * dense activations: channel-last, zero-bordered images kept under private ``_nhwc_*`` keys of the
+    batch_dict; the NCHW tensors the reference's keys promise are zero-copy permuted views.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import DetZeroHipError
+
+K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+
+
+def _inference_only(module):
+    if module.training:
+        raise DetZeroHipError('%s: only the inference path is implemented on the HIP backend '
+                              '(call .eval()); training is out of scope' % type(module).__name__)
+
+
+def fold_bn(bn, conv_bias=None):
+    """Eval-mode BatchNorm (+ preceding conv bias) as y = x*scale + shift, computed in fp64."""
+    w = bn.weight.detach().double()
+    b = bn.bias.detach().double()
+    mean = bn.running_mean.detach().double()
+    var = bn.running_var.detach().double()
+    scale = w / torch.sqrt(var + bn.eps)
+    shift = b - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class _Cached(nn.Module):
+    """Modules that cache kernel-layout parameters; the cache is dropped when weights change."""
+
+    def __init__(self):
+        super().__init__()
+        self._plan = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    def invalidate(self):
+        self._plan = None
+
+    def _apply(self, fn, *a, **kw):
+        self._plan = None
+        return super()._apply(fn, *a, **kw)
+
+
+# ================================================================================================
+# sparse containers / parameter holders (names and weight layouts of spconv.pytorch 2.x)
+# ================================================================================================
+class SparseConvTensor:
+    """What the reference reads from spconv's tensor: features, indices, spatial_shape, batch_size,
+    dense() (pdv_head.py:567-637, height_compression.py:21)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, level=None, padded=None):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = batch_size
+        self._level = level
+        self._padded = padded      # (capacity-sized feature matrix, SparseLevel) for the fast path
+
+    def replace_feature(self, new_features):
+        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._level)
+
+    def dense(self):
+        """(B, C, D, H, W) like spconv's .dense()."""
+        c = self.features.shape[1]
+        d, h, w = self.spatial_shape
+        bev = ops.sparse_to_bev(self.features, self._level, c, pad=0)          # (B,H,W,C*D)
+        return bev.view(self.batch_size, h, w, c, d).permute(0, 3, 4, 1, 2)
+
+
+class _SparseConvBase(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None,
+                 subm=False):
+        super().__init__()
+        k = (kernel_size,) * 3 if isinstance(kernel_size, int) else tuple(kernel_size)
+        s = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        p = (padding,) * 3 if isinstance(padding, int) else tuple(padding)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, s, p
+        self.indice_key, self.subm = indice_key, subm
+        # spconv 2.x implicit-GEMM layout: (Cout, kD, kH, kW, Cin)
+        self.weight = nn.Parameter(torch.empty(out_channels, *k, in_channels))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter('bias', None)
+
+    def taps(self, cin_pad=None):
+        """(kvol, Cin[padded], Cout) fp32 contiguous."""
+        co, kd, kh, kw, ci = self.weight.shape
+        w = self.weight.detach().permute(1, 2, 3, 4, 0).reshape(kd * kh * kw, ci, co)
+        if cin_pad is not None and cin_pad > ci:
+            w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - ci, co)], dim=1)
+        return w.float().contiguous()
+
+
+class SubMConv3d(_SparseConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+        # SubMConv3d ignores stride/padding: always "same"
+        super().__init__(in_channels, out_channels, kernel_size, 1, 1, bias, indice_key, subm=True)
+
+
+class SparseConv3d(_SparseConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, indice_key, subm=False)
+
+
+class SparseSequential(nn.Sequential):
+    pass
+
+
+class SparseBasicBlock(nn.Module):
+    """backbone3d.py:85-121."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        self.conv1 = SubMConv3d(inplanes, planes, 3, stride=stride, padding=1, bias=True, indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = SubMConv3d(planes, planes, 3, stride=stride, padding=1, bias=True, indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm',
+                   norm_fn=None):
+    """backbone3d.py:64-83."""
+    if conv_type == 'subm':
+        conv = SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                            indice_key=indice_key)
+    else:
+        raise NotImplementedError(conv_type)
+    return SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+# ================================================================================================
+# VFE
+# ================================================================================================
+class MeanVFE(nn.Module):
+    """vfe.py:58-83."""
+
+    def __init__(self, model_cfg, num_point_features, **kwargs):
+        super().__init__()
+        self.num_point_features = num_point_features
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def forward(self, batch_dict, **kwargs):
+        voxels, num_points = batch_dict['voxels'], batch_dict['voxel_num_points']
+        batch_dict['voxel_features'] = ops.mean_vfe(voxels.float().contiguous(), num_points.int().contiguous())
+        return batch_dict
+
+
+class DynamicMeanVFE(nn.Module):
+    """vfe.py:86-147: voxelization on the device from ``batch_dict['points']`` (N,1+C)."""
+
+    def __init__(self, model_cfg, num_point_features, voxel_size, grid_size, point_cloud_range, **kwargs):
+        super().__init__()
+        self.num_point_features = num_point_features
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.grid_size = [int(g) for g in grid_size]
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    @torch.no_grad()
+    def forward(self, batch_dict, **kwargs):
+        points = batch_dict['points'].float().contiguous()
+        feats, coords = ops.voxelize_dynamic(points, self.point_cloud_range, self.voxel_size,
+                                             batch_dict['batch_size'])
+        batch_dict['voxel_features'] = feats
+        batch_dict['voxel_coords'] = coords
+        return batch_dict
+
+
+# ================================================================================================
+# sparse 3-D backbone
+# ================================================================================================
+class VoxelResBackBone8x(_Cached):
+    """backbone3d.py:231-338.  21 sparse convolutions executed as fused
+    gather -> MFMA -> (BN, bias, residual, ReLU) kernels on a bitmap-indexed sparse tensor."""
+
+    CIN_PAD = 16
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        channels = list(model_cfg.get('CHANNELS', [16, 32, 64, 128])) if hasattr(model_cfg, 'get') else [16, 32, 64, 128]
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        grid_size = [int(g) for g in grid_size]
+        self.sparse_shape = [grid_size[2] + 1, grid_size[1], grid_size[0]]
+        self.input_channels = input_channels
+
+        self.conv_input = SparseSequential(
+            SubMConv3d(input_channels, channels[0], 3, padding=1, bias=False, indice_key='subm1'),
+            norm_fn(channels[0]), nn.ReLU())
+        block = post_act_block
+        self.conv1 = SparseSequential(
+            SparseBasicBlock(channels[0], channels[0], norm_fn=norm_fn, indice_key='res1'),
+            SparseBasicBlock(channels[0], channels[0], norm_fn=norm_fn, indice_key='res1'))
+        self.conv2 = SparseSequential(
+            block(channels[0], channels[1], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+            SparseBasicBlock(channels[1], channels[1], norm_fn=norm_fn, indice_key='res2'),
+            SparseBasicBlock(channels[1], channels[1], norm_fn=norm_fn, indice_key='res2'))
+        self.conv3 = SparseSequential(
+            block(channels[1], channels[2], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+            SparseBasicBlock(channels[2], channels[2], norm_fn=norm_fn, indice_key='res3'),
+            SparseBasicBlock(channels[2], channels[2], norm_fn=norm_fn, indice_key='res3'))
+        self.conv4 = SparseSequential(
+            block(channels[2], channels[3], 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
+            SparseBasicBlock(channels[3], channels[3], norm_fn=norm_fn, indice_key='res4'),
+            SparseBasicBlock(channels[3], channels[3], norm_fn=norm_fn, indice_key='res4'))
+        last_pad = model_cfg.get('last_pad', 0) if hasattr(model_cfg, 'get') else 0
+        self.conv_out = SparseSequential(
+            SparseConv3d(channels[3], channels[3], (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                         indice_key='spconv_down2'),
+            norm_fn(channels[3]), nn.ReLU())
+        self.num_point_features = channels[3]
+        self.backbone_channels = {'x_conv1': channels[0], 'x_conv2': channels[1], 'x_conv3': channels[2],
+                                  'x_conv4': channels[3]}
+        self.channels = channels
+
+    # ---- kernel-layout parameters -------------------------------------------------------------
+    def plan(self):
+        if self._plan is not None:
+            return self._plan
+
+        def conv_bn(conv, bn, cin_pad=None):
+            scale, shift = fold_bn(bn, conv.bias)
+            return {'w': conv.taps(cin_pad), 'scale': scale, 'shift': shift, 'k': conv.kernel_size,
+                    's': conv.stride, 'p': conv.padding}
+
+        def blk(b):
+            return (conv_bn(b.conv1, b.bn1), conv_bn(b.conv2, b.bn2))
+
+        p = {'conv_input': conv_bn(self.conv_input[0], self.conv_input[1], self.CIN_PAD)}
+        p['conv1'] = [blk(self.conv1[0]), blk(self.conv1[1])]
+        for name in ('conv2', 'conv3', 'conv4'):
+            seq = getattr(self, name)
+            p[name] = {'down': conv_bn(seq[0][0], seq[0][1]), 'blocks': [blk(seq[1]), blk(seq[2])]}
+        p['conv_out'] = conv_bn(self.conv_out[0], self.conv_out[1])
+        self._plan = p
+        return p
+
+    # ---- execution ------------------------------------------------------------------------------
+    @staticmethod
+    def _res_block(x, nbr, level, params):
+        c1, c2 = params
+        y = ops.spconv_forward(x, nbr, level, c1['w'], c1['scale'], c1['shift'], None, True)
+        return ops.spconv_forward(y, nbr, level, c2['w'], c2['scale'], c2['shift'], x, True)
+
+    def run(self, voxel_features, voxel_coords, batch_size, d_n=None):
+        """Capacity-sized execution without host syncs.  Returns dict of (features, SparseLevel)."""
+        p = self.plan()
+        n = voxel_features.shape[0]
+        dev = voxel_features.device
+        lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
+        rank = lvl1.build_from_coords(voxel_coords, d_n)
+        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n)
+        nbr = lvl1.neighbors_to(lvl1, K3, S1, P1)
+        ci = p['conv_input']
+        x = ops.spconv_forward(x, nbr, lvl1, ci['w'], ci['scale'], ci['shift'], None, True)
+        for bp in p['conv1']:
+            x = self._res_block(x, nbr, lvl1, bp)
+        out = {'x_conv1': (x, lvl1)}
+        level = lvl1
+        for i, name in enumerate(('conv2', 'conv3', 'conv4')):
+            dp = p[name]['down']
+            nxt = level.downsample(dp['k'], dp['s'], dp['p'])
+            nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
+            x = ops.spconv_forward(x, nbr_d, nxt, dp['w'], dp['scale'], dp['shift'], None, True, in_level=level)
+            nbr = nxt.neighbors_to(nxt, K3, S1, P1)
+            for bp in p[name]['blocks']:
+                x = self._res_block(x, nbr, nxt, bp)
+            out['x_conv%d' % (i + 2)] = (x, nxt)
+            level = nxt
+        dp = p['conv_out']
+        nxt = level.downsample(dp['k'], dp['s'], dp['p'])
+        nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
+        x = ops.spconv_forward(x, nbr_d, nxt, dp['w'], dp['scale'], dp['shift'], None, True, in_level=level)
+        out['encoded'] = (x, nxt)
+        return out
+
+    def forward(self, batch_dict):
+        _inference_only(self)
+        vf = batch_dict['voxel_features'].float().contiguous()
+        vc = batch_dict['voxel_coords'].int().contiguous()
+        batch_size = batch_dict['batch_size']
+        with torch.no_grad():
+            res = self.run(vf, vc, batch_size)
+
+        def as_tensor(item):
+            feats, level = item
+            m = level.num_active()
+            return SparseConvTensor(feats[:m], level.coords[:m], level.shape, batch_size, level=level,
+                                    padded=(feats, level))
+        batch_dict.update({'encoded_spconv_tensor': as_tensor(res['encoded']), 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {k: as_tensor(res[k]) for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4')}})
+        batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
+        return batch_dict
+
+
+# ================================================================================================
+# map to BEV
+# ================================================================================================
+class HeightCompression(nn.Module):
+    """height_compression.py:4-26."""
+
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_bev_features = self.model_cfg.NUM_BEV_FEATURES
+
+    def forward(self, batch_dict):
+        t = batch_dict['encoded_spconv_tensor']
+        feats, level = t._padded if t._padded is not None else (t.features, t._level)
+        c = feats.shape[1]
+        bev = ops.sparse_to_bev(feats, level, c, pad=1)                 # (B, H+2, W+2, C*D)
+        batch_dict['_nhwc_spatial_features'] = bev
+        batch_dict['spatial_features'] = bev[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)   # NCHW view
+        batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
+        return batch_dict
+
+
+# ================================================================================================
+# dense BEV backbone
+# ================================================================================================
+def _conv_weight_taps(weight, cout_pad=None):
+    """torch Conv2d weight (Cout,Cin,kh,kw) -> (kh*kw, Cin, Cout_pad)."""
+    co, ci, kh, kw = weight.shape
+    w = weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, ci, co).float()
+    if cout_pad is not None and cout_pad > co:
+        w = torch.cat([w, w.new_zeros(kh * kw, ci, cout_pad - co)], dim=2)
+    return w.contiguous()
+
+
+def _pad_vec(v, n, fill=0.0):
+    if v.numel() == n:
+        return v.contiguous()
+    out = v.new_full((n,), fill)
+    out[:v.numel()] = v
+    return out
+
+
+def nchw_to_padded_nhwc(x, pad=1):
+    b, c, h, w = x.shape
+    out = x.new_zeros((b, h + 2 * pad, w + 2 * pad, c))
+    out[:, pad:pad + h, pad:pad + w, :] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_cstride, in_coff=0, ksize=3,
+               stride=1, in_off=0, out_cstride, out_coff=0, out_s=1, out_d=(0, 0), groups=1, cout_pad=None,
+               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1):
+    """One dz_conv2d_forward call.  in_shape/out_shape = (Hp, Wp) of the (padded) images."""
+    cout_pad = w.shape[-1] if cout_pad is None else cout_pad
+    ops.conv2d(dict(
+        inp=inp.data_ptr(), out=out.data_ptr(), w=w.data_ptr(),
+        scale=scale.data_ptr() if scale is not None else None,
+        shift=shift.data_ptr() if shift is not None else None,
+        batch=batch, ho=ho, wo=wo, in_hp=in_shape[0], in_wp=in_shape[1], in_cstride=in_cstride, in_coff=in_coff,
+        cin=cin, kh=ksize, kw=ksize, stride=stride, in_off=in_off,
+        out_hp=out_shape[0], out_wp=out_shape[1], out_cstride=out_cstride, out_coff=out_coff,
+        out_sy=out_s, out_sx=out_s, out_dy=out_d[0], out_dx=out_d[1],
+        groups=groups, cout_pad=cout_pad,
+        g_cout=g_cout if g_cout is not None else [cout_pad], g_ooff=g_ooff if g_ooff is not None else [0],
+        relu=1 if relu else 0))
+
+
+class BaseBEVBackbone(_Cached):
+    """backbone2d.py:6-120 for the layouts used by every DetZero config: per level
+    ZeroPad+Conv3x3(stride s)+BN+ReLU, n x [Conv3x3+BN+ReLU], and a ConvTranspose2d(k=s) deblock."""
+
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        layer_nums = list(model_cfg.LAYER_NUMS)
+        layer_strides = list(model_cfg.LAYER_STRIDES)
+        num_filters = list(model_cfg.NUM_FILTERS)
+        upsample_strides = list(model_cfg.UPSAMPLE_STRIDES)
+        num_upsample_filters = list(model_cfg.NUM_UPSAMPLE_FILTERS)
+        assert len(layer_nums) == len(layer_strides) == len(num_filters) == len(upsample_strides)
+        c_in_list = [input_channels, *num_filters[:-1]]
+        self.blocks = nn.ModuleList()
+        self.deblocks = nn.ModuleList()
+        for idx in range(len(layer_nums)):
+            cur = [nn.ZeroPad2d(1),
+                   nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0, bias=False),
+                   nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()]
+            for _ in range(layer_nums[idx]):
+                cur.extend([nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
+                            nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()])
+            self.blocks.append(nn.Sequential(*cur))
+            s = upsample_strides[idx]
+            if not (isinstance(s, int) and s >= 1):
+                raise DetZeroHipError('BaseBEVBackbone: only integer UPSAMPLE_STRIDES >= 1 are supported')
+            self.deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], s, stride=s, bias=False),
+                nn.BatchNorm2d(num_upsample_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()))
+        self.num_bev_features = sum(num_upsample_filters)
+        self.layer_strides, self.upsample_strides = layer_strides, upsample_strides
+        self.num_filters, self.num_upsample_filters = num_filters, num_upsample_filters
+        self.input_channels = input_channels
+
+    def plan(self):
+        if self._plan is not None:
+            return self._plan
+        levels = []
+        for idx, blk in enumerate(self.blocks):
+            convs = []
+            mods = list(blk)
+            i = 1
+            while i < len(mods):
+                conv, bn = mods[i], mods[i + 1]
+                scale, shift = fold_bn(bn, conv.bias)
+                convs.append({'w': _conv_weight_taps(conv.weight), 'scale': scale, 'shift': shift,
+                              'stride': conv.stride[0], 'cin': conv.in_channels, 'cout': conv.out_channels})
+                i += 3
+            de, dbn = self.deblocks[idx][0], self.deblocks[idx][1]
+            scale, shift = fold_bn(dbn, de.bias)
+            s = de.stride[0]
+            wt = de.weight.detach().float()                            # (Cin, Cout, s, s)
+            phases = [[wt[:, :, dy, dx].contiguous().unsqueeze(0).contiguous() for dx in range(s)] for dy in range(s)]
+            levels.append({'convs': convs, 'de': {'phases': phases, 'scale': scale, 'shift': shift, 's': s,
+                                                  'cin': de.in_channels, 'cout': de.out_channels}})
+        self._plan = levels
+        return levels
+
+    def run(self, bev, batch):
+        """bev (B, H+2, W+2, Cin) zero-bordered channel-last -> concat (B, H+2, W+2, sum(upsample)) zero-bordered."""
+        plan = self.plan()
+        dev = bev.device
+        h, w = bev.shape[1] - 2, bev.shape[2] - 2
+        ctot = self.num_bev_features
+        concat = torch.zeros((batch, h + 2, w + 2, ctot), dtype=torch.float32, device=dev)
+        x, xh, xw, xc = bev, h, w, bev.shape[3]
+        coff = 0
+        total_stride = 1
+        for lvl in plan:
+            bufs = None
+            for ci, cv in enumerate(lvl['convs']):
+                s = cv['stride']
+                oh, ow = (xh + 2 - 3) // s + 1, (xw + 2 - 3) // s + 1
+                if bufs is None or ci == 0:
+                    bufs = [torch.zeros((batch, oh + 2, ow + 2, cv['cout']), dtype=torch.float32, device=dev)
+                            for _ in range(2)]
+                y = bufs[ci % 2]
+                conv_layer(x, (xh + 2, xw + 2), cv['w'], cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                           cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
+                           out_d=(1, 1), ho=oh, wo=ow, batch=batch)
+                x, xh, xw, xc = y, oh, ow, cv['cout']
+                if ci == 0:
+                    total_stride *= s
+            de = lvl['de']
+            s = de['s']
+            if xh * s != h or xw * s != w:
+                raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
+            for dy in range(s):
+                for dx in range(s):
+                    conv_layer(x, (xh + 2, xw + 2), de['phases'][dy][dx], de['scale'], de['shift'], True, concat,
+                               (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
+                               out_cstride=ctot, out_coff=coff, out_s=s, out_d=(dy + 1, dx + 1), ho=xh, wo=xw,
+                               batch=batch)
+            coff += de['cout']
+        return concat
+
+    def forward(self, data_dict):
+        _inference_only(self)
+        with torch.no_grad():
+            bev = data_dict.get('_nhwc_spatial_features', None)
+            if bev is None:
+                bev = nchw_to_padded_nhwc(data_dict['spatial_features'].float())
+            concat = self.run(bev, bev.shape[0])
+        data_dict['_nhwc_spatial_features_2d'] = concat
+        data_dict['spatial_features_2d'] = concat[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
+        return data_dict
+
+
+# ================================================================================================
+# CenterHead
+# ================================================================================================
+class SeparateHead(nn.Module):
+    """center_head.py:14-48 (parameter holder; executed batched by CenterHead)."""
+
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name in self.sep_head_dict:
+            output_channels = self.sep_head_dict[cur_name]['out_channels']
+            num_conv = self.sep_head_dict[cur_name]['num_conv']
+            fc_list = []
+            for _ in range(num_conv - 1):
+                fc_list.append(nn.Sequential(
+                    nn.Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                    nn.BatchNorm2d(input_channels), nn.ReLU()))
+            fc_list.append(nn.Conv2d(input_channels, output_channels, kernel_size=3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*fc_list)
+            if 'hm' in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.kaiming_normal_(m.weight.data)
+                        if m.bias is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(cur_name, fc)
+
+
+class CenterHead(_Cached):
+    """center_head.py:51-488, inference path: shared conv, six branches (batched into one 64->384
+    conv and one grouped 384->12 conv), decode + rotated NMS on the device.
+    ``gt_boxes`` is not needed (the reference runs its CPU target assignment even in eval, :448)."""
+
+    COLS = {'center': (0, 2), 'center_z': (2, 1), 'dim': (3, 3), 'rot': (6, 2), 'iou': (8, 1), 'hm': (9, 3)}
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 tta=False, predict_boxes_when_training=True):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.TTA = tta
+        self.iou_weight = self.model_cfg.get('IOU_WEIGHT', 0)
+        self.feature_map_stride = self.model_cfg.TARGET_ASSIGNER_CONFIG.get('FEATURE_MAP_STRIDE', None)
+        self.class_names = class_names
+        self.class_names_each_head = []
+        self.class_id_mapping_each_head = []
+        for cur_class_names in self.model_cfg.CLASS_NAMES_EACH_HEAD:
+            self.class_names_each_head.append([x for x in cur_class_names if x in class_names])
+            self.class_id_mapping_each_head.append(
+                torch.from_numpy(np.array([self.class_names.index(x) for x in cur_class_names if x in class_names])))
+        total_classes = sum(len(x) for x in self.class_names_each_head)
+        assert total_classes == len(self.class_names), f'class_names_each_head={self.class_names_each_head}'
+        if len(self.class_names_each_head) != 1:
+            raise DetZeroHipError('CenterHead: the HIP backend implements the single-head layout of the DetZero configs')
+        use_bias = self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(input_channels, self.model_cfg.SHARED_CONV_CHANNEL, 3, stride=1, padding=1, bias=use_bias),
+            nn.BatchNorm2d(self.model_cfg.SHARED_CONV_CHANNEL), nn.ReLU())
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = self.model_cfg.SEPARATE_HEAD_CFG
+        for cur_class_names in self.class_names_each_head:
+            cur_head_dict = {k: dict(v) for k, v in self.separate_head_cfg.HEAD_DICT.items()}
+            cur_head_dict['hm'] = dict(out_channels=len(cur_class_names), num_conv=self.model_cfg.NUM_HM_CONV)
+            self.heads_list.append(SeparateHead(self.model_cfg.SHARED_CONV_CHANNEL, cur_head_dict, init_bias=-2.19,
+                                                use_bias=use_bias))
+        self.head_names = list(self.heads_list[0].sep_head_dict.keys())
+        for name in self.head_names:
+            cfgd = self.heads_list[0].sep_head_dict[name]
+            if name not in self.COLS or cfgd['num_conv'] != 2 or cfgd['out_channels'] != self.COLS[name][1]:
+                raise DetZeroHipError('CenterHead: unsupported branch %s %s' % (name, dict(cfgd)))
+        if sorted(self.head_names) != sorted(self.COLS):
+            raise DetZeroHipError('CenterHead: branches must be %s (got %s)' % (sorted(self.COLS), self.head_names))
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.forward_ret_dict = {}
+        self.input_channels = input_channels
+
+    def plan(self):
+        if self._plan is not None:
+            return self._plan
+        sc, sbn = self.shared_conv[0], self.shared_conv[1]
+        s_scale, s_shift = fold_bn(sbn, sc.bias)
+        c = self.model_cfg.SHARED_CONV_CHANNEL
+        order = ['center', 'center_z', 'dim', 'rot', 'iou', 'hm']      # fixed column layout of the decode kernel
+        head = self.heads_list[0]
+        w1, sc1, sh1, w2, b2 = [], [], [], [], []
+        for name in order:
+            fc = getattr(head, name)
+            conv1, bn1, conv2 = fc[0][0], fc[0][1], fc[1]
+            a, b = fold_bn(bn1, conv1.bias)
+            w1.append(_conv_weight_taps(conv1.weight)); sc1.append(a); sh1.append(b)
+            w2.append(_conv_weight_taps(conv2.weight, 16))
+            b2.append(_pad_vec(conv2.bias.detach().float(), 16))
+        self._plan = {
+            'shared': {'w': _conv_weight_taps(sc.weight), 'scale': s_scale, 'shift': s_shift, 'cin': sc.in_channels},
+            'hidden': {'w': torch.cat(w1, dim=2).contiguous(), 'scale': torch.cat(sc1).contiguous(),
+                       'shift': torch.cat(sh1).contiguous()},
+            'final': {'w': torch.stack(w2, dim=0).contiguous(),          # (6, 9, 64, 16)
+                      'shift': torch.cat(b2).contiguous(),
+                      'g_cout': [self.COLS[n][1] for n in order], 'g_ooff': [self.COLS[n][0] for n in order]},
+            'c': c, 'order': order,
+        }
+        return self._plan
+
+    def run_convs(self, concat, batch):
+        """concat (B,H+2,W+2,Cin) zero-bordered -> head map (B, H*W, 12) channel-last."""
+        p = self.plan()
+        dev = concat.device
+        hp, wp = concat.shape[1], concat.shape[2]
+        h, w = hp - 2, wp - 2
+        c = p['c']
+        shared = torch.zeros((batch, hp, wp, c), dtype=torch.float32, device=dev)
+        conv_layer(concat, (hp, wp), p['shared']['w'], p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
+                   cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=h, wo=w, batch=batch)
+        hidden = torch.zeros((batch, hp, wp, 6 * c), dtype=torch.float32, device=dev)
+        conv_layer(shared, (hp, wp), p['hidden']['w'], p['hidden']['scale'], p['hidden']['shift'], True, hidden, (hp, wp),
+                   cin=c, in_cstride=c, out_cstride=6 * c, out_d=(1, 1), ho=h, wo=w, batch=batch)
+        head = torch.empty((batch, h * w, 12), dtype=torch.float32, device=dev)
+        conv_layer(hidden, (hp, wp), p['final']['w'], None, p['final']['shift'], False, head, (h, w), cin=c,
+                   in_cstride=6 * c, out_cstride=12, out_d=(0, 0), groups=6, cout_pad=16, g_cout=p['final']['g_cout'],
+                   g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch)
+        return head, h, w
+
+    def decode_nosync(self, head, h, w):
+        post = self.model_cfg.POST_PROCESSING
+        nms = post.NMS_CONFIG
+        if nms.NMS_TYPE != 'nms_gpu':
+            raise DetZeroHipError('CenterHead: NMS_TYPE %s not supported (nms_gpu only)' % nms.NMS_TYPE)
+        k = post.MAX_OBJ_PER_SAMPLE
+        boxes, scores, labels, counts = ops.centerhead_decode(
+            head, h, w, len(self.class_names_each_head[0]), k, post.SCORE_THRESH, post.POST_CENTER_LIMIT_RANGE,
+            self.point_cloud_range, self.voxel_size, self.feature_map_stride, use_iou=self.iou_weight > 0)
+        outs = []
+        for b in range(head.shape[0]):
+            # candidates are already in descending score order and K <= NMS_PRE_MAXSIZE, so the
+            # reference's topk(pre_max) + sort (model_nms_utils.py:15-20) is the identity here
+            if k > nms.NMS_PRE_MAXSIZE:
+                raise DetZeroHipError('MAX_OBJ_PER_SAMPLE > NMS_PRE_MAXSIZE is not supported')
+            keep, d_nk = ops.nms_rotated_nosync(boxes[b], counts[b:b + 1], nms.NMS_THRESH, nms.NMS_POST_MAXSIZE)
+            outs.append((boxes[b], scores[b], labels[b], keep, d_nk))
+        return outs
+
+    def generate_predicted_boxes(self, head, h, w):
+        mapping = self.class_id_mapping_each_head[0].to(head.device)
+        ret = []
+        for boxes, scores, labels, keep, d_nk in self.decode_nosync(head, h, w):
+            nk = int(d_nk.item())
+            sel = keep[:nk].long()
+            ret.append({'pred_boxes': boxes[sel], 'pred_scores': scores[sel],
+                        'pred_labels': mapping[labels[sel].long()] + 1})
+        return ret
+
+    def forward(self, data_dict):
+        _inference_only(self)
+        with torch.no_grad():
+            concat = data_dict.get('_nhwc_spatial_features_2d', None)
+            if concat is None:
+                concat = nchw_to_padded_nhwc(data_dict['spatial_features_2d'].float())
+            head, h, w = self.run_convs(concat, concat.shape[0])
+            pred = {n: head.view(head.shape[0], h, w, 12)[..., o:o + c].permute(0, 3, 1, 2)
+                    for n, (o, c) in self.COLS.items()}
+            self.forward_ret_dict['pred_dicts'] = [pred]
+            data_dict['final_box_dicts'] = self.generate_predicted_boxes(head, h, w)
+        return data_dict
+
+
+__all__ = {
+    'MeanVFE': MeanVFE,
+    'DynamicMeanVFE': DynamicMeanVFE,
+    'VoxelResBackBone8x': VoxelResBackBone8x,
+    'HeightCompression': HeightCompression,
+    'BaseBEVBackbone': BaseBEVBackbone,
+    'CenterHead': CenterHead,
+}

@@ -14,7 +14,10 @@ import numpy as np
 
 POINT_CLOUD_RANGE = np.array([-75.2, -75.2, -2.0, 75.2, 75.2, 4.0], dtype=np.float32)
 VOXEL_SIZE_01 = [0.1, 0.1, 0.15]      # BASELINE.json configs[1]  -> grid 1504 x 1504 x 40
-VOXEL_SIZE_02 = [0.2, 0.2, 0.3]       # BASELINE.json configs[0]  -> grid  752 x  752 x 20
+# BASELINE.json configs[0] (20k points, 0.2 m voxels).  z stays 0.15 m: with the 0.3 m of BASELINE.md's
+# sketch the grid is 20 cells high, stage 4 of VoxelResBackBone8x is 2 cells high and its (3,1,1) conv_out
+# has no output at all - the reference network needs >= 33 z cells.  -> grid 752 x 752 x 40
+VOXEL_SIZE_02 = [0.2, 0.2, 0.15]
 
 
 def synth_waymo_frame(seed, n_points=160_000, n_beams=64, n_objects=40):

@@ -44,10 +44,13 @@ int dz_device_cu_count(void);
  *   points (n,c) f32; h_range6 = [x0,y0,z0,x1,y1,z1]; h_vsize3; h_grid3 = (gx,gy,gz)
  *   voxels (max_voxels,max_points,c) f32 zero padded; coords_zyx (max_voxels,3) i32;
  *   num_points (max_voxels) i32; d_num_voxels: device i32, number of voxels produced.
- * Voxel order = first appearance in the input, points per voxel = first max_points in input order. */
+ * Voxel order = first appearance in the input, points per voxel = first max_points in input order.
+ * xy_range_mask != 0 additionally applies DataProcessor.mask_points_and_boxes_outside_range
+ * (data_processor.py:24-37: keep lo <= x,y <= hi, inclusive) so device-resident frames need no
+ * separate compaction pass. */
 size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_points);
 int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
-                     const int *h_grid3, int max_points, int max_voxels, float *voxels,
+                     const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels,
                      int *coords_zyx, int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes,
                      void *stream);
 
@@ -62,7 +65,7 @@ int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int 
  *   ascending merge-key order (key = b*gx*gy*gz + cx*gy*gz + cy*gz + cz). */
 size_t dz_voxelize_dynamic_workspace_bytes(int n, int batch, int gx, int gy, int gz, int c, int cap);
 int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h_range6,
-                             const float *h_vsize3, const int *h_grid3, int batch, float *feats,
+                             const float *h_vsize3, const int *h_grid3, int xy_range_mask, int batch, float *feats,
                              int *coords_bzyx, int *d_num_voxels, int cap, void *ws, size_t ws_bytes,
                              void *stream);
 
@@ -137,6 +140,9 @@ typedef struct dz_conv2d_desc {
     int relu;
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
+/* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
+const char *dz_conv2d_variant(const dz_conv2d_desc *h_desc);
+const char *dz_spconv_variant(int cin, int cout);
 
 /* ---------------------------------------------------------------------------------------------
  * CenterHead decode + NMS (center_head.py:315-368, centernet_utils.py:138-230,

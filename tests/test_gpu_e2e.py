@@ -1,0 +1,174 @@
+"""GPU (MI355X): module-level and end-to-end parity of the detector against the CPU oracle with the
+same seeded weights, plus size-independent properties at BASELINE.json's full frame size."""
+import numpy as np
+import pytest
+import torch
+
+from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_01, VOXEL_SIZE_02
+from tests.util import POST, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def small(device):
+    """BASELINE configs[0]: 20k-point frame, 0.2 m voxels, full CenterPoint-1stage network."""
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
+    sd = cpu_state_dict(model)
+    pts = masked_frame(0, 20000)
+    ref = oracle_detect(sd, pts, info)
+    return model.to(device), cfg, info, pts, ref
+
+
+def _batch_dict(model, cfg, info, pts, device):
+    from detzero_amd.data_processor import DataProcessor
+    dp = DataProcessor(cfg.DATA_CONFIG.DATA_PROCESSOR, info.point_cloud_range, training=False, num_point_features=5)
+    d = dp.forward({'points': torch.from_numpy(pts).to(device), 'use_lead_xyz': True})
+    coords = torch.cat([d['voxel_coords'].new_zeros((d['voxel_coords'].shape[0], 1)), d['voxel_coords']], 1)
+    return {'voxels': d['voxels'], 'voxel_coords': coords.float(), 'voxel_num_points': d['voxel_num_points'].float(),
+            'batch_size': 1}
+
+
+def test_modules_match_oracle_stage_by_stage(small, device):
+    model, cfg, info, pts, ref = small
+    bd = _batch_dict(model, cfg, info, pts, device)
+    # data processor (hard voxelizer): bit-exact
+    assert np.array_equal(bd['voxels'].cpu().numpy(), ref['voxels'])
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy().astype(np.int32), ref['coords'])
+    bd = model.vfe(bd)
+    np.testing.assert_allclose(bd['voxel_features'].cpu().numpy(), ref['feats'], rtol=0, atol=1e-6)
+    bd = model.backbone3d(bd)
+    for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
+        t = bd['multi_scale_3d_features'][name]
+        rf, rc, rs = ref['backbone'][name]
+        assert t.spatial_shape == list(rs)
+        assert np.array_equal(t.indices.cpu().numpy(), rc), name                        # active sets: bit-exact
+        torch.testing.assert_close(t.features.cpu(), rf, rtol=1e-3, atol=1e-3)
+    t = bd['encoded_spconv_tensor']
+    rf, rc, rs = ref['backbone']['encoded']
+    assert np.array_equal(t.indices.cpu().numpy(), rc)
+    torch.testing.assert_close(t.features.cpu(), rf, rtol=1e-3, atol=1e-3)
+    dense = t.dense()
+    assert tuple(dense.shape) == (1, 128, rs[0], rs[1], rs[2])
+    bd = model.map_to_bev(bd)
+    torch.testing.assert_close(bd['spatial_features'].cpu(), ref['bev'], rtol=1e-3, atol=1e-3)
+    assert torch.equal(dense.reshape(1, -1, rs[1], rs[2]).cpu(), bd['spatial_features'].cpu())
+    bd = model.backbone2d(bd)
+    torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=2e-3, atol=2e-3)
+    bd = model.dense_head(bd)
+    pred = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for k, v in ref['pred'].items():
+        torch.testing.assert_close(pred[k].cpu(), v, rtol=2e-3, atol=2e-3)
+
+
+def test_end_to_end_boxes_within_1e3(small, device):
+    """north_star: boxes within 1e-3 of the reference-semantics path on identical weights/inputs."""
+    model, cfg, info, pts, ref = small
+    bd = _batch_dict(model, cfg, info, pts, device)
+    pred_dicts, recall = model(bd)
+    rb = ref['final'][0]
+    got = pred_dicts[0]
+    n_ref = rb['pred_boxes'].shape[0]
+    assert n_ref > 20
+    nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), got['pred_boxes'].cpu().numpy(),
+                            got['pred_scores'].cpu().numpy(), tol=1e-3)
+    # a candidate sitting exactly on the score threshold / NMS threshold may flip; everything else must match
+    assert abs(got['pred_boxes'].shape[0] - n_ref) <= 2, (got['pred_boxes'].shape[0], n_ref)
+    assert nm >= n_ref - 2, (nm, n_ref, worst)
+    assert set(got['pred_labels'].cpu().tolist()) <= {1, 2, 3}
+
+
+def test_frame_pipeline_equals_module_path(small, device):
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, pts, ref = small
+    bd = _batch_dict(model, cfg, info, pts, device)
+    pred_dicts, _ = model(bd)
+    pipe = FramePipeline(model, info)
+    out, d_n = pipe(torch.from_numpy(pts).to(device))
+    n = int(d_n.item())
+    got = pred_dicts[0]
+    assert n == got['pred_boxes'].shape[0]
+    assert torch.equal(out[:n, :7], got['pred_boxes']) and torch.equal(out[:n, 7], got['pred_scores'])
+    assert torch.equal(out[:n, 8].long(), got['pred_labels'])
+    out2, d_n2 = pipe(torch.from_numpy(pts).to(device))            # idempotent
+    assert int(d_n2.item()) == n and torch.equal(out2[:n], out[:n])
+
+
+def test_full_size_frame_properties(device):
+    """BASELINE configs[1]: 160k points, 0.1 m voxels, full network.  The oracle needs minutes at this
+    size, so check size-independent properties and cross-check the cheap stages exactly."""
+    from detzero_amd import ops
+    from detzero_amd.centerpoint import FramePipeline
+    from oracle import sparse as osp
+    from oracle import voxelize as ov
+    model, cfg, info = make_model(VOXEL_SIZE_01, seed=1)
+    model = model.to(device)
+    pts = masked_frame(0, 160000)
+    pipe = FramePipeline(model, info)
+    tp = torch.from_numpy(pts).to(device)
+    out, d_n = pipe(tp)
+    n = int(d_n.item())
+    assert 0 < n <= 500
+    s = out[:n, 7].cpu().numpy()
+    assert np.all(np.diff(s) <= 0) and s.min() > 0.03                         # sorted, above SCORE_THRESH
+    b = out[:n].cpu().numpy()
+    assert np.all(np.abs(b[:, 0]) <= 80) and np.all(np.abs(b[:, 1]) <= 80) and np.all(np.isfinite(b))
+    assert set(b[:, 8].astype(int).tolist()) <= {1, 2, 3}
+    # survivors of NMS do not overlap above the threshold
+    from oracle import cref
+    iou = cref.boxes_iou_bev(b[:, :7], b[:, :7])
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.7 + 1e-4
+    # permuting the input points changes voxel order but not the detections (order-independence of the
+    # backbone w.r.t. voxel order; the 5-point truncation is order dependent, so permute whole voxels only)
+    vox, czyx, nump = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 200000)
+    feats = ov.mean_vfe(vox, nump)
+    coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    perm = np.random.default_rng(0).permutation(coords.shape[0])
+    r1 = model.backbone3d.run(torch.from_numpy(feats).to(device), torch.from_numpy(coords).to(device), 1)
+    r2 = model.backbone3d.run(torch.from_numpy(feats[perm]).to(device), torch.from_numpy(coords[perm]).to(device), 1)
+    x1, l1 = r1['encoded']; x2, l2 = r2['encoded']
+    m = l1.num_active()
+    assert m == l2.num_active() and torch.equal(l1.coords[:m], l2.coords[:m]) and torch.equal(x1[:m], x2[:m])
+    # active-site counts per stage equal the oracle's rulebook builder (cheap at full size)
+    cur, shape = coords[osp.canonical_order(coords, [41, 1504, 1504])], [41, 1504, 1504]
+    for name, (k, s, p) in zip(('x_conv2', 'x_conv3', 'x_conv4', 'encoded'),
+                               [((3, 3, 3), (2, 2, 2), (1, 1, 1))] * 2 + [((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]):
+        cur, shape = osp.conv_out_coords(cur, shape, k, s, p)
+        lvl = r1[name][1]
+        assert lvl.num_active() == cur.shape[0] and np.array_equal(lvl.coords[:cur.shape[0]].cpu().numpy(), cur)
+
+
+def test_hip_graph_capture_of_frame_pipeline(device):
+    """The whole frame (no host sync inside) replays from a HIP graph and reproduces eager results."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=2)
+    model = model.to(device)
+    pts = torch.from_numpy(masked_frame(3, 20000)).to(device)
+    pipe = FramePipeline(model, info)
+    ref_out, ref_n = pipe(pts)
+    torch.cuda.synchronize()
+    static_in = pts.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            pipe(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_out, g_n = pipe(static_in)
+    g.replay()
+    torch.cuda.synchronize()
+    n = int(ref_n.item())
+    assert int(g_n.item()) == n and torch.equal(g_out[:n], ref_out[:n])
+    # new frame through the same graph
+    pts2 = torch.from_numpy(masked_frame(4, 20000)).to(device)
+    e_out, e_n = pipe(pts2)
+    m = min(static_in.shape[0], pts2.shape[0])
+    static_in.zero_(); static_in[:m] = pts2[:m]
+    if pts2.shape[0] <= static_in.shape[0]:
+        static_in[pts2.shape[0]:, 0] = 1e6                 # padding rows fall outside the range
+        g.replay()
+        torch.cuda.synchronize()
+        n2 = int(e_n.item())
+        assert int(g_n.item()) == n2 and torch.equal(g_out[:n2], e_out[:n2])

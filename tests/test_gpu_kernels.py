@@ -1,0 +1,427 @@
+"""GPU (MI355X): every HIP entry point, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the committed golden fixtures of the reference's own code.
+Bit-exact for indices / rulebooks / integer outputs; stated tolerances for fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_01, VOXEL_SIZE_02, synth_boxes, synth_waymo_frame
+from tests.util import masked_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# voxelization
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('seed,n,vs,max_voxels', [
+    (0, 20000, VOXEL_SIZE_02, 200000),       # BASELINE configs[0]
+    (1, 160000, VOXEL_SIZE_01, 200000),      # BASELINE configs[1]
+    (2, 160000, VOXEL_SIZE_01, 30000),       # max_voxels binds: later voxels are refused
+    (3, 257, VOXEL_SIZE_02, 16),
+    (4, 1, VOXEL_SIZE_02, 8),
+])
+def test_voxelize_hard_bit_exact(device, seed, n, vs, max_voxels):
+    from detzero_amd import ops
+    from oracle import voxelize as ov
+    pts = masked_frame(seed, n) if n > 1 else np.array([[1.0, 2.0, 0.5, 0.3, 0.1]], np.float32)
+    v0, c0, n0 = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, vs, 5, max_voxels)
+    v1, c1, n1 = ops.voxelize_hard(_t(pts, device), POINT_CLOUD_RANGE, vs, 5, max_voxels)
+    assert v1.shape[0] == v0.shape[0]
+    assert np.array_equal(c1.cpu().numpy(), c0)                  # (z,y,x) indices, first-appearance order
+    assert np.array_equal(n1.cpu().numpy(), n0)
+    assert np.array_equal(v1.cpu().numpy(), v0)                  # point copies: bit-exact
+
+
+def test_voxelize_hard_edges(device):
+    from detzero_amd import ops
+    from oracle import voxelize as ov
+    # nothing in range / boundary values / many points in one voxel / unmasked input + xy mask flag
+    out = np.array([[500.0, 0, 0, 0, 0], [0, 0, 50.0, 0, 0]], np.float32)
+    v, c, n = ops.voxelize_hard(_t(out, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    assert v.shape[0] == 0
+    edge = np.array([[75.2, 0, 0, 1, 1], [-75.2, -75.2, -2, 2, 2], [0, 0, 4.0, 3, 3], [0, 0, 3.9999, 4, 4],
+                     [np.nextafter(np.float32(75.2), np.float32(100)), 0, 0, 5, 5]], np.float32)
+    for mask in (False, True):
+        pts = edge if not mask else edge
+        ref_pts = pts[ov.mask_points_by_range(pts, POINT_CLOUD_RANGE)] if mask else pts
+        v0, c0, n0 = ov.hard_voxelize(ref_pts, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+        v1, c1, n1, d = ops.voxelize_hard_nosync(_t(pts, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100, xy_range_mask=mask)
+        m = int(d.item())
+        assert m == v0.shape[0]
+        assert np.array_equal(c1[:m].cpu().numpy(), c0) and np.array_equal(v1[:m].cpu().numpy(), v0)
+    many = np.tile(np.array([[1.01, 2.02, 0.5, 0, 0]], np.float32), (300, 1))
+    many[:, 3] = np.arange(300)
+    v0, c0, n0 = ov.hard_voxelize(many, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    v1, c1, n1 = ops.voxelize_hard(_t(many, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    assert np.array_equal(v1.cpu().numpy(), v0) and list(n1.cpu().numpy()) == [5]
+    empty = torch.zeros((0, 5), device=device)
+    v1, c1, n1 = ops.voxelize_hard(empty, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    assert v1.shape[0] == 0
+
+
+def test_mean_vfe(device, golden_dir):
+    from detzero_amd import ops
+    g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
+    out = ops.mean_vfe(_t(g['meanvfe_voxels'], device), _t(g['meanvfe_num'], device, torch.int32))
+    np.testing.assert_allclose(out.cpu().numpy(), g['meanvfe_out'], rtol=0, atol=1e-6)   # reference MeanVFE output
+    out16 = ops.mean_vfe(_t(g['meanvfe_voxels'], device), _t(g['meanvfe_num'], device, torch.int32), c_out=16)
+    assert torch.equal(out16[:, :5], out) and float(out16[:, 5:].abs().max()) == 0.0
+
+
+def test_dynamic_vfe(device, golden_dir):
+    from detzero_amd import ops
+    from oracle import voxelize as ov
+    g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
+    feats, coords = ops.voxelize_dynamic(_t(g['dynvfe_points'], device), POINT_CLOUD_RANGE, VOXEL_SIZE_02, 2)
+    assert np.array_equal(coords.cpu().numpy(), g['dynvfe_coords'])                  # reference order, bit-exact
+    np.testing.assert_allclose(feats.cpu().numpy(), g['dynvfe_feats'], rtol=1e-5, atol=1e-5)
+    # BASELINE configs[4] shape: two merged sweeps, 6 features, 320k points
+    from detzero_amd.synth import merge_two_sweeps
+    pts = merge_two_sweeps(synth_waymo_frame(7, 160000), synth_waymo_frame(8, 160000))
+    pb = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts], 1)
+    f0, c0 = ov.dynamic_mean_vfe(pb, POINT_CLOUD_RANGE, VOXEL_SIZE_01)
+    f1, c1 = ops.voxelize_dynamic(_t(pb, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 1)
+    assert np.array_equal(c1.cpu().numpy(), c0)
+    np.testing.assert_allclose(f1.cpu().numpy(), f0, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse index / rulebook
+# ------------------------------------------------------------------------------------------------
+def _voxel_coords(seed, n, vs, batch=1):
+    from oracle import voxelize as ov
+    cs = []
+    for b in range(batch):
+        pts = masked_frame(seed + b, n)
+        _, c, _ = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, vs, 5, 200000)
+        cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    return np.concatenate(cs, 0)
+
+
+@pytest.mark.parametrize('seed,n,vs,batch', [(0, 20000, VOXEL_SIZE_02, 2), (1, 160000, VOXEL_SIZE_01, 1)])
+def test_index_and_rulebooks_bit_exact(device, seed, n, vs, batch):
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    from oracle import voxelize as ov
+    coords = _voxel_coords(seed, n, vs, batch)
+    grid = ov.grid_size_of(POINT_CLOUD_RANGE, vs)
+    shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
+    lvl = ops.SparseLevel(batch, shape, coords.shape[0], device)
+    rank = lvl.build_from_coords(_t(coords, device))
+    order = osp.canonical_order(coords, shape)
+    m = lvl.num_active()
+    assert m == coords.shape[0]
+    assert np.array_equal(lvl.coords[:m].cpu().numpy(), coords[order])               # canonical (sorted) order
+    inv = np.empty_like(order); inv[order] = np.arange(order.size)
+    assert np.array_equal(rank.cpu().numpy(), inv.astype(np.int32))
+    cur, cur_shape, cur_lvl = coords[order], shape, lvl
+    K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    for k, s, p in [(K3, (2, 2, 2), (1, 1, 1)), (K3, (2, 2, 2), (1, 1, 1)), (K3, (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]:
+        # submanifold rulebook of the current level
+        nbr = cur_lvl.neighbors_to(cur_lvl, K3, S1, P1)
+        ref = osp.neighbor_table(cur, cur_shape, cur, K3, S1, P1)
+        assert np.array_equal(nbr[:, :cur.shape[0]].cpu().numpy(), ref)
+        # strided conv: output set + rulebook
+        nxt = cur_lvl.downsample(k, s, p)
+        oc, oshape = osp.conv_out_coords(cur, cur_shape, k, s, p)
+        assert nxt.shape == list(oshape) and nxt.num_active() == oc.shape[0]
+        assert np.array_equal(nxt.coords[:oc.shape[0]].cpu().numpy(), oc)
+        nbr = cur_lvl.neighbors_to(nxt, k, s, p)
+        ref = osp.neighbor_table(cur, cur_shape, oc, k, s, p)
+        assert np.array_equal(nbr[:, :oc.shape[0]].cpu().numpy(), ref)
+        cur, cur_shape, cur_lvl = oc, oshape, nxt
+
+
+def test_index_duplicates_and_empty(device):
+    from detzero_amd import ops
+    coords = np.array([[0, 1, 2, 3], [0, 1, 2, 3], [0, 0, 0, 0], [1, 4, 7, 7], [0, 1, 2, 2]], np.int32)
+    lvl = ops.SparseLevel(2, [5, 8, 8], 8, device)
+    rank = lvl.build_from_coords(_t(coords, device))
+    assert lvl.num_active() == 4
+    assert lvl.coords[:4].cpu().tolist() == [[0, 0, 0, 0], [0, 1, 2, 2], [0, 1, 2, 3], [1, 4, 7, 7]]
+    assert rank.cpu().tolist() == [2, 2, 0, 3, 1]
+    lvl0 = ops.SparseLevel(1, [5, 8, 8], 4, device)
+    lvl0.build_from_coords(torch.zeros((0, 4), dtype=torch.int32, device=device), want_rank=False)
+    assert lvl0.num_active() == 0
+    nxt = lvl0.downsample((3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert nxt.num_active() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse convolution
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,kvol', [(16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27),
+                                           (64, 128, 27), (128, 128, 27), (128, 128, 3)])
+def test_spconv_forward_vs_oracle(device, cin, cout, kvol):
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    rng = np.random.default_rng(cin * 1000 + cout + kvol)
+    shape = [9, 40, 40]
+    n = 3000
+    lin = rng.choice(shape[0] * shape[1] * shape[2], size=n, replace=False)
+    coords = np.stack([np.zeros(n, np.int64), lin // 1600, (lin // 40) % 40, lin % 40], 1).astype(np.int32)
+    coords = coords[osp.canonical_order(coords, shape)]
+    feats = rng.standard_normal((n, cin)).astype(np.float32)
+    if kvol == 27:
+        k, s, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+        oc = coords
+    else:
+        k, s, p = (3, 1, 1), (2, 1, 1), (0, 0, 0)
+        oc, _ = osp.conv_out_coords(coords, shape, k, s, p)
+    w = (rng.standard_normal((kvol, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32) * 0.1
+    res = rng.standard_normal((oc.shape[0], cout)).astype(np.float32)
+    rb = osp.build_rulebook(coords, shape, oc, k, s, p)
+    ref = osp.sparse_conv(torch.from_numpy(feats), rb, torch.from_numpy(w), oc.shape[0])
+    ref = torch.relu(ref * torch.from_numpy(scale) + torch.from_numpy(shift) + torch.from_numpy(res))
+
+    lvl = ops.SparseLevel(1, shape, n, device)
+    lvl.build_from_coords(_t(coords, device), want_rank=False)
+    out_lvl = lvl if kvol == 27 else lvl.downsample(k, s, p)
+    nbr = lvl.neighbors_to(out_lvl, k, s, p)
+    res_pad = np.zeros((out_lvl.cap, cout), np.float32); res_pad[:oc.shape[0]] = res
+    out = ops.spconv_forward(_t(feats, device), nbr, out_lvl, _t(w, device), _t(scale, device), _t(shift, device),
+                             _t(res_pad, device), relu=True)
+    torch.testing.assert_close(out[:oc.shape[0]].cpu(), ref, rtol=2e-4, atol=2e-4)
+    # no epilogue: plain accumulation
+    out2 = ops.spconv_forward(_t(feats, device), nbr, out_lvl, _t(w, device), None, None, None, relu=False)
+    ref2 = osp.sparse_conv(torch.from_numpy(feats), rb, torch.from_numpy(w), oc.shape[0])
+    torch.testing.assert_close(out2[:oc.shape[0]].cpu(), ref2, rtol=2e-4, atol=2e-4)
+
+
+def test_sparse_to_bev(device):
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    rng = np.random.default_rng(3)
+    shape = [2, 30, 31]
+    n = 500
+    lin = rng.choice(2 * shape[0] * shape[1] * shape[2], size=n, replace=False)
+    cells = shape[0] * shape[1] * shape[2]
+    coords = np.stack([lin // cells, (lin % cells) // (30 * 31), (lin // 31) % 30, lin % 31], 1).astype(np.int32)
+    coords = coords[osp.canonical_order(coords, shape)]
+    feats = rng.standard_normal((n, 128)).astype(np.float32)
+    lvl = ops.SparseLevel(2, shape, n, device)
+    lvl.build_from_coords(_t(coords, device), want_rank=False)
+    bev = ops.sparse_to_bev(_t(feats, device), lvl, 128, pad=1)
+    ref = osp.to_bev(torch.from_numpy(feats), coords, shape, 2)                 # (B, C*D, H, W)
+    got = bev[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got, ref)
+    assert float(bev[:, 0].abs().max()) == 0 and float(bev[:, :, -1].abs().max()) == 0   # zero border
+
+
+# ------------------------------------------------------------------------------------------------
+# dense convolutions: reference BaseBEVBackbone / CenterHead golden
+# ------------------------------------------------------------------------------------------------
+def test_bev_backbone_matches_reference_golden(device, golden_dir):
+    from detzero_amd.config import AttrDict
+    from detzero_amd.det_modules import BaseBEVBackbone
+    g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
+    cfg = AttrDict({'LAYER_NUMS': [2, 2], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [32, 64], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [32, 32]})
+    bb = BaseBEVBackbone(cfg, 32)
+    sd = {k[len('bev_backbone2d.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('bev_backbone2d.')}
+    bb.load_state_dict(sd, strict=True)
+    bb = bb.to(device).eval()
+    out = bb({'spatial_features': _t(g['bev_in'], device)})['spatial_features_2d']
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(g['bev_out']), rtol=1e-4, atol=1e-4)
+
+
+def _golden_head(g, device):
+    from detzero_amd.config import AttrDict
+    from detzero_amd.det_modules import CenterHead
+    from oracle import voxelize as ov
+    hcfg = AttrDict({
+        'CLASS_NAMES_EACH_HEAD': [['Vehicle', 'Pedestrian', 'Cyclist']], 'SHARED_CONV_CHANNEL': 32,
+        'USE_BIAS_BEFORE_NORM': True, 'NUM_HM_CONV': 2, 'IOU_WEIGHT': 1,
+        'SEPARATE_HEAD_CFG': {'HEAD_ORDER': ['center', 'center_z', 'dim', 'rot', 'iou'],
+                              'HEAD_DICT': {'center': {'out_channels': 2, 'num_conv': 2}, 'center_z': {'out_channels': 1, 'num_conv': 2},
+                                            'dim': {'out_channels': 3, 'num_conv': 2}, 'rot': {'out_channels': 2, 'num_conv': 2},
+                                            'iou': {'out_channels': 1, 'num_conv': 2}}},
+        'TARGET_ASSIGNER_CONFIG': {'FEATURE_MAP_STRIDE': 8},
+        'POST_PROCESSING': {'SCORE_THRESH': 0.03, 'POST_CENTER_LIMIT_RANGE': [-80, -80, -10.0, 80, 80, 10.0],
+                            'MAX_OBJ_PER_SAMPLE': 100,
+                            'NMS_CONFIG': {'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}}})
+    grid = ov.grid_size_of(POINT_CLOUD_RANGE, VOXEL_SIZE_02)
+    head = CenterHead(hcfg, 64, 3, ['Vehicle', 'Pedestrian', 'Cyclist'], grid, POINT_CLOUD_RANGE, VOXEL_SIZE_02)
+    sd = {k[len('head_dense_head.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('head_dense_head.')}
+    missing = head.load_state_dict(sd, strict=True)
+    return head.to(device).eval()
+
+
+def test_center_head_matches_reference_golden(device, golden_dir):
+    from tests.util import match_boxes
+    g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
+    head = _golden_head(g, device)
+    dd = head({'spatial_features_2d': _t(g['head_in'], device), 'batch_size': 2})
+    pred = head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'iou', 'hm'):
+        torch.testing.assert_close(pred[name].cpu(), torch.from_numpy(g['head_pred_' + name]), rtol=1e-4, atol=1e-4)
+    for i, fb in enumerate(dd['final_box_dicts']):
+        ref_b, ref_s, ref_l = g['head_boxes_%d' % i], g['head_scores_%d' % i], g['head_labels_%d' % i]
+        got_b, got_s, got_l = fb['pred_boxes'].cpu().numpy(), fb['pred_scores'].cpu().numpy(), fb['pred_labels'].cpu().numpy()
+        nm, worst = match_boxes(ref_b, ref_s, got_b, got_s, tol=1e-3)
+        assert got_b.shape[0] == ref_b.shape[0], (got_b.shape, ref_b.shape)
+        assert nm == ref_b.shape[0], (nm, ref_b.shape[0], worst)                  # boxes within 1e-3 of the reference
+        assert sorted(got_l.tolist()) == sorted(ref_l.tolist())
+        assert np.all(np.diff(got_s) <= 1e-7)                                      # descending scores
+
+
+def test_decode_topk_matches_reference_golden(device, golden_dir):
+    """Decode kernel alone, fed with the REFERENCE's head maps (so conv rounding cannot move the top-K)."""
+    from detzero_amd import ops
+    g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
+    maps = [g['head_pred_' + n] for n in ('center', 'center_z', 'dim', 'rot', 'iou', 'hm')]
+    head = np.concatenate(maps, axis=1)                                   # (B,12,H,W)
+    b, _, h, w = head.shape
+    head_cl = np.ascontiguousarray(head.transpose(0, 2, 3, 1).reshape(b, h * w, 12))
+    boxes, scores, labels, counts = ops.centerhead_decode(_t(head_cl, device), h, w, 3, 100, 0.03, [-80, -80, -10.0, 80, 80, 10.0],
+                                                          POINT_CLOUD_RANGE, VOXEL_SIZE_02, 8, use_iou=True)
+    for i in range(b):
+        n = int(counts[i].item())
+        assert n == g['dec_boxes_%d' % i].shape[0]
+        assert np.array_equal(labels[i, :n].cpu().numpy(), g['dec_labels_%d' % i])          # same cells, same order
+        np.testing.assert_allclose(scores[i, :n].cpu().numpy(), g['dec_scores_%d' % i], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(boxes[i, :n].cpu().numpy(), g['dec_boxes_%d' % i], rtol=0, atol=1e-4)
+
+
+def test_topk_ties_and_small_maps(device):
+    from detzero_amd import ops
+    # all-equal scores: ties resolve to ascending flat index (class-major); K larger than the map
+    h, w = 4, 5
+    head = np.zeros((1, h * w, 12), np.float32)
+    head[..., 8] = 1.0                               # iou = 1
+    boxes, scores, labels, counts = ops.centerhead_decode(_t(head, device), h, w, 3, 32, 0.03, [-80, -80, -10.0, 80, 80, 10.0],
+                                                          POINT_CLOUD_RANGE, VOXEL_SIZE_02, 8, use_iou=True)
+    n = int(counts[0].item())
+    assert n == 32
+    assert labels[0, :n].cpu().tolist() == [0] * 20 + [1] * 12
+    assert torch.allclose(scores[0, :n].cpu(), torch.full((n,), 0.5))
+    # iou <= 0 -> score 0 -> nothing passes the 0.03 threshold
+    head[..., 8] = -1.0
+    _, _, _, counts = ops.centerhead_decode(_t(head, device), h, w, 3, 32, 0.03, [-80, -80, -10.0, 80, 80, 10.0],
+                                            POINT_CLOUD_RANGE, VOXEL_SIZE_02, 8, use_iou=True)
+    assert int(counts[0].item()) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# rotated IoU / NMS / points in boxes
+# ------------------------------------------------------------------------------------------------
+def test_rotated_iou_matches_reference_cpp_golden(device, golden_dir):
+    from detzero_amd import iou3d_nms_utils
+    from oracle import cref
+    z = np.load(os.path.join(golden_dir, 'iou_golden.npz'))
+    iou = iou3d_nms_utils.boxes_iou_bev(_t(z['a'], device), _t(z['b'], device)).cpu().numpy()
+    np.testing.assert_allclose(iou, z['iou'], rtol=0, atol=2e-5)       # reference iou3d_cpu.cpp; sin/cos/atan2 are ocml vs libm
+    ov = iou3d_nms_utils.boxes_overlap_bev_gpu(_t(z['a'], device), _t(z['b'], device)).cpu().numpy()
+    np.testing.assert_allclose(ov, cref.boxes_overlap_bev(z['a'], z['b']), rtol=1e-5, atol=1e-4)
+    assert (iou > 0.7).sum() >= 20
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 500, 1500])
+def test_rotated_nms_vs_oracle(device, n):
+    from detzero_amd import iou3d_nms_utils
+    from oracle import cref
+    boxes = synth_boxes(100 + n, n, xy_range=20.0 if n > 100 else 8.0, near_duplicates=0.5)
+    scores = np.random.default_rng(n).permutation(n).astype(np.float32) / n          # distinct scores
+    keep, _ = iou3d_nms_utils.nms_gpu(_t(boxes, device), _t(scores, device), 0.7)
+    order = np.argsort(-scores, kind='stable')
+    ref = order[cref.nms_sorted(boxes[order], 0.7)]
+    got = keep.cpu().numpy()
+    if not np.array_equal(got, ref):
+        # a decision may legitimately flip only when an IoU sits within float noise of the threshold
+        iou = cref.boxes_iou_bev(boxes[order], boxes[order])
+        near = np.abs(iou - 0.7) < 1e-5
+        assert near.any(), 'NMS differs from the oracle without any near-threshold IoU'
+        pytest.skip('NMS differs only through a near-threshold IoU (%d pairs)' % int(near.sum()))
+    assert len(got) < n or n < 3
+
+
+def test_nms_empty(device):
+    from detzero_amd import ops
+    keep, d = ops.nms_rotated_nosync(torch.zeros((0, 7), device=device), None, 0.7, 500)
+    assert int(d.item()) == 0
+    boxes = _t(synth_boxes(1, 10), device)
+    zero = torch.zeros((1,), dtype=torch.int32, device=device)
+    keep, d = ops.nms_rotated_nosync(boxes, zero, 0.7, 500)
+    assert int(d.item()) == 0
+    keep, d = ops.nms_rotated_nosync(boxes, None, 0.7, 3)           # post_max cut
+    assert int(d.item()) <= 3
+
+
+def test_points_in_boxes_bit_exact(device):
+    from detzero_amd import roiaware_pool3d_utils
+    from oracle import cref
+    boxes = synth_boxes(9, 70, xy_range=40.0)
+    boxes[:, 3:6] *= 1.1                                     # daemon/prepare_object_data.py enlarges x1.1
+    pts = synth_waymo_frame(9, 180000)[:, :3]
+    pts = pts[(np.abs(pts[:, 0]) < 45) & (np.abs(pts[:, 1]) < 45)]
+    mask = roiaware_pool3d_utils.points_in_boxes_gpu_v2(_t(pts[None], device), _t(boxes[None], device))[0].cpu().numpy()
+    ref = cref.points_in_boxes_v2(pts, boxes)
+    diff = int((mask != ref).sum())
+    assert ref.sum() > 100
+    assert diff <= 2, diff                                   # cos/sin ulp differences on the box surface only
+    e = roiaware_pool3d_utils.points_in_boxes_gpu_v2(torch.zeros((1, 0, 3), device=device), _t(boxes[None], device))
+    assert tuple(e.shape) == (1, 70, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# refiner: linear (1x1 conv) and attention core
+# ------------------------------------------------------------------------------------------------
+def test_linear_forward(device):
+    from detzero_amd import ops
+    rng = np.random.default_rng(0)
+    for rows, cin, cout in [(1000, 32, 128), (4096, 128, 512), (77, 256, 256), (300, 16, 64), (513, 640, 512)]:
+        x = rng.standard_normal((rows, cin)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, cout).astype(np.float32); sh = rng.standard_normal(cout).astype(np.float32)
+        y = ops.linear(_t(x, device), _t(w, device), _t(sc, device), _t(sh, device), True, cout)
+        ref = np.maximum((x.astype(np.float64) @ w.astype(np.float64)) * sc + sh, 0)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+def test_mha_core_matches_reference_golden(device, golden_dir):
+    """q/k/v projections done in torch on the CPU with the reference module's weights; the fused
+    attention core must reproduce the reference MultiheadAttention output."""
+    from detzero_amd import ops
+    g = np.load(os.path.join(golden_dir, 'mha_golden.npz'))
+    q, k, v = (torch.from_numpy(g[n]) for n in ('q', 'k', 'v'))          # (L,B,E)
+    w, b = torch.from_numpy(g['mha_in_proj_weight']), torch.from_numpy(g['mha_in_proj_bias'])
+    e = 64
+    qp = torch.nn.functional.linear(q, w[:e], b[:e]).transpose(0, 1).contiguous()
+    kp = torch.nn.functional.linear(k, w[e:2 * e], b[e:2 * e]).transpose(0, 1).contiguous()
+    vp = torch.nn.functional.linear(v, w[2 * e:], b[2 * e:]).transpose(0, 1).contiguous()
+    o = ops.mha_core(qp.to(device), kp.to(device), vp.to(device), torch.from_numpy(g['kpm']).to(device), 2, 32 ** -0.5).cpu()
+    o = torch.nn.functional.linear(o, torch.from_numpy(g['mha_out_proj.weight']), torch.from_numpy(g['mha_out_proj.bias']))
+    torch.testing.assert_close(o.transpose(0, 1), torch.from_numpy(g['out']), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('b,lq,lk,heads,masked', [(3, 3, 4096, 8, False), (2, 200, 9600, 8, True), (2, 200, 200, 8, True), (1, 17, 50, 8, True)])
+def test_mha_core_vs_torch(device, b, lq, lk, heads, masked):
+    from detzero_amd import ops
+    gen = torch.Generator().manual_seed(lq * 7 + lk)
+    e = heads * 32
+    q = torch.randn((b, lq, e), generator=gen); k = torch.randn((b, lk, e), generator=gen); v = torch.randn((b, lk, e), generator=gen)
+    kpm = None
+    if masked:
+        lens = torch.randint(5, lk + 1, (b,), generator=gen)
+        kpm = torch.arange(lk)[None, :] >= lens[:, None]
+    out = ops.mha_core(q.to(device), k.to(device), v.to(device), kpm.to(device) if masked else None, heads, 32 ** -0.5).cpu()
+    qh = (q * 32 ** -0.5).view(b, lq, heads, 32).transpose(1, 2).double()
+    kh = k.view(b, lk, heads, 32).transpose(1, 2).double()
+    vh = v.view(b, lk, heads, 32).transpose(1, 2).double()
+    s = qh @ kh.transpose(-1, -2)
+    if masked:
+        s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(b, lq, e).float()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)

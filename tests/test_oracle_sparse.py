@@ -1,0 +1,104 @@
+"""CPU: the sparse-conv oracle (spconv is un-vendored -> parity unpinned) is cross-checked against
+dense torch.nn.functional.conv3d on densified inputs, as SURVEY.md §7 'hard parts' prescribes."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import sparse as osp
+
+
+def _random_sparse(seed, shape, n, c, batch=2):
+    rng = np.random.default_rng(seed)
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=n, replace=False)
+    b = lin // (shape[0] * shape[1] * shape[2])
+    r = lin % (shape[0] * shape[1] * shape[2])
+    z, y, x = r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]
+    coords = np.stack([b, z, y, x], 1).astype(np.int32)
+    feats = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32))
+    return coords, feats
+
+
+def _densify(coords, feats, shape, batch):
+    d = torch.zeros((batch, feats.shape[1], *shape))
+    cc = torch.from_numpy(coords.astype(np.int64))
+    d[cc[:, 0], :, cc[:, 1], cc[:, 2], cc[:, 3]] = feats
+    return d
+
+
+def test_subm_conv_equals_masked_dense_conv():
+    shape, batch = (6, 9, 10), 2
+    coords, feats = _random_sparse(0, shape, 150, 4, batch)
+    w = torch.randn(8, 3, 3, 3, 4)                      # spconv layout (Cout,kD,kH,kW,Cin)
+    rb = osp.build_rulebook(coords, shape, coords, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    out = osp.sparse_conv(feats, rb, osp.weight_to_taps(w), coords.shape[0])
+    dense = F.conv3d(_densify(coords, feats, shape, batch), w.permute(0, 4, 1, 2, 3), padding=1)
+    cc = torch.from_numpy(coords.astype(np.int64))
+    ref = dense[cc[:, 0], :, cc[:, 1], cc[:, 2], cc[:, 3]]
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def _check_strided(k, s, p, shape):
+    batch = 2
+    coords, feats = _random_sparse(1, shape, 120, 3, batch)
+    w = torch.randn(5, *k, 3)
+    oc, oshape = osp.conv_out_coords(coords, shape, k, s, p)
+    rb = osp.build_rulebook(coords, shape, oc, k, s, p)
+    out = osp.sparse_conv(feats, rb, osp.weight_to_taps(w), oc.shape[0])
+    dense = F.conv3d(_densify(coords, feats, shape, batch), w.permute(0, 4, 1, 2, 3), stride=s, padding=p)
+    assert list(dense.shape[2:]) == list(oshape)
+    cc = torch.from_numpy(oc.astype(np.int64))
+    torch.testing.assert_close(out, dense[cc[:, 0], :, cc[:, 1], cc[:, 2], cc[:, 3]], rtol=1e-5, atol=1e-5)
+    # active output set == cells whose receptive field touches >= 1 active input (ones-kernel test)
+    occ = _densify(coords, torch.ones(coords.shape[0], 1), shape, batch)
+    touched = F.conv3d(occ, torch.ones(1, 1, *k), stride=s, padding=p)[:, 0] > 0
+    mask = torch.zeros_like(touched)
+    mask[cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3]] = True
+    assert torch.equal(mask, touched)
+    # canonical order
+    key = osp.lin_key(oc, oshape)
+    assert np.all(np.diff(key) > 0)
+
+
+def test_strided_conv_equals_dense_conv():
+    _check_strided((3, 3, 3), (2, 2, 2), (1, 1, 1), (7, 10, 12))      # spconv2 / spconv3 geometry (odd + even extents)
+    _check_strided((3, 3, 3), (2, 2, 2), (0, 1, 1), (11, 8, 8))       # spconv4: padding (0,1,1)
+    _check_strided((3, 1, 1), (2, 1, 1), (0, 0, 0), (5, 6, 6))        # conv_out
+
+
+def test_neighbor_table_matches_rulebook():
+    shape = (5, 8, 8)
+    coords, _ = _random_sparse(2, shape, 90, 1, 1)
+    order = osp.canonical_order(coords, shape)
+    coords = coords[order]
+    i, o, t = osp.build_rulebook(coords, shape, coords, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    tab = osp.neighbor_table(coords, shape, coords, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert (tab >= 0).sum() == i.size
+    assert np.all(tab[13] == np.arange(coords.shape[0]))               # centre tap = identity for subm
+    assert np.array_equal(tab[t, o], i)
+
+
+def test_backbone_shapes_and_bev():
+    from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_02, synth_waymo_frame
+    from oracle import voxelize as ov
+    from detzero_amd.det_modules import VoxelResBackBone8x
+    from detzero_amd.config import AttrDict
+    pts = synth_waymo_frame(0, 4000)
+    pts = pts[ov.mask_points_by_range(pts, POINT_CLOUD_RANGE)]
+    vox, c, n = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000)
+    feats = ov.mean_vfe(vox, n)
+    coords = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    grid = ov.grid_size_of(POINT_CLOUD_RANGE, VOXEL_SIZE_02)
+    bb = VoxelResBackBone8x(AttrDict({}), 5, grid).eval()
+    sd = {('backbone3d.' + k): v for k, v in bb.state_dict().items()}
+    res = osp.backbone_forward(sd, feats, coords, bb.sparse_shape)
+    assert res['x_conv1'][2] == [41, 752, 752] and res['x_conv2'][2] == [21, 376, 376]
+    assert res['x_conv3'][2] == [11, 188, 188] and res['x_conv4'][2] == [5, 94, 94]
+    x, oc, shape = res['encoded']
+    assert shape == [2, 94, 94] and x.shape[1] == 128 and x.shape[0] == oc.shape[0] > 0
+    bev = osp.to_bev(x, oc, shape, 1)
+    assert tuple(bev.shape) == (1, 256, 94, 94)
+    # channel index = c*D + d (height_compression.py:23)
+    j = 0
+    b, z, y, xx = oc[j]
+    assert torch.equal(bev[0, z::2, y, xx], x[j])

@@ -1,0 +1,67 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network
+from detzero_amd.config import centerpoint_1sweep_cfg
+from detzero_amd.synth import POINT_CLOUD_RANGE, synth_waymo_frame
+
+POST = {'SCORE_THRESH': 0.03, 'POST_CENTER_LIMIT_RANGE': [-80, -80, -10.0, 80, 80, 10.0], 'MAX_OBJ_PER_SAMPLE': 500,
+        'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}
+
+
+def make_model(voxel_size, seed=0):
+    """Seeded random-init CenterPoint (reference architecture) - see detzero_amd.centerpoint.synth_detector."""
+    from detzero_amd.centerpoint import synth_detector
+    return synth_detector(voxel_size, seed)
+
+
+def cpu_state_dict(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def masked_frame(seed, n):
+    pts = synth_waymo_frame(seed, n)
+    m = (pts[:, 0] >= POINT_CLOUD_RANGE[0]) & (pts[:, 0] <= POINT_CLOUD_RANGE[3]) & \
+        (pts[:, 1] >= POINT_CLOUD_RANGE[1]) & (pts[:, 1] <= POINT_CLOUD_RANGE[4])
+    return pts[m]
+
+
+def oracle_detect(sd, points, info, post=POST):
+    """Whole per-frame path on the CPU oracle: returns dict of intermediates + final boxes."""
+    from oracle import dense, sparse as osp, voxelize as ov
+    vox, czyx, nump = ov.hard_voxelize(points, info.point_cloud_range, info.voxel_size, 5, info.max_voxels['test'])
+    feats = ov.mean_vfe(vox, nump)
+    coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    grid = info.grid_size
+    sparse_shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
+    res = osp.backbone_forward(sd, feats, coords, sparse_shape)
+    x, oc, shape = res['encoded']
+    bev = osp.to_bev(x, oc, shape, 1)
+    f2d = dense.bev_backbone_forward(sd, bev)
+    pred = dense.center_head_forward(sd, f2d)
+    final = dense.generate_predicted_boxes(pred, info.point_cloud_range, info.voxel_size, 8, post)
+    return {'voxels': vox, 'coords': coords, 'num_points': nump, 'feats': feats, 'backbone': res, 'bev': bev,
+            'f2d': f2d, 'pred': pred, 'final': final}
+
+
+def match_boxes(a_boxes, a_scores, b_boxes, b_scores, tol=1e-3):
+    """Greedy one-to-one match by centre distance; returns (n_matched, max_abs_diff over matched)."""
+    a_boxes, b_boxes = np.asarray(a_boxes), np.asarray(b_boxes)
+    if a_boxes.shape[0] == 0 or b_boxes.shape[0] == 0:
+        return 0, 0.0
+    d = np.abs(a_boxes[:, None, :3] - b_boxes[None, :, :3]).max(-1)
+    used = set()
+    n, worst = 0, 0.0
+    for i in range(a_boxes.shape[0]):
+        j = int(np.argmin(d[i]))
+        if d[i, j] <= tol and j not in used:
+            diff = np.abs(a_boxes[i] - b_boxes[j])
+            diff[6] = min(diff[6], abs(diff[6] - 2 * np.pi))
+            sd = abs(float(a_scores[i]) - float(b_scores[j]))
+            if diff.max() <= tol and sd <= tol:
+                used.add(j)
+                n += 1
+                worst = max(worst, float(diff.max()), sd)
+    return n, worst
