@@ -23,6 +23,7 @@ namespace dz {
 
 constexpr int HD = 32;  // head dim of every DetZero refiner config (256 / 8 heads)
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, const float *__restrict__ k,
                                                   const float *__restrict__ v, const uint8_t *__restrict__ kpm,
                                                   int batch, int lq, int lk, int heads, float scale,
@@ -67,14 +68,20 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
             s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qreg[sl][2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qreg[sl][3], s, 0, 0, 0);
         }
-        // lane (g,r): s[e] = score(query r, key key0 + 4g + e)
+        // lane (g,r): s[e] = score(query r, key key0 + 4g + e); masked / out-of-range keys -> -inf
+        // (branch-free selects on scalars: no conditional writes into the accumulator vector)
+        float sv[4];
         float tmax = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int key = key0 + g * 4 + e;
-            const bool dead = (key >= lk) || (mb && mb[key]);
-            if (dead) s[e] = -INFINITY;
-            tmax = fmaxf(tmax, s[e]);
+            bool dead = key >= lk;
+            if (MASK) {
+                const unsigned char mk = mb[min(key, lk - 1)];
+                dead = dead | (mk != 0);
+            }
+            sv[e] = dead ? -INFINITY : s[e];
+            tmax = fmaxf(tmax, sv[e]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
         if (m_new != -INFINITY) {
             alpha = expf(m_run - m_new);               // m_run = -inf -> 0
 #pragma unroll
-            for (int e = 0; e < 4; ++e) p[e] = expf(s[e] - m_new);
+            for (int e = 0; e < 4; ++e) p[e] = expf(sv[e] - m_new);
         }
         l_run = l_run * alpha + (p[0] + p[1] + p[2] + p[3]);   // in-lane partial; reduced over g at the end
         m_run = m_new;
@@ -131,8 +138,12 @@ int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *k
     if (batch == 0 || lq == 0) return DZ_OK;
     DZ_CHECK_ARG(q && k && v && out, "dz_mha_core: null pointer");
     const long items = (long)batch * heads * ((lq + 15) / 16);
-    hipLaunchKernelGGL(k_mha_core, dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, key_padding_mask, batch, lq,
-                       lk, heads, scale, out);
+    if (key_padding_mask)
+        hipLaunchKernelGGL(k_mha_core<true>, dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, key_padding_mask,
+                           batch, lq, lk, heads, scale, out);
+    else
+        hipLaunchKernelGGL(k_mha_core<false>, dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, key_padding_mask,
+                           batch, lq, lk, heads, scale, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

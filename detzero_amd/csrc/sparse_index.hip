@@ -309,7 +309,7 @@ int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, in
                          uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap_out,
                          int *rank_of_input, void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(coords && bitmap && prefix && coords_out && d_m && n_cap >= 0 && cap_out >= 0,
+    DZ_CHECK_ARG((coords || n_cap == 0) && bitmap && prefix && coords_out && d_m && n_cap >= 0 && cap_out >= 0,
                  "dz_index_from_coords: null/negative argument");
     int rc = check_cells(b, d, h, w);
     if (rc) return rc;
