@@ -29,6 +29,27 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, not os.cpu_count()
+    (a container limited to a few CPUs on a many-core host otherwise oversubscribes OpenMP 10-100x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def log(*a):
+    print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -62,6 +83,8 @@ def main():
     from detzero_amd.synth import VOXEL_SIZE_01, synth_waymo_frame
     from detzero_amd import frame_parallel as fp
 
+    torch.set_num_threads(min(usable_cores(), 32))
+    log('rank', rank, 'of', world, 'usable host cores', usable_cores())
     model, cfg, info = synth_detector(VOXEL_SIZE_01, seed=0)
     model = model.to(dev)
     pipe = FramePipeline(model, info)
@@ -110,9 +133,11 @@ def main():
         results[i].copy_(g_out, non_blocking=True)
         counts[i:i + 1].copy_(g_n, non_blocking=True)
 
+    log('launch mode:', graph_note)
     for i in range(W):
         step(i % K)
     torch.cuda.synchronize()
+    log('warm-up done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,6 +156,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_boxes = counts.float().mean().item()
+    log('timed region: %d steps in %.3f s' % (K, dt))
 
     out = None
     if rank == 0:
@@ -179,12 +205,13 @@ def main():
                                'note': 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; '
                                        'algorithmic FLOP = 2*pixels*taps*Cin*Cout'}
         out['kernels'] = kern
+        log('per-kernel profile done')
         out['conv_ms_per_frame'] = round(sum(r['ms_per_frame'] for r in kern), 4)
 
     # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests.util import cpu_state_dict, oracle_detect       # oracle = checker/baseline only
-        cores = os.cpu_count() or 1
+        cores = min(usable_cores(), 32)
         torch.set_num_threads(cores)
         sd = cpu_state_dict(model)
         pts = [f.cpu().numpy() for f in frames]

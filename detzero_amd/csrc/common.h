@@ -98,6 +98,9 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *ld
 struct ScanDims { int d0, d1, d2; };
 constexpr int SCAN_WORDS_PER_THREAD = 8;
 constexpr int SCAN_CHUNK = 256 * SCAN_WORDS_PER_THREAD;
+// device fill (32-bit pattern) as a plain kernel: no memset nodes, so whole frames capture into a hipGraph
+// as kernels only
+int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream);
 size_t bitmap_scan_workspace_bytes(size_t nwords);
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,

@@ -69,67 +69,80 @@ __device__ __forceinline__ void spin(P2 c, float ac, float as, P2 &p) {
     p.x = nx; p.y = ny;
 }
 
-__device__ float rect_overlap(const float *A, const float *B) {
+// Intersection polygon vertices live in LDS (column `tid` of a [16][nthreads] array): a dynamically
+// indexed private array would be spilled to scratch memory, which we avoid in every kernel so that
+// whole frames replay from hipGraphs without a scratch segment.
+__device__ float rect_overlap(const float *A, const float *B, P2 *cp, float *ang, int ld) {
     const float adx = A[3] / 2, bdx = B[3] / 2, ady = A[4] / 2, bdy = B[4] / 2;
     const P2 ca{A[0], A[1]}, cb{B[0], B[1]};
-    P2 ac[5], bc[5];
-    ac[0] = P2{A[0] - adx, A[1] - ady}; ac[1] = P2{A[0] + adx, A[1] - ady};
-    ac[2] = P2{A[0] + adx, A[1] + ady}; ac[3] = P2{A[0] - adx, A[1] + ady};
-    bc[0] = P2{B[0] - bdx, B[1] - bdy}; bc[1] = P2{B[0] + bdx, B[1] - bdy};
-    bc[2] = P2{B[0] + bdx, B[1] + bdy}; bc[3] = P2{B[0] - bdx, B[1] + bdy};
+    P2 a0{A[0] - adx, A[1] - ady}, a1{A[0] + adx, A[1] - ady}, a2{A[0] + adx, A[1] + ady}, a3{A[0] - adx, A[1] + ady};
+    P2 b0{B[0] - bdx, B[1] - bdy}, b1{B[0] + bdx, B[1] - bdy}, b2{B[0] + bdx, B[1] + bdy}, b3{B[0] - bdx, B[1] + bdy};
     const float acs = cosf(A[6]), asn = sinf(A[6]), bcs = cosf(B[6]), bsn = sinf(B[6]);
-    for (int k = 0; k < 4; ++k) { spin(ca, acs, asn, ac[k]); spin(cb, bcs, bsn, bc[k]); }
-    ac[4] = ac[0]; bc[4] = bc[0];
+    spin(ca, acs, asn, a0); spin(ca, acs, asn, a1); spin(ca, acs, asn, a2); spin(ca, acs, asn, a3);
+    spin(cb, bcs, bsn, b0); spin(cb, bcs, bsn, b1); spin(cb, bcs, bsn, b2); spin(cb, bcs, bsn, b3);
+    const P2 ac[5] = {a0, a1, a2, a3, a0};     // constant indices only after full unrolling -> registers
+    const P2 bc[5] = {b0, b1, b2, b3, b0};
 
-    P2 cp[16];
     P2 pc{0.f, 0.f};
     int cnt = 0;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             P2 t;
             if (edge_cross(ac[i + 1], ac[i], bc[j + 1], bc[j], t)) {
-                cp[cnt] = t; pc.x = pc.x + t.x; pc.y = pc.y + t.y; ++cnt;
+                cp[cnt * ld] = t; pc.x = pc.x + t.x; pc.y = pc.y + t.y; ++cnt;
             }
         }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (corner_in_box(A, bc[k])) { pc.x = pc.x + bc[k].x; pc.y = pc.y + bc[k].y; cp[cnt++] = bc[k]; }
-        if (corner_in_box(B, ac[k])) { pc.x = pc.x + ac[k].x; pc.y = pc.y + ac[k].y; cp[cnt++] = ac[k]; }
+        if (corner_in_box(A, bc[k])) { pc.x = pc.x + bc[k].x; pc.y = pc.y + bc[k].y; cp[cnt * ld] = bc[k]; ++cnt; }
+        if (corner_in_box(B, ac[k])) { pc.x = pc.x + ac[k].x; pc.y = pc.y + ac[k].y; cp[cnt * ld] = ac[k]; ++cnt; }
     }
     pc.x /= cnt; pc.y /= cnt;   // cnt == 0 gives NaN exactly as the reference; the loops below do not run
     // bubble sort by polar angle around the centroid (angles cached; comparisons identical)
-    float ang[16];
-    for (int i = 0; i < cnt; ++i) ang[i] = atan2f(cp[i].y - pc.y, cp[i].x - pc.x);
+    for (int i = 0; i < cnt; ++i) ang[i * ld] = atan2f(cp[i * ld].y - pc.y, cp[i * ld].x - pc.x);
     for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i)
-            if (ang[i] > ang[i + 1]) {
-                const P2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
-                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const float x0 = ang[i * ld], x1 = ang[(i + 1) * ld];
+            if (x0 > x1) {
+                const P2 t = cp[i * ld]; cp[i * ld] = cp[(i + 1) * ld]; cp[(i + 1) * ld] = t;
+                ang[i * ld] = x1; ang[(i + 1) * ld] = x0;
             }
+        }
     float area = 0.f;
+    const P2 c0 = cp[0];
     for (int k = 0; k < cnt - 1; ++k) {
-        const P2 u{cp[k].x - cp[0].x, cp[k].y - cp[0].y};
-        const P2 v{cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        const P2 ck = cp[k * ld], cn = cp[(k + 1) * ld];
+        const P2 u{ck.x - c0.x, ck.y - c0.y};
+        const P2 v{cn.x - c0.x, cn.y - c0.y};
         area += cr2(u, v);
     }
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float rect_iou(const float *A, const float *B) {
+__device__ __forceinline__ float rect_iou(const float *A, const float *B, P2 *cp, float *ang, int ld) {
     const float sa = A[3] * A[4], sb = B[3] * B[4];
-    const float so = rect_overlap(A, B);
+    const float so = rect_overlap(A, B, cp, ang, ld);
     return so / fmaxf(sa + sb - so, GEO_EPS);
 }
+
+constexpr int PAIR_THREADS = 128;
 
 template <bool IOU>
 __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__restrict__ b, int nb,
                            float *__restrict__ out) {
+    __shared__ P2 cp_s[16 * PAIR_THREADS];
+    __shared__ float ang_s[16 * PAIR_THREADS];
     const long total = (long)na * nb;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int i = (int)(idx / nb), j = (int)(idx % nb);
         float A[7], B[7];
+#pragma unroll
         for (int q = 0; q < 7; ++q) { A[q] = a[i * 7 + q]; B[q] = b[j * 7 + q]; }
-        out[idx] = IOU ? rect_iou(A, B) : rect_overlap(A, B);
+        out[idx] = IOU ? rect_iou(A, B, cp_s + threadIdx.x, ang_s + threadIdx.x, PAIR_THREADS)
+                       : rect_overlap(A, B, cp_s + threadIdx.x, ang_s + threadIdx.x, PAIR_THREADS);
     }
 }
 
@@ -143,6 +156,8 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (rb * 64 >= n) return;
     __shared__ float cbx[64 * 7];
+    __shared__ P2 cp_s[16 * 64];
+    __shared__ float ang_s[16 * 64];
     const int col_size = min(n - cb * 64, 64);
     const int t = threadIdx.x;
     const int i = rb * 64 + t;
@@ -155,11 +170,16 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes
     __syncthreads();
     if (i < n) {
         float A[7];
+#pragma unroll
         for (int q = 0; q < 7; ++q) A[q] = boxes[i * 7 + q];
         unsigned long long bits = 0ull;
         const int start = (rb == cb) ? t + 1 : 0;
-        for (int j = start; j < col_size; ++j)
-            if (rect_iou(A, cbx + j * 7) > thr) bits |= 1ull << j;
+        for (int j = start; j < col_size; ++j) {
+            float Bq[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) Bq[q] = cbx[j * 7 + q];
+            if (rect_iou(A, Bq, cp_s + t, ang_s + t, 64) > thr) bits |= 1ull << j;
+        }
         mask[(size_t)i * col_blocks + cb] = bits;
     }
 }
@@ -430,7 +450,7 @@ int dz_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *
     DZ_CHECK_ARG(na >= 0 && nb >= 0, "dz_boxes_overlap_bev: negative size");
     if (na == 0 || nb == 0) return DZ_OK;
     DZ_CHECK_ARG(a && b && out, "dz_boxes_overlap_bev: null pointer");
-    hipLaunchKernelGGL(k_pairwise<false>, dim3(stream_grid((long)na * nb, 128)), dim3(128), 0, stream, a, na, b, nb, out);
+    hipLaunchKernelGGL(k_pairwise<false>, dim3(stream_grid((long)na * nb, PAIR_THREADS)), dim3(PAIR_THREADS), 0, stream, a, na, b, nb, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -440,7 +460,7 @@ int dz_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out,
     DZ_CHECK_ARG(na >= 0 && nb >= 0, "dz_boxes_iou_bev: negative size");
     if (na == 0 || nb == 0) return DZ_OK;
     DZ_CHECK_ARG(a && b && out, "dz_boxes_iou_bev: null pointer");
-    hipLaunchKernelGGL(k_pairwise<true>, dim3(stream_grid((long)na * nb, 128)), dim3(128), 0, stream, a, na, b, nb, out);
+    hipLaunchKernelGGL(k_pairwise<true>, dim3(stream_grid((long)na * nb, PAIR_THREADS)), dim3(PAIR_THREADS), 0, stream, a, na, b, nb, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -454,7 +474,7 @@ int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, 
                    void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(keep && d_num_keep && n_cap >= 0 && post_max >= 0, "dz_nms_rotated: bad argument");
-    if (n_cap == 0) { DZ_HIP(hipMemsetAsync(d_num_keep, 0, sizeof(int), stream)); return DZ_OK; }
+    if (n_cap == 0) return fill_u32(d_num_keep, 0u, 1, stream);
     DZ_CHECK_ARG(boxes && ws, "dz_nms_rotated: null pointer");
     DZ_CHECK_ARG(n_cap <= 4096, "dz_nms_rotated: n_cap %d > 4096 (NMS_PRE_MAXSIZE of the reference configs)", n_cap);
     if (ws_bytes < dz_nms_workspace_bytes(n_cap)) { set_error("dz_nms_rotated: workspace too small"); return DZ_ERR_WORKSPACE; }

@@ -24,6 +24,23 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
+__global__ void k_fill_u32(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    const size_t n4 = n / 4;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p4[i] = v4;
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream) {
+    if (nwords == 0) return DZ_OK;
+    if (((uintptr_t)ptr & 15u) != 0) { set_error("fill_u32: pointer not 16-byte aligned"); return DZ_ERR_INVALID; }
+    hipLaunchKernelGGL(k_fill_u32, dim3(stream_grid((long)(nwords / 4 + 1), 256)), dim3(256), 0, stream,
+                       reinterpret_cast<uint32_t *>(ptr), value, nwords);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // bitmap scan
 // ------------------------------------------------------------------------------------------
@@ -314,7 +331,8 @@ int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, in
     int rc = check_cells(b, d, h, w);
     if (rc) return rc;
     const size_t nwords = dz_index_words(b, d, h, w);
-    DZ_HIP(hipMemsetAsync(bitmap, 0, nwords * sizeof(uint32_t), stream));
+    rc = fill_u32(bitmap, 0u, nwords, stream);
+    if (rc) return rc;
     if (n_cap > 0)
         hipLaunchKernelGGL(k_set_bits_from_coords, dim3(stream_grid(n_cap, 256)), dim3(256), 0, stream, coords,
                            d_n, n_cap, b, d, h, w, bitmap);
@@ -339,7 +357,8 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
     int rc = check_cells(b, g.od, g.oh, g.ow);
     if (rc) return rc;
     const size_t nwords = dz_index_words(b, g.od, g.oh, g.ow);
-    DZ_HIP(hipMemsetAsync(bitmap_out, 0, nwords * sizeof(uint32_t), stream));
+    rc = fill_u32(bitmap_out, 0u, nwords, stream);
+    if (rc) return rc;
     if (cap_in > 0)
         hipLaunchKernelGGL(k_mark_outputs, dim3(stream_grid(cap_in, 256)), dim3(256), 0, stream, coords_in, d_m_in,
                            cap_in, g, bitmap_out);

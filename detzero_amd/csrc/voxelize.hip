@@ -231,7 +231,7 @@ int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, c
     DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_hard: bad geometry");
     const size_t cells = (size_t)g.g[0] * g.g[1] * g.g[2];
     if (cells >= 0xFFFFFFFFull) { set_error("dz_voxelize_hard: grid too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
-    if (n == 0) { DZ_HIP(hipMemsetAsync(d_num_voxels, 0, sizeof(int), stream)); return DZ_OK; }
+    if (n == 0) return fill_u32(d_num_voxels, 0u, 1, stream);
     DZ_CHECK_ARG(points, "dz_voxelize_hard: null points");
     const size_t nwords = dz_index_words(1, g.g[2], g.g[1], g.g[0]);
     HardWs w = carve_hard(ws, n, nwords, max_points);
@@ -239,12 +239,13 @@ int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, c
     const size_t pt_words = align_up(((size_t)n + 31) / 32, 8);
     const int cap = n;  // a frame of n points opens at most n voxels
 
-    DZ_HIP(hipMemsetAsync(w.bitmap, 0, nwords * 4, stream));
-    DZ_HIP(hipMemsetAsync(w.pt_bitmap, 0, pt_words * 4, stream));
-    DZ_HIP(hipMemsetAsync(w.mins, 0x7f, (size_t)max_points * cap * 4, stream));
+    int rc = fill_u32(w.bitmap, 0u, nwords, stream);
+    if (!rc) rc = fill_u32(w.pt_bitmap, 0u, pt_words, stream);
+    if (!rc) rc = fill_u32(w.mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
+    if (rc) return rc;
     const int grid_n = stream_grid(n, 256);
     hipLaunchKernelGGL(k_hard_keys, dim3(grid_n), dim3(256), 0, stream, points, n, c, g, w.keys, w.bitmap);
-    int rc = bitmap_scan(w.bitmap, nwords, w.prefix, w.d_m, 0, ScanDims{g.g[2], g.g[1], g.g[0]}, w.canon_coords, cap,
+    rc = bitmap_scan(w.bitmap, nwords, w.prefix, w.d_m, 0, ScanDims{g.g[2], g.g[1], g.g[0]}, w.canon_coords, cap,
                          w.scan_ws, w.scan_ws_bytes, stream);
     if (rc) return rc;
     for (int r = 0; r < max_points; ++r)
@@ -313,17 +314,16 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
     uint32_t *keys = (uint32_t *)(base + o_keys), *bitmap = (uint32_t *)(base + o_bm), *prefix = (uint32_t *)(base + o_pf);
     int *counts = (int *)(base + o_cnt);
 
-    DZ_HIP(hipMemsetAsync(bitmap, 0, nwords * 4, stream));
-    if (cap > 0) {
-        DZ_HIP(hipMemsetAsync(feats, 0, (size_t)cap * c * 4, stream));
-        DZ_HIP(hipMemsetAsync(counts, 0, (size_t)cap * 4, stream));
-    }
+    int rc = fill_u32(bitmap, 0u, nwords, stream);
+    if (!rc && cap > 0) rc = fill_u32(feats, 0u, (size_t)cap * c, stream);
+    if (!rc && cap > 0) rc = fill_u32(counts, 0u, (size_t)cap, stream);
+    if (rc) return rc;
     if (n > 0) {
         DZ_CHECK_ARG(points_b, "dz_voxelize_dynamic_mean: null points");
         hipLaunchKernelGGL(k_dyn_keys, dim3(stream_grid(n, 256)), dim3(256), 0, stream, points_b, n, c + 1, g, batch, keys,
                            bitmap);
     }
-    int rc = bitmap_scan(bitmap, nwords, prefix, d_num_voxels, 1, ScanDims{g.g[0], g.g[1], g.g[2]}, coords_bzyx, cap,
+    rc = bitmap_scan(bitmap, nwords, prefix, d_num_voxels, 1, ScanDims{g.g[0], g.g[1], g.g[2]}, coords_bzyx, cap,
                          base + o_sw, sw_bytes, stream);
     if (rc) return rc;
     if (n > 0 && cap > 0) {
