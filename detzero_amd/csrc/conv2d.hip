@@ -15,8 +15,8 @@ namespace dz {
 
 template <class T>
 __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) {
-    __shared__ __attribute__((aligned(16))) float As[T::AS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[T::BS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
+    float *const As0 = smem, *const Bs0 = smem + 2 * T::AS_FLOATS;     // [2][AS], [2][BS]
     __shared__ int in_pix[T::BM];    // input pixel index of the (0,0) tap, -1 past the end
     __shared__ int out_pix[T::BM];   // output pixel index
 
@@ -57,27 +57,24 @@ __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) 
 
     Stage<T> st;
     int tap = 0, kc = 0;
-    {
+    auto issue = [&]() {   // loads of chunk (tap, kc) into registers
         const long add = (long)((tap / p.kw) * p.in_wp + (tap % p.kw)) * p.in_cstride + cbase + (long)kc * T::KC;
         load_a<T>(st, p.in, in_pix, p.in_cstride, add, tid);
         load_b<T>(st, wg + ((size_t)tap * p.cin + (size_t)kc * T::KC) * p.cout_pad, p.cout_pad, n0, tid);
-    }
-    store_stage<T>(st, As, Bs, tid);
+    };
+    auto advance = [&]() { if (++kc == kchunks) { kc = 0; ++tap; } };
+    issue();
+    store_stage<T>(st, As0, Bs0, tid);
     __syncthreads();
+    if (nchunks > 1) { advance(); issue(); }
     for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1 < nchunks);
-        if (more) {
-            if (++kc == kchunks) { kc = 0; ++tap; }
-            const long add = (long)((tap / p.kw) * p.in_wp + (tap % p.kw)) * p.in_cstride + cbase + (long)kc * T::KC;
-            load_a<T>(st, p.in, in_pix, p.in_cstride, add, tid);
-            load_b<T>(st, wg + ((size_t)tap * p.cin + (size_t)kc * T::KC) * p.cout_pad, p.cout_pad, n0, tid);
+        const int cur = c & 1;
+        mma_chunk<T>(As0 + cur * T::AS_FLOATS, Bs0 + cur * T::BS_FLOATS, acc, wm, wn, lane);
+        if (c + 1 < nchunks) {
+            store_stage<T>(st, As0 + (cur ^ 1) * T::AS_FLOATS, Bs0 + (cur ^ 1) * T::BS_FLOATS, tid);
+            if (c + 2 < nchunks) { advance(); issue(); }
         }
-        mma_chunk<T>(As, Bs, acc, wm, wn, lane);
         __syncthreads();
-        if (more) {
-            store_stage<T>(st, As, Bs, tid);
-            __syncthreads();
-        }
     }
 
     const int r = lane & 15, g = lane >> 4;
@@ -126,9 +123,11 @@ static ConvVariant conv2d_select(const dz_conv2d_desc &p) {
     }
     if (p.cin % 32 == 0) {
         if (p.cout_pad % 64 == 0) {
-            // pick the M tile so that the grid has at least ~2 workgroups per CU (256 CUs)
+            // pick the M tile so that the grid has >= 4 workgroups per CU (256 CUs): with fewer, the last
+            // partial round of workgroups leaves most of the chip idle (measured: 554 blocks -> 75 TF/s,
+            // 1662 blocks -> 97 TF/s with the same tile)
             const long blocks128 = (long)ceil_div(m_total, 128) * (p.cout_pad / 64) * p.groups;
-            return blocks128 >= 512 ? CV_128_64_32 : CV_64_64_32;
+            return blocks128 >= 1024 ? CV_128_64_32 : CV_64_64_32;
         }
         if (p.cout_pad % 32 == 0) return CV_128_32_32;
         if (p.cout_pad % 16 == 0) return CV_128_16_32;

@@ -149,38 +149,47 @@ __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__r
 // ------------------------------------------------------------------------------------------
 // rotated NMS
 // ------------------------------------------------------------------------------------------
-// mask[i][cb] bit j: iou(box i, box cb*64+j) > thr, only for j > i (upper triangle)
+// mask[i][cb] bit j: iou(box i, box cb*64+j) > thr, only for j > i (upper triangle).
+// One wavefront per (16 rows, 64 columns): lane = column box, the wave walks its 16 row boxes and
+// every lane evaluates ONE rotated IoU per step; __ballot packs the 64 verdicts into the mask word.
+// Pairs whose circumscribed circles are more than 5 cm apart cannot touch (the reference's corner
+// test has a 1 cm margin), so their IoU is exactly 0 and the polygon clipping is skipped.
+constexpr int NMS_ROWS_PER_WAVE = 16;
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, const int *__restrict__ d_n, int n_cap,
                                                  float thr, unsigned long long *__restrict__ mask, int col_blocks) {
     const int n = d_n ? min(*d_n, n_cap) : n_cap;
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    if (rb * 64 >= n) return;
-    __shared__ float cbx[64 * 7];
+    const int cb = blockIdx.x;
+    const int rb = blockIdx.y / (64 / NMS_ROWS_PER_WAVE), part = blockIdx.y % (64 / NMS_ROWS_PER_WAVE);
+    const int row0 = rb * 64 + part * NMS_ROWS_PER_WAVE;
+    if (row0 >= n) return;
     __shared__ P2 cp_s[16 * 64];
     __shared__ float ang_s[16 * 64];
-    const int col_size = min(n - cb * 64, 64);
     const int t = threadIdx.x;
-    const int i = rb * 64 + t;
-    if (cb < rb || col_size <= 0) {       // lower triangle / beyond n: nothing can be suppressed there
-        if (i < n) mask[(size_t)i * col_blocks + cb] = 0ull;
+    const int rows = min(NMS_ROWS_PER_WAVE, n - row0);
+    const int col = cb * 64 + t;
+    if (cb < rb || cb * 64 >= n) {        // lower triangle / beyond n: nothing can be suppressed there
+        if (t < rows) mask[(size_t)(row0 + t) * col_blocks + cb] = 0ull;
         return;
     }
-    if (t < col_size)
-        for (int q = 0; q < 7; ++q) cbx[t * 7 + q] = boxes[(cb * 64 + t) * 7 + q];
-    __syncthreads();
-    if (i < n) {
+    float B[7];
+    const bool col_ok = col < n;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) B[q] = col_ok ? boxes[col * 7 + q] : 0.f;
+    const float rb2 = 0.25f * (B[3] * B[3] + B[4] * B[4]);          // squared half diagonal
+    const float rbr = sqrtf(rb2);
+    for (int i = 0; i < rows; ++i) {
+        const int row = row0 + i;
         float A[7];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) A[q] = boxes[i * 7 + q];
-        unsigned long long bits = 0ull;
-        const int start = (rb == cb) ? t + 1 : 0;
-        for (int j = start; j < col_size; ++j) {
-            float Bq[7];
-#pragma unroll
-            for (int q = 0; q < 7; ++q) Bq[q] = cbx[j * 7 + q];
-            if (rect_iou(A, Bq, cp_s + t, ang_s + t, 64) > thr) bits |= 1ull << j;
+        for (int q = 0; q < 7; ++q) A[q] = boxes[row * 7 + q];       // wave-uniform -> scalar loads
+        bool hit = false;
+        if (col_ok && col > row) {
+            const float dx = A[0] - B[0], dy = A[1] - B[1];
+            const float reach = sqrtf(0.25f * (A[3] * A[3] + A[4] * A[4])) + rbr + 0.05f;
+            if (dx * dx + dy * dy <= reach * reach) hit = rect_iou(A, B, cp_s + t, ang_s + t, 64) > thr;
         }
-        mask[(size_t)i * col_blocks + cb] = bits;
+        const unsigned long long bits = __ballot(hit);
+        if (t == 0) mask[(size_t)row * col_blocks + cb] = bits;
     }
 }
 
@@ -480,7 +489,8 @@ int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, 
     if (ws_bytes < dz_nms_workspace_bytes(n_cap)) { set_error("dz_nms_rotated: workspace too small"); return DZ_ERR_WORKSPACE; }
     const int cb = (n_cap + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
-    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, stream, boxes, d_n, n_cap, thresh, mask, cb);
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb * (64 / NMS_ROWS_PER_WAVE)), dim3(64), 0, stream, boxes, d_n, n_cap, thresh,
+                       mask, cb);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(256), (size_t)64 * cb * sizeof(unsigned long long), stream, mask, d_n,
                        n_cap, cb, post_max, keep, d_num_keep);
     DZ_LAUNCH_CHECK();

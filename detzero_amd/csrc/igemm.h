@@ -14,9 +14,10 @@
 // kappa = 16q + 4g + e on BOTH operands (any bijection of k is a valid GEMM), which is what lets
 // A come from a single 16-byte LDS read.
 //
-// Global->LDS staging is register-staged and software pipelined: the loads of chunk i+1 are
-// issued before the MFMAs of chunk i and written to LDS after them, so HBM/L2 latency hides
-// behind 32-128 MFMAs per wave even at 1-2 workgroups per CU.
+// Global->LDS staging is register-staged, software pipelined and DOUBLE-BUFFERED in LDS: while the
+// MFMAs of chunk i read buffer i&1, the loads of chunk i+1 (issued one chunk earlier) land in
+// registers and are written to buffer (i+1)&1, so there is ONE barrier per chunk and HBM/L2 latency
+// hides behind 32-128 MFMAs per wave even at 1-2 workgroups per CU.
 #pragma once
 #include "common.h"
 
@@ -36,8 +37,9 @@ struct TileCfg {
     static constexpr int B_F4 = KC * (BN / 4);            // float4 elements of the B chunk
     static constexpr int A_PER_THREAD = (A_F4 + THREADS - 1) / THREADS;
     static constexpr int B_PER_THREAD = (B_F4 + THREADS - 1) / THREADS;
-    static constexpr int AS_FLOATS = BM * LDA;
+    static constexpr int AS_FLOATS = BM * LDA;            // one buffer
     static constexpr int BS_FLOATS = KC * LDB;
+    static constexpr int LDS_FLOATS = 2 * (AS_FLOATS + BS_FLOATS);   // double buffered
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "tile must split into 16x16 fragments");
     static_assert(KC % 16 == 0, "KC must be a multiple of the 16-deep k slice");

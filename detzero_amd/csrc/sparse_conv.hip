@@ -32,8 +32,8 @@ struct SpConvArgs {
 
 template <class T>
 __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[T::AS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[T::BS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
+    float *const As0 = smem, *const Bs0 = smem + 2 * T::AS_FLOATS;     // [2][AS], [2][BS]
     __shared__ int nbr_s[KVOL_MAX * T::BM];
     __shared__ unsigned int mask_s;
 
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
     const int m = min(*a.d_m_out, a.cap);
     const int ntiles = (m + T::BM - 1) / T::BM;
     const int kchunks = a.cin / T::KC;
+    const int n0 = blockIdx.y * T::BN;          // column tile (Cout may be split over blockIdx.y)
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * T::BM;
@@ -71,27 +72,25 @@ __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
             // chunk iterator: (current tap = lowest set bit of `rem`, channel chunk kc)
             unsigned int rem = taps;
             int tap = __ffs((int)rem) - 1, kc = 0;
-            load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
-            load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, 0, tid);
-            store_stage<T>(st, As, Bs, tid);
+            auto issue = [&]() {
+                load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
+                load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, n0, tid);
+            };
+            auto advance = [&]() {
+                if (++kc == kchunks) { kc = 0; rem &= rem - 1; tap = __ffs((int)rem) - 1; }
+            };
+            issue();
+            store_stage<T>(st, As0, Bs0, tid);
             __syncthreads();
+            if (nchunks > 1) { advance(); issue(); }
             for (int c = 0; c < nchunks; ++c) {
-                const bool more = (c + 1 < nchunks);
-                if (more) {
-                    if (++kc == kchunks) {
-                        kc = 0;
-                        rem &= rem - 1;
-                        tap = __ffs((int)rem) - 1;
-                    }
-                    load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
-                    load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, 0, tid);
+                const int cur = c & 1;
+                mma_chunk<T>(As0 + cur * T::AS_FLOATS, Bs0 + cur * T::BS_FLOATS, acc, wm, wn, lane);
+                if (c + 1 < nchunks) {
+                    store_stage<T>(st, As0 + (cur ^ 1) * T::AS_FLOATS, Bs0 + (cur ^ 1) * T::BS_FLOATS, tid);
+                    if (c + 2 < nchunks) { advance(); issue(); }
                 }
-                mma_chunk<T>(As, Bs, acc, wm, wn, lane);
                 __syncthreads();
-                if (more) {
-                    store_stage<T>(st, As, Bs, tid);
-                    __syncthreads();
-                }
             }
         }
 
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
         const int r = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int nt = 0; nt < T::NT; ++nt) {
-            const int col = wn * T::NT * 16 + nt * 16 + r;
+            const int col = n0 + wn * T::NT * 16 + nt * 16 + r;
             const float sc = a.scale ? a.scale[col] : 1.f;
             const float sh = a.shift ? a.shift[col] : 0.f;
 #pragma unroll
@@ -141,7 +140,7 @@ static int launch_spconv(const SpConvArgs &a, hipStream_t stream) {
     int grid = ceil_div(a.cap, T::BM);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_spconv<T>, dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_spconv<T>, dim3(grid, a.cout / T::BN), dim3(256), 0, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -167,8 +166,10 @@ int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int ca
     if (cin == 32 && cout == 32) return launch_spconv<TileCfg<128, 32, 32, 4, 1>>(a, stream);
     if (cin == 32 && cout == 64) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
     if (cin == 64 && cout == 64) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
-    if (cin == 64 && cout == 128) return launch_spconv<TileCfg<64, 128, 32, 2, 2>>(a, stream);
-    if (cin == 128 && cout == 128) return launch_spconv<TileCfg<64, 128, 32, 2, 2>>(a, stream);
+    // 128-channel levels have only ~20k sites (~330 row tiles for 256 CUs): split Cout over two
+    // workgroups so that every CU holds >= 2 of them
+    if (cin == 64 && cout == 128) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
+    if (cin == 128 && cout == 128) return launch_spconv<TileCfg<64, 64, 32, 2, 2>>(a, stream);
     set_error("dz_spconv_forward: unsupported channels cin=%d cout=%d", cin, cout);
     return DZ_ERR_UNSUPPORTED;
 }
@@ -178,7 +179,7 @@ const char *dz_spconv_variant(int cin, int cout) {
     if (cin == 16 && cout == 32) return "k_spconv<128x32x16>";
     if (cin == 32 && cout == 32) return "k_spconv<128x32x32>";
     if ((cin == 32 || cin == 64) && cout == 64) return "k_spconv<64x64x32>";
-    if ((cin == 64 || cin == 128) && cout == 128) return "k_spconv<64x128x32>";
+    if ((cin == 64 || cin == 128) && cout == 128) return "k_spconv<64x64x32>(N-split)";
     return "none";
 }
 

@@ -79,48 +79,82 @@ __global__ __launch_bounds__(256) void k_scan_partials(uint32_t *__restrict__ pa
     if (threadIdx.x == 0) *d_total = (int)carry;
 }
 
+// exact n / d, n % d for 32-bit n through one fp64 multiply + one fix-up (d > 0)
+struct FastDiv { uint32_t d; double inv; };
+__device__ __forceinline__ uint32_t fast_divmod(uint32_t n, const FastDiv f, uint32_t &rem) {
+    uint32_t q = (uint32_t)__double2uint_rz((double)n * f.inv);
+    uint32_t r = n - q * f.d;
+    if ((int32_t)r < 0) { --q; r += f.d; }
+    else if (r >= f.d) { ++q; r -= f.d; }
+    rem = r;
+    return q;
+}
+struct ScanDecode { FastDiv d0, d1, d2; };
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ bitmap, size_t nwords,
                                                    const uint32_t *__restrict__ partial,
-                                                   uint32_t *__restrict__ prefix, ScanDims dims,
+                                                   uint32_t *__restrict__ prefix, ScanDecode dec,
                                                    int *__restrict__ coords_out, int cap_out) {
     __shared__ uint32_t lds[4];
+    __shared__ __attribute__((aligned(16))) uint32_t w_s[SCAN_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint32_t p_s[SCAN_CHUNK];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_WORDS_PER_THREAD;
     uint32_t wv[SCAN_WORDS_PER_THREAD];
+    const bool full = base + SCAN_WORDS_PER_THREAD <= nwords;      // nwords is a multiple of 8: all or nothing
+    if (full) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(bitmap + base);
+        const uint4 b = *reinterpret_cast<const uint4 *>(bitmap + base + 4);
+        wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w; wv[4] = b.x; wv[5] = b.y; wv[6] = b.z; wv[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) wv[j] = (base + j < nwords) ? bitmap[base + j] : 0u;
+    }
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) {
-        wv[j] = (base + j < nwords) ? bitmap[base + j] : 0u;
-        s += __popc(wv[j]);
-    }
+    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) s += __popc(wv[j]);
     uint32_t total;
     uint32_t run = block_excl_scan_256(s, lds, total) + partial[blockIdx.x];
+    uint32_t pv[SCAN_WORDS_PER_THREAD];
 #pragma unroll
+    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) { pv[j] = run; run += __popc(wv[j]); }
+    if (full) {
+        *reinterpret_cast<uint4 *>(prefix + base) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+        *reinterpret_cast<uint4 *>(prefix + base + 4) = make_uint4(pv[4], pv[5], pv[6], pv[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) if (base + j < nwords) prefix[base + j] = pv[j];
+    }
+    if (MODE < 0 || total == 0) return;
+    // coordinate emission: words are re-distributed round-robin over the threads (dense clusters of
+    // set bits are consecutive words; 8 consecutive words per thread serialised them on one lane)
+    uint32_t *wl = w_s + threadIdx.x * SCAN_WORDS_PER_THREAD, *pl = p_s + threadIdx.x * SCAN_WORDS_PER_THREAD;
+    *reinterpret_cast<uint4 *>(wl) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    *reinterpret_cast<uint4 *>(wl + 4) = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+    *reinterpret_cast<uint4 *>(pl) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<uint4 *>(pl + 4) = make_uint4(pv[4], pv[5], pv[6], pv[7]);
+    __syncthreads();
+#pragma unroll 1
     for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) {
-        if (base + j < nwords) prefix[base + j] = run;
-        if (MODE >= 0) {
-            uint32_t word = wv[j];
-            uint32_t r = run;
-            while (word) {
-                const int bit = __ffs((int)word) - 1;
-                word &= word - 1;
-                if ((int)r < cap_out) {
-                    const uint32_t key = (uint32_t)((base + j) << 5) + (uint32_t)bit;
-                    const uint32_t c2 = key % (uint32_t)dims.d2;
-                    const uint32_t t1 = key / (uint32_t)dims.d2;
-                    const uint32_t c1 = t1 % (uint32_t)dims.d1;
-                    const uint32_t t0 = t1 / (uint32_t)dims.d1;
-                    const uint32_t c0 = t0 % (uint32_t)dims.d0;
-                    const uint32_t b = t0 / (uint32_t)dims.d0;
-                    int4 o;
-                    if (MODE == 0) o = make_int4((int)b, (int)c0, (int)c1, (int)c2);   // [b,z,y,x]
-                    else o = make_int4((int)b, (int)c2, (int)c1, (int)c0);             // key (x,y,z) -> [b,z,y,x]
-                    reinterpret_cast<int4 *>(coords_out)[r] = o;
-                }
-                ++r;
+        const int idx = threadIdx.x + 256 * j;
+        uint32_t word = w_s[idx];
+        uint32_t r = p_s[idx];
+        const uint32_t key0 = (uint32_t)(((size_t)blockIdx.x * SCAN_CHUNK + idx) << 5);
+        while (word) {
+            const int bit = __ffs((int)word) - 1;
+            word &= word - 1;
+            if ((int)r < cap_out) {
+                uint32_t c2, c1, c0;
+                const uint32_t t1 = fast_divmod(key0 + (uint32_t)bit, dec.d2, c2);
+                const uint32_t t0 = fast_divmod(t1, dec.d1, c1);
+                const uint32_t b = fast_divmod(t0, dec.d0, c0);
+                int4 o;
+                if (MODE == 0) o = make_int4((int)b, (int)c0, (int)c1, (int)c2);   // [b,z,y,x]
+                else o = make_int4((int)b, (int)c2, (int)c1, (int)c0);             // key (x,y,z) -> [b,z,y,x]
+                reinterpret_cast<int4 *>(coords_out)[r] = o;
             }
+            ++r;
         }
-        run += __popc(wv[j]);
     }
 }
 
@@ -138,17 +172,21 @@ int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_
     }
     const int nblocks = (int)((nwords + SCAN_CHUNK - 1) / SCAN_CHUNK);
     uint32_t *partial = reinterpret_cast<uint32_t *>(ws);
+    ScanDecode dec;
+    dec.d0 = FastDiv{(uint32_t)(dims.d0 > 0 ? dims.d0 : 1), 1.0 / (double)(dims.d0 > 0 ? dims.d0 : 1)};
+    dec.d1 = FastDiv{(uint32_t)(dims.d1 > 0 ? dims.d1 : 1), 1.0 / (double)(dims.d1 > 0 ? dims.d1 : 1)};
+    dec.d2 = FastDiv{(uint32_t)(dims.d2 > 0 ? dims.d2 : 1), 1.0 / (double)(dims.d2 > 0 ? dims.d2 : 1)};
     hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
     if (mode == 0)
         hipLaunchKernelGGL(k_scan_down<0>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dims, coords_out, cap_out);
+                           prefix, dec, coords_out, cap_out);
     else if (mode == 1)
         hipLaunchKernelGGL(k_scan_down<1>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dims, coords_out, cap_out);
+                           prefix, dec, coords_out, cap_out);
     else
         hipLaunchKernelGGL(k_scan_down<-1>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dims, coords_out, cap_out);
+                           prefix, dec, coords_out, cap_out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -214,7 +252,10 @@ __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__r
                     const int wx = nx / g.s[2];
                     if (wx >= g.ow) continue;
                     const uint32_t key = (uint32_t)(((c.x * g.od + wz) * g.oh + wy) * g.ow + wx);
-                    atomicOr(&bitmap_out[key >> 5], 1u << (key & 31u));
+                    // ~8 inputs feed every output: test before the atomic (a stale read only costs a
+                    // redundant atomicOr)
+                    const uint32_t bit = 1u << (key & 31u);
+                    if (!(__builtin_nontemporal_load(&bitmap_out[key >> 5]) & bit)) atomicOr(&bitmap_out[key >> 5], bit);
                 }
             }
         }

@@ -1,20 +1,36 @@
 #!/bin/bash
-# One GPU-box session: full gpu test-suite (single process, as the driver runs it), smoke, bench, rocprofv3.
+# One GPU-box session: gpu test-suite (single process, as the driver runs it), smoke, bench, rocprofv3.
+# usage: tools/gpu_round.sh [quick|full]   (quick: no PMC passes, no eager bench)
+MODE=${1:-full}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
-echo "==== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 2>&1 | tail -8
+echo "==== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 2>&1 | tail -15
 echo "==== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-echo "==== bench (graph)"; timeout 600 python bench.py --steps 100 --warmup 10 2> gpurun_out/bench_graph.err | tee gpurun_out/bench_graph.json | cut -c1-900; tail -8 gpurun_out/bench_graph.err
-echo "==== bench (eager)"; timeout 300 python bench.py --steps 50 --warmup 5 --no-graph --no-cpu-baseline 2> gpurun_out/bench_eager.err | tee gpurun_out/bench_eager.json | cut -c1-400
-echo "==== rocprofv3 kernel-trace stats (eager, 20 steps)"
+echo "==== bench (graph)"; timeout 600 python bench.py --steps 100 --warmup 10 2> gpurun_out/bench_graph.err | tee gpurun_out/bench_graph.json | cut -c1-700; tail -4 gpurun_out/bench_graph.err
+python - <<'PY'
+import json
+try:
+    d = json.load(open('gpurun_out/bench_graph.json'))
+    print('value', d['value'], 'ms', d['ms_per_step'], 'cpu', d.get('cpu_baseline', {}).get('value'))
+    for k in d['kernels']:
+        print('  %-32s x%-5.1f avg %8.2f us  %7.3f ms/frame  %6.2f TF/s  %7.1f GB/s' % (k['kernel'], k['launches_per_frame'], k['avg_us'], k['ms_per_frame'], k['tflops'], k['algorithmic_gbs']))
+except Exception as e:
+    print('no bench json', e)
+PY
+if [ "$MODE" = "full" ]; then
+echo "==== bench (eager)"; timeout 300 python bench.py --steps 50 --warmup 5 --no-graph --no-cpu-baseline 2> gpurun_out/bench_eager.err | tee gpurun_out/bench_eager.json | cut -c1-300
+fi
+echo "==== rocprofv3 kernel-trace (eager, 20 steps)"
+rm -rf gpurun_out/prof/trace
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/trace_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-ls -R gpurun_out/prof/trace | head -20
-f=$(find gpurun_out/prof/trace -name "*kernel_stats*.csv" | head -1); echo "stats file: $f"; head -40 "$f" | cut -c1-200
-echo "==== rocprofv3 pmc FETCH_SIZE"
-cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_fetch -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_fetch_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-echo "==== rocprofv3 pmc WRITE_SIZE"
-cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_write -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_write_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-find gpurun_out/prof -name "*.csv" | head; du -sh gpurun_out/prof
-# keep the merged output small: drop raw traces > 20 MB
+python tools/rocpd_summary.py gpurun_out/prof/trace/bench_results.db | head -32
+if [ "$MODE" = "full" ]; then
+for c in FETCH_SIZE WRITE_SIZE; do
+echo "==== rocprofv3 pmc $c"
+rm -rf gpurun_out/prof/pmc_$c
+cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$c -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_${c}_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
+python tools/rocpd_summary.py gpurun_out/prof/pmc_$c/bench_results.db | sed -n '/PMC/,$p' | head -12
+done
+fi
 find gpurun_out/prof -size +20M -delete
