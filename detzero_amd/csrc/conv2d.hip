@@ -55,14 +55,34 @@ __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) 
     const float *wg = p.w + (size_t)grp * taps * p.cin * p.cout_pad;
     const long cbase = p.in_coff + (long)grp * p.cin;
 
+    // per-thread A row pointers (tap (0,0), channel chunk 0), fixed for the whole tile
+    const float *rowp[T::A_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < T::A_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        rowp[i] = nullptr;
+        if (T::A_F4 % T::THREADS == 0 || idx < T::A_F4) {
+            const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
+            const int ip = in_pix[rr];
+            if (ip >= 0) rowp[i] = p.in + (long)ip * p.in_cstride + cbase + q * 4;
+        }
+    }
     Stage<T> st;
-    int tap = 0, kc = 0;
-    auto issue = [&]() {   // loads of chunk (tap, kc) into registers
-        const long add = (long)((tap / p.kw) * p.in_wp + (tap % p.kw)) * p.in_cstride + cbase + (long)kc * T::KC;
-        load_a<T>(st, p.in, in_pix, p.in_cstride, add, tid);
-        load_b<T>(st, wg + ((size_t)tap * p.cin + (size_t)kc * T::KC) * p.cout_pad, p.cout_pad, n0, tid);
+    int ky = 0, kx = 0, kc = 0;          // chunk iterator without divisions
+    const float *wp = wg;                 // weight slice of the current chunk
+    long aoff = 0;                        // element offset of the current (tap, chunk) relative to rowp
+    auto issue = [&]() {
+        load_a_ptr<T>(st, rowp, aoff);
+        load_b<T>(st, wp, p.cout_pad, n0, tid);
     };
-    auto advance = [&]() { if (++kc == kchunks) { kc = 0; ++tap; } };
+    auto advance = [&]() {
+        wp += (size_t)T::KC * p.cout_pad;
+        if (++kc == kchunks) {
+            kc = 0;
+            if (++kx == p.kw) { kx = 0; ++ky; }
+        }
+        aoff = (long)(ky * p.in_wp + kx) * p.in_cstride + (long)kc * T::KC;
+    };
     issue();
     store_stage<T>(st, As0, Bs0, tid);
     __syncthreads();
@@ -111,10 +131,16 @@ static int launch_conv(const dz_conv2d_desc &p, hipStream_t stream) {
 }
 
 // variant ids: tile BM x BN x KC
-enum ConvVariant { CV_NONE = 0, CV_64_64_16, CV_128_16_16, CV_128_64_32, CV_64_64_32, CV_128_32_32, CV_128_16_32 };
+enum ConvVariant { CV_NONE = 0, CV_64_64_16, CV_128_16_16, CV_128_64_32, CV_96_64_32, CV_64_64_32, CV_48_64_32,
+                   CV_128_32_32, CV_128_16_32 };
 static const char *kConvVariantName[] = {"none", "k_conv2d<64x64x16>", "k_conv2d<128x16x16>", "k_conv2d<128x64x32>",
-                                         "k_conv2d<64x64x32>", "k_conv2d<128x32x32>", "k_conv2d<128x16x32>"};
+                                         "k_conv2d<96x64x32>", "k_conv2d<64x64x32>", "k_conv2d<48x64x32>",
+                                         "k_conv2d<128x32x32>", "k_conv2d<128x16x32>"};
 
+// The BEV layers are a few hundred tiles for 256 CUs, so the M tile is chosen to fill the chip: with T
+// equal tiles the busiest CU runs ceil(T/256) of them while the average is T/256; e.g. 94x94x256 as
+// 64x64 tiles = 556 tiles -> 72 % fill, as 48x64 tiles = 740 -> 96 %.  Larger tiles amortise the
+// per-chunk barrier / staging better, which `tile_eff` prices in (measured, approximate).
 static ConvVariant conv2d_select(const dz_conv2d_desc &p) {
     const long m_total = (long)p.batch * p.ho * p.wo;
     if (p.cin % 32 != 0 && p.cin % 16 == 0) {
@@ -123,11 +149,20 @@ static ConvVariant conv2d_select(const dz_conv2d_desc &p) {
     }
     if (p.cin % 32 == 0) {
         if (p.cout_pad % 64 == 0) {
-            // pick the M tile so that the grid has >= 4 workgroups per CU (256 CUs): with fewer, the last
-            // partial round of workgroups leaves most of the chip idle (measured: 554 blocks -> 75 TF/s,
-            // 1662 blocks -> 97 TF/s with the same tile)
-            const long blocks128 = (long)ceil_div(m_total, 128) * (p.cout_pad / 64) * p.groups;
-            return blocks128 >= 1024 ? CV_128_64_32 : CV_64_64_32;
+            static const int bms[4] = {128, 96, 64, 48};
+            static const ConvVariant cvs[4] = {CV_128_64_32, CV_96_64_32, CV_64_64_32, CV_48_64_32};
+            static const double tile_eff[4] = {1.00, 0.97, 0.92, 0.86};
+            const int cus = 256;
+            double best = -1.0;
+            ConvVariant pick = CV_64_64_32;
+            for (int i = 0; i < 4; ++i) {
+                const long tiles = (long)ceil_div(m_total, bms[i]) * (p.cout_pad / 64) * p.groups;
+                const long rounds = (tiles + cus - 1) / cus;
+                const double useful = (double)m_total / ((double)ceil_div(m_total, bms[i]) * bms[i]);   // ragged last tile
+                const double score = tile_eff[i] * useful * (double)tiles / (double)(rounds * cus);
+                if (score > best) { best = score; pick = cvs[i]; }
+            }
+            return pick;
         }
         if (p.cout_pad % 32 == 0) return CV_128_32_32;
         if (p.cout_pad % 16 == 0) return CV_128_16_32;
@@ -142,7 +177,9 @@ static int conv2d_dispatch(const dz_conv2d_desc &p, hipStream_t stream) {
         case CV_64_64_16: return launch_conv<TileCfg<64, 64, 16, 2, 2>>(p, stream);
         case CV_128_16_16: return launch_conv<TileCfg<128, 16, 16, 4, 1>>(p, stream);
         case CV_128_64_32: return launch_conv<TileCfg<128, 64, 32, 2, 2>>(p, stream);
+        case CV_96_64_32: return launch_conv<TileCfg<96, 64, 32, 2, 2>>(p, stream);
         case CV_64_64_32: return launch_conv<TileCfg<64, 64, 32, 2, 2>>(p, stream);
+        case CV_48_64_32: return launch_conv<TileCfg<48, 64, 32, 1, 4>>(p, stream);
         case CV_128_32_32: return launch_conv<TileCfg<128, 32, 32, 4, 1>>(p, stream);
         case CV_128_16_32: return launch_conv<TileCfg<128, 16, 32, 4, 1>>(p, stream);
         default: break;

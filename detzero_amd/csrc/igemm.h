@@ -45,29 +45,48 @@ struct TileCfg {
     static_assert(KC % 16 == 0, "KC must be a multiple of the 16-deep k slice");
 };
 
-// MFMAs of one staged chunk.
+// MFMAs of one staged chunk.  Operands of k-slice q+1 are fetched from LDS before the MFMAs of slice q
+// are issued (explicit register double buffer), so the matrix pipe never waits on an LDS round trip.
+template <class T>
+struct Frag {
+    f32x4 a[T::MT];
+    float b[4][T::NT];
+};
+
+template <class T>
+__device__ __forceinline__ void load_frag(Frag<T> &f, const float *__restrict__ ap, const float *__restrict__ bp, int q) {
+#pragma unroll
+    for (int mt = 0; mt < T::MT; ++mt) f.a[mt] = *reinterpret_cast<const f32x4 *>(ap + mt * 16 * T::LDA + q * 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < T::NT; ++nt) f.b[e][nt] = bp[(q * 16 + e) * T::LDB + nt * 16];
+}
+
 template <class T>
 __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const float *__restrict__ Bs,
                                           f32x4 (&acc)[T::MT][T::NT], int wm, int wn, int lane) {
     const int r = lane & 15, g = lane >> 4;
+    const float *ap = As + (wm * T::MT * 16 + r) * T::LDA + g * 4;
+    const float *bp = Bs + (g * 4) * T::LDB + wn * T::NT * 16 + r;
+    constexpr int Q = T::KC / 16;
+    Frag<T> f[2];
+    load_frag<T>(f[0], ap, bp, 0);
 #pragma unroll
-    for (int q = 0; q < T::KC / 16; ++q) {
-        f32x4 a[T::MT];
+    for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) load_frag<T>(f[(q + 1) & 1], ap, bp, q + 1);
+        // keep the prefetch above the MFMAs (hipcc otherwise sinks every ds_read next to its first use
+        // and waits lgkmcnt(0) in front of each group of MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag<T> &c = f[q & 1];
 #pragma unroll
-        for (int mt = 0; mt < T::MT; ++mt)
-            a[mt] = *reinterpret_cast<const f32x4 *>(&As[(wm * T::MT * 16 + mt * 16 + r) * T::LDA + q * 16 + g * 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float b[T::NT];
-#pragma unroll
-            for (int nt = 0; nt < T::NT; ++nt)
-                b[nt] = Bs[(q * 16 + g * 4 + e) * T::LDB + wn * T::NT * 16 + nt * 16 + r];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < T::NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[nt], acc[mt][nt], 0, 0, 0);
-        }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[mt][e], c.b[e][nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -106,6 +125,18 @@ __device__ __forceinline__ void load_a(Stage<T> &st, const float *__restrict__ i
             if (rb >= 0) v = *reinterpret_cast<const float4 *>(in + (long)rb * scale + add + q * 4);
             st.a[i] = v;
         }
+    }
+}
+
+// A chunk from per-thread row pointers computed once per tile (nullptr = zero row): no LDS lookup and
+// no 64-bit multiply in the chunk loop.
+template <class T>
+__device__ __forceinline__ void load_a_ptr(Stage<T> &st, const float *const (&rowp)[T::A_PER_THREAD], long add) {
+#pragma unroll
+    for (int i = 0; i < T::A_PER_THREAD; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowp[i] != nullptr) v = *reinterpret_cast<const float4 *>(rowp[i] + add);
+        st.a[i] = v;
     }
 }
 
