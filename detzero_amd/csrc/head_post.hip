@@ -154,7 +154,7 @@ __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__r
 // every lane evaluates ONE rotated IoU per step; __ballot packs the 64 verdicts into the mask word.
 // Pairs whose circumscribed circles are more than 5 cm apart cannot touch (the reference's corner
 // test has a 1 cm margin), so their IoU is exactly 0 and the polygon clipping is skipped.
-constexpr int NMS_ROWS_PER_WAVE = 16;
+constexpr int NMS_ROWS_PER_WAVE = 2;     // 500 candidates -> ~1150 independent wavefronts
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, const int *__restrict__ d_n, int n_cap,
                                                  float thr, unsigned long long *__restrict__ mask, int col_blocks) {
     const int n = d_n ? min(*d_n, n_cap) : n_cap;
@@ -230,23 +230,115 @@ constexpr int HEAD_COLS = 12;  // center 0:2 | center_z 2 | dim 3:6 | rot 6:8 | 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// keys[b][cls*HW + pix] = bits of score (>= 0, so uint order == float order)
-__global__ void k_score_keys(const float *__restrict__ head, int batch, int hw, int ncls, int use_iou,
-                             uint32_t *__restrict__ keys) {
-    const long total = (long)batch * hw;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / hw), pix = (int)(idx % hw);
-        const float *row = head + idx * HEAD_COLS;
+// Exact top-K by a chip-wide radix select over the score bits (scores >= 0, so uint order == float
+// order): three digit levels of 11 + 11 + 10 bits.  Every level is one grid-wide histogram pass (LDS
+// private histograms, flushed with atomics) and a one-workgroup pick of the digit that contains the
+// K-th largest key.  Per batch item the state is {hist[2048], prefix, need, n_gt, n_eq}.
+constexpr int RADIX_BINS = 2048;
+constexpr int TOPK_STATE_WORDS = RADIX_BINS + 8;
+constexpr int ST_PREFIX = RADIX_BINS + 0, ST_NEED = RADIX_BINS + 1, ST_NGT = RADIX_BINS + 2, ST_NEQ = RADIX_BINS + 3;
+constexpr int TIE_CAP = 4096;
+
+__device__ __forceinline__ void hist_flush(const uint32_t *lh, uint32_t *gh) {
+    for (int i = threadIdx.x; i < RADIX_BINS; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// level 0 fused with the score map: keys[b][cls*HW + pix] = bits of sigmoid(hm)*clamp(iou,0,1)^2
+__global__ __launch_bounds__(256) void k_score_hist0(const float *__restrict__ head, int hw, int ncls, int use_iou,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ state) {
+    __shared__ uint32_t lh[RADIX_BINS];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < RADIX_BINS; i += 256) lh[i] = 0u;
+    __syncthreads();
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const float *row = head + ((size_t)b * hw + pix) * HEAD_COLS;
         float w = 1.f;
         if (use_iou) {
             const float iou = fminf(fmaxf(row[8], 0.f), 1.f);
             w = iou * iou;
         }
         for (int c = 0; c < ncls; ++c) {
-            float s = sigmoidf_(row[9 + c]);
-            if (use_iou) s = s * w;
-            keys[((size_t)b * ncls + c) * hw + pix] = __float_as_uint(s);
+            float sc = sigmoidf_(row[9 + c]);
+            if (use_iou) sc = sc * w;
+            const uint32_t kv = __float_as_uint(sc);
+            keys[((size_t)b * ncls + c) * hw + pix] = kv;
+            atomicAdd(&lh[kv >> 21], 1u);
+        }
+    }
+    __syncthreads();
+    hist_flush(lh, state + (size_t)b * TOPK_STATE_WORDS);
+}
+
+// levels 1 (bits 20..10) and 2 (bits 9..0): histogram of the keys that match the prefix found so far
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__ keys, int n, uint32_t *__restrict__ state) {
+    __shared__ uint32_t lh[RADIX_BINS];
+    const int b = blockIdx.y;
+    uint32_t *st = state + (size_t)b * TOPK_STATE_WORDS;
+    const uint32_t prefix = st[ST_PREFIX];
+    constexpr uint32_t himask = LEVEL == 1 ? 0xFFE00000u : 0xFFFFFC00u;
+    constexpr int shift = LEVEL == 1 ? 10 : 0;
+    constexpr uint32_t dmask = LEVEL == 1 ? 2047u : 1023u;
+    for (int i = threadIdx.x; i < RADIX_BINS; i += 256) lh[i] = 0u;
+    __syncthreads();
+    const uint32_t *kb = keys + (size_t)b * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t kv = kb[i];
+        if ((kv & himask) == prefix) atomicAdd(&lh[(kv >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    hist_flush(lh, st);
+}
+
+// one workgroup per batch item: digit d with  #keys(digit > d) < need <= #keys(digit >= d); clears the histogram
+__global__ __launch_bounds__(256) void k_radix_pick(uint32_t *__restrict__ state, int level, int k, int n) {
+    __shared__ uint32_t lds[4];
+    uint32_t *st = state + (size_t)blockIdx.x * TOPK_STATE_WORDS;
+    const int t = threadIdx.x;
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const uint32_t need = level == 0 ? (uint32_t)min(k, n) : st[ST_NEED];
+    const uint32_t prefix = level == 0 ? 0u : st[ST_PREFIX];
+    // thread t owns bins 2047-8t ... 2040-8t (descending)
+    uint32_t h[8], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = st[RADIX_BINS - 1 - (8 * t + j)]; sum += h[j]; }
+    uint32_t total;
+    const uint32_t above = block_excl_scan_256(sum, lds, total);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[RADIX_BINS - 1 - (8 * t + j)] = 0u;
+    if (above < need && need <= above + sum) {
+        uint32_t acc = above;
+        int d = RADIX_BINS - 1 - 8 * t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (acc + h[j] >= need) { d = RADIX_BINS - 1 - (8 * t + j); break; }
+            acc += h[j];
+        }
+        st[ST_PREFIX] = prefix | ((uint32_t)d << shift);
+        st[ST_NEED] = need - acc;
+        if (level == 2) { st[ST_NGT] = 0u; st[ST_NEQ] = 0u; }
+    }
+}
+
+// candidates: every key > T (any order); indices of keys == T (any order, up to TIE_CAP)
+__global__ __launch_bounds__(256) void k_topk_collect(const uint32_t *__restrict__ keys, int n, uint32_t *__restrict__ state,
+                                                      unsigned long long *__restrict__ cand, uint32_t *__restrict__ ties,
+                                                      int maxk) {
+    const int b = blockIdx.y;
+    uint32_t *st = state + (size_t)b * TOPK_STATE_WORDS;
+    const uint32_t T = st[ST_PREFIX];
+    const uint32_t *kb = keys + (size_t)b * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t kv = kb[i];
+        if (kv > T) {
+            const uint32_t pos = atomicAdd(&st[ST_NGT], 1u);
+            if ((int)pos < maxk) cand[(size_t)b * maxk + pos] = ((unsigned long long)kv << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+        } else if (kv == T) {
+            const uint32_t pos = atomicAdd(&st[ST_NEQ], 1u);
+            if (pos < (uint32_t)TIE_CAP) ties[(size_t)b * TIE_CAP + pos] = (uint32_t)i;
         }
     }
 }
@@ -276,6 +368,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, u
 struct DecodeArgs {
     const float *head;
     const uint32_t *keys;
+    const uint32_t *state;
+    const unsigned long long *gcand;
+    const uint32_t *ties;
     float *boxes, *scores;
     int *labels, *counts;
     int hw, w, ncls, k, stride;
@@ -286,71 +381,45 @@ struct DecodeArgs {
 constexpr int TOPK_THREADS = 1024;
 constexpr int TOPK_MAXK = 1024;
 
-// one workgroup per batch item: exact radix select of the K largest keys (ties -> smaller flat
-// index first), bitonic sort (score desc, index asc), decode, masks, ordered compaction.
+// one workgroup per batch item: gathers the <= K candidates found by the radix select (ties at the
+// threshold value resolved to the smallest flat indices), bitonic sort (score desc, index asc), decode,
+// masks, ordered compaction.
 __global__ __launch_bounds__(TOPK_THREADS) void k_topk_decode(DecodeArgs a) {
-    __shared__ uint32_t hist[256];
     __shared__ uint32_t scan_lds[TOPK_THREADS / 64];
     __shared__ unsigned long long cand[TOPK_MAXK];
-    __shared__ uint32_t s_prefix, s_need, s_cnt;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.ncls * a.hw;
     const uint32_t *keys = a.keys + (size_t)b * n;
     const int K = min(a.k, n);
+    const uint32_t *st = a.state + (size_t)b * TOPK_STATE_WORDS;
+    const uint32_t T = st[ST_PREFIX];
+    const uint32_t need_eq = st[ST_NEED];          // number of keys == T to take (smallest indices first)
+    const uint32_t n_gt = st[ST_NGT];              // == K - need_eq
+    const uint32_t n_eq = st[ST_NEQ];              // keys == T in the whole map
 
-    // ---- radix select: find T = K-th largest key
-    if (tid == 0) { s_prefix = 0u; s_need = (uint32_t)K; }
+    cand[tid] = (tid < (int)n_gt && tid < TOPK_MAXK) ? a.gcand[(size_t)b * TOPK_MAXK + tid] : 0ull;
     __syncthreads();
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        const uint32_t prefix = s_prefix;
-        for (int i = tid; i < n; i += TOPK_THREADS) {
-            const uint32_t kv = keys[i];
-            if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
+    if (n_eq == need_eq && n_eq <= (uint32_t)TIE_CAP) {
+        // common case: every key equal to the threshold is selected, no ordering question
+        for (uint32_t j = tid; j < need_eq; j += TOPK_THREADS) {
+            const uint32_t pos = n_gt + j;
+            if (pos < TOPK_MAXK)
+                cand[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xFFFFFFFFu - a.ties[(size_t)b * TIE_CAP + j]);
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t need = s_need, acc = 0u;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (acc + hist[d] >= need) break;
-                acc += hist[d];
+    } else {
+        // more ties than needed (flat / saturated score maps): take the first need_eq in index order
+        uint32_t taken = 0u;
+        for (int base = 0; base < n && taken < need_eq; base += TOPK_THREADS) {
+            const int i = base + tid;
+            const uint32_t flag = (i < n && keys[i] == T) ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<TOPK_THREADS / 64>(flag, scan_lds, tot);
+            if (flag && taken + ex < need_eq) {
+                const uint32_t pos = n_gt + taken + ex;
+                if (pos < TOPK_MAXK) cand[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
             }
-            s_need = need - acc;                 // still needed among keys with this digit
-            s_prefix = prefix | ((uint32_t)d << shift);
+            taken += tot;
         }
-        __syncthreads();
-    }
-    const uint32_t T = s_prefix;
-    const uint32_t need_eq = s_need;             // number of keys == T to take (in index order)
-
-    // ---- collect: all keys > T (any order), then the first need_eq keys == T in index order
-    if (tid == 0) s_cnt = 0u;
-    for (int i = tid; i < TOPK_MAXK; i += TOPK_THREADS) cand[i] = 0ull;
-    __syncthreads();
-    for (int i = tid; i < n; i += TOPK_THREADS) {
-        const uint32_t kv = keys[i];
-        if (kv > T) {
-            const uint32_t pos = atomicAdd(&s_cnt, 1u);
-            if (pos < TOPK_MAXK) cand[pos] = ((unsigned long long)kv << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
-        }
-    }
-    __syncthreads();
-    const uint32_t n_gt = s_cnt;
-    uint32_t taken = 0u;
-    for (int base = 0; base < n && taken < need_eq; base += TOPK_THREADS) {
-        const int i = base + tid;
-        const uint32_t flag = (i < n && keys[i] == T) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<TOPK_THREADS / 64>(flag, scan_lds, tot);
-        if (flag && taken + ex < need_eq) {
-            const uint32_t pos = n_gt + taken + ex;
-            if (pos < TOPK_MAXK) cand[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
-        }
-        taken += tot;
     }
     __syncthreads();
 
@@ -497,9 +566,20 @@ int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, 
     return DZ_OK;
 }
 
+static size_t decode_layout(int batch, int hw, int ncls, size_t *o_keys, size_t *o_state, size_t *o_cand, size_t *o_ties) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    *o_keys = take((size_t)batch * hw * ncls * sizeof(uint32_t));
+    *o_state = take((size_t)batch * TOPK_STATE_WORDS * sizeof(uint32_t));
+    *o_cand = take((size_t)batch * TOPK_MAXK * sizeof(unsigned long long));
+    *o_ties = take((size_t)batch * TIE_CAP * sizeof(uint32_t));
+    return off;
+}
+
 size_t dz_centerhead_decode_workspace_bytes(int batch, int hw, int ncls, int k) {
     (void)k;
-    return align_up((size_t)batch * hw * ncls * sizeof(uint32_t), 256);
+    size_t a, b, c, d;
+    return decode_layout(batch, hw, ncls, &a, &b, &c, &d);
 }
 
 int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, int k, float score_thresh,
@@ -515,11 +595,26 @@ int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, i
         set_error("dz_centerhead_decode: workspace too small");
         return DZ_ERR_WORKSPACE;
     }
-    uint32_t *keys = (uint32_t *)ws;
-    hipLaunchKernelGGL(k_score_keys, dim3(stream_grid((long)batch * hw, 256)), dim3(256), 0, stream, head, batch, hw, ncls,
-                       use_iou, keys);
+    size_t o_keys, o_state, o_cand, o_ties;
+    decode_layout(batch, hw, ncls, &o_keys, &o_state, &o_cand, &o_ties);
+    uint32_t *keys = (uint32_t *)((char *)ws + o_keys);
+    uint32_t *state = (uint32_t *)((char *)ws + o_state);
+    unsigned long long *gcand = (unsigned long long *)((char *)ws + o_cand);
+    uint32_t *ties = (uint32_t *)((char *)ws + o_ties);
+    const int n = ncls * hw;
+    int rc = fill_u32(state, 0u, (size_t)batch * TOPK_STATE_WORDS, stream);
+    if (rc) return rc;
+    const dim3 gpix(stream_grid(hw, 256) > 512 ? 512 : stream_grid(hw, 256), batch);
+    const dim3 gkey(stream_grid(n, 256) > 512 ? 512 : stream_grid(n, 256), batch);
+    hipLaunchKernelGGL(k_score_hist0, gpix, dim3(256), 0, stream, head, hw, ncls, use_iou, keys, state);
+    hipLaunchKernelGGL(k_radix_pick, dim3(batch), dim3(256), 0, stream, state, 0, k, n);
+    hipLaunchKernelGGL(k_radix_hist<1>, gkey, dim3(256), 0, stream, keys, n, state);
+    hipLaunchKernelGGL(k_radix_pick, dim3(batch), dim3(256), 0, stream, state, 1, k, n);
+    hipLaunchKernelGGL(k_radix_hist<2>, gkey, dim3(256), 0, stream, keys, n, state);
+    hipLaunchKernelGGL(k_radix_pick, dim3(batch), dim3(256), 0, stream, state, 2, k, n);
+    hipLaunchKernelGGL(k_topk_collect, gkey, dim3(256), 0, stream, keys, n, state, gcand, ties, TOPK_MAXK);
     DecodeArgs a;
-    a.head = head; a.keys = keys; a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = d_counts;
+    a.head = head; a.keys = keys; a.state = state; a.gcand = gcand; a.ties = ties; a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = d_counts;
     a.hw = hw; a.w = w; a.ncls = ncls; a.k = k; a.stride = stride; a.score_thresh = score_thresh;
     for (int i = 0; i < 6; ++i) a.lim[i] = h_limit6[i];
     for (int i = 0; i < 3; ++i) { a.lo[i] = h_range6[i]; a.vs[i] = h_vsize3[i]; }

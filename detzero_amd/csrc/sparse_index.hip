@@ -138,19 +138,28 @@ __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ 
     for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) {
         const int idx = threadIdx.x + 256 * j;
         uint32_t word = w_s[idx];
+        if (!word) continue;
         uint32_t r = p_s[idx];
+        // decode the word's first cell once (3 divisions), then walk the bits with carries only
         const uint32_t key0 = (uint32_t)(((size_t)blockIdx.x * SCAN_CHUNK + idx) << 5);
+        uint32_t c2, c1, c0;
+        const uint32_t t1 = fast_divmod(key0, dec.d2, c2);
+        const uint32_t t0 = fast_divmod(t1, dec.d1, c1);
+        uint32_t bb = fast_divmod(t0, dec.d0, c0);
+        int last = 0;
         while (word) {
             const int bit = __ffs((int)word) - 1;
             word &= word - 1;
+            c2 += (uint32_t)(bit - last);
+            last = bit;
+            while (c2 >= dec.d2.d) {
+                c2 -= dec.d2.d;
+                if (++c1 == dec.d1.d) { c1 = 0; if (++c0 == dec.d0.d) { c0 = 0; ++bb; } }
+            }
             if ((int)r < cap_out) {
-                uint32_t c2, c1, c0;
-                const uint32_t t1 = fast_divmod(key0 + (uint32_t)bit, dec.d2, c2);
-                const uint32_t t0 = fast_divmod(t1, dec.d1, c1);
-                const uint32_t b = fast_divmod(t0, dec.d0, c0);
                 int4 o;
-                if (MODE == 0) o = make_int4((int)b, (int)c0, (int)c1, (int)c2);   // [b,z,y,x]
-                else o = make_int4((int)b, (int)c2, (int)c1, (int)c0);             // key (x,y,z) -> [b,z,y,x]
+                if (MODE == 0) o = make_int4((int)bb, (int)c0, (int)c1, (int)c2);   // [b,z,y,x]
+                else o = make_int4((int)bb, (int)c2, (int)c1, (int)c0);             // key (x,y,z) -> [b,z,y,x]
                 reinterpret_cast<int4 *>(coords_out)[r] = o;
             }
             ++r;
