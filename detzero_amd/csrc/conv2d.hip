@@ -14,9 +14,8 @@
 namespace dz {
 
 template <class T>
-__global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) {
+__global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total, unsigned int in_bytes) {
     __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
-    float *const As0 = smem, *const Bs0 = smem + 2 * T::AS_FLOATS;     // [2][AS], [2][BS]
     __shared__ int in_pix[T::BM];    // input pixel index of the (0,0) tap, -1 past the end
     __shared__ int out_pix[T::BM];   // output pixel index
 
@@ -55,24 +54,26 @@ __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) 
     const float *wg = p.w + (size_t)grp * taps * p.cin * p.cout_pad;
     const long cbase = p.in_coff + (long)grp * p.cin;
 
-    // per-thread A row pointers (tap (0,0), channel chunk 0), fixed for the whole tile
-    const float *rowp[T::A_PER_THREAD];
+    // per-thread A byte offsets (tap (0,0), channel chunk 0), fixed for the whole tile; rows past the end of
+    // the image get an out-of-range offset and read as zeros
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.in, in_bytes);
+    unsigned int voff[T::A_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < T::A_PER_THREAD; ++i) {
         const int idx = tid + i * T::THREADS;
-        rowp[i] = nullptr;
+        voff[i] = OOB_OFFSET;
         if (T::A_F4 % T::THREADS == 0 || idx < T::A_F4) {
             const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
             const int ip = in_pix[rr];
-            if (ip >= 0) rowp[i] = p.in + (long)ip * p.in_cstride + cbase + q * 4;
+            if (ip >= 0) voff[i] = (unsigned int)(((long)ip * p.in_cstride + cbase + q * 4) * 4);
         }
     }
     Stage<T> st;
     int ky = 0, kx = 0, kc = 0;          // chunk iterator without divisions
     const float *wp = wg;                 // weight slice of the current chunk
-    long aoff = 0;                        // element offset of the current (tap, chunk) relative to rowp
+    unsigned int aoff = 0;                // byte offset of the current (tap, chunk) relative to voff
     auto issue = [&]() {
-        load_a_ptr<T>(st, rowp, aoff);
+        load_a_buf<T>(st, rsrc, voff, aoff);
         load_b<T>(st, wp, p.cout_pad, n0, tid);
     };
     auto advance = [&]() {
@@ -81,21 +82,9 @@ __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total) 
             kc = 0;
             if (++kx == p.kw) { kx = 0; ++ky; }
         }
-        aoff = (long)(ky * p.in_wp + kx) * p.in_cstride + (long)kc * T::KC;
+        aoff = (unsigned int)(((ky * p.in_wp + kx) * p.in_cstride + kc * T::KC) * 4);
     };
-    issue();
-    store_stage<T>(st, As0, Bs0, tid);
-    __syncthreads();
-    if (nchunks > 1) { advance(); issue(); }
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        mma_chunk<T>(As0 + cur * T::AS_FLOATS, Bs0 + cur * T::BS_FLOATS, acc, wm, wn, lane);
-        if (c + 1 < nchunks) {
-            store_stage<T>(st, As0 + (cur ^ 1) * T::AS_FLOATS, Bs0 + (cur ^ 1) * T::BS_FLOATS, tid);
-            if (c + 2 < nchunks) { advance(); issue(); }
-        }
-        __syncthreads();
-    }
+    gemm_pipeline<T>(nchunks, smem, st, issue, advance, acc, wm, wn, lane, tid);
 
     const int r = lane & 15, g = lane >> 4;
     const int gcout = p.g_cout[grp];
@@ -125,7 +114,12 @@ template <class T>
 static int launch_conv(const dz_conv2d_desc &p, hipStream_t stream) {
     const long m_total = (long)p.batch * p.ho * p.wo;
     dim3 grid(ceil_div(m_total, T::BM), (p.cout_pad / T::BN) * p.groups);
-    hipLaunchKernelGGL(k_conv2d<T>, grid, dim3(256), 0, stream, p, m_total);
+    const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
+    if (in_bytes >= 0x80000000ull) {
+        set_error("dz_conv2d_forward: input image of %zu bytes exceeds the 2 GiB buffer-addressing limit", in_bytes);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_conv2d<T>, grid, dim3(256), 0, stream, p, m_total, (unsigned int)in_bytes);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -19,6 +19,8 @@
 // registers and are written to buffer (i+1)&1, so there is ONE barrier per chunk and HBM/L2 latency
 // hides behind 32-128 MFMAs per wave even at 1-2 workgroups per CU.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace dz {
@@ -64,29 +66,24 @@ __device__ __forceinline__ void load_frag(Frag<T> &f, const float *__restrict__ 
 }
 
 template <class T>
-__device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const float *__restrict__ Bs,
-                                          f32x4 (&acc)[T::MT][T::NT], int wm, int wn, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    const float *ap = As + (wm * T::MT * 16 + r) * T::LDA + g * 4;
-    const float *bp = Bs + (g * 4) * T::LDB + wn * T::NT * 16 + r;
-    constexpr int Q = T::KC / 16;
-    Frag<T> f[2];
-    load_frag<T>(f[0], ap, bp, 0);
+__device__ __forceinline__ void mma_frag(const Frag<T> &c, f32x4 (&acc)[T::MT][T::NT]) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        if (q + 1 < Q) load_frag<T>(f[(q + 1) & 1], ap, bp, q + 1);
-        // keep the prefetch above the MFMAs (hipcc otherwise sinks every ds_read next to its first use
-        // and waits lgkmcnt(0) in front of each group of MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-        const Frag<T> &c = f[q & 1];
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < T::MT; ++mt)
+            for (int nt = 0; nt < T::NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[mt][e], c.b[e][nt], acc[mt][nt], 0, 0, 0);
+}
+
+// scheduling hint: interleave `n` groups of (mfma_per MFMAs, one instruction of class `mask`)
+// masks (LLVM sched_group_barrier): 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write
+template <int MASK, int N, int MFMA_PER>
+__device__ __forceinline__ void interleave_hint() {
 #pragma unroll
-                for (int nt = 0; nt < T::NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[mt][e], c.b[e][nt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER, 0);
+        __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
     }
 }
 
@@ -110,33 +107,24 @@ __device__ __forceinline__ void load_b(Stage<T> &st, const float *__restrict__ w
     }
 }
 
-// A chunk: row r of the tile comes from element offset rowoff[r] (or is zero when rowoff[r] < 0);
-// `rowoff` lives in LDS and already includes tap / channel-chunk offsets via `add`.
-template <class T>
-__device__ __forceinline__ void load_a(Stage<T> &st, const float *__restrict__ in, const int *rowbase, long scale,
-                                       long add, int tid) {
-#pragma unroll
-    for (int i = 0; i < T::A_PER_THREAD; ++i) {
-        const int idx = tid + i * T::THREADS;
-        if (T::A_F4 % T::THREADS == 0 || idx < T::A_F4) {
-            const int r = idx / (T::KC / 4), q = idx % (T::KC / 4);
-            const int rb = rowbase[r];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rb >= 0) v = *reinterpret_cast<const float4 *>(in + (long)rb * scale + add + q * 4);
-            st.a[i] = v;
-        }
-    }
+// A operand rows are fetched with raw buffer loads: an offset past `num_records` returns zeros, so rows
+// without a neighbour (sparse conv) or past the end of the image need no branch - the chunk loop stays one
+// basic block, which is what lets the scheduler interleave staging with the MFMAs.
+using v4u = __attribute__((ext_vector_type(4))) unsigned int;
+constexpr unsigned int OOB_OFFSET = 0x80000000u;       // + any chunk offset < 2^31 stays out of range (buffers < 2 GiB)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
 
-// A chunk from per-thread row pointers computed once per tile (nullptr = zero row): no LDS lookup and
-// no 64-bit multiply in the chunk loop.
+// byte offsets voff[i] (row start + 16*q, or OOB_OFFSET) computed by the caller; `add` = chunk byte offset
 template <class T>
-__device__ __forceinline__ void load_a_ptr(Stage<T> &st, const float *const (&rowp)[T::A_PER_THREAD], long add) {
+__device__ __forceinline__ void load_a_buf(Stage<T> &st, __amdgpu_buffer_rsrc_t rsrc, const unsigned int (&voff)[T::A_PER_THREAD],
+                                           unsigned int add) {
 #pragma unroll
     for (int i = 0; i < T::A_PER_THREAD; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rowp[i] != nullptr) v = *reinterpret_cast<const float4 *>(rowp[i] + add);
-        st.a[i] = v;
+        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i] + add, 0, 0);
+        st.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
 }
 
@@ -158,6 +146,74 @@ __device__ __forceinline__ void store_stage(const Stage<T> &st, float *__restric
             *reinterpret_cast<float4 *>(&Bs[kk * T::LDB + q * 4]) = st.b[i];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The chunk pipeline.  `issue()` loads the chunk the caller's iterator points at into `st` (global ->
+// registers), `advance()` moves the iterator.  Per chunk c (two 16-deep k slices q0, q1 when KC = 32):
+//
+//   P1:  MFMAs(q0 of c)  ||  LDS reads of q1 of c  ||  wait for chunk c+1's global loads, write them to
+//                                                      the other LDS buffer
+//   --- barrier ---
+//   P2:  MFMAs(q1 of c)  ||  LDS reads of q0 of c+1 (other buffer)  ||  issue global loads of chunk c+2
+//
+// One barrier per chunk; every LDS / global latency of a wave sits in the shadow of its own MFMAs, so the
+// matrix pipe stays fed even when the co-resident waves of a SIMD run in lock step.
+// Hazards: the buffer written in P1 of c was last read by fragment loads issued before the barrier of
+// chunk c-1 (LDS services requests in arrival order); it is read again only after the barrier of c.
+// ------------------------------------------------------------------------------------------------
+template <class T, class Issue, class Advance>
+__device__ __forceinline__ void gemm_pipeline(int nchunks, float *__restrict__ smem, Stage<T> &st, Issue &&issue,
+                                              Advance &&advance, f32x4 (&acc)[T::MT][T::NT], int wm, int wn, int lane,
+                                              int tid) {
+    float *const As0 = smem, *const Bs0 = smem + 2 * T::AS_FLOATS;     // [2][AS], [2][BS]
+    constexpr int Q = T::KC / 16;
+    static_assert(Q == 1 || Q == 2, "KC must be 16 or 32");
+    const int r = lane & 15, g = lane >> 4;
+    const int aoff = (wm * T::MT * 16 + r) * T::LDA + g * 4;
+    const int boff = (g * 4) * T::LDB + wn * T::NT * 16 + r;
+    constexpr int MFMA_N = 4 * T::MT * T::NT;                     // MFMAs per k slice
+    constexpr int NLD = T::MT + 2 * T::NT;                        // ~LDS read instructions per slice (b reads pair up)
+    constexpr int NST = T::A_PER_THREAD + T::B_PER_THREAD;        // staging loads / stores per chunk
+    constexpr int REST1 = MFMA_N - (Q == 2 ? NLD : 0);
+    constexpr int PER1 = (REST1 / NST) > 0 ? (REST1 / NST) : 1;
+    constexpr int REST2 = MFMA_N - NLD;
+    constexpr int PER2 = (REST2 / NST) > 0 ? (REST2 / NST) : 1;
+
+    issue();
+    store_stage<T>(st, As0, Bs0, tid);
+    __syncthreads();
+    if (nchunks > 1) { advance(); issue(); }
+    Frag<T> f0, f1;
+    load_frag<T>(f0, As0 + aoff, Bs0 + boff, 0);
+    // the loop body, specialised at compile time on "a chunk c+1 / c+2 exists" so that it has no branches
+    auto body = [&](int c, auto has1_t, auto has2_t) {
+        constexpr bool HAS1 = decltype(has1_t)::value, HAS2 = decltype(has2_t)::value;
+        const int cur = c & 1;
+        const float *Ac = As0 + cur * T::AS_FLOATS + aoff, *Bc = Bs0 + cur * T::BS_FLOATS + boff;
+        const float *An = As0 + (cur ^ 1) * T::AS_FLOATS + aoff, *Bn = Bs0 + (cur ^ 1) * T::BS_FLOATS + boff;
+        // ---- P1
+        if (Q == 2) load_frag<T>(f1, Ac, Bc, 1);
+        if (HAS1) store_stage<T>(st, As0 + (cur ^ 1) * T::AS_FLOATS, Bs0 + (cur ^ 1) * T::BS_FLOATS, tid);
+        mma_frag<T>(f0, acc);
+        if (Q == 2) interleave_hint<0x100, NLD, 1>();
+        if (HAS1) interleave_hint<0x200, NST, PER1>();
+        __syncthreads();
+        // ---- P2
+        if (HAS1) load_frag<T>(f0, An, Bn, 0);
+        if (HAS2) { advance(); issue(); }
+        if (Q == 2) {
+            mma_frag<T>(f1, acc);
+            if (HAS1) interleave_hint<0x100, NLD, 1>();
+            if (HAS2) interleave_hint<0x020, NST, PER2>();
+        }
+    };
+    using TT = std::integral_constant<bool, true>;
+    using FF = std::integral_constant<bool, false>;
+    int c = 0;
+    for (; c + 2 < nchunks; ++c) body(c, TT{}, TT{});
+    if (c + 1 < nchunks) { body(c, TT{}, FF{}); ++c; }
+    body(c, FF{}, FF{});
 }
 
 }  // namespace dz

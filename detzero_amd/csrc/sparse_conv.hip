@@ -28,12 +28,12 @@ struct SpConvArgs {
     const float *residual;
     float *out;
     int cin, cout, kvol, cap, relu;
+    unsigned int in_bytes;      // size of the input feature matrix (buffer-load range)
 };
 
 template <class T>
 __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
-    float *const As0 = smem, *const Bs0 = smem + 2 * T::AS_FLOATS;     // [2][AS], [2][BS]
     __shared__ int nbr_s[KVOL_MAX * T::BM];
     __shared__ unsigned int mask_s;
 
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
     const int ntiles = (m + T::BM - 1) / T::BM;
     const int kchunks = a.cin / T::KC;
     const int n0 = blockIdx.y * T::BN;          // column tile (Cout may be split over blockIdx.y)
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in, a.in_bytes);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * T::BM;
@@ -73,25 +74,25 @@ __global__ __launch_bounds__(256) void k_spconv(SpConvArgs a) {
             unsigned int rem = taps;
             int tap = __ffs((int)rem) - 1, kc = 0;
             auto issue = [&]() {
-                load_a<T>(st, a.in, &nbr_s[tap * T::BM], a.cin, (long)kc * T::KC, tid);
+                // gather offsets of this tap from the staged neighbour list; missing neighbours read as zeros
+                unsigned int voff[T::A_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < T::A_PER_THREAD; ++i) {
+                    const int idx = tid + i * T::THREADS;
+                    voff[i] = OOB_OFFSET;
+                    if (T::A_F4 % T::THREADS == 0 || idx < T::A_F4) {
+                        const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
+                        const int rb = nbr_s[tap * T::BM + rr];
+                        voff[i] = rb >= 0 ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
+                    }
+                }
+                load_a_buf<T>(st, rsrc, voff, (unsigned int)(kc * T::KC * 4));
                 load_b<T>(st, a.w + ((size_t)tap * a.cin + (size_t)kc * T::KC) * a.cout, a.cout, n0, tid);
             };
             auto advance = [&]() {
                 if (++kc == kchunks) { kc = 0; rem &= rem - 1; tap = __ffs((int)rem) - 1; }
             };
-            issue();
-            store_stage<T>(st, As0, Bs0, tid);
-            __syncthreads();
-            if (nchunks > 1) { advance(); issue(); }
-            for (int c = 0; c < nchunks; ++c) {
-                const int cur = c & 1;
-                mma_chunk<T>(As0 + cur * T::AS_FLOATS, Bs0 + cur * T::BS_FLOATS, acc, wm, wn, lane);
-                if (c + 1 < nchunks) {
-                    store_stage<T>(st, As0 + (cur ^ 1) * T::AS_FLOATS, Bs0 + (cur ^ 1) * T::BS_FLOATS, tid);
-                    if (c + 2 < nchunks) { advance(); issue(); }
-                }
-                __syncthreads();
-            }
+            gemm_pipeline<T>(nchunks, smem, st, issue, advance, acc, wm, wn, lane, tid);
         }
 
         // epilogue: C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
@@ -151,14 +152,19 @@ using namespace dz;
 
 extern "C" {
 
-int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+int dz_spconv_forward(const float *in, int in_rows, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
                       const float *w, const float *scale, const float *shift, const float *residual, int relu,
                       float *out, int cout, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(in && nbr && d_m_out && w && out, "dz_spconv_forward: null pointer");
     DZ_CHECK_ARG(kvol >= 1 && kvol <= KVOL_MAX, "dz_spconv_forward: kvol %d not in [1,27]", kvol);
     if (cap_out == 0) return DZ_OK;
-    SpConvArgs a{in, nbr, d_m_out, w, scale, shift, residual, out, cin, cout, kvol, cap_out, relu};
+    const size_t in_bytes = (size_t)in_rows * cin * sizeof(float);
+    if (in_rows < 0 || in_bytes >= 0x80000000ull) {
+        set_error("dz_spconv_forward: input of %zu bytes exceeds the 2 GiB buffer-addressing limit", in_bytes);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    SpConvArgs a{in, nbr, d_m_out, w, scale, shift, residual, out, cin, cout, kvol, cap_out, relu, (unsigned int)in_bytes};
     // tile shapes: BM x BN=cout, KC = min(cin,32); small BM for the deep, small levels so that
     // a level of ~20-40k sites still yields >= 2 workgroups per CU
     if (cin == 16 && cout == 16) return launch_spconv<TileCfg<128, 16, 16, 4, 1>>(a, stream);

@@ -192,7 +192,7 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     if out is None:
         out = torch.empty((cap, cout), dtype=torch.float32, device=feats.device)
     def launch():
-        rc = lib.dz_spconv_forward(L.ptr(feats), cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps),
+        rc = lib.dz_spconv_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps),
                                    L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout,
                                    L.stream())
         L.check(rc, 'dz_spconv_forward')

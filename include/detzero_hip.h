@@ -108,8 +108,9 @@ int dz_scatter_rows(const float *src, const int *rank, const int *d_n, int n_cap
  *   out[o] = relu?( (sum_t in[nbr[t][o]] . W[t]) * scale + shift (+ residual[o]) )
  * == SubMConv3d/SparseConv3d + BatchNorm1d(eval, folded into scale/shift together with the conv
  * bias) + residual add + ReLU of backbone3d.py:77-81,105-121.  fp32 in, fp32 MFMA accumulate.
- *   in (m_in, cin) f32, cin in {16,32,64,128}; w (kvol,cin,cout) f32; cout in {16,32,64,128}. */
-int dz_spconv_forward(const float *in, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+ *   in (in_rows, cin) f32 (in_rows = row capacity of the buffer, < 2 GiB), cin in {16,32,64,128};
+ *   w (kvol,cin,cout) f32; cout in {16,32,64,128}. */
+int dz_spconv_forward(const float *in, int in_rows, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
                       const float *w, const float *scale, const float *shift, const float *residual,
                       int relu, float *out, int cout, void *stream);
 
