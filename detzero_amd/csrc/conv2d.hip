@@ -99,9 +99,12 @@ __global__ __launch_bounds__(256) void k_conv2d(dz_conv2d_desc p, long m_total, 
         for (int mt = 0; mt < T::MT; ++mt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int op = out_pix[wm * T::MT * 16 + mt * 16 + g * 4 + e];
+                const int lr = wm * T::MT * 16 + mt * 16 + g * 4 + e;
+                const int op = out_pix[lr];
                 if (op >= 0) {
-                    float v = fmaf(acc[mt][nt][e], sc, sh);
+                    float a = acc[mt][nt][e];
+                    if (p.group_shift) a += p.group_shift[((row0 + lr) / p.group_rows) * p.cout_pad + col];
+                    float v = fmaf(a, sc, sh);
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.out[(size_t)op * p.out_cstride + ooff + col] = v;
                 }
@@ -192,6 +195,7 @@ int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward: null pointer");
     DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward: groups %d not in [1,8]", d->groups);
+    DZ_CHECK_ARG(!d->group_shift || (d->group_rows >= 1 && d->groups == 1), "dz_conv2d_forward: group_shift needs group_rows >= 1, groups == 1");
     DZ_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->cin >= 16, "dz_conv2d_forward: bad kernel/cin");
     DZ_CHECK_ARG(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0 && d->cout_pad % 16 == 0,
                  "dz_conv2d_forward: channel strides must keep 16-byte alignment");
@@ -209,7 +213,8 @@ int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
 const char *dz_conv2d_variant(const dz_conv2d_desc *d) { return d ? kConvVariantName[conv2d_select(*d)] : "none"; }
 
 int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
-                      const float *scale, const float *shift, int relu, float *y, int y_stride, void *stream_) {
+                      const float *scale, const float *shift, const float *group_shift, int group_rows, int relu,
+                      float *y, int y_stride, void *stream_) {
     dz_conv2d_desc d = {};
     d.in = x; d.out = y; d.w = w; d.scale = scale; d.shift = shift;
     d.batch = 1; d.ho = 1; d.wo = rows;
@@ -218,6 +223,7 @@ int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const flo
     d.out_hp = 1; d.out_wp = rows; d.out_cstride = y_stride; d.out_coff = 0;
     d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
     d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
+    d.group_shift = group_shift; d.group_rows = group_rows > 0 ? group_rows : 1;
     return dz_conv2d_forward(&d, stream_);
 }
 

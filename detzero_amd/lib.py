@@ -36,6 +36,7 @@ class Conv2dDesc(ctypes.Structure):
         ('groups', c_int), ('cout_pad', c_int),
         ('g_cout', _I8), ('g_ooff', _I8),
         ('relu', c_int),
+        ('group_shift', c_void_p), ('group_rows', c_int),
     ]
 
 
@@ -81,8 +82,10 @@ _SIGS = {
     'dz_points_in_boxes_v2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_mha_core': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                             c_void_p]),
-    'dz_linear_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
-                                  c_void_p, c_int, c_void_p]),
+    'dz_linear_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_void_p, c_int, c_void_p]),
+    'dz_group_max': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_add_layernorm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

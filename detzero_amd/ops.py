@@ -240,17 +240,42 @@ def conv2d(desc_kwargs):
     L.check(rc, 'dz_conv2d_forward')
 
 
-def linear(x, w, scale, shift, relu, cout, out=None):
-    """x (rows, cin) @ w (cin, cout_pad) -> (rows, cout)."""
+def linear(x, w, scale, shift, relu, cout, out=None, group_shift=None, group_rows=0):
+    """x (rows, cin) @ w (cin, cout_pad) -> (rows, cout); optional per-row-group pre-activation addend."""
     lib = L.load()
-    L.require_cuda(x, w, scale, shift)
+    L.require_cuda(x, w, scale, shift, group_shift)
     rows, cin = x.shape
     cout_pad = w.shape[1]
     if out is None:
         out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     rc = lib.dz_linear_forward(L.ptr(x), rows, cin, x.stride(0), L.ptr(w), cout, cout_pad, L.ptr(scale),
-                               L.ptr(shift), 1 if relu else 0, L.ptr(out), out.stride(0), L.stream())
+                               L.ptr(shift), L.ptr(group_shift), int(group_rows), 1 if relu else 0, L.ptr(out),
+                               out.stride(0), L.stream())
     L.check(rc, 'dz_linear_forward')
+    return out
+
+
+def group_max(x, groups, length):
+    """x (groups*length, c) -> (groups, c) max over each group's rows."""
+    lib = L.load()
+    L.require_cuda(x)
+    c = x.shape[1]
+    out = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+    rc = lib.dz_group_max(L.ptr(x), groups, length, c, L.ptr(out), L.stream())
+    L.check(rc, 'dz_group_max')
+    return out
+
+
+def add_layernorm(x, y, gamma, beta, eps=1e-5, norm=True):
+    """LayerNorm(x + y) (or x + y when norm=False) over the last dimension."""
+    lib = L.load()
+    L.require_cuda(x, y, gamma, beta)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    out = torch.empty_like(x)
+    rc = lib.dz_add_layernorm(L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(beta), rows, c, float(eps), 1 if norm else 0,
+                              L.ptr(out), L.stream())
+    L.check(rc, 'dz_add_layernorm')
     return out
 
 

@@ -1,0 +1,468 @@
+"""Refining module (GRM / PRM) regression networks under the reference's names, on the HIP backend.
+
+Mirror of /root/reference/refining/detzero_refine/models/modules/:
+  geometry_transformer.py:11-156 (GeometryTransformer), position_transformer.py:14-141 (PositionTransformer),
+  head/{geometry_head.py,position_head.py} (decoder stacks), transformer/{decoder.py, multi_head_attention.py,
+  ffn.py, position_encoding.py, conv_module.py}, target_assign.py:73-104 (decode),
+  utils/detzero_utils/model_utils.py:81-135 (make_linear/fc/conv_layers).
+Same constructor arguments, ``forward(data_dict)`` keys and ``state_dict()`` names/shapes (checked against the
+reference's own manifest in tests/golden/refine_golden.npz).  Inference only.
+
+Execution (all tensors channel-last, one row per point / query):
+  * every Conv1d/Conv2d(1x1)/Linear + BatchNorm(eval) + ReLU is one ``dz_linear_forward`` (fp32 MFMA, folded BN);
+  * ``torch.max`` over points = ``dz_group_max``; the ``repeat`` + ``cat`` of the pooled feature with the
+    per-point feature is never materialised: its product with the first MLP layer is a per-object vector that
+    enters the GEMM epilogue as a row-group addend;
+  * attention = in-projections (``dz_linear_forward``) + ``dz_mha_core`` (scores never leave registers) +
+    out-projection; residual + LayerNorm = ``dz_add_layernorm``.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .det_modules import _Cached, _inference_only, fold_bn
+from .lib import DetZeroHipError
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders with the reference's module tree (names matter for state_dict compatibility)
+# ------------------------------------------------------------------------------------------------
+def make_linear_layers(linear_cfg, input_channels, output_channels, output_use_norm=False):
+    """model_utils.py:81-97."""
+    layers, c_in = [], input_channels
+    for k in range(len(linear_cfg)):
+        layers.extend([nn.Linear(c_in, linear_cfg[k], bias=False), nn.BatchNorm1d(linear_cfg[k], eps=1e-3, momentum=0.01), nn.ReLU()])
+        c_in = linear_cfg[k]
+    if output_use_norm:
+        layers.extend([nn.Linear(c_in, output_channels, bias=False), nn.BatchNorm1d(output_channels, eps=1e-3, momentum=0.01), nn.ReLU()])
+    else:
+        layers.append(nn.Linear(c_in, output_channels, bias=True))
+    return nn.Sequential(*layers)
+
+
+def make_fc_layers(linear_cfg, input_channels, output_channels, output_use_norm=False):
+    """model_utils.py:99-115."""
+    layers, c_in = [], input_channels
+    for k in range(len(linear_cfg)):
+        layers.extend([nn.Conv1d(c_in, linear_cfg[k], kernel_size=1, bias=False), nn.BatchNorm1d(linear_cfg[k], eps=1e-3, momentum=0.01), nn.ReLU()])
+        c_in = linear_cfg[k]
+    if output_use_norm:
+        layers.extend([nn.Conv1d(c_in, output_channels, kernel_size=1, bias=False), nn.BatchNorm1d(output_channels, eps=1e-3, momentum=0.01), nn.ReLU()])
+    else:
+        layers.append(nn.Conv1d(c_in, output_channels, kernel_size=1, bias=True))
+    return nn.Sequential(*layers)
+
+
+def make_conv_layers(conv_cfg, input_channels, output_channels, output_use_norm=False):
+    """model_utils.py:117-135."""
+    layers, c_in = [], input_channels
+    for k in range(len(conv_cfg)):
+        layers.extend([nn.Conv2d(c_in, conv_cfg[k], kernel_size=1, bias=False), nn.BatchNorm2d(conv_cfg[k], eps=1e-3, momentum=0.01), nn.ReLU()])
+        c_in = conv_cfg[k]
+    if output_use_norm:
+        layers.extend([nn.Conv2d(c_in, output_channels, kernel_size=1, bias=False), nn.BatchNorm2d(output_channels, eps=1e-3, momentum=0.01), nn.ReLU()])
+    else:
+        layers.append(nn.Conv2d(c_in, output_channels, kernel_size=1, bias=True))
+    return nn.Sequential(*layers)
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter layout of transformer/multi_head_attention.py:7-62 (in_proj_weight/bias, out_proj)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.head_dim = embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """transformer/position_encoding.py:4-21."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1), nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+
+class TransformerDecoderLayer(nn.Module):
+    """transformer/decoder.py:7-46 (parameters only; executed by ``decoder_layer_forward``)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', self_posembed=None,
+                 cross_posembed=None, cross_only=False):
+        super().__init__()
+        if activation != 'relu':
+            raise DetZeroHipError('TransformerDecoderLayer: only relu is implemented (all DetZero configs)')
+        if cross_posembed is not None:
+            raise DetZeroHipError('TransformerDecoderLayer: cross_posembed is not used by any DetZero config')
+        self.cross_only = cross_only
+        if not cross_only:
+            self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.self_posembed = self_posembed
+        self.nhead = nhead
+
+
+class ConvModule(nn.Module):
+    """conv + bn(+relu) with the attribute names of transformer/conv_module.py:182-320 ('conv', 'bn')."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)      # bias='auto' with a norm -> no bias
+        self.bn = nn.BatchNorm1d(out_channels)
+
+
+class FFN(nn.Module):
+    """transformer/ffn.py:6-67: per head [ConvModule(C->64)] + Conv1d(64->classes, bias)."""
+
+    def __init__(self, in_channels, heads, head_conv=64):
+        super().__init__()
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            if num_conv != 2:
+                raise DetZeroHipError('FFN: num_conv must be 2 (all DetZero configs)')
+            self.__setattr__(head, nn.Sequential(ConvModule(in_channels, head_conv), nn.Conv1d(head_conv, classes, kernel_size=1, bias=True)))
+
+
+class _Head(nn.Module):
+    """head/geometry_head.py:13-95 / head/position_head.py:13-82: decoder layers + prediction heads."""
+
+    def __init__(self, pos_dims, common_heads, num_decoder_layers=1, num_heads=8, hidden_channel=256, ffn_channel=256,
+                 dropout=0.1, activation='relu', cross_only=False, auxiliary=True, **kwargs):
+        super().__init__()
+        if num_decoder_layers != 1:
+            raise DetZeroHipError('refiner heads: num_decoder_layers must be 1 (all DetZero configs)')
+        self.decoder = nn.ModuleList([TransformerDecoderLayer(
+            hidden_channel, num_heads, ffn_channel, dropout, activation,
+            self_posembed=PositionEmbeddingLearned(pos_dims, hidden_channel), cross_only=cross_only)])
+        self.prediction_heads = nn.ModuleList([FFN(hidden_channel, dict(common_heads))])
+
+
+class GeometryHead(_Head):
+    def __init__(self, num_classes=3, **kw):
+        super().__init__(3, {'geometry_cls': (num_classes, 2), 'geometry_reg': (num_classes * 3, 2)}, **kw)
+
+
+class PositionHead(_Head):
+    def __init__(self, num_classes=3, **kw):
+        super().__init__(4, {'center_reg': (3, 2), 'heading_cls': (12, 2), 'heading_reg': (12, 2)}, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-layout parameter preparation
+# ------------------------------------------------------------------------------------------------
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def _wt(weight, cin_pad=None, cout_pad=None):
+    """(Cout, Cin[,1[,1]]) conv/linear weight -> (Cin_pad, Cout_pad) fp32 for dz_linear_forward."""
+    w = weight.detach().float().reshape(weight.shape[0], weight.shape[1]).t().contiguous()
+    ci, co = w.shape
+    cin_pad = ci if cin_pad is None else cin_pad
+    cout_pad = _pad16(co) if cout_pad is None else cout_pad
+    out = w.new_zeros((cin_pad, cout_pad))
+    out[:ci, :co] = w
+    return out
+
+
+def _vec(v, n, fill=0.0):
+    out = v.new_full((n,), fill, dtype=torch.float32)
+    out[:v.numel()] = v.detach().float()
+    return out
+
+
+def _stack_plan(seq, cin_pad=None):
+    """nn.Sequential of [conv|linear, bn, relu]* (+ optional final conv with bias) -> list of layer dicts."""
+    mods = list(seq)
+    layers, i = [], 0
+    while i < len(mods):
+        lin = mods[i]
+        cout = lin.weight.shape[0]
+        if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d)):
+            scale, shift = fold_bn(mods[i + 1], lin.bias)
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            i += 3 if relu else 2
+        else:
+            scale = torch.ones(cout, device=lin.weight.device)
+            shift = lin.bias.detach().float() if lin.bias is not None else torch.zeros(cout, device=lin.weight.device)
+            relu = False
+            i += 1
+        cp = _pad16(cout)
+        layers.append({'w': _wt(lin.weight, cin_pad if not layers else None, cp), 'scale': _vec(scale, cp, 1.0),
+                       'shift': _vec(shift, cp), 'relu': relu, 'cout': cout})
+    return layers
+
+
+def _run_stack(x, layers, upto=None):
+    outs = []
+    for li, l in enumerate(layers if upto is None else layers[:upto]):
+        x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
+        outs.append(x)
+    return x, outs
+
+
+def _pad_cols(x, n):
+    if x.shape[1] == n:
+        return x.contiguous()
+    out = x.new_zeros((x.shape[0], n))
+    out[:, :x.shape[1]] = x
+    return out
+
+
+def _mha_plan(m):
+    e = m.embed_dim
+    w, b = m.in_proj_weight.detach().float(), m.in_proj_bias.detach().float()
+    one = torch.ones(e, device=w.device)
+    return {'wq': w[:e].t().contiguous(), 'wk': w[e:2 * e].t().contiguous(), 'wv': w[2 * e:].t().contiguous(),
+            'bq': b[:e].contiguous(), 'bk': b[e:2 * e].contiguous(), 'bv': b[2 * e:].contiguous(),
+            'wo': m.out_proj.weight.detach().float().t().contiguous(), 'bo': m.out_proj.bias.detach().float().contiguous(),
+            'one': one, 'heads': m.num_heads, 'scale': float(m.head_dim) ** -0.5, 'e': e}
+
+
+def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask):
+    """rows are (B*L, E) channel-last.  multi_head_attention.py:199-288."""
+    e = p['e']
+    q = ops.linear(q_rows, p['wq'], p['one'], p['bq'], False, e)
+    k = ops.linear(k_rows, p['wk'], p['one'], p['bk'], False, e)
+    v = ops.linear(v_rows, p['wv'], p['one'], p['bv'], False, e)
+    o = ops.mha_core(q.view(b, lq, e), k.view(b, lk, e), v.view(b, lk, e), key_padding_mask, p['heads'], p['scale'])
+    return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
+
+
+def decoder_layer_plan(layer):
+    pe = layer.self_posembed.position_embedding_head
+    one = torch.ones(layer.linear1.out_features, device=layer.linear1.weight.device)
+    return {
+        'pos': _stack_plan(pe, cin_pad=16),
+        'sa': None if layer.cross_only else _mha_plan(layer.self_attn), 'ca': _mha_plan(layer.multihead_attn),
+        'w1': layer.linear1.weight.detach().float().t().contiguous(), 'b1': layer.linear1.bias.detach().float().contiguous(),
+        'w2': layer.linear2.weight.detach().float().t().contiguous(), 'b2': layer.linear2.bias.detach().float().contiguous(),
+        'one1': one, 'one2': torch.ones(layer.linear2.out_features, device=one.device),
+        'ln': [(n.weight.detach().float().contiguous(), n.bias.detach().float().contiguous(), n.eps)
+               for n in (layer.norm1, layer.norm2, layer.norm3)],
+    }
+
+
+def decoder_layer_forward(p, query, memory, query_pos, b, lq, lk, sa_mask=None, ca_mask=None):
+    """decoder.py:48-92.  query (B*Lq, C), memory (B*Lk, C), query_pos (B*Lq, pos_dims) -> (B*Lq, C)."""
+    pos, _ = _run_stack(_pad_cols(query_pos, 16), p['pos'])
+    if p['sa'] is not None:
+        qk = ops.add_layernorm(query, pos, None, None, norm=False)              # q = k = v = query + pos
+        q2 = _mha_forward(p['sa'], qk, qk, qk, b, lq, lq, sa_mask)
+        g, be, eps = p['ln'][0]
+        query = ops.add_layernorm(query, q2, g, be, eps)
+    qp = ops.add_layernorm(query, pos, None, None, norm=False)
+    q2 = _mha_forward(p['ca'], qp, memory, memory, b, lq, lk, ca_mask)
+    g, be, eps = p['ln'][1]
+    query = ops.add_layernorm(query, q2, g, be, eps)
+    h = ops.linear(query, p['w1'], p['one1'], p['b1'], True, p['w1'].shape[1])
+    q2 = ops.linear(h, p['w2'], p['one2'], p['b2'], False, p['w2'].shape[1])
+    g, be, eps = p['ln'][2]
+    return ops.add_layernorm(query, q2, g, be, eps)
+
+
+def ffn_plan(ffn):
+    plan = {}
+    for name in ffn.heads:
+        seq = getattr(ffn, name)
+        cm, last = seq[0], seq[1]
+        scale, shift = fold_bn(cm.bn, cm.conv.bias)
+        c1 = cm.conv.weight.shape[0]
+        co = last.weight.shape[0]
+        plan[name] = [{'w': _wt(cm.conv.weight, None, _pad16(c1)), 'scale': _vec(scale, _pad16(c1), 1.0), 'shift': _vec(shift, _pad16(c1)),
+                       'relu': True, 'cout': c1},
+                      {'w': _wt(last.weight, None, _pad16(co)), 'scale': _vec(torch.ones(co, device=scale.device), _pad16(co), 1.0),
+                       'shift': _vec(last.bias, _pad16(co)), 'relu': False, 'cout': co}]
+    return plan
+
+
+def ffn_forward(plan, x):
+    return {name: _run_stack(x, layers)[0] for name, layers in plan.items()}
+
+
+class _PointNetPlan:
+    """encoder (3 layers, tap the 2nd) + max pool + concat-MLP, as used for the `memory` branch of GRM and PRM."""
+
+    def __init__(self, encoder, mlp, cin, pooled_first):
+        self.enc = _stack_plan(encoder, cin_pad=_pad16(cin))
+        self.cin_pad = _pad16(cin)
+        c_mid = self.enc[1]['cout']                 # hooked intermediate (encoder[5] = ReLU after the 2nd conv)
+        c_pool = self.enc[2]['cout']
+        first = list(mlp)[0]
+        w = first.weight.detach().float().reshape(first.weight.shape[0], first.weight.shape[1]).t().contiguous()   # (Cin, Cout)
+        if pooled_first:                            # PRM: cat([pooled, intermediate])
+            w_pool, w_mid = w[:c_pool], w[c_pool:]
+        else:                                       # GRM: cat([intermediate, pooled])
+            w_mid, w_pool = w[:c_mid], w[c_mid:]
+        self.w_pool = w_pool.contiguous()
+        self.mlp = _stack_plan(mlp)
+        self.mlp[0]['w'] = w_mid.contiguous()
+        self.ones = torch.ones(w.shape[1], device=w.device)
+        self.zeros = torch.zeros(w.shape[1], device=w.device)
+
+    def forward(self, pts_rows, groups, length):
+        x = _pad_cols(pts_rows, self.cin_pad)
+        feat, outs = _run_stack(x, self.enc)
+        pooled = ops.group_max(feat, groups, length)                               # (G, Cpool)
+        gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])   # (G, C1) pre-BN addend
+        l0 = self.mlp[0]
+        y = ops.linear(outs[1], l0['w'], l0['scale'], l0['shift'], l0['relu'], l0['cout'], group_shift=gshift, group_rows=length)
+        y, _ = _run_stack(y, self.mlp[1:])
+        return y
+
+
+# ------------------------------------------------------------------------------------------------
+# GRM
+# ------------------------------------------------------------------------------------------------
+class GeometryTransformer(_Cached):
+    def __init__(self, model_cfg, query_point_dims=None, memory_point_dims=None):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.query_point_dims, self.memory_point_dims = query_point_dims, memory_point_dims
+        self.embed_dims = model_cfg.get('EMBED_DIMS', 256)
+        self.anchor_sizes = model_cfg.get('ANCHOR_SIZES', [[4.8, 1.8, 1.5], [10.0, 2.6, 3.2], [2.0, 1.0, 1.6]])
+        e = self.embed_dims
+        # (sic) the reference builds `memory_encoder` on query_point_dims and `query_encoder` on memory_point_dims
+        self.memory_encoder = make_fc_layers(model_cfg.MEMORY_ENCODER, query_point_dims, e * 2, output_use_norm=True)
+        self.memory_mlp = make_fc_layers(model_cfg.REGRESSION_MLP, e * 2 + model_cfg.MEMORY_ENCODER[1], e, output_use_norm=True)
+        self.query_encoder = make_fc_layers(model_cfg.QUERY_ENCODER, memory_point_dims, e, output_use_norm=True)
+        self.query_mlp = make_linear_layers(model_cfg.REGRESSION_MLP, e, e, output_use_norm=True)
+        dec = dict(model_cfg.DECODER)
+        if dec.pop('NAME') != 'GeometryHead':
+            raise DetZeroHipError('GeometryTransformer: DECODER.NAME must be GeometryHead')
+        self.decoder = GeometryHead(**dec)
+        self.preds_dict = {}
+
+    def plan(self):
+        if self._plan is None:
+            self._plan = {
+                'memory': _PointNetPlan(self.memory_encoder, self.memory_mlp, self.query_point_dims, pooled_first=False),
+                'q_enc': _stack_plan(self.query_encoder, cin_pad=_pad16(self.memory_point_dims)),
+                'q_mlp': _stack_plan(self.query_mlp),
+                'layer': decoder_layer_plan(self.decoder.decoder[0]),
+                'ffn': ffn_plan(self.decoder.prediction_heads[0]),
+                'anchors': torch.tensor(self.anchor_sizes, dtype=torch.float32, device=self.query_mlp[0].weight.device),
+            }
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        _inference_only(self)
+        p = self.plan()
+        m_pts = data_dict['geo_memory_points'].float()
+        b, lm, cm = m_pts.shape
+        memory = p['memory'].forward(m_pts.reshape(b * lm, cm), b, lm)                        # (B*Lm, E)
+        q_pts = data_dict['geo_query_points'].float()
+        _, pp, npts, cq = q_pts.shape
+        qf, _ = _run_stack(_pad_cols(q_pts.reshape(b * pp * npts, cq), _pad16(cq)), p['q_enc'])
+        qf = ops.group_max(qf, b * pp, npts)
+        qf, _ = _run_stack(qf, p['q_mlp'])                                                       # (B*pp, E)
+        qpos = data_dict['geo_query_boxes'][..., 3:6].float().reshape(b * pp, 3).contiguous()
+        out = decoder_layer_forward(p['layer'], qf, memory, qpos, b, pp, lm)
+        preds = ffn_forward(p['ffn'], out)
+        e = self.embed_dims
+        data_dict['query'] = qf.view(b, pp, e).permute(0, 2, 1)
+        data_dict['memory'] = memory.view(b, lm, e).permute(0, 2, 1)
+        self.preds_dict = {k: v.view(1, b, pp, -1) for k, v in preds.items()}                 # (layers, B, queries, ch)
+        self.preds_dict['geo_query_num'] = data_dict['geo_query_num']
+        data_dict['batch_box_preds'] = self.generate_predicted_boxes(self.preds_dict, p['anchors'])
+        return data_dict
+
+    def generate_predicted_boxes(self, preds, anchors):
+        """geometry_transformer.py:91-116 + target_assign.py:74-89: per query pick the arg-max anchor class, size =
+        reg * anchor + anchor, then average over the valid queries of each object (a few flops per object)."""
+        cls, reg = preds['geometry_cls'][0], preds['geometry_reg'][0]            # (B, Q, 3), (B, Q, 9)
+        b, q, n = cls.shape
+        size = reg.reshape(b, q, n, 3) * anchors + anchors
+        pick = cls.argmax(dim=-1)
+        size = torch.gather(size, 2, pick[..., None, None].expand(b, q, 1, 3)).squeeze(2)        # (B, Q, 3)
+        qn = torch.as_tensor(preds['geo_query_num'], device=cls.device).long()
+        valid = (torch.arange(q, device=cls.device)[None, :] < qn[:, None]).float()
+        mean = (size * valid[..., None]).sum(1) / qn[:, None].float()
+        boxes = torch.zeros((b, 7), dtype=torch.float32, device=cls.device)
+        boxes[:, 3:6] = mean
+        return boxes
+
+
+# ------------------------------------------------------------------------------------------------
+# PRM
+# ------------------------------------------------------------------------------------------------
+class PositionTransformer(_Cached):
+    MEM_PTS_PER_BOX = 48        # hard-coded in the reference (position_head.py:91)
+
+    def __init__(self, model_cfg, query_point_dims=None, memory_point_dims=None):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.query_point_dims, self.memory_point_dims = query_point_dims, memory_point_dims
+        self.embed_dims = model_cfg.get('EMBED_DIMS', 256)
+        e = self.embed_dims
+        self.query_encoder = make_conv_layers(model_cfg.QUERY_ENCODER, query_point_dims, e, output_use_norm=True)
+        self.query_mlp = make_fc_layers(model_cfg.REGRESSION_MLP, e, e, output_use_norm=True)
+        self.memory_encoder = make_fc_layers(model_cfg.MEMORY_ENCODER, memory_point_dims, e, output_use_norm=True)
+        self.memory_mlp = make_fc_layers(model_cfg.REGRESSION_MLP, e + model_cfg.MEMORY_ENCODER[1], e, output_use_norm=True)
+        dec = dict(model_cfg.DECODER)
+        if dec.pop('NAME') != 'PositionHead':
+            raise DetZeroHipError('PositionTransformer: DECODER.NAME must be PositionHead')
+        self.decoder = PositionHead(**dec)
+        self.preds_dict = {}
+        self.dir_bin_num = 12
+
+    def plan(self):
+        if self._plan is None:
+            dev = self.query_mlp[0].weight.device
+            self._plan = {
+                'memory': _PointNetPlan(self.memory_encoder, self.memory_mlp, self.memory_point_dims, pooled_first=True),
+                'q_enc': _stack_plan(self.query_encoder, cin_pad=_pad16(self.query_point_dims)),
+                'q_mlp': _stack_plan(self.query_mlp),
+                'layer': decoder_layer_plan(self.decoder.decoder[0]),
+                'ffn': ffn_plan(self.decoder.prediction_heads[0]),
+                'anchor_angles': torch.arange(12, dtype=torch.float32, device=dev) * (2 * np.pi / 12) - np.pi,
+            }
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        _inference_only(self)
+        p = self.plan()
+        local_pts = data_dict['pos_query_points'].float()
+        global_pts = data_dict['pos_memory_points'].float()
+        traj = data_dict['pos_trajectory'].float()
+        b, nb, npts, cq = local_pts.shape
+        gp = global_pts.shape[2]
+        if gp != self.MEM_PTS_PER_BOX:
+            raise DetZeroHipError('PositionTransformer: %d memory points per box (the reference hard-codes 48)' % gp)
+        e = self.embed_dims
+        qf, _ = _run_stack(_pad_cols(local_pts.reshape(b * nb * npts, cq), _pad16(cq)), p['q_enc'])
+        qf = ops.group_max(qf, b * nb, npts)
+        qf, _ = _run_stack(qf, p['q_mlp'])                                                       # (B*nb, E)
+        qpos = torch.cat([traj[..., :3], traj[..., 6:]], dim=-1).reshape(b * nb, -1).contiguous()
+        lk = nb * gp
+        memory = p['memory'].forward(global_pts.reshape(b * lk, global_pts.shape[3]), b, lk)     # (B*Lk, E)
+        kpm = data_dict['padding_mask'].to(torch.bool)
+        ca = kpm.reshape(b, nb, 1).repeat(1, 1, gp).reshape(b, -1)
+        out = decoder_layer_forward(p['layer'], qf, memory, qpos, b, nb, lk, sa_mask=kpm, ca_mask=ca)
+        preds = {k: v.view(b, nb, -1) for k, v in ffn_forward(p['ffn'], out).items()}
+        preds['size_reg'] = traj[:, :, 3:6]
+        data_dict['query'] = qf.view(b, nb, e).permute(0, 2, 1)
+        data_dict['memory'] = memory.view(b, lk, e).permute(0, 2, 1)
+        data_dict['query_pos'] = qpos.view(b, nb, -1)
+        self.preds_dict = preds
+        # target_assign.py:91-102
+        center = preds['center_reg'] + traj[:, :, :3]
+        dir_reg = preds['heading_reg'] * (np.pi / self.dir_bin_num) + p['anchor_angles']
+        pick = preds['heading_cls'].argmax(dim=-1, keepdim=True)
+        heading = torch.gather(dir_reg, 2, pick)
+        data_dict['batch_box_preds'] = torch.cat([center, preds['size_reg'], heading], dim=-1)
+        return data_dict
+
+
+__all__ = {'GeometryTransformer': GeometryTransformer, 'PositionTransformer': PositionTransformer}

@@ -111,3 +111,34 @@ def merge_two_sweeps(frame_a, frame_b, dt=0.1):
     a = np.concatenate([frame_a, np.zeros((frame_a.shape[0], 1), np.float32)], axis=1)
     b = np.concatenate([frame_b, np.full((frame_b.shape[0], 1), dt, np.float32)], axis=1)
     return np.concatenate([a, b], axis=0)
+
+
+def synth_state_dict(shapes, seed=0):
+    """Deterministic synthetic weights as a pure function of (key, shape, seed): lets a golden fixture
+    omit the weights (the generator of the fixture and the test both call this).  `shapes`: {key: shape}.
+    Conv/linear weights ~ N(0, 1/fan_in), biases small, BatchNorm/LayerNorm gains in [0.5,1.5],
+    running_var in [0.5,1.5], running_mean small, counters zero."""
+    import zlib
+
+    import torch
+    out = {}
+    for key, shape in shapes.items():
+        rng = np.random.default_rng(zlib.crc32(key.encode()) + 7919 * seed)
+        shape = tuple(int(s) for s in shape)
+        last = key.rsplit('.', 1)[-1]
+        if last == 'num_batches_tracked':
+            t = np.zeros(shape, np.int64)
+        elif last == 'running_var':
+            t = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif last == 'running_mean':
+            t = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        elif len(shape) <= 1:
+            if last == 'weight':                       # norm gains
+                t = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+            else:                                      # biases
+                t = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = (rng.standard_normal(shape) / np.sqrt(max(fan_in, 1))).astype(np.float32)
+        out[key] = torch.from_numpy(t)
+    return out

@@ -139,6 +139,8 @@ typedef struct dz_conv2d_desc {
     int g_cout[8];        /* valid output channels of each group                               */
     int g_ooff[8];        /* output channel offset of each group (added to out_coff)           */
     int relu;
+    const float *group_shift; /* optional (n_row_groups, cout_pad): added to the accumulator BEFORE scale/shift, */
+    int group_rows;           /* row group = output row / group_rows (per-object bias of the PointNet concat)   */
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
@@ -193,7 +195,17 @@ int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *k
  * + BatchNorm + ReLU stacks of the GRM/PRM PointNet encoders
  * (refining/detzero_refine/models/modules/geometry_transformer.py:34-67), same MFMA engine. */
 int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
-                      const float *scale, const float *shift, int relu, float *y, int y_stride, void *stream);
+                      const float *scale, const float *shift, const float *group_shift, int group_rows, int relu,
+                      float *y, int y_stride, void *stream);
+
+/* out (groups, c) = max over the `len` rows of each group of x (groups*len, c): the point-wise max pooling of
+ * the GRM/PRM PointNet encoders (geometry_transformer.py:124,137; position_transformer.py:108,117). */
+int dz_group_max(const float *x, int groups, int len, int c, float *out, void *stream);
+
+/* out = LayerNorm(x + y) * gamma + beta over rows of 256 channels (decoder.py:75-88: residual + post-LN);
+ * y may be NULL; do_norm == 0 gives the plain sum x + y (with_pos_embed, decoder.py:50-51). */
+int dz_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c,
+                     float eps, int do_norm, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -134,3 +134,15 @@ def test_config_yaml_include(tmp_path):
                                  '    DATASET: Y\nMODEL:\n    NAME: CenterPoint\n')
     cfg = cfg_from_yaml_file(str(mdir / 'm.yaml'), base_dir=str(tmp_path))
     assert cfg.DATA_CONFIG.DATASET == 'Y' and cfg.DATA_CONFIG.POINT_CLOUD_RANGE[0] == -75.2 and cfg.MODEL.NAME == 'CenterPoint'
+
+
+def test_collate_batch_matches_reference_layout():
+    from detzero_amd.dataset_utils import collate_batch
+    a = {'voxels': np.zeros((3, 5, 5), np.float32), 'voxel_coords': np.ones((3, 3), np.int32), 'voxel_num_points': np.ones(3, np.int32),
+         'points': np.zeros((7, 5), np.float32), 'gt_boxes': np.ones((2, 8), np.float32), 'frame_id': 4}
+    b = {'voxels': np.zeros((2, 5, 5), np.float32), 'voxel_coords': np.ones((2, 3), np.int32), 'voxel_num_points': np.ones(2, np.int32),
+         'points': np.zeros((4, 5), np.float32), 'gt_boxes': np.ones((5, 8), np.float32), 'frame_id': 5}
+    out = collate_batch([a, b])
+    assert out['batch_size'] == 2 and out['voxels'].shape == (5, 5, 5) and out['voxel_coords'].shape == (5, 4)
+    assert out['voxel_coords'][:, 0].tolist() == [0, 0, 0, 1, 1] and out['points'].shape == (11, 6)
+    assert out['gt_boxes'].shape == (2, 5, 8) and out['gt_boxes'][0, 2:].sum() == 0 and out['frame_id'].tolist() == [4, 5]

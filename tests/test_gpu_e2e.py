@@ -172,3 +172,32 @@ def test_hip_graph_capture_of_frame_pipeline(device):
         torch.cuda.synchronize()
         n2 = int(e_n.item())
         assert int(g_n.item()) == n2 and torch.equal(g_out[:n2], e_out[:n2])
+
+
+def test_batch_of_two_frames_matches_single_frames(small, device):
+    """The reference evaluates batches (collate_batch concatenates voxels and prepends the batch index);
+    a batch of 2 must give, per frame, exactly what the frames give alone."""
+    from detzero_amd.data_processor import DataProcessor
+    from detzero_amd.dataset_utils import collate_batch, generate_prediction_dicts
+    model, cfg, info, pts0, ref = small
+    pts1 = masked_frame(7, 20000)
+    dp = DataProcessor(cfg.DATA_CONFIG.DATA_PROCESSOR, info.point_cloud_range, training=False, num_point_features=5)
+    samples = []
+    for p in (pts0, pts1):
+        d = dp.forward({'points': torch.from_numpy(p).to(device), 'use_lead_xyz': True})
+        samples.append({'voxels': d['voxels'], 'voxel_coords': d['voxel_coords'], 'voxel_num_points': d['voxel_num_points'],
+                        'frame_id': np.int64(len(samples))})
+    batch = collate_batch(samples)
+    assert batch['batch_size'] == 2 and batch['voxel_coords'].shape[1] == 4
+    pred, _ = model({k: (v.float() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    singles = []
+    for smp in samples:
+        b1 = collate_batch([smp])
+        singles.append(model({k: (v.float() if torch.is_tensor(v) else v) for k, v in b1.items()})[0][0])
+    for i in range(2):
+        assert pred[i]['pred_boxes'].shape == singles[i]['pred_boxes'].shape
+        torch.testing.assert_close(pred[i]['pred_boxes'], singles[i]['pred_boxes'], rtol=0, atol=1e-5)
+        assert torch.equal(pred[i]['pred_labels'], singles[i]['pred_labels'])
+    annos = generate_prediction_dicts(batch, pred, info.class_names)
+    assert len(annos) == 2 and annos[0]['boxes_lidar'].shape[1] == 7 and annos[1]['frame_id'] == 1
+    assert set(annos[0]['name'].tolist()) <= set(info.class_names)

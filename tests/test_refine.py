@@ -1,0 +1,87 @@
+"""Refining module (GRM / PRM): state-dict compatibility with the reference (CPU) and parity of the HIP path
+with the outputs of the reference's own GeometryTransformer / PositionTransformer (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from detzero_amd.config import AttrDict
+from detzero_amd.synth import synth_state_dict
+
+GCFG = AttrDict({'QUERY_ENCODER': [128, 128], 'MEMORY_ENCODER': [128, 128], 'REGRESSION_MLP': [512], 'EMBED_DIMS': 256,
+                 'ANCHOR_SIZES': [[4.8, 1.8, 1.5], [10.0, 2.6, 3.2], [2.0, 1.0, 1.6]],
+                 'DECODER': {'NAME': 'GeometryHead', 'num_classes': 3, 'num_heads': 8, 'num_decoder_layers': 1,
+                             'auxiliary': True, 'cross_only': False, 'memory_self_attn': False, 'hidden_channel': 256,
+                             'ffn_channel': 256, 'dropout': 0.1, 'bn_momentum': 0.1, 'activation': 'relu'}})
+PCFG = AttrDict({'QUERY_ENCODER': [128, 128], 'MEMORY_ENCODER': [128, 128], 'REGRESSION_MLP': [512],
+                 'LOSS_CLS': {'type': 'CrossEntropyLoss'},
+                 'DECODER': {'NAME': 'PositionHead', 'num_classes': 3, 'num_heads': 8, 'num_decoder_layers': 1,
+                             'auxiliary': True, 'cross_only': False, 'hidden_channel': 256, 'dropout': 0.1,
+                             'bn_momentum': 0.1, 'activation': 'relu', 'ffn_channel': 256}})
+
+
+@pytest.fixture(scope='module')
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, 'refine_golden.npz'))
+
+
+def _models():
+    from detzero_amd.refine_modules import GeometryTransformer, PositionTransformer
+    return GeometryTransformer(GCFG, query_point_dims=11, memory_point_dims=4).eval(), \
+        PositionTransformer(PCFG, query_point_dims=32, memory_point_dims=32).eval()
+
+
+def test_state_dict_identical_to_reference_manifest(g):
+    """Key names AND shapes equal the reference modules' own state_dict (recorded when the golden was made)."""
+    grm, prm = _models()
+    for model, tag in ((grm, 'grm'), (prm, 'prm')):
+        ref = dict(zip(g[tag + '_keys'].tolist(), g[tag + '_shapes'].tolist()))
+        mine = {k: str(tuple(v.shape)) for k, v in model.state_dict().items()}
+        assert mine == ref, (sorted(set(mine) ^ set(ref))[:6], [(k, mine[k], ref[k]) for k in mine if k in ref and mine[k] != ref[k]][:4])
+        model.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1), strict=True)
+
+
+@pytest.mark.gpu
+def test_grm_matches_reference(device, g):
+    grm, _ = _models()
+    grm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in grm.state_dict().items()}, seed=5), strict=True)
+    grm = grm.to(device)
+    data = {k[len('grm_in_'):]: torch.from_numpy(g[k]).to(device) for k in g.files if k.startswith('grm_in_')}
+    res = grm(data)
+    torch.testing.assert_close(res['memory'].cpu(), torch.from_numpy(g['grm_memory']), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(res['query'].cpu(), torch.from_numpy(g['grm_query']), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(grm.preds_dict['geometry_cls'].cpu(), torch.from_numpy(g['grm_cls']), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(grm.preds_dict['geometry_reg'].cpu(), torch.from_numpy(g['grm_reg']), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(res['batch_box_preds'].cpu(), torch.from_numpy(g['grm_boxes']), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_prm_matches_reference(device, g):
+    _, prm = _models()
+    prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, seed=6), strict=True)
+    prm = prm.to(device)
+    data = {k[len('prm_in_'):]: torch.from_numpy(g[k]).to(device) for k in g.files if k.startswith('prm_in_')}
+    res = prm(data)
+    torch.testing.assert_close(res['query'].cpu(), torch.from_numpy(g['prm_query']), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(res['memory'].cpu()[:, :, ::16], torch.from_numpy(g['prm_memory']), rtol=1e-3, atol=1e-4)
+    valid = torch.from_numpy(g['prm_in_padding_mask']) == 0          # padded queries attend to nothing meaningful
+    for k in ('center_reg', 'heading_cls', 'heading_reg'):
+        torch.testing.assert_close(prm.preds_dict[k].cpu()[valid], torch.from_numpy(g['prm_' + k])[valid], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(res['batch_box_preds'].cpu()[valid], torch.from_numpy(g['prm_boxes'])[valid], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_group_max_and_layernorm(device):
+    from detzero_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn((5 * 37, 192), generator=gen)
+    out = ops.group_max(x.to(device), 5, 37).cpu()
+    assert torch.equal(out, x.view(5, 37, 192).max(dim=1)[0])
+    a = torch.randn((77, 256), generator=gen); b = torch.randn((77, 256), generator=gen)
+    gm = torch.rand(256, generator=gen) + 0.5; bt = torch.randn(256, generator=gen)
+    ln = ops.add_layernorm(a.to(device), b.to(device), gm.to(device), bt.to(device), 1e-5).cpu()
+    ref = torch.nn.functional.layer_norm(a + b, (256,), gm, bt, 1e-5)
+    torch.testing.assert_close(ln, ref, rtol=1e-5, atol=1e-5)
+    s = ops.add_layernorm(a.to(device), b.to(device), None, None, norm=False).cpu()
+    assert torch.equal(s, a + b)
