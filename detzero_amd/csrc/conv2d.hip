@@ -215,16 +215,29 @@ const char *dz_conv2d_variant(const dz_conv2d_desc *d) { return d ? kConvVariant
 int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad,
                       const float *scale, const float *shift, const float *group_shift, int group_rows, int relu,
                       float *y, int y_stride, void *stream_) {
-    dz_conv2d_desc d = {};
-    d.in = x; d.out = y; d.w = w; d.scale = scale; d.shift = shift;
-    d.batch = 1; d.ho = 1; d.wo = rows;
-    d.in_hp = 1; d.in_wp = rows; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin;
-    d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
-    d.out_hp = 1; d.out_wp = rows; d.out_cstride = y_stride; d.out_coff = 0;
-    d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
-    d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
-    d.group_shift = group_shift; d.group_rows = group_rows > 0 ? group_rows : 1;
-    return dz_conv2d_forward(&d, stream_);
+    DZ_CHECK_ARG(rows >= 0 && x_stride >= cin && y_stride >= cout, "dz_linear_forward: bad sizes");
+    if (group_rows < 1) group_rows = 1;
+    // the A operand is fetched through 32-bit buffer offsets: feed the engine at most ~2 GiB of rows per launch
+    long max_rows = (long)(0x7FF00000ull / ((size_t)x_stride * sizeof(float)));
+    if (group_shift) max_rows = max_rows / group_rows * group_rows;     // keep launches aligned to row groups
+    DZ_CHECK_ARG(max_rows >= 1, "dz_linear_forward: one row group exceeds the 2 GiB addressing window");
+    for (long r0 = 0; r0 < rows || r0 == 0; r0 += max_rows) {
+        const int n = (int)((rows - r0) < max_rows ? (rows - r0) : max_rows);
+        dz_conv2d_desc d = {};
+        d.in = x + (size_t)r0 * x_stride; d.out = y + (size_t)r0 * y_stride; d.w = w; d.scale = scale; d.shift = shift;
+        d.batch = 1; d.ho = 1; d.wo = n;
+        d.in_hp = 1; d.in_wp = n; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin;
+        d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
+        d.out_hp = 1; d.out_wp = n; d.out_cstride = y_stride; d.out_coff = 0;
+        d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
+        d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
+        d.group_shift = group_shift ? group_shift + (size_t)(r0 / group_rows) * cout_pad : nullptr;
+        d.group_rows = group_rows;
+        if (n == 0) return DZ_OK;
+        const int rc = dz_conv2d_forward(&d, stream_);
+        if (rc) return rc;
+    }
+    return DZ_OK;
 }
 
 }  // extern "C"

@@ -85,3 +85,21 @@ def test_group_max_and_layernorm(device):
     torch.testing.assert_close(ln, ref, rtol=1e-5, atol=1e-5)
     s = ops.add_layernorm(a.to(device), b.to(device), None, None, norm=False).cpu()
     assert torch.equal(s, a + b)
+
+
+@pytest.mark.gpu
+def test_linear_over_the_2gib_buffer_window(device):
+    """Inputs larger than the 32-bit buffer-offset window are processed in row chunks (group addend aligned)."""
+    from detzero_amd import ops
+    rows, cin, cout, grp = 9_000_000, 64, 16, 1000                  # 2.3 GB input
+    x = torch.empty((rows, cin), dtype=torch.float32, device=device)
+    x.copy_(torch.arange(rows, device=device, dtype=torch.float32)[:, None] % 7.0 - 3.0)
+    x[:, 1] = 1.0
+    w = torch.zeros((cin, cout), device=device); w[0, 0] = 1.0; w[1, 1] = 2.0
+    gs = torch.arange(rows // grp, device=device, dtype=torch.float32)[:, None].repeat(1, cout).contiguous()
+    one = torch.ones(cout, device=device); zero = torch.zeros(cout, device=device)
+    y = ops.linear(x, w, one, zero, False, cout, group_shift=gs, group_rows=grp)
+    idx = torch.tensor([0, 999, 1000, 8_388_607, 8_388_608, rows - 1], device=device)
+    exp0 = (idx.float() % 7.0 - 3.0) + (idx // grp).float()
+    exp1 = 2.0 + (idx // grp).float()
+    assert torch.equal(y[idx, 0], exp0) and torch.equal(y[idx, 1], exp1)
