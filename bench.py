@@ -4,11 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one pass of the whole hot path over one synthetic 160k-point frame (BASELINE.json
-configs[1]: 0.1 m voxels, grid 1504x1504x40, full VoxelResBackBone8x + BaseBEVBackbone + CenterHead +
-decode + rotated NMS), frame already resident in HBM when the timed region starts, fp32 throughout
-(fp32 MFMA = exact fp32).  One process per GPU, frames sharded one-per-GPU (weak scaling); with N>1 the
-per-frame boxes are gathered to rank 0 with one RCCL all-gather at the end of the timed region.
+A "step" = one pass of the whole hot path over one batch of --batch synthetic 160k-point frames
+(BASELINE.json configs[1]: 0.1 m voxels, grid 1504x1504x40, full VoxelResBackBone8x + BaseBEVBackbone +
+CenterHead + decode + rotated NMS; the reference evaluates with BATCH_SIZE_PER_GPU frames per pass the same
+way), frames already resident in HBM when the timed region starts, fp32 throughout (fp32 MFMA = exact
+fp32).  One process per GPU, frames sharded across GPUs (weak scaling); with N>1 the per-frame boxes are
+gathered to rank 0 with one RCCL all-gather at the end of the timed region.  value = frames/s over all GPUs.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -56,10 +57,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
+    ap.add_argument('--batch', type=int, default=4, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
-    ap.add_argument('--profile-frames', type=int, default=3)
+    ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
     return ap.parse_args()
 
 
@@ -88,13 +90,18 @@ def main():
     model, cfg, info = synth_detector(VOXEL_SIZE_01, seed=0)
     model = model.to(dev)
     pipe = FramePipeline(model, info)
-    n_distinct = 4
+    B = max(1, args.batch)
+    n_distinct = max(4, B + 1)
     frames = [torch.from_numpy(synth_waymo_frame(1000 * rank + i, args.points)).to(dev) for i in range(n_distinct)]
-    static_in = frames[0].clone()
+    static_in = [frames[j].clone() for j in range(B)]
     K, W = args.steps, args.warmup
     post_max = pipe.post_max
-    results = torch.zeros((K, post_max, 9), dtype=torch.float32, device=dev)
-    counts = torch.zeros((K,), dtype=torch.int32, device=dev)
+    results = torch.zeros((K, B, post_max, 9), dtype=torch.float32, device=dev)
+    counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
+
+    def load_inputs(i):
+        for j in range(B):
+            static_in[j].copy_(frames[(i * B + j) % n_distinct], non_blocking=True)
 
     # warm-up (also primes the caching allocator and builds the kernel-layout weights)
     use_graph = not args.no_graph
@@ -104,7 +111,7 @@ def main():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for i in range(max(W, 3)):
-            static_in.copy_(frames[i % n_distinct])
+            load_inputs(i)
             g_out, g_n = pipe(static_in)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
@@ -125,13 +132,13 @@ def main():
 
     def step(i):
         nonlocal g_out, g_n
-        static_in.copy_(frames[i % n_distinct], non_blocking=True)
+        load_inputs(i)
         if graph is not None:
             graph.replay()
         else:
             g_out, g_n = pipe(static_in)
         results[i].copy_(g_out, non_blocking=True)
-        counts[i:i + 1].copy_(g_n, non_blocking=True)
+        counts[i].copy_(g_n, non_blocking=True)
 
     log('launch mode:', graph_note)
     for i in range(W):
@@ -145,7 +152,7 @@ def main():
     for i in range(K):
         step(i)
     if world > 1:
-        all_b, all_c = fp.gather_frame_boxes(results, counts)
+        all_b, all_c = fp.gather_frame_boxes(results.view(K * B, post_max, 9), counts.view(K * B))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -156,19 +163,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_boxes = counts.float().mean().item()
-    log('timed region: %d steps in %.3f s' % (K, dt))
+    log('timed region: %d steps x %d frames in %.3f s' % (K, B, dt))
 
     out = None
     if rank == 0:
-        value = world * K / dt
+        value = world * K * B / dt
         out = {
             'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(value, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: single %d-pt synthetic Waymo frame per step, 0.1 m voxels '
+            'config': {'workload': 'BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
                                    '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
                                    '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
-                       'frames_per_step_per_gpu': 1, 'parallelism': 'frame-parallel x%d' % world,
+                       'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'parallelism': 'frame-parallel x%d' % world,
                        'launch': graph_note, 'weights': 'seeded random init (no checkpoints offline)',
                        'mean_boxes_per_frame': round(n_boxes, 1)},
         }
@@ -180,7 +187,7 @@ def main():
         stage_ms = {}
         try:
             for i in range(args.profile_frames):
-                static_in.copy_(frames[i % n_distinct])
+                load_inputs(i)
                 pipe(static_in)
             agg = prof.summary()
         finally:
@@ -188,11 +195,11 @@ def main():
         kern = []
         for name, a in agg.items():
             per = a['ms'] / a['launches']
-            kern.append({'kernel': name, 'launches_per_frame': a['launches'] / args.profile_frames,
-                         'avg_us': round(1000.0 * per, 2), 'ms_per_frame': round(a['ms'] / args.profile_frames, 4),
+            kern.append({'kernel': name, 'launches_per_step': a['launches'] / args.profile_frames,
+                         'avg_us': round(1000.0 * per, 2), 'ms_per_step': round(a['ms'] / args.profile_frames, 4),
                          'tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
                          'algorithmic_gbs': round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)})
-        kern.sort(key=lambda r: -r['ms_per_frame'])
+        kern.sort(key=lambda r: -r['ms_per_step'])
         if kern:
             top = kern[0]
             a = agg[top['kernel']]
@@ -206,7 +213,7 @@ def main():
                                        'algorithmic FLOP = 2*pixels*taps*Cin*Cout'}
         out['kernels'] = kern
         log('per-kernel profile done')
-        out['conv_ms_per_frame'] = round(sum(r['ms_per_frame'] for r in kern), 4)
+        out['conv_ms_per_frame'] = round(sum(r['ms_per_step'] for r in kern) / B, 4)
 
     # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -156,11 +156,14 @@ class SyntheticDatasetInfo:
 
 
 class FramePipeline:
-    """Sync-free single-frame detector step on one GPU (batch = 1 frame per call).
+    """Sync-free detector step on one GPU over a batch of frames (reference eval batches frames the same way:
+    tools/test.py builds the loader with OPTIMIZATION.BATCH_SIZE_PER_GPU, collate_batch stacks the voxels with
+    a batch-index column).
 
-    ``__call__(points)``: points (N,C) float32 device tensor (already range-masked or not - the xy
-    mask of data_processor.py:24-37 is applied on the device) -> (boxes9 (K,9), count (1,) i32) where
-    rows [0,count) are ``[x,y,z,dx,dy,dz,heading,score,label(1-based)]`` after NMS.
+    ``__call__(points)``: points = one (N,C) float32 device tensor or a list of B such tensors (already
+    range-masked or not - the xy mask of data_processor.py:24-37 is applied on the device).
+    Returns (boxes9, count): for a single tensor (K,9) and (1,) i32; for a list (B,K,9) and (B,) i32.  Rows
+    [0,count) are ``[x,y,z,dx,dy,dz,heading,score,label(1-based)]`` after NMS.
     """
 
     def __init__(self, model, dataset_info, mode='test', dynamic=False):
@@ -172,30 +175,56 @@ class FramePipeline:
         post = self.head.model_cfg.POST_PROCESSING
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
+        self._iota = None
+
+    def _voxelize(self, frames):
+        """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
+        voxel count carry b = -1 and are ignored by the index build (no host sync, capacity-sized)."""
+        info = self.info
+        rng = info.point_cloud_range
+        nb = len(frames)
+        if self.dynamic:
+            pb = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p], dim=1) for i, p in enumerate(frames)], dim=0)
+            return ops.voxelize_dynamic_nosync(pb.contiguous(), rng, info.voxel_size, nb, xy_range_mask=True)
+        feats, coords = [], []
+        d_n = None
+        for i, p in enumerate(frames):
+            # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
+            voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(p, rng, info.voxel_size, info.max_points_per_voxel,
+                                                              info.max_voxels[self.mode], xy_range_mask=True)
+            feats.append(ops.mean_vfe(voxels, nump, d_m=d_n))
+            if nb == 1:
+                bcol = zyx.new_zeros((zyx.shape[0], 1))
+            else:
+                cap = zyx.shape[0]
+                if self._iota is None or self._iota.shape[0] < cap or self._iota.device != zyx.device:
+                    self._iota = torch.arange(cap, dtype=torch.int32, device=zyx.device)
+                bcol = torch.where(self._iota[:cap] < d_n, i, -1).to(torch.int32)[:, None]
+            coords.append(torch.cat([bcol, zyx], dim=1))
+        if nb == 1:
+            return feats[0], coords[0].contiguous(), d_n
+        return torch.cat(feats, dim=0), torch.cat(coords, dim=0).contiguous(), None
 
     @torch.no_grad()
     def __call__(self, points):
-        info, m = self.info, self.model
-        rng = info.point_cloud_range
-        if self.dynamic:
-            pb = torch.cat([points.new_zeros((points.shape[0], 1)), points], dim=1).contiguous()
-            feats, coords, d_n = ops.voxelize_dynamic_nosync(pb, rng, info.voxel_size, 1, xy_range_mask=True)
-        else:
-            # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
-            voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(points, rng, info.voxel_size,
-                                                              info.max_points_per_voxel, info.max_voxels[self.mode],
-                                                              xy_range_mask=True)
-            feats = ops.mean_vfe(voxels, nump, d_m=d_n)
-            coords = torch.cat([zyx.new_zeros((zyx.shape[0], 1)), zyx], dim=1).contiguous()
-        res = m.backbone3d.run(feats, coords, 1, d_n)
+        m = self.model
+        single = torch.is_tensor(points)
+        frames = [points] if single else list(points)
+        nb = len(frames)
+        feats, coords, d_n = self._voxelize(frames)
+        res = m.backbone3d.run(feats, coords, nb, d_n)
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1)
-        concat = m.backbone2d.run(bev, 1)
-        head, h, w = self.head.run_convs(concat, 1)
-        boxes, scores, labels, keep, d_nk = self.head.decode_nosync(head, h, w)[0]
-        packed = torch.cat([boxes, scores[:, None], (labels + 1).float()[:, None]], dim=1).contiguous()
-        out = ops.gather_rows(packed, keep, d_nk, self.post_max)
-        return out, d_nk
+        concat = m.backbone2d.run(bev, nb)
+        head, h, w = self.head.run_convs(concat, nb)
+        outs, cnts = [], []
+        for boxes, scores, labels, keep, d_nk in self.head.decode_nosync(head, h, w):
+            packed = torch.cat([boxes, scores[:, None], (labels + 1).float()[:, None]], dim=1).contiguous()
+            outs.append(ops.gather_rows(packed, keep, d_nk, self.post_max))
+            cnts.append(d_nk)
+        if single:
+            return outs[0], cnts[0]
+        return torch.stack(outs, dim=0), torch.cat(cnts, dim=0)
 
 
 def synth_detector(voxel_size, seed=0):

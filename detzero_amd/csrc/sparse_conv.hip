@@ -185,7 +185,7 @@ const char *dz_spconv_variant(int cin, int cout) {
     if (cin == 16 && cout == 32) return "k_spconv<128x32x16>";
     if (cin == 32 && cout == 32) return "k_spconv<128x32x32>";
     if ((cin == 32 || cin == 64) && cout == 64) return "k_spconv<64x64x32>";
-    if ((cin == 64 || cin == 128) && cout == 128) return "k_spconv<64x64x32>(N-split)";
+    if ((cin == 64 || cin == 128) && cout == 128) return "k_spconv<64x64x32>";
     return "none";
 }
 

@@ -94,6 +94,25 @@ def test_frame_pipeline_equals_module_path(small, device):
     assert int(d_n2.item()) == n and torch.equal(out2[:n], out[:n])
 
 
+@pytest.mark.parametrize('dynamic', [False, True])
+def test_batched_frames_equal_single_frames(small, device, dynamic):
+    """B frames in one pass (batch-index column, reference collate_batch layout) give, per frame, bit-identical
+    detections to B single-frame passes: the frames never mix in the sparse index, BEV scatter, convs, top-K
+    or NMS."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, pts, ref = small
+    pipe = FramePipeline(model, info, dynamic=dynamic)
+    frames = [torch.from_numpy(pts).to(device), torch.from_numpy(masked_frame(11, 9000)).to(device),
+              torch.from_numpy(masked_frame(12, 14000)).to(device)]
+    singles = [pipe(f) for f in frames]
+    out, cnt = pipe(frames)
+    assert out.shape[0] == 3 and cnt.shape == (3,)
+    for i, (o1, n1) in enumerate(singles):
+        n = int(n1.item())
+        assert n > 0 and int(cnt[i].item()) == n
+        assert torch.equal(out[i, :n], o1[:n])
+
+
 def test_full_size_frame_properties(device):
     """BASELINE configs[1]: 160k points, 0.1 m voxels, full network.  The oracle needs minutes at this
     size, so check size-independent properties and cross-check the cheap stages exactly."""

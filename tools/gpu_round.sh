@@ -14,7 +14,7 @@ try:
     d = json.load(open('gpurun_out/bench_graph.json'))
     print('value', d['value'], 'ms', d['ms_per_step'], 'cpu', d.get('cpu_baseline', {}).get('value'))
     for k in d['kernels']:
-        print('  %-32s x%-5.1f avg %8.2f us  %7.3f ms/frame  %6.2f TF/s  %7.1f GB/s' % (k['kernel'], k['launches_per_frame'], k['avg_us'], k['ms_per_frame'], k['tflops'], k['algorithmic_gbs']))
+        print('  %-32s x%-5.1f avg %8.2f us  %7.3f ms/step  %6.2f TF/s  %7.1f GB/s' % (k['kernel'], k['launches_per_step'], k['avg_us'], k['ms_per_step'], k['tflops'], k['algorithmic_gbs']))
 except Exception as e:
     print('no bench json', e)
 PY
