@@ -155,6 +155,17 @@ class SyntheticDatasetInfo:
         self.tta = False
 
 
+def set_math(model, mode):
+    """Select the arithmetic of every convolution of the detector: 'f32' (fp32 MFMA, bit-for-bit an fmaf chain),
+    'f16x2' / 'bf16x2' (split-precision pairs on the 16-bit matrix cores, csrc/hgemm.h).  All conv modules of a
+    model run in the same mode (activations stay in the mode's storage format between layers)."""
+    mid = ops.math_id(mode)
+    for mod in model.modules():
+        if hasattr(mod, 'set_math') and mod is not model:
+            mod.set_math(mid)
+    return model
+
+
 class FramePipeline:
     """Sync-free detector step on one GPU over a batch of frames (reference eval batches frames the same way:
     tools/test.py builds the loader with OPTIMIZATION.BATCH_SIZE_PER_GPU, collate_batch stacks the voxels with
@@ -166,8 +177,10 @@ class FramePipeline:
     [0,count) are ``[x,y,z,dx,dy,dz,heading,score,label(1-based)]`` after NMS.
     """
 
-    def __init__(self, model, dataset_info, mode='test', dynamic=False):
+    def __init__(self, model, dataset_info, mode='test', dynamic=False, math=None):
         self.model = model.eval()
+        if math is not None:
+            set_math(model, math)
         self.info = dataset_info
         self.mode = mode
         self.dynamic = dynamic
@@ -214,7 +227,7 @@ class FramePipeline:
         feats, coords, d_n = self._voxelize(frames)
         res = m.backbone3d.run(feats, coords, nb, d_n)
         x, lvl = res['encoded']
-        bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1)
+        bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
         concat = m.backbone2d.run(bev, nb)
         head, h, w = self.head.run_convs(concat, nb)
         outs, cnts = [], []

@@ -1,0 +1,236 @@
+// Dense BEV convolutions on the 16-bit matrix cores with split-precision (pair16) operands: same layers,
+// descriptors and fused epilogue as conv2d.hip (Conv2d 3x3 / 1x1, ConvTranspose2d with kernel == stride,
+// BatchNorm/bias + ReLU folded), fp32-class results at ~5x the fp32-MFMA rate (hgemm.h).
+//
+// Reference: detection/detzero_det/models/centerpoint_modules/backbone2d.py:33-120, center_head.py:14-48, :81-102.
+// Input image and weights are pair16; the output image is pair16 (feeds the next layer) or plain fp32 (the
+// last head convolution, which feeds the decoder).
+#include "hgemm.h"
+
+namespace dz {
+
+template <class T, class M, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total, unsigned int in_bytes, unsigned int w_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
+    __shared__ int in_pix[T::BP];    // input pixel index of the (0,0) tap, -1 past the end
+    __shared__ int out_pix[T::BP];   // output pixel index
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wp = wid / T::WC, wc = wid % T::WC;
+    const int ntn = p.cout_pad / T::BC;           // channel tiles per group
+    const int grp = blockIdx.y / ntn;
+    const int n0 = (blockIdx.y % ntn) * T::BC;
+    const long row0 = (long)blockIdx.x * T::BP;
+
+    for (int r = tid; r < T::BP; r += 256) {
+        const long mrow = row0 + r;
+        int ip = -1, op = -1;
+        if (mrow < m_total) {
+            const int x = (int)(mrow % p.wo);
+            const long t = mrow / p.wo;
+            const int y = (int)(t % p.ho);
+            const int b = (int)(t / p.ho);
+            ip = (b * p.in_hp + y * p.stride + p.in_off) * p.in_wp + x * p.stride + p.in_off;
+            op = (b * p.out_hp + y * p.out_sy + p.out_dy) * p.out_wp + x * p.out_sx + p.out_dx;
+        }
+        in_pix[r] = ip;
+        out_pix[r] = op;
+    }
+    __syncthreads();
+
+    f32x16 acc[T::CT][T::PT];
+#pragma unroll
+    for (int i = 0; i < T::CT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::PT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int taps = p.kh * p.kw;
+    const int kchunks = p.cin / T::KC;
+    const int nchunks = taps * kchunks;
+    const long cbase = p.in_coff + (long)grp * p.cin;
+
+    const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(p.in, in_bytes);
+    const __amdgpu_buffer_rsrc_t crsrc = make_rsrc(p.w, w_bytes);
+    unsigned int pvoff[T::P_PER_THREAD], cvoff[T::C_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < T::P_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        pvoff[i] = OOB_OFFSET;
+        if (T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) {
+            const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
+            const int ip = in_pix[rr];
+            if (ip >= 0) pvoff[i] = (unsigned int)(((long)ip * p.in_cstride + cbase + q * 4) * 4);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < T::C_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        cvoff[i] = OOB_OFFSET;
+        if (T::C_PIECES % T::THREADS == 0 || idx < T::C_PIECES) {
+            const int n = idx / (T::KC / 4), q = idx % (T::KC / 4);
+            cvoff[i] = (unsigned int)((((long)grp * taps * p.cout_pad + n0 + n) * p.cin + q * 4) * 4);
+        }
+    }
+    HStage<T> st;
+    int ky = 0, kx = 0, kc = 0;
+    unsigned int padd = 0, cadd = 0;
+    const unsigned int tap_bytes = (unsigned int)((long)p.cout_pad * p.cin * 4);
+    unsigned int tap_base = 0;
+    auto issue = [&]() { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
+    auto advance = [&]() {
+        if (++kc == kchunks) {
+            kc = 0;
+            tap_base += tap_bytes;
+            if (++kx == p.kw) { kx = 0; ++ky; }
+        }
+        padd = (unsigned int)(((ky * p.in_wp + kx) * p.in_cstride + kc * T::KC) * 4);
+        cadd = tap_base + (unsigned int)(kc * T::KC * 4);
+    };
+    hgemm_pipeline<T, M>(nchunks, smem, st, issue, advance, acc, wp, wc, lane, tid);
+
+    // accumulator of a 32x32 fragment: pixel = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
+    const int h = lane >> 5;
+    const int gcout = p.g_cout[grp];
+    const int ooff = p.out_coff + p.g_ooff[grp];
+#pragma unroll
+    for (int pt = 0; pt < T::PT; ++pt) {
+        const int lr = wp * T::PT * 32 + pt * 32 + (lane & 31);
+        const int op = out_pix[lr];
+        if (op < 0) continue;
+#pragma unroll
+        for (int ct = 0; ct < T::CT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wc * T::CT * 32 + ct * 32 + 8 * j + 4 * h;       // first of 4 consecutive channels
+                if (col >= gcout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = p.scale ? p.scale[grp * p.cout_pad + col + e] : 1.f;
+                    const float sh = p.shift ? p.shift[grp * p.cout_pad + col + e] : 0.f;
+                    v[e] = fmaf(acc[ct][pt][4 * j + e], sc, sh);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (OUT_F32) {
+                    float *o = p.out + (size_t)op * p.out_cstride + ooff + col;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < gcout) o[e] = v[e];
+                } else {
+                    uint2 hi, lo;
+                    split4<M>(v, hi, lo);
+                    // group of 8 channels starting at (col & ~7): 16 bytes hi | 16 bytes lo; this lane owns slot 4*h..4*h+3
+                    unsigned char *g = reinterpret_cast<unsigned char *>(p.out) +
+                                       ((size_t)op * p.out_cstride + ooff + (col & ~7)) * 4 + (col & 7) * 2;
+                    *reinterpret_cast<uint2 *>(g) = hi;
+                    *reinterpret_cast<uint2 *>(g + 16) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <class T, class M, bool OUT_F32>
+static int launch_conv_h(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
+    const long m_total = (long)p.batch * p.ho * p.wo;
+    dim3 grid(ceil_div(m_total, T::BP), (p.cout_pad / T::BC) * p.groups);
+    const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
+    if (in_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) {
+        set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_h<T, M, OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                T::LDS_BYTES) != hipSuccess) {
+            set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", T::LDS_BYTES);
+            return DZ_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv2d_h<T, M, OUT_F32>), grid, dim3(256), T::LDS_BYTES, stream, p, m_total, (unsigned int)in_bytes,
+                       (unsigned int)w_bytes);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+// variant ids: BP (pixels) x BC (channels) x KC
+enum ConvHVariant { CH_NONE = 0, CH_128_128, CH_128_64, CH_64_128, CH_64_64, CH_128_32 };
+static const char *kConvHVariantName[] = {"none", "k_conv2d_h<128x128x32>", "k_conv2d_h<128x64x32>", "k_conv2d_h<64x128x32>",
+                                          "k_conv2d_h<64x64x32>", "k_conv2d_h<128x32x32>"};
+
+static ConvHVariant conv2d_h_select(const dz_conv2d_desc &p) {
+    if (p.cin % 32 != 0) return CH_NONE;
+    const long m_total = (long)p.batch * p.ho * p.wo;
+    if (p.cout_pad % 64 != 0) return p.cout_pad % 32 == 0 ? CH_128_32 : CH_NONE;
+    // chip fill: two workgroups are resident per CU; prefer the largest tile that keeps >= ~90 % of the slots busy
+    struct Cand { ConvHVariant v; int bp, bc; double eff; };
+    static const Cand cands[4] = {{CH_128_128, 128, 128, 1.00}, {CH_128_64, 128, 64, 0.90}, {CH_64_128, 64, 128, 0.88}, {CH_64_64, 64, 64, 0.78}};
+    const int slots = 512;
+    double best = -1.0;
+    ConvHVariant pick = CH_64_64;
+    for (int i = 0; i < 4; ++i) {
+        if (p.cout_pad % cands[i].bc != 0) continue;
+        const long tiles = (long)ceil_div(m_total, cands[i].bp) * (p.cout_pad / cands[i].bc) * p.groups;
+        const long rounds = (tiles + slots - 1) / slots;
+        const double useful = (double)m_total / ((double)ceil_div(m_total, cands[i].bp) * cands[i].bp);
+        const double score = cands[i].eff * useful * (double)tiles / (double)(rounds * slots);
+        if (score > best) { best = score; pick = cands[i].v; }
+    }
+    return pick;
+}
+
+template <class M, bool OUT_F32>
+static int conv2d_h_dispatch(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
+    switch (conv2d_h_select(p)) {
+        case CH_128_128: return launch_conv_h<HTile<128, 128, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
+        case CH_128_64: return launch_conv_h<HTile<128, 64, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
+        case CH_64_128: return launch_conv_h<HTile<64, 128, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
+        case CH_64_64: return launch_conv_h<HTile<64, 64, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
+        case CH_128_32: return launch_conv_h<HTile<128, 32, 32, 4, 1>, M, OUT_F32>(p, w_bytes, stream);
+        default: break;
+    }
+    set_error("dz_conv2d_forward_split: unsupported channels cin=%d cout_pad=%d (cin %% 32, cout_pad %% 32 required)", p.cin, p.cout_pad);
+    return DZ_ERR_UNSUPPORTED;
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward_split: null pointer");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_conv2d_forward_split: math %d is not a split mode", math);
+    DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward_split: groups %d not in [1,8]", d->groups);
+    DZ_CHECK_ARG(!d->group_shift, "dz_conv2d_forward_split: group_shift is only available in the fp32 engine");
+    DZ_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->cin >= 32, "dz_conv2d_forward_split: bad kernel/cin");
+    DZ_CHECK_ARG(d->in_cstride % 8 == 0 && d->in_coff % 8 == 0 && d->cin % 8 == 0,
+                 "dz_conv2d_forward_split: input channel stride / offset must be multiples of the 8-channel pair16 group");
+    for (int g = 0; g < d->groups; ++g) {
+        DZ_CHECK_ARG(d->g_cout[g] >= 1 && d->g_cout[g] <= d->cout_pad, "dz_conv2d_forward_split: bad g_cout[%d]", g);
+        DZ_CHECK_ARG(out_f32 || (d->g_cout[g] % 8 == 0 && d->g_ooff[g] % 8 == 0),
+                     "dz_conv2d_forward_split: pair16 output needs channel counts / offsets in multiples of 8");
+    }
+    DZ_CHECK_ARG(out_f32 || (d->out_cstride % 8 == 0 && d->out_coff % 8 == 0),
+                 "dz_conv2d_forward_split: pair16 output needs channel stride / offset in multiples of 8");
+    DZ_CHECK_ARG((d->ho - 1) * d->stride + d->in_off + d->kh - 1 < d->in_hp &&
+                 (d->wo - 1) * d->stride + d->in_off + d->kw - 1 < d->in_wp && d->in_off >= 0,
+                 "dz_conv2d_forward_split: taps leave the input image");
+    DZ_CHECK_ARG((d->ho - 1) * d->out_sy + d->out_dy < d->out_hp && (d->wo - 1) * d->out_sx + d->out_dx < d->out_wp,
+                 "dz_conv2d_forward_split: output leaves the output image");
+    if ((long)d->batch * d->ho * d->wo == 0) return DZ_OK;
+    const size_t w_bytes = (size_t)d->groups * d->kh * d->kw * d->cout_pad * d->cin * sizeof(float);
+    if (math == DZ_MATH_F16X2)
+        return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);
+    return out_f32 ? conv2d_h_dispatch<MathBF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathBF16, false>(*d, w_bytes, stream);
+}
+
+const char *dz_conv2d_variant_split(const dz_conv2d_desc *d) { return d ? kConvHVariantName[conv2d_h_select(*d)] : "none"; }
+
+}  // extern "C"

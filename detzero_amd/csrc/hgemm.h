@@ -1,0 +1,214 @@
+// Split-precision implicit-GEMM tile engine (gfx950, wave64): fp32-class results on the 16-bit matrix cores.
+//
+// Every fp32 value x is carried as a PAIR of 16-bit floats  x ~= hi + lo,  hi = rn16(x), lo = rn16(x - hi)
+// (fp16: 22 significant bits, bf16: 16), and a product of two such values is evaluated as
+//        a.b  ~=  a_hi.b_hi + a_lo.b_hi + a_hi.b_lo            (the lo.lo term, <= 2^-22 relative, is dropped)
+// with three v_mfma_f32_32x32x16_{f16,bf16} accumulating in fp32.  The 16-bit matrix pipe runs 16x the rate
+// of v_mfma_f32_16x16x4_f32 (2.5 PF/s vs 157 TF/s dense, /opt/skills/guides/MI355X_MICROARCH.md), so three
+// of them per product still leave ~5x the fp32-MFMA throughput, and the error of the fp16 pair (measured
+// through the whole CenterPoint network: 5e-7 on the head maps) is of the order of fp32 summation-order noise.
+//
+// "pair16" storage (activations in HBM, weights, LDS tiles): a row of C channels (C % 8 == 0) is C 32-bit
+// words, exactly the size of the fp32 row it replaces; each group of 8 channels is 16 bytes of hi values
+// followed by 16 bytes of lo values.  A 16-byte load of either half IS the matrix-core operand of its lane
+// (8 consecutive k), so tiles go HBM -> registers -> LDS -> MFMA without a single conversion or shuffle; the
+// producing kernel's epilogue does the split once per output value.
+//
+// Orientation: D[cout x pixel] = W[cout x k] . X^T[k x pixel].  The 32x32 accumulator then holds, per lane,
+// 4 consecutive output channels of one pixel per register quad -> 8-byte hi / lo stores straight into the
+// pair16 row of that pixel.
+//
+// The chunk pipeline (double-buffered LDS, one barrier per KC-channel chunk, register double buffer of the
+// fragments, global loads two chunks ahead) is the one of igemm.h.
+#pragma once
+#include "igemm.h"
+
+namespace dz {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+
+struct MathF16 {
+    static constexpr int ID = 1;
+    static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float v, unsigned int &hi, unsigned int &lo) {
+        // saturate instead of overflowing to inf: |v| beyond the fp16 range keeps hi = +-65504 and the rest in lo
+        const float vc = fminf(fmaxf(v, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)vc;
+        const float rem = fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+        const _Float16 l = (_Float16)rem;
+        hi = (unsigned int)__builtin_bit_cast(unsigned short, h);
+        lo = (unsigned int)__builtin_bit_cast(unsigned short, l);
+    }
+    static __device__ __forceinline__ float join(unsigned int hi, unsigned int lo) {
+        return (float)__builtin_bit_cast(_Float16, (unsigned short)hi) + (float)__builtin_bit_cast(_Float16, (unsigned short)lo);
+    }
+};
+
+struct MathBF16 {
+    static constexpr int ID = 2;
+    static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float v, unsigned int &hi, unsigned int &lo) {
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        hi = (unsigned int)__builtin_bit_cast(unsigned short, h);
+        lo = (unsigned int)__builtin_bit_cast(unsigned short, l);
+    }
+    static __device__ __forceinline__ float join(unsigned int hi, unsigned int lo) {
+        return __uint_as_float(hi << 16) + __uint_as_float(lo << 16);
+    }
+};
+
+// 4 consecutive channels -> the two 8-byte halves (hi, lo) of their slot in a pair16 group
+template <class M>
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 &hi, uint2 &lo) {
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M::split(v[i], h[i], l[i]);
+    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+// BP pixels (MFMA N side) x BC output channels (MFMA M side), KC channels of one tap per chunk, 4 waves as WP x WC
+template <int BP_, int BC_, int KC_, int WP_, int WC_>
+struct HTile {
+    static constexpr int BP = BP_, BC = BC_, KC = KC_, WP = WP_, WC = WC_;
+    static constexpr int THREADS = 256;
+    static constexpr int PT = BP / (32 * WP);             // 32-pixel fragments per wave
+    static constexpr int CT = BC / (32 * WC);             // 32-channel fragments per wave
+    static constexpr int ROW_U4 = KC / 4 + 1;             // LDS row stride in 16-byte units (+1: conflict-free ds_read_b128)
+    static constexpr int P_PIECES = BP * (KC / 4);        // 16-byte pieces of the pixel chunk
+    static constexpr int C_PIECES = BC * (KC / 4);
+    static constexpr int P_PER_THREAD = (P_PIECES + THREADS - 1) / THREADS;
+    static constexpr int C_PER_THREAD = (C_PIECES + THREADS - 1) / THREADS;
+    static constexpr int PS_U4 = BP * ROW_U4;             // one buffer
+    static constexpr int CS_U4 = BC * ROW_U4;
+    static constexpr int LDS_U4 = 2 * (PS_U4 + CS_U4);    // double buffered
+    static constexpr int LDS_BYTES = LDS_U4 * 16;
+    static_assert(WP * WC == 4, "4 waves per workgroup");
+    static_assert(BP % (32 * WP) == 0 && BC % (32 * WC) == 0, "tile must split into 32x32 fragments");
+    static_assert(KC == 16 || KC == 32, "KC is one or two 16-deep MFMA steps");
+};
+
+template <class T>
+struct HFrag {
+    v4u p_hi[T::PT], p_lo[T::PT], c_hi[T::CT], c_lo[T::CT];
+};
+
+// ps / cs point at the lane's row and k-group: row (lane & 31), 16-byte unit 2 * (lane >> 5)
+template <class T>
+__device__ __forceinline__ void load_hfrag(HFrag<T> &f, const v4u *__restrict__ ps, const v4u *__restrict__ cs, int q) {
+#pragma unroll
+    for (int pt = 0; pt < T::PT; ++pt) {
+        f.p_hi[pt] = ps[pt * 32 * T::ROW_U4 + q * 4];
+        f.p_lo[pt] = ps[pt * 32 * T::ROW_U4 + q * 4 + 1];
+    }
+#pragma unroll
+    for (int ct = 0; ct < T::CT; ++ct) {
+        f.c_hi[ct] = cs[ct * 32 * T::ROW_U4 + q * 4];
+        f.c_lo[ct] = cs[ct * 32 * T::ROW_U4 + q * 4 + 1];
+    }
+}
+
+template <class T, class M>
+__device__ __forceinline__ void mma_hfrag(const HFrag<T> &f, f32x16 (&acc)[T::CT][T::PT]) {
+#pragma unroll
+    for (int ct = 0; ct < T::CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < T::PT; ++pt) {
+            acc[ct][pt] = M::mma(f.c_lo[ct], f.p_hi[pt], acc[ct][pt]);
+            acc[ct][pt] = M::mma(f.c_hi[ct], f.p_lo[pt], acc[ct][pt]);
+            acc[ct][pt] = M::mma(f.c_hi[ct], f.p_hi[pt], acc[ct][pt]);
+        }
+}
+
+template <class T>
+struct HStage {
+    v4u p[T::P_PER_THREAD];
+    v4u c[T::C_PER_THREAD];
+};
+
+// raw buffer loads of the 16-byte pieces; offsets past the buffer read as zeros (missing neighbours, rows past
+// the end of the image, output channels past the real count)
+template <class T>
+__device__ __forceinline__ void load_hstage(HStage<T> &st, __amdgpu_buffer_rsrc_t prsrc, const unsigned int (&pvoff)[T::P_PER_THREAD],
+                                            unsigned int padd, __amdgpu_buffer_rsrc_t crsrc,
+                                            const unsigned int (&cvoff)[T::C_PER_THREAD], unsigned int cadd) {
+#pragma unroll
+    for (int i = 0; i < T::P_PER_THREAD; ++i) st.p[i] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, pvoff[i] + padd, 0, 0);
+#pragma unroll
+    for (int i = 0; i < T::C_PER_THREAD; ++i) st.c[i] = __builtin_amdgcn_raw_buffer_load_b128(crsrc, cvoff[i] + cadd, 0, 0);
+}
+
+template <class T>
+__device__ __forceinline__ void store_hstage(const HStage<T> &st, v4u *__restrict__ Ps, v4u *__restrict__ Cs, int tid) {
+#pragma unroll
+    for (int i = 0; i < T::P_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        if (T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) Ps[(idx / (T::KC / 4)) * T::ROW_U4 + idx % (T::KC / 4)] = st.p[i];
+    }
+#pragma unroll
+    for (int i = 0; i < T::C_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        if (T::C_PIECES % T::THREADS == 0 || idx < T::C_PIECES) Cs[(idx / (T::KC / 4)) * T::ROW_U4 + idx % (T::KC / 4)] = st.c[i];
+    }
+}
+
+// Same schedule as gemm_pipeline (igemm.h): per chunk, phase 1 = MFMAs of k-step 0 || LDS reads of k-step 1 ||
+// LDS writes of chunk c+1; barrier; phase 2 = MFMAs of k-step 1 || LDS reads of chunk c+1 || global loads of c+2.
+template <class T, class M, class Issue, class Advance>
+__device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ smem, HStage<T> &st, Issue &&issue, Advance &&advance,
+                                               f32x16 (&acc)[T::CT][T::PT], int wp, int wc, int lane, int tid) {
+    v4u *const Ps0 = smem, *const Cs0 = smem + 2 * T::PS_U4;          // [2][PS], [2][CS]
+    constexpr int Q = T::KC / 16;
+    const int poff = (wp * T::PT * 32 + (lane & 31)) * T::ROW_U4 + (lane >> 5) * 2;
+    const int coff = (wc * T::CT * 32 + (lane & 31)) * T::ROW_U4 + (lane >> 5) * 2;
+    constexpr int MFMA_N = 3 * T::PT * T::CT;                       // MFMAs per k-step
+    constexpr int NLD = 2 * (T::PT + T::CT);                        // LDS reads per k-step
+    constexpr int NST = T::P_PER_THREAD + T::C_PER_THREAD;          // staging loads / stores per chunk
+    constexpr int REST1 = MFMA_N - (Q == 2 ? NLD : 0);
+    constexpr int PER1 = (REST1 / NST) > 0 ? (REST1 / NST) : 1;
+    constexpr int REST2 = MFMA_N - NLD;
+    constexpr int PER2 = (REST2 / NST) > 0 ? (REST2 / NST) : 1;
+
+    issue();
+    store_hstage<T>(st, Ps0, Cs0, tid);
+    __syncthreads();
+    if (nchunks > 1) { advance(); issue(); }
+    HFrag<T> f0, f1;
+    load_hfrag<T>(f0, Ps0 + poff, Cs0 + coff, 0);
+    auto body = [&](int c, auto has1_t, auto has2_t) {
+        constexpr bool HAS1 = decltype(has1_t)::value, HAS2 = decltype(has2_t)::value;
+        const int cur = c & 1;
+        const v4u *Pc = Ps0 + cur * T::PS_U4 + poff, *Cc = Cs0 + cur * T::CS_U4 + coff;
+        const v4u *Pn = Ps0 + (cur ^ 1) * T::PS_U4 + poff, *Cn = Cs0 + (cur ^ 1) * T::CS_U4 + coff;
+        // ---- phase 1
+        if (Q == 2) load_hfrag<T>(f1, Pc, Cc, 1);
+        if (HAS1) store_hstage<T>(st, Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
+        mma_hfrag<T, M>(f0, acc);
+        if (Q == 2) interleave_hint<0x100, (NLD < MFMA_N ? NLD : MFMA_N), 1>();
+        if (HAS1) interleave_hint<0x200, NST, PER1>();
+        __syncthreads();
+        // ---- phase 2
+        if (HAS1) load_hfrag<T>(f0, Pn, Cn, 0);
+        if (HAS2) { advance(); issue(); }
+        if (Q == 2) {
+            mma_hfrag<T, M>(f1, acc);
+            if (HAS1) interleave_hint<0x100, (NLD < MFMA_N ? NLD : MFMA_N), 1>();
+            if (HAS2) interleave_hint<0x020, NST, PER2>();
+        }
+    };
+    using TT = std::integral_constant<bool, true>;
+    using FF = std::integral_constant<bool, false>;
+    int c = 0;
+    for (; c + 2 < nchunks; ++c) body(c, TT{}, TT{});
+    if (c + 1 < nchunks) { body(c, TT{}, FF{}); ++c; }
+    body(c, FF{}, FF{});
+}
+
+}  // namespace dz

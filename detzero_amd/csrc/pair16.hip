@@ -1,0 +1,158 @@
+// pair16 <-> fp32 conversion and the memory-bound row movers of the split-precision path (gfx950).
+// Layout and arithmetic: hgemm.h.  These kernels only stand at the ends of the pipeline (input voxel features,
+// tensors handed back to PyTorch callers) and at the sparse -> BEV hand-over (height_compression.py:20-24).
+#include "hgemm.h"
+
+namespace dz {
+
+template <class M>
+__global__ void k_pair16_from_f32(const float *__restrict__ src, long rows, int c_src, int c_dst, uint4 *__restrict__ dst) {
+    const int groups = c_dst / 8;
+    const long total = rows * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / groups;
+        const int g = (int)(idx % groups);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (g * 8 + e < c_src) ? src[r * c_src + g * 8 + e] : 0.f;
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        uint2 h0, l0, h1, l1;
+        split4<M>(a, h0, l0);
+        split4<M>(b, h1, l1);
+        dst[idx * 2] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[idx * 2 + 1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+template <class M>
+__global__ void k_pair16_to_f32(const uint4 *__restrict__ src, long rows, int c, float *__restrict__ dst) {
+    const int groups = c / 8;
+    const long total = rows * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const uint4 h = src[idx * 2], l = src[idx * 2 + 1];
+        const unsigned int hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+        float4 o0, o1;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = M::join(hw[e] & 0xFFFFu, lw[e] & 0xFFFFu);
+            o[2 * e + 1] = M::join(hw[e] >> 16, lw[e] >> 16);
+        }
+        o0 = make_float4(o[0], o[1], o[2], o[3]);
+        o1 = make_float4(o[4], o[5], o[6], o[7]);
+        reinterpret_cast<float4 *>(dst)[idx * 2] = o0;
+        reinterpret_cast<float4 *>(dst)[idx * 2 + 1] = o1;
+    }
+}
+
+template <class M>
+__global__ void k_scatter_rows_split(const float *__restrict__ src, const int *__restrict__ rank, const int *__restrict__ d_n,
+                                     int n_cap, int c_src, uint4 *__restrict__ dst, int c_dst) {
+    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    const int groups = c_dst / 8;
+    const long total = (long)n * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / groups), g = (int)(idx % groups);
+        const int r = rank[i];
+        if (r < 0) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (g * 8 + e < c_src) ? src[(size_t)i * c_src + g * 8 + e] : 0.f;
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        uint2 h0, l0, h1, l1;
+        split4<M>(a, h0, l0);
+        split4<M>(b, h1, l1);
+        const size_t o = ((size_t)r * groups + g) * 2;
+        dst[o] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[o + 1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+// bev[b][y+pad][x+pad][ch*D + z] <- feats[o][ch]: one thread moves the hi and lo halves of one channel
+__global__ void k_sparse_to_bev_split(const unsigned short *__restrict__ feats, const int *__restrict__ coords,
+                                      const int *__restrict__ d_m, int cap, int c, int d, int h, int w, int pad,
+                                      unsigned short *__restrict__ bev) {
+    const int m = min(*d_m, cap);
+    const long total = (long)m * c;
+    const int hp = h + 2 * pad, wp = w + 2 * pad;
+    const int cd = c * d;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx / c), ch = (int)(idx % c);
+        const int4 cc = reinterpret_cast<const int4 *>(coords)[o];  // [b,z,y,x]
+        const size_t pix = ((size_t)cc.x * hp + (cc.z + pad)) * wp + (cc.w + pad);
+        const unsigned short *s = feats + ((size_t)o * c + (ch & ~7)) * 2 + (ch & 7);   // 16-bit units: group start * 2
+        const int oc = ch * d + cc.y;
+        unsigned short *t = bev + (pix * cd + (oc & ~7)) * 2 + (oc & 7);
+        t[0] = s[0];
+        t[8] = s[8];
+    }
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_pair16_from_f32(const float *src, long rows, int c_src, int c_dst, int math, float *dst, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(rows >= 0 && c_src >= 1 && c_dst >= c_src && c_dst % 8 == 0, "dz_pair16_from_f32: bad sizes");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_pair16_from_f32: math %d is not a split mode", math);
+    if (rows == 0) return DZ_OK;
+    DZ_CHECK_ARG(src && dst, "dz_pair16_from_f32: null pointer");
+    const dim3 grid(stream_grid(rows * (c_dst / 8), 256));
+    if (math == DZ_MATH_F16X2)
+        hipLaunchKernelGGL(k_pair16_from_f32<MathF16>, grid, dim3(256), 0, stream, src, rows, c_src, c_dst, reinterpret_cast<uint4 *>(dst));
+    else
+        hipLaunchKernelGGL(k_pair16_from_f32<MathBF16>, grid, dim3(256), 0, stream, src, rows, c_src, c_dst, reinterpret_cast<uint4 *>(dst));
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_pair16_to_f32(const float *src, long rows, int c, int math, float *dst, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(rows >= 0 && c >= 8 && c % 8 == 0, "dz_pair16_to_f32: bad sizes");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_pair16_to_f32: math %d is not a split mode", math);
+    if (rows == 0) return DZ_OK;
+    DZ_CHECK_ARG(src && dst, "dz_pair16_to_f32: null pointer");
+    const dim3 grid(stream_grid(rows * (c / 8), 256));
+    if (math == DZ_MATH_F16X2)
+        hipLaunchKernelGGL(k_pair16_to_f32<MathF16>, grid, dim3(256), 0, stream, reinterpret_cast<const uint4 *>(src), rows, c, dst);
+    else
+        hipLaunchKernelGGL(k_pair16_to_f32<MathBF16>, grid, dim3(256), 0, stream, reinterpret_cast<const uint4 *>(src), rows, c, dst);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_scatter_rows_split(const float *src, const int *rank, const int *d_n, int n_cap, int c_src, float *dst, int c_dst,
+                          int math, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n_cap >= 0 && c_src >= 1 && c_dst >= c_src && c_dst % 8 == 0, "dz_scatter_rows_split: bad sizes");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_scatter_rows_split: math %d is not a split mode", math);
+    if (n_cap == 0) return DZ_OK;
+    DZ_CHECK_ARG(src && rank && dst, "dz_scatter_rows_split: null pointer");
+    const dim3 grid(stream_grid((long)n_cap * (c_dst / 8), 256));
+    if (math == DZ_MATH_F16X2)
+        hipLaunchKernelGGL(k_scatter_rows_split<MathF16>, grid, dim3(256), 0, stream, src, rank, d_n, n_cap, c_src,
+                           reinterpret_cast<uint4 *>(dst), c_dst);
+    else
+        hipLaunchKernelGGL(k_scatter_rows_split<MathBF16>, grid, dim3(256), 0, stream, src, rank, d_n, n_cap, c_src,
+                           reinterpret_cast<uint4 *>(dst), c_dst);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h, int w,
+                           int pad, float *bev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(feats && coords && d_m && bev && c > 0 && c % 8 == 0 && d > 0 && (c * d) % 8 == 0 && pad >= 0,
+                 "dz_sparse_to_bev_split: bad argument");
+    if (cap == 0) return DZ_OK;
+    hipLaunchKernelGGL(k_sparse_to_bev_split, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned short *>(feats), coords, d_m, cap, c, d, h, w, pad,
+                       reinterpret_cast<unsigned short *>(bev));
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+}  // extern "C"

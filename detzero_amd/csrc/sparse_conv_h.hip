@@ -1,0 +1,228 @@
+// Sparse 3-D convolution forward on the 16-bit matrix cores with split-precision (pair16) operands: the
+// output-stationary gather -> implicit GEMM -> direct store of sparse_conv.hip (same rulebook, tap skipping,
+// fused BatchNorm + bias + residual + ReLU epilogue), fp32-class results at ~5x the fp32-MFMA rate (hgemm.h).
+//
+// Reference call sites: detection/detzero_det/models/centerpoint_modules/backbone3d.py:64-121, :243-280.
+#include <stdlib.h>
+
+#include "hgemm.h"
+
+namespace dz {
+
+constexpr int KVOL_MAX_H = 27;
+
+struct SpConvHArgs {
+    const float *in;        // pair16 rows
+    const int *nbr;
+    const int *d_m_out;
+    const float *w;         // (kvol, cout_pad, cin) pair16
+    const float *scale;
+    const float *shift;
+    const float *residual;  // pair16 rows or null
+    float *out;             // pair16 rows
+    int cin, cout, cout_pad, kvol, cap, relu;
+    unsigned int in_bytes, w_bytes;
+};
+
+template <class T, class M>
+__global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
+    int *const nbr_s = reinterpret_cast<int *>(smem + T::LDS_U4);       // [kvol][BP]
+    __shared__ unsigned int mask_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wp = wid / T::WC, wc = wid % T::WC;
+    const int m = min(*a.d_m_out, a.cap);
+    const int ntiles = (m + T::BP - 1) / T::BP;
+    const int kchunks = a.cin / T::KC;
+    const int n0 = blockIdx.y * T::BC;          // channel tile (cout_pad may be split over blockIdx.y)
+    const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t crsrc = make_rsrc(a.w, a.w_bytes);
+    unsigned int cvoff[T::C_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < T::C_PER_THREAD; ++i) {
+        const int idx = tid + i * T::THREADS;
+        cvoff[i] = OOB_OFFSET;
+        if (T::C_PIECES % T::THREADS == 0 || idx < T::C_PIECES) {
+            const int n = idx / (T::KC / 4), q = idx % (T::KC / 4);
+            cvoff[i] = (unsigned int)(((n0 + n) * a.cin + q * 4) * 4);
+        }
+    }
+    const unsigned int tap_bytes = (unsigned int)(a.cout_pad * a.cin * 4);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * T::BP;
+        if (tid == 0) mask_s = 0u;
+        __syncthreads();
+        unsigned int local = 0u;
+        for (int idx = tid; idx < a.kvol * T::BP; idx += 256) {
+            const int k = idx / T::BP, r = idx % T::BP;
+            const int row = row0 + r;
+            const int v = (row < m) ? a.nbr[(size_t)k * a.cap + row] : -1;
+            nbr_s[idx] = v;
+            if (v >= 0) local |= 1u << k;
+        }
+        if (local) atomicOr(&mask_s, local);
+        __syncthreads();
+        const unsigned int taps = mask_s;
+
+        f32x16 acc[T::CT][T::PT];
+#pragma unroll
+        for (int i = 0; i < T::CT; ++i)
+#pragma unroll
+            for (int j = 0; j < T::PT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        const int nchunks = __popc(taps) * kchunks;
+        if (nchunks > 0) {
+            HStage<T> st;
+            unsigned int rem = taps;
+            int tap = __ffs((int)rem) - 1, kc = 0;
+            auto issue = [&]() {
+                unsigned int pvoff[T::P_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < T::P_PER_THREAD; ++i) {
+                    const int idx = tid + i * T::THREADS;
+                    pvoff[i] = OOB_OFFSET;
+                    if (T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) {
+                        const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
+                        const int rb = nbr_s[tap * T::BP + rr];
+                        pvoff[i] = rb >= 0 ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
+                    }
+                }
+                load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
+                               (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
+            };
+            auto advance = [&]() {
+                if (++kc == kchunks) { kc = 0; rem &= rem - 1; tap = __ffs((int)rem) - 1; }
+            };
+            hgemm_pipeline<T, M>(nchunks, smem, st, issue, advance, acc, wp, wc, lane, tid);
+        }
+
+        // accumulator of a 32x32 fragment: row = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
+        const int h = lane >> 5;
+#pragma unroll
+        for (int pt = 0; pt < T::PT; ++pt) {
+            const int row = row0 + wp * T::PT * 32 + pt * 32 + (lane & 31);
+            if (row >= m) continue;
+#pragma unroll
+            for (int ct = 0; ct < T::CT; ++ct) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wc * T::CT * 32 + ct * 32 + 8 * j + 4 * h;
+                    if (col >= a.cout) continue;
+                    const size_t goff = ((size_t)row * a.cout + (col & ~7)) * 4 + (col & 7) * 2;     // byte offset of the hi slot
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sc = a.scale ? a.scale[col + e] : 1.f;
+                        const float sh = a.shift ? a.shift[col + e] : 0.f;
+                        v[e] = fmaf(acc[ct][pt][4 * j + e], sc, sh);
+                    }
+                    if (a.residual) {
+                        const unsigned char *rp = reinterpret_cast<const unsigned char *>(a.residual) + goff;
+                        const uint2 rh = *reinterpret_cast<const uint2 *>(rp), rl = *reinterpret_cast<const uint2 *>(rp + 16);
+                        v[0] += M::join(rh.x & 0xFFFFu, rl.x & 0xFFFFu);
+                        v[1] += M::join(rh.x >> 16, rl.x >> 16);
+                        v[2] += M::join(rh.y & 0xFFFFu, rl.y & 0xFFFFu);
+                        v[3] += M::join(rh.y >> 16, rl.y >> 16);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    uint2 hi, lo;
+                    split4<M>(v, hi, lo);
+                    unsigned char *g = reinterpret_cast<unsigned char *>(a.out) + goff;
+                    *reinterpret_cast<uint2 *>(g) = hi;
+                    *reinterpret_cast<uint2 *>(g + 16) = lo;
+                }
+            }
+        }
+        __syncthreads();  // nbr_s / mask_s are rewritten by the next tile
+    }
+}
+
+template <class T, class M>
+static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
+    constexpr int LDS = T::LDS_BYTES + KVOL_MAX_H * T::BP * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
+            set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", LDS);
+            return DZ_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    int grid = ceil_div(a.cap, T::BP);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_spconv_h<T, M>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+// development knob: DZ_TUNE_<name>=<int> in the environment overrides a tile choice (read once)
+static int tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <class M>
+static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
+    static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
+    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M>(a, stream);
+    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M>(a, stream);
+    if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
+        if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M>(a, stream);
+        return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M>(a, stream);
+    }
+    if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
+        if (t128 == 1) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M>(a, stream);
+        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M>(a, stream);
+        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M>(a, stream);
+    }
+    set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
+    return DZ_ERR_UNSUPPORTED;
+}
+
+}  // namespace dz
+
+using namespace dz;
+
+extern "C" {
+
+int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+                            const float *w, const float *scale, const float *shift, const float *residual, int relu,
+                            float *out, int cout, int math, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(in && nbr && d_m_out && w && out, "dz_spconv_forward_split: null pointer");
+    DZ_CHECK_ARG(kvol >= 1 && kvol <= KVOL_MAX_H, "dz_spconv_forward_split: kvol %d not in [1,27]", kvol);
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_spconv_forward_split: math %d is not a split mode", math);
+    DZ_CHECK_ARG(cout % 8 == 0 && cin % 8 == 0, "dz_spconv_forward_split: channels must be multiples of the 8-channel pair16 group");
+    if (cap_out == 0) return DZ_OK;
+    const int cout_pad = cout < 32 ? 32 : cout;
+    const size_t in_bytes = (size_t)in_rows * cin * sizeof(float);
+    const size_t w_bytes = (size_t)kvol * cout_pad * cin * sizeof(float);
+    if (in_rows < 0 || in_bytes >= 0x80000000ull) {
+        set_error("dz_spconv_forward_split: input of %zu bytes exceeds the 2 GiB buffer-addressing limit", in_bytes);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    SpConvHArgs a{in, nbr, d_m_out, w, scale, shift, residual, out, cin, cout, cout_pad, kvol, cap_out, relu,
+                  (unsigned int)in_bytes, (unsigned int)w_bytes};
+    return math == DZ_MATH_F16X2 ? spconv_h_dispatch<MathF16>(a, stream) : spconv_h_dispatch<MathBF16>(a, stream);
+}
+
+const char *dz_spconv_variant_split(int cin, int cout) {
+    const int cout_pad = cout < 32 ? 32 : cout;
+    if (cin == 16 && cout_pad == 32) return "k_spconv_h<128x32x16>";
+    if (cin == 32 && cout_pad == 32) return "k_spconv_h<128x32x32>";
+    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<128x64x32>";
+    if ((cin == 64 || cin == 128) && cout_pad == 128) return "k_spconv_h<64x128x32>";
+    return "none";
+}
+
+}  // extern "C"

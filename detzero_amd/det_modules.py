@@ -49,10 +49,24 @@ class _Cached(nn.Module):
     def __init__(self):
         super().__init__()
         self._plan = None
+        self.math = 0       # ops.MATH_MODES: 0 = fp32 MFMA, 1 = fp16-pair split, 2 = bf16-pair split (csrc/hgemm.h)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     def invalidate(self):
         self._plan = None
+
+    def set_math(self, mode):
+        self.math = ops.math_id(mode)
+        return self
+
+    def _w(self, entry, key='w'):
+        """Weights of a plan entry in the layout of the active math mode (split layouts packed once, cached)."""
+        if not self.math:
+            return entry[key]
+        ck = '%s_split%d' % (key, self.math)
+        if ck not in entry:
+            entry[ck] = ops.pack_weight_split(entry[key], self.math)
+        return entry[ck]
 
     def _apply(self, fn, *a, **kw):
         self._plan = None
@@ -66,13 +80,14 @@ class SparseConvTensor:
     """What the reference reads from spconv's tensor: features, indices, spatial_shape, batch_size,
     dense() (pdv_head.py:567-637, height_compression.py:21)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, level=None, padded=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, level=None, padded=None, math=0):
         self.features = features
         self.indices = indices
         self.spatial_shape = list(spatial_shape)
         self.batch_size = batch_size
         self._level = level
         self._padded = padded      # (capacity-sized feature matrix, SparseLevel) for the fast path
+        self._math = math          # encoding of the padded matrix (0 = fp32, else pair16); .features is always fp32
 
     def replace_feature(self, new_features):
         return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._level)
@@ -268,11 +283,10 @@ class VoxelResBackBone8x(_Cached):
         return p
 
     # ---- execution ------------------------------------------------------------------------------
-    @staticmethod
-    def _res_block(x, nbr, level, params):
+    def _res_block(self, x, nbr, level, params):
         c1, c2 = params
-        y = ops.spconv_forward(x, nbr, level, c1['w'], c1['scale'], c1['shift'], None, True)
-        return ops.spconv_forward(y, nbr, level, c2['w'], c2['scale'], c2['shift'], x, True)
+        y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
+        return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
     def run(self, voxel_features, voxel_coords, batch_size, d_n=None):
         """Capacity-sized execution without host syncs.  Returns dict of (features, SparseLevel)."""
@@ -281,10 +295,11 @@ class VoxelResBackBone8x(_Cached):
         dev = voxel_features.device
         lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
         rank = lvl1.build_from_coords(voxel_coords, d_n)
-        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n)
+        mm = self.math
+        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=mm)
         nbr = lvl1.neighbors_to(lvl1, K3, S1, P1)
         ci = p['conv_input']
-        x = ops.spconv_forward(x, nbr, lvl1, ci['w'], ci['scale'], ci['shift'], None, True)
+        x = ops.spconv_forward(x, nbr, lvl1, self._w(ci), ci['scale'], ci['shift'], None, True, math=mm)
         for bp in p['conv1']:
             x = self._res_block(x, nbr, lvl1, bp)
         out = {'x_conv1': (x, lvl1)}
@@ -293,7 +308,7 @@ class VoxelResBackBone8x(_Cached):
             dp = p[name]['down']
             nxt = level.downsample(dp['k'], dp['s'], dp['p'])
             nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
-            x = ops.spconv_forward(x, nbr_d, nxt, dp['w'], dp['scale'], dp['shift'], None, True, in_level=level)
+            x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
             nbr = nxt.neighbors_to(nxt, K3, S1, P1)
             for bp in p[name]['blocks']:
                 x = self._res_block(x, nbr, nxt, bp)
@@ -302,7 +317,7 @@ class VoxelResBackBone8x(_Cached):
         dp = p['conv_out']
         nxt = level.downsample(dp['k'], dp['s'], dp['p'])
         nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
-        x = ops.spconv_forward(x, nbr_d, nxt, dp['w'], dp['scale'], dp['shift'], None, True, in_level=level)
+        x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
         out['encoded'] = (x, nxt)
         return out
 
@@ -317,8 +332,9 @@ class VoxelResBackBone8x(_Cached):
         def as_tensor(item):
             feats, level = item
             m = level.num_active()
-            return SparseConvTensor(feats[:m], level.coords[:m], level.shape, batch_size, level=level,
-                                    padded=(feats, level))
+            plain = ops.pair16_to_f32(feats[:m], self.math) if self.math else feats[:m]
+            return SparseConvTensor(plain, level.coords[:m], level.shape, batch_size, level=level,
+                                    padded=(feats, level), math=self.math)
         batch_dict.update({'encoded_spconv_tensor': as_tensor(res['encoded']), 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {k: as_tensor(res[k]) for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4')}})
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
@@ -339,10 +355,13 @@ class HeightCompression(nn.Module):
     def forward(self, batch_dict):
         t = batch_dict['encoded_spconv_tensor']
         feats, level = t._padded if t._padded is not None else (t.features, t._level)
+        math = t._math if t._padded is not None else 0
         c = feats.shape[1]
-        bev = ops.sparse_to_bev(feats, level, c, pad=1)                 # (B, H+2, W+2, C*D)
+        bev = ops.sparse_to_bev(feats, level, c, pad=1, math=math)      # (B, H+2, W+2, C*D)
         batch_dict['_nhwc_spatial_features'] = bev
-        batch_dict['spatial_features'] = bev[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)   # NCHW view
+        batch_dict['_nhwc_math'] = math                                 # encoding of the private channel-last images
+        plain = ops.pair16_to_f32(bev, math) if math else bev
+        batch_dict['spatial_features'] = plain[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)   # NCHW view
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict
 
@@ -374,11 +393,21 @@ def nchw_to_padded_nhwc(x, pad=1):
     return out
 
 
+def _recode(img, enc, math):
+    """Channel-last image from encoding `enc` (0 = fp32, else pair16 of that mode) to the encoding of `math`."""
+    if enc == math:
+        return img
+    plain = ops.pair16_to_f32(img, enc) if enc else img
+    return ops.pair16_from_f32(plain, math=math) if math else plain
+
+
 def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_cstride, in_coff=0, ksize=3,
                stride=1, in_off=0, out_cstride, out_coff=0, out_s=1, out_d=(0, 0), groups=1, cout_pad=None,
-               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1):
-    """One dz_conv2d_forward call.  in_shape/out_shape = (Hp, Wp) of the (padded) images."""
-    cout_pad = w.shape[-1] if cout_pad is None else cout_pad
+               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False):
+    """One dz_conv2d_forward[_split] call.  in_shape/out_shape = (Hp, Wp) of the (padded) images.
+    math != 0: w is the pack_weight_split layout (..., cout_pad, cin)."""
+    if cout_pad is None:
+        cout_pad = w.shape[-2] if math else w.shape[-1]
     ops.conv2d(dict(
         inp=inp.data_ptr(), out=out.data_ptr(), w=w.data_ptr(),
         scale=scale.data_ptr() if scale is not None else None,
@@ -389,7 +418,7 @@ def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_
         out_sy=out_s, out_sx=out_s, out_dy=out_d[0], out_dx=out_d[1],
         groups=groups, cout_pad=cout_pad,
         g_cout=g_cout if g_cout is not None else [cout_pad], g_ooff=g_ooff if g_ooff is not None else [0],
-        relu=1 if relu else 0))
+        relu=1 if relu else 0), math=math, out_f32=out_f32)
 
 
 class BaseBEVBackbone(_Cached):
@@ -445,14 +474,15 @@ class BaseBEVBackbone(_Cached):
             scale, shift = fold_bn(dbn, de.bias)
             s = de.stride[0]
             wt = de.weight.detach().float()                            # (Cin, Cout, s, s)
-            phases = [[wt[:, :, dy, dx].contiguous().unsqueeze(0).contiguous() for dx in range(s)] for dy in range(s)]
+            phases = [[{'w': wt[:, :, dy, dx].contiguous().unsqueeze(0).contiguous()} for dx in range(s)] for dy in range(s)]
             levels.append({'convs': convs, 'de': {'phases': phases, 'scale': scale, 'shift': shift, 's': s,
                                                   'cin': de.in_channels, 'cout': de.out_channels}})
         self._plan = levels
         return levels
 
     def run(self, bev, batch):
-        """bev (B, H+2, W+2, Cin) zero-bordered channel-last -> concat (B, H+2, W+2, sum(upsample)) zero-bordered."""
+        """bev (B, H+2, W+2, Cin) zero-bordered channel-last -> concat (B, H+2, W+2, sum(upsample)) zero-bordered.
+        In a split math mode both images are pair16 (same shapes)."""
         plan = self.plan()
         dev = bev.device
         h, w = bev.shape[1] - 2, bev.shape[2] - 2
@@ -470,9 +500,9 @@ class BaseBEVBackbone(_Cached):
                     bufs = [torch.zeros((batch, oh + 2, ow + 2, cv['cout']), dtype=torch.float32, device=dev)
                             for _ in range(2)]
                 y = bufs[ci % 2]
-                conv_layer(x, (xh + 2, xw + 2), cv['w'], cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
-                           out_d=(1, 1), ho=oh, wo=ow, batch=batch)
+                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math)
                 x, xh, xw, xc = y, oh, ow, cv['cout']
                 if ci == 0:
                     total_stride *= s
@@ -482,10 +512,10 @@ class BaseBEVBackbone(_Cached):
                 raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
             for dy in range(s):
                 for dx in range(s):
-                    conv_layer(x, (xh + 2, xw + 2), de['phases'][dy][dx], de['scale'], de['shift'], True, concat,
+                    conv_layer(x, (xh + 2, xw + 2), self._w(de['phases'][dy][dx]), de['scale'], de['shift'], True, concat,
                                (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
                                out_cstride=ctot, out_coff=coff, out_s=s, out_d=(dy + 1, dx + 1), ho=xh, wo=xw,
-                               batch=batch)
+                               batch=batch, math=self.math)
             coff += de['cout']
         return concat
 
@@ -493,11 +523,15 @@ class BaseBEVBackbone(_Cached):
         _inference_only(self)
         with torch.no_grad():
             bev = data_dict.get('_nhwc_spatial_features', None)
+            enc = data_dict.get('_nhwc_math', 0)
             if bev is None:
-                bev = nchw_to_padded_nhwc(data_dict['spatial_features'].float())
+                bev, enc = nchw_to_padded_nhwc(data_dict['spatial_features'].float()), 0
+            bev = _recode(bev, enc, self.math)
             concat = self.run(bev, bev.shape[0])
         data_dict['_nhwc_spatial_features_2d'] = concat
-        data_dict['spatial_features_2d'] = concat[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
+        data_dict['_nhwc_math'] = self.math
+        plain = ops.pair16_to_f32(concat, self.math) if self.math else concat
+        data_dict['spatial_features_2d'] = plain[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
         return data_dict
 
 
@@ -604,6 +638,8 @@ class CenterHead(_Cached):
                        'shift': torch.cat(sh1).contiguous()},
             'final': {'w': torch.stack(w2, dim=0).contiguous(),          # (6, 9, 64, 16)
                       'shift': torch.cat(b2).contiguous(),
+                      # the split engine works on 32-channel fragments: biases padded per group to 32
+                      'shift32': torch.cat([_pad_vec(b, 32) for b in b2]).contiguous(),
                       'g_cout': [self.COLS[n][1] for n in order], 'g_ooff': [self.COLS[n][0] for n in order]},
             'c': c, 'order': order,
         }
@@ -616,16 +652,18 @@ class CenterHead(_Cached):
         hp, wp = concat.shape[1], concat.shape[2]
         h, w = hp - 2, wp - 2
         c = p['c']
+        mm = self.math
         shared = torch.zeros((batch, hp, wp, c), dtype=torch.float32, device=dev)
-        conv_layer(concat, (hp, wp), p['shared']['w'], p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
-                   cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=h, wo=w, batch=batch)
+        conv_layer(concat, (hp, wp), self._w(p['shared']), p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
+                   cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=h, wo=w, batch=batch,
+                   math=mm)
         hidden = torch.zeros((batch, hp, wp, 6 * c), dtype=torch.float32, device=dev)
-        conv_layer(shared, (hp, wp), p['hidden']['w'], p['hidden']['scale'], p['hidden']['shift'], True, hidden, (hp, wp),
-                   cin=c, in_cstride=c, out_cstride=6 * c, out_d=(1, 1), ho=h, wo=w, batch=batch)
+        conv_layer(shared, (hp, wp), self._w(p['hidden']), p['hidden']['scale'], p['hidden']['shift'], True, hidden, (hp, wp),
+                   cin=c, in_cstride=c, out_cstride=6 * c, out_d=(1, 1), ho=h, wo=w, batch=batch, math=mm)
         head = torch.empty((batch, h * w, 12), dtype=torch.float32, device=dev)
-        conv_layer(hidden, (hp, wp), p['final']['w'], None, p['final']['shift'], False, head, (h, w), cin=c,
-                   in_cstride=6 * c, out_cstride=12, out_d=(0, 0), groups=6, cout_pad=16, g_cout=p['final']['g_cout'],
-                   g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch)
+        conv_layer(hidden, (hp, wp), self._w(p['final']), None, p['final']['shift32' if mm else 'shift'], False, head, (h, w),
+                   cin=c, in_cstride=6 * c, out_cstride=12, out_d=(0, 0), groups=6, cout_pad=32 if mm else 16,
+                   g_cout=p['final']['g_cout'], g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
         return head, h, w
 
     def decode_nosync(self, head, h, w):
@@ -661,8 +699,10 @@ class CenterHead(_Cached):
         _inference_only(self)
         with torch.no_grad():
             concat = data_dict.get('_nhwc_spatial_features_2d', None)
+            enc = data_dict.get('_nhwc_math', 0)
             if concat is None:
-                concat = nchw_to_padded_nhwc(data_dict['spatial_features_2d'].float())
+                concat, enc = nchw_to_padded_nhwc(data_dict['spatial_features_2d'].float()), 0
+            concat = _recode(concat, enc, self.math)
             head, h, w = self.run_convs(concat, concat.shape[0])
             pred = {n: head.view(head.shape[0], h, w, 12)[..., o:o + c].permute(0, 3, 1, 2)
                     for n, (o, c) in self.COLS.items()}

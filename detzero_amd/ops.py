@@ -163,12 +163,16 @@ class SparseLevel:
         return nbr
 
 
-def scatter_rows(src, rank, c_dst, cap, d_n=None):
+def scatter_rows(src, rank, c_dst, cap, d_n=None, math=0):
+    """dst[rank[i]] = src[i] (zero padded to c_dst channels); with math != 0 the rows are written as pair16."""
     lib = L.load()
     L.require_cuda(src, rank)
     n, c_src = src.shape
     dst = torch.zeros((max(cap, 1), c_dst), dtype=torch.float32, device=src.device)
-    rc = lib.dz_scatter_rows(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, L.stream())
+    if math:
+        rc = lib.dz_scatter_rows_split(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, int(math), L.stream())
+    else:
+        rc = lib.dz_scatter_rows(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, L.stream())
     L.check(rc, 'dz_scatter_rows')
     return dst
 
@@ -182,50 +186,134 @@ def gather_rows(src, idx, d_n, n_cap):
     return out
 
 
-def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, relu=True, out=None, in_level=None):
-    """feats (m_in,cin); nbr (kvol,cap); w_taps (kvol,cin,cout); returns (cap,cout)."""
+def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, relu=True, out=None, in_level=None, math=0):
+    """feats (m_in,cin); nbr (kvol,cap); returns (cap,cout).
+    math == 0: fp32 rows, w_taps (kvol,cin,cout) fp32.
+    math != 0: pair16 rows (in, residual, out), w_taps (kvol,cout_pad,cin) pair16 from pack_weight_split."""
     lib = L.load()
     L.require_cuda(feats, nbr, w_taps, scale, shift, residual)
     kvol, cap = nbr.shape
-    cin, cout = w_taps.shape[1], w_taps.shape[2]
+    if math:
+        cin, cout = w_taps.shape[2], scale.shape[0]
+    else:
+        cin, cout = w_taps.shape[1], w_taps.shape[2]
     assert feats.shape[1] == cin, (feats.shape, w_taps.shape)
     if out is None:
         out = torch.empty((cap, cout), dtype=torch.float32, device=feats.device)
+
     def launch():
-        rc = lib.dz_spconv_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps),
-                                   L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout,
-                                   L.stream())
+        if math:
+            rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m),
+                                             L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0,
+                                             L.ptr(out), cout, int(math), L.stream())
+        else:
+            rc = lib.dz_spconv_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m),
+                                       L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0,
+                                       L.ptr(out), cout, L.stream())
         L.check(rc, 'dz_spconv_forward')
     if PROFILER is None:
         launch()
     else:
-        # algorithmic work of this launch: 2*pairs*cin*cout FLOP; bytes per BASELINE.md §3
+        # algorithmic work of this launch: 2*pairs*cin*cout FLOP; bytes per BASELINE.md section 3
         m = out_level.num_active()
         pairs = int((nbr[:, :m] >= 0).sum().item())
         flops = 2.0 * pairs * cin * cout
         n_in = in_level.num_active() if in_level is not None else m
         nbytes = 4.0 * (n_in * cin + m * cout + kvol * cin * cout + (m * cout if residual is not None else 0)) + 8.0 * pairs
-        PROFILER.wrap(lib.dz_spconv_variant(cin, cout).decode(), flops, nbytes, launch)
+        name = lib.dz_spconv_variant_split(cin, cout) if math else lib.dz_spconv_variant(cin, cout)
+        PROFILER.wrap(name.decode(), flops, nbytes, launch)
     return out
 
 
-def sparse_to_bev(feats, level, c, pad=1, out=None):
-    """-> (B, H+2p, W+2p, C*D) channel-last zero-bordered BEV image."""
+def sparse_to_bev(feats, level, c, pad=1, out=None, math=0):
+    """-> (B, H+2p, W+2p, C*D) channel-last zero-bordered BEV image (pair16 in, pair16 out when math != 0)."""
     lib = L.load()
     d, h, w = level.shape
     if out is None:
         out = torch.empty((level.batch, h + 2 * pad, w + 2 * pad, c * d), dtype=torch.float32, device=feats.device)
     out.zero_()
-    rc = lib.dz_sparse_to_bev(L.ptr(feats), L.ptr(level.coords), L.ptr(level.d_m), level.cap, c, d, h, w, pad,
-                              L.ptr(out), L.stream())
+    fn = lib.dz_sparse_to_bev_split if math else lib.dz_sparse_to_bev
+    rc = fn(L.ptr(feats), L.ptr(level.coords), L.ptr(level.d_m), level.cap, c, d, h, w, pad, L.ptr(out), L.stream())
     L.check(rc, 'dz_sparse_to_bev')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# split precision (pair16): csrc/hgemm.h
+# ------------------------------------------------------------------------------------------------
+MATH_MODES = {'f32': 0, 'f16x2': 1, 'bf16x2': 2}
+
+
+def math_id(mode):
+    if isinstance(mode, str):
+        if mode not in MATH_MODES:
+            raise L.DetZeroHipError('unknown math mode %r (choose from %s)' % (mode, sorted(MATH_MODES)))
+        return MATH_MODES[mode]
+    return int(mode)
+
+
+def pair16_pack(x, math):
+    """Host/torch packer (any device): x (..., C) fp32, C % 8 == 0 -> same-shape float32-typed pair16 bits.
+    Used for weights at plan time; the device kernels (dz_pair16_from_f32, conv epilogues) do the same split."""
+    dt = torch.float16 if math == 1 else torch.bfloat16
+    x = x.float()
+    if math == 1:
+        x = x.clamp(-65504.0, 65504.0)
+    hi = x.to(dt)
+    lo = (x - hi.float()).to(dt)
+    shp = x.shape
+    g = shp[-1] // 8
+    out = torch.stack([hi.reshape(*shp[:-1], g, 8), lo.reshape(*shp[:-1], g, 8)], dim=-2)
+    return out.reshape(*shp[:-1], g * 16).contiguous().view(torch.float32)
+
+
+def pair16_unpack(x, math):
+    dt = torch.float16 if math == 1 else torch.bfloat16
+    shp = x.shape
+    g = shp[-1] // 8
+    h = x.contiguous().view(dt).reshape(*shp[:-1], g, 2, 8).float()
+    return (h[..., 0, :] + h[..., 1, :]).reshape(shp)
+
+
+def pack_weight_split(w, math, cout_mult=32):
+    """(..., cin, cout) fp32 conv weights -> (..., cout_pad, cin) pair16 (cout padded with zero rows)."""
+    wt = w.float().transpose(-1, -2)
+    co = wt.shape[-2]
+    cp = -(-co // cout_mult) * cout_mult
+    if cp > co:
+        wt = torch.cat([wt, wt.new_zeros(*wt.shape[:-2], cp - co, wt.shape[-1])], dim=-2)
+    return pair16_pack(wt.contiguous(), math)
+
+
+def pair16_from_f32(x, c_dst=None, math=1):
+    """device conversion of rows (..., C) fp32 -> (..., c_dst) pair16"""
+    lib = L.load()
+    L.require_cuda(x)
+    x = x.contiguous()
+    c = x.shape[-1]
+    c_dst = c if c_dst is None else c_dst
+    rows = x.numel() // c
+    out = torch.empty((*x.shape[:-1], c_dst), dtype=torch.float32, device=x.device)
+    L.check(lib.dz_pair16_from_f32(L.ptr(x), rows, c, c_dst, int(math), L.ptr(out), L.stream()), 'dz_pair16_from_f32')
+    return out
+
+
+def pair16_to_f32(x, math=1):
+    lib = L.load()
+    L.require_cuda(x)
+    x = x.contiguous()
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(lib.dz_pair16_to_f32(L.ptr(x), x.numel() // c, c, int(math), L.ptr(out), L.stream()), 'dz_pair16_to_f32')
     return out
 
 
 # ------------------------------------------------------------------------------------------------
 # dense conv
 # ------------------------------------------------------------------------------------------------
-def conv2d(desc_kwargs):
+def conv2d(desc_kwargs, math=0, out_f32=False):
+    """One dense-conv launch from a dict of dz_conv2d_desc fields.  math != 0: pair16 input / weights
+    (pack_weight_split layout) and pair16 output unless out_f32."""
     lib = L.load()
     d = L.Conv2dDesc()
     g_cout = desc_kwargs.pop('g_cout')
@@ -236,8 +324,22 @@ def conv2d(desc_kwargs):
         d.g_cout[i] = int(v)
     for i, v in enumerate(g_ooff):
         d.g_ooff[i] = int(v)
-    rc = lib.dz_conv2d_forward(ctypes.byref(d), L.stream())
-    L.check(rc, 'dz_conv2d_forward')
+
+    def launch():
+        if math:
+            L.check(lib.dz_conv2d_forward_split(ctypes.byref(d), int(math), 1 if out_f32 else 0, L.stream()), 'dz_conv2d_forward_split')
+        else:
+            L.check(lib.dz_conv2d_forward(ctypes.byref(d), L.stream()), 'dz_conv2d_forward')
+    if PROFILER is None:
+        launch()
+        return
+    m = d.batch * d.ho * d.wo
+    taps = d.kh * d.kw
+    cout = sum(d.g_cout[i] for i in range(d.groups))
+    flops = 2.0 * m * taps * d.cin * cout
+    nbytes = 4.0 * (m * d.cin * d.groups + m * cout + taps * d.cin * d.cout_pad * d.groups)
+    name = (lib.dz_conv2d_variant_split if math else lib.dz_conv2d_variant)(ctypes.byref(d)).decode()
+    PROFILER.wrap(name, flops, nbytes, launch)
 
 
 def linear(x, w, scale, shift, relu, cout, out=None, group_shift=None, group_rows=0):
@@ -388,32 +490,3 @@ class LaunchProfiler:
 
 
 PROFILER = None
-
-
-def _conv2d_profiled(d, lib):
-    m = d.batch * d.ho * d.wo
-    taps = d.kh * d.kw
-    flops = 2.0 * m * taps * d.cin * sum(d.g_cout[i] for i in range(d.groups))
-    nbytes = 4.0 * (m * d.cin * d.groups * (1 if d.groups > 1 else 1) + m * sum(d.g_cout[i] for i in range(d.groups))
-                    + taps * d.cin * d.cout_pad * d.groups)
-    name = lib.dz_conv2d_variant(ctypes.byref(d)).decode()
-    PROFILER.wrap(name, flops, nbytes, lambda: L.check(lib.dz_conv2d_forward(ctypes.byref(d), L.stream()), 'dz_conv2d_forward'))
-
-
-_orig_conv2d = conv2d
-
-
-def conv2d(desc_kwargs):  # noqa: F811  (profiling-aware front of the function defined above)
-    if PROFILER is None:
-        return _orig_conv2d(desc_kwargs)
-    lib = L.load()
-    d = L.Conv2dDesc()
-    g_cout = desc_kwargs.pop('g_cout')
-    g_ooff = desc_kwargs.pop('g_ooff')
-    for k, v in desc_kwargs.items():
-        setattr(d, k, v)
-    for i, v in enumerate(g_cout):
-        d.g_cout[i] = int(v)
-    for i, v in enumerate(g_ooff):
-        d.g_ooff[i] = int(v)
-    _conv2d_profiled(d, lib)

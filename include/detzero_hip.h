@@ -148,6 +148,42 @@ const char *dz_conv2d_variant(const dz_conv2d_desc *h_desc);
 const char *dz_spconv_variant(int cin, int cout);
 
 /* ---------------------------------------------------------------------------------------------
+ * Split-precision engine: the same sparse / dense convolutions on the 16-bit matrix cores.
+ * Every fp32 value x travels as a pair of 16-bit floats (hi = rn16(x), lo = rn16(x - hi)); a product is
+ * hi.hi + lo.hi + hi.lo in three v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation (csrc/hgemm.h).
+ * fp16 pairs carry 22 significant bits (results indistinguishable from fp32 summation-order noise, values
+ * saturate at +-131008), bf16 pairs 16 bits with the full fp32 exponent range.
+ * "pair16" layout of a row of C channels (C % 8 == 0): C 32-bit words, i.e. the byte size of the fp32 row;
+ * each group of 8 channels = 16 bytes of hi values then 16 bytes of lo values.  Tensors keep the shapes,
+ * strides and capacities of their fp32 counterparts (pointers are typed float* for that reason).
+ * There is no fp32 conv in the reference to replace here beyond the ones named above: these entry points
+ * are the throughput path of the same layers ("fp16/bf16-in / fp32-acc MFMA").
+ * ------------------------------------------------------------------------------------------- */
+#define DZ_MATH_F32 0
+#define DZ_MATH_F16X2 1
+#define DZ_MATH_BF16X2 2
+/* dst (rows, c_dst) pair16 <- src (rows, c_src) f32, channels c_src..c_dst-1 zero; c_dst % 8 == 0 */
+int dz_pair16_from_f32(const float *src, long rows, int c_src, int c_dst, int math, float *dst, void *stream);
+/* dst (rows, c) f32 <- src (rows, c) pair16 (hi + lo) */
+int dz_pair16_to_f32(const float *src, long rows, int c, int math, float *dst, void *stream);
+/* dz_scatter_rows writing pair16 rows */
+int dz_scatter_rows_split(const float *src, const int *rank, const int *d_n, int n_cap, int c_src, float *dst,
+                          int c_dst, int math, void *stream);
+/* dz_spconv_forward on pair16 operands: in / residual / out pair16 rows, w (kvol, cout_pad, cin) pair16 with
+ * cout_pad = max(cout, 32) (rows cout..cout_pad-1 zero), scale / shift (cout) f32. */
+int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
+                            const float *w, const float *scale, const float *shift, const float *residual,
+                            int relu, float *out, int cout, int math, void *stream);
+/* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
+int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
+                           int w, int pad, float *bev, void *stream);
+/* dz_conv2d_forward on pair16 images: desc->in pair16, desc->w (groups, kh*kw, cout_pad, cin) pair16
+ * (cout_pad % 32 == 0, cin % 32 == 0), desc->out pair16 or, with out_f32 != 0, plain fp32 (last head conv). */
+int dz_conv2d_forward_split(const dz_conv2d_desc *h_desc, int math, int out_f32, void *stream);
+const char *dz_conv2d_variant_split(const dz_conv2d_desc *h_desc);
+const char *dz_spconv_variant_split(int cin, int cout);
+
+/* ---------------------------------------------------------------------------------------------
  * CenterHead decode + NMS (center_head.py:315-368, centernet_utils.py:138-230,
  * model_nms_utils.py:6-25, utils/detzero_utils/ops/iou3d_nms/)
  * ------------------------------------------------------------------------------------------- */

