@@ -9,7 +9,7 @@
 
 namespace dz {
 
-template <class T, class M, bool OUT_F32>
+template <class T, class M, bool OUT_F32, int NS>
 __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total, unsigned int in_bytes, unsigned int w_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const int nchunks = taps * kchunks;
     const long cbase = p.in_coff + (long)grp * p.cin;
 
-    const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(p.in, in_bytes);
-    const __amdgpu_buffer_rsrc_t crsrc = make_rsrc(p.w, w_bytes);
+    const srsrc_t prsrc = make_srsrc(p.in, in_bytes);
+    const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
     unsigned int pvoff[T::P_PER_THREAD], cvoff[T::C_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < T::P_PER_THREAD; ++i) {
@@ -74,12 +74,11 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
             cvoff[i] = (unsigned int)((((long)grp * taps * p.cout_pad + n0 + n) * p.cin + q * 4) * 4);
         }
     }
-    HStage<T> st;
     int ky = 0, kx = 0, kc = 0;
     unsigned int padd = 0, cadd = 0;
     const unsigned int tap_bytes = (unsigned int)((long)p.cout_pad * p.cin * 4);
     unsigned int tap_base = 0;
-    auto issue = [&]() { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
+    auto issue = [&](HStage<T> &st) { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
     auto advance = [&]() {
         if (++kc == kchunks) {
             kc = 0;
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
         padd = (unsigned int)(((ky * p.in_wp + kx) * p.in_cstride + kc * T::KC) * 4);
         cadd = tap_base + (unsigned int)(kc * T::KC * 4);
     };
-    hgemm_pipeline<T, M>(nchunks, smem, st, issue, advance, acc, wp, wc, lane, tid);
+    hgemm_pipeline<T, M, NS>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
 
     // accumulator of a 32x32 fragment: pixel = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
     const int h = lane >> 5;
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     }
 }
 
-template <class T, class M, bool OUT_F32>
+template <class T, class M, bool OUT_F32, int NS>
 static int launch_conv_h(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
     const long m_total = (long)p.batch * p.ho * p.wo;
     dim3 grid(ceil_div(m_total, T::BP), (p.cout_pad / T::BC) * p.groups);
@@ -144,14 +143,14 @@ static int launch_conv_h(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t st
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_h<T, M, OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_h<T, M, OUT_F32, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES) != hipSuccess) {
             set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", T::LDS_BYTES);
             return DZ_ERR_HIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv2d_h<T, M, OUT_F32>), grid, dim3(256), T::LDS_BYTES, stream, p, m_total, (unsigned int)in_bytes,
+    hipLaunchKernelGGL((k_conv2d_h<T, M, OUT_F32, NS>), grid, dim3(256), T::LDS_BYTES, stream, p, m_total, (unsigned int)in_bytes,
                        (unsigned int)w_bytes);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
@@ -186,11 +185,11 @@ static ConvHVariant conv2d_h_select(const dz_conv2d_desc &p) {
 template <class M, bool OUT_F32>
 static int conv2d_h_dispatch(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
     switch (conv2d_h_select(p)) {
-        case CH_128_128: return launch_conv_h<HTile<128, 128, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
-        case CH_128_64: return launch_conv_h<HTile<128, 64, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
-        case CH_64_128: return launch_conv_h<HTile<64, 128, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
-        case CH_64_64: return launch_conv_h<HTile<64, 64, 32, 2, 2>, M, OUT_F32>(p, w_bytes, stream);
-        case CH_128_32: return launch_conv_h<HTile<128, 32, 32, 4, 1>, M, OUT_F32>(p, w_bytes, stream);
+        case CH_128_128: return launch_conv_h<HTile<128, 128, 32, 2, 2>, M, OUT_F32, 2>(p, w_bytes, stream);
+        case CH_128_64: return launch_conv_h<HTile<128, 64, 32, 2, 2>, M, OUT_F32, 3>(p, w_bytes, stream);
+        case CH_64_128: return launch_conv_h<HTile<64, 128, 32, 2, 2>, M, OUT_F32, 3>(p, w_bytes, stream);
+        case CH_64_64: return launch_conv_h<HTile<64, 64, 32, 2, 2>, M, OUT_F32, 3>(p, w_bytes, stream);
+        case CH_128_32: return launch_conv_h<HTile<128, 32, 32, 4, 1>, M, OUT_F32, 3>(p, w_bytes, stream);
         default: break;
     }
     set_error("dz_conv2d_forward_split: unsupported channels cin=%d cout_pad=%d (cin %% 32, cout_pad %% 32 required)", p.cin, p.cout_pad);

@@ -133,16 +133,46 @@ struct HStage {
     v4u c[T::C_PER_THREAD];
 };
 
-// raw buffer loads of the 16-byte pieces; offsets past the buffer read as zeros (missing neighbours, rows past
-// the end of the image, output channels past the real count)
+// Global loads of the 16-byte pieces.  They are issued from inline asm so that THIS file owns the vmcnt
+// bookkeeping: with builtin loads the compiler's waitcnt pass cannot see through the rotating register stages of
+// the NS-deep pipeline and drains the whole queue (vmcnt(0)) once per trip.  Contract:
+//   * every thread issues exactly NST = P_PER_THREAD + C_PER_THREAD loads per stage (threads without a piece use
+//     the out-of-range offset: zeros come back, nothing is fetched), so the per-wave counter is uniform;
+//   * loads return in order, so "stage s has landed" == vmcnt(<= loads issued after it) (wait_hstage);
+//   * a stage's registers are touched only through wait_hstage's "+v" operands before they are stored to LDS.
+// Offsets past the buffer read as zeros (missing neighbours, rows past the end of the image).
+using srsrc_t = v4u;     // buffer resource words held in 4 consecutive SGPRs
+
+__device__ __forceinline__ srsrc_t make_srsrc(const void *base, unsigned int bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    srsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned int)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned int)(a >> 32) & 0xFFFFu);      // stride 0
+    r.z = __builtin_amdgcn_readfirstlane(bytes);                                   // num_records (bytes)
+    r.w = 0x00020000u;
+    return r;
+}
+
 template <class T>
-__device__ __forceinline__ void load_hstage(HStage<T> &st, __amdgpu_buffer_rsrc_t prsrc, const unsigned int (&pvoff)[T::P_PER_THREAD],
-                                            unsigned int padd, __amdgpu_buffer_rsrc_t crsrc,
-                                            const unsigned int (&cvoff)[T::C_PER_THREAD], unsigned int cadd) {
+__device__ __forceinline__ void load_hstage(HStage<T> &st, srsrc_t prsrc, const unsigned int (&pvoff)[T::P_PER_THREAD],
+                                            unsigned int padd, srsrc_t crsrc, const unsigned int (&cvoff)[T::C_PER_THREAD],
+                                            unsigned int cadd) {
 #pragma unroll
-    for (int i = 0; i < T::P_PER_THREAD; ++i) st.p[i] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, pvoff[i] + padd, 0, 0);
+    for (int i = 0; i < T::P_PER_THREAD; ++i)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st.p[i]) : "v"(pvoff[i] + padd), "s"(prsrc));
 #pragma unroll
-    for (int i = 0; i < T::C_PER_THREAD; ++i) st.c[i] = __builtin_amdgcn_raw_buffer_load_b128(crsrc, cvoff[i] + cadd, 0, 0);
+    for (int i = 0; i < T::C_PER_THREAD; ++i)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st.c[i]) : "v"(cvoff[i] + cadd), "s"(crsrc));
+}
+
+// wait until at most N younger loads are outstanding, then hand the stage's registers back to the compiler
+template <class T, int N>
+__device__ __forceinline__ void wait_hstage(HStage<T> &st) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+#pragma unroll
+    for (int i = 0; i < T::P_PER_THREAD; ++i) asm volatile("" : "+v"(st.p[i]));
+#pragma unroll
+    for (int i = 0; i < T::C_PER_THREAD; ++i) asm volatile("" : "+v"(st.c[i]));
 }
 
 template <class T>
@@ -159,10 +189,15 @@ __device__ __forceinline__ void store_hstage(const HStage<T> &st, v4u *__restric
     }
 }
 
-// Same schedule as gemm_pipeline (igemm.h): per chunk, phase 1 = MFMAs of k-step 0 || LDS reads of k-step 1 ||
-// LDS writes of chunk c+1; barrier; phase 2 = MFMAs of k-step 1 || LDS reads of chunk c+1 || global loads of c+2.
-template <class T, class M, class Issue, class Advance>
-__device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ smem, HStage<T> &st, Issue &&issue, Advance &&advance,
+// Schedule of gemm_pipeline (igemm.h) with a DEEPER global-load pipeline: at 16-bit MFMA rates a chunk lasts only
+// a few hundred cycles per wave, less than an L2 / HBM round trip, so the loads run NS chunks ahead in NS
+// register stages (the loop is unrolled NS times so that every stage index is static):
+//   per chunk c, phase 1 = MFMAs of k-step 0 || LDS reads of k-step 1 || LDS writes of chunk c+1 (loaded NS chunks ago)
+//   barrier
+//   phase 2 = MFMAs of k-step 1 || LDS reads of chunk c+1 || global loads of chunk c+1+NS into the stage just freed
+// `issue(stage)` loads the chunk the caller's iterator points at, `advance()` moves the iterator (chunk order).
+template <class T, class M, int NS, class Issue, class Advance>
+__device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ smem, Issue &&issue, Advance &&advance,
                                                f32x16 (&acc)[T::CT][T::PT], int wp, int wc, int lane, int tid) {
     v4u *const Ps0 = smem, *const Cs0 = smem + 2 * T::PS_U4;          // [2][PS], [2][CS]
     constexpr int Q = T::KC / 16;
@@ -170,45 +205,80 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
     const int coff = (wc * T::CT * 32 + (lane & 31)) * T::ROW_U4 + (lane >> 5) * 2;
     constexpr int MFMA_N = 3 * T::PT * T::CT;                       // MFMAs per k-step
     constexpr int NLD = 2 * (T::PT + T::CT);                        // LDS reads per k-step
+    constexpr int NLDH = NLD < MFMA_N ? NLD : MFMA_N;
     constexpr int NST = T::P_PER_THREAD + T::C_PER_THREAD;          // staging loads / stores per chunk
     constexpr int REST1 = MFMA_N - (Q == 2 ? NLD : 0);
     constexpr int PER1 = (REST1 / NST) > 0 ? (REST1 / NST) : 1;
     constexpr int REST2 = MFMA_N - NLD;
     constexpr int PER2 = (REST2 / NST) > 0 ? (REST2 / NST) : 1;
 
-    issue();
-    store_hstage<T>(st, Ps0, Cs0, tid);
+    HStage<T> st[NS];
+    issue(st[0]);
+    wait_hstage<T, 0>(st[0]);
+    store_hstage<T>(st[0], Ps0, Cs0, tid);
     __syncthreads();
-    if (nchunks > 1) { advance(); issue(); }
+    // the steady-state loop below is entered only through the branch with UNCONDITIONAL prefetches, so that the
+    // compiler's s_waitcnt vmcnt(N) bookkeeping knows exactly NS stages are in flight at the loop header (with
+    // conditional prefetches it falls back to vmcnt(0) there, which serialises the pipeline again)
+    const bool steady = nchunks > 2 * NS;
+    if (steady) {
+#pragma unroll
+        for (int j = 1; j <= NS; ++j) { advance(); issue(st[j % NS]); }
+    } else {
+#pragma unroll
+        for (int j = 1; j <= NS; ++j)
+            if (j < nchunks) { advance(); issue(st[j % NS]); }
+    }
     HFrag<T> f0, f1;
     load_hfrag<T>(f0, Ps0 + poff, Cs0 + coff, 0);
-    auto body = [&](int c, auto has1_t, auto has2_t) {
-        constexpr bool HAS1 = decltype(has1_t)::value, HAS2 = decltype(has2_t)::value;
+    // chunk c with its stage index S = (c + 1) % NS static; has1: chunk c+1 exists, has2: chunk c+1+NS exists
+    auto body = [&](int c, auto s_t, auto static_t, bool has1, bool has2) {
+        constexpr int S = decltype(s_t)::value;
+        constexpr bool ALL = decltype(static_t)::value;              // both known true at compile time: no branches
         const int cur = c & 1;
         const v4u *Pc = Ps0 + cur * T::PS_U4 + poff, *Cc = Cs0 + cur * T::CS_U4 + coff;
         const v4u *Pn = Ps0 + (cur ^ 1) * T::PS_U4 + poff, *Cn = Cs0 + (cur ^ 1) * T::CS_U4 + coff;
         // ---- phase 1
         if (Q == 2) load_hfrag<T>(f1, Pc, Cc, 1);
-        if (HAS1) store_hstage<T>(st, Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
+        if (ALL) {
+            wait_hstage<T, (NS - 1) * NST>(st[S]);     // steady state: the NS-1 younger stages stay in flight
+            store_hstage<T>(st[S], Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
+        } else if (has1) {
+            wait_hstage<T, 0>(st[S]);                  // tail: fewer stages may be in flight - drain
+            store_hstage<T>(st[S], Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
+        }
         mma_hfrag<T, M>(f0, acc);
-        if (Q == 2) interleave_hint<0x100, (NLD < MFMA_N ? NLD : MFMA_N), 1>();
-        if (HAS1) interleave_hint<0x200, NST, PER1>();
+        if (ALL) {
+            if (Q == 2) interleave_hint<0x100, NLDH, 1>();
+            interleave_hint<0x200, NST, PER1>();
+        }
         __syncthreads();
         // ---- phase 2
-        if (HAS1) load_hfrag<T>(f0, Pn, Cn, 0);
-        if (HAS2) { advance(); issue(); }
+        if (ALL || has1) load_hfrag<T>(f0, Pn, Cn, 0);
+        if (ALL || has2) { advance(); issue(st[S]); }
         if (Q == 2) {
             mma_hfrag<T, M>(f1, acc);
-            if (HAS1) interleave_hint<0x100, (NLD < MFMA_N ? NLD : MFMA_N), 1>();
-            if (HAS2) interleave_hint<0x020, NST, PER2>();
+            if (ALL) {
+                interleave_hint<0x100, NLDH, 1>();
+                interleave_hint<0x020, NST, PER2>();
+            }
         }
     };
     using TT = std::integral_constant<bool, true>;
     using FF = std::integral_constant<bool, false>;
     int c = 0;
-    for (; c + 2 < nchunks; ++c) body(c, TT{}, TT{});
-    if (c + 1 < nchunks) { body(c, TT{}, FF{}); ++c; }
-    body(c, FF{}, FF{});
+    // steady state: NS chunks per trip, every predicate true
+    for (; c + 2 * NS < nchunks; c += NS) {
+        body(c, std::integral_constant<int, 1 % NS>{}, TT{}, true, true);
+        if (NS >= 2) body(c + 1, std::integral_constant<int, 2 % NS>{}, TT{}, true, true);
+        if (NS >= 3) body(c + 2, std::integral_constant<int, 3 % NS>{}, TT{}, true, true);
+    }
+    // tail (c is a multiple of NS): same stage rotation, run-time predicates
+    for (; c < nchunks; c += NS) {
+        body(c, std::integral_constant<int, 1 % NS>{}, FF{}, c + 1 < nchunks, c + 1 + NS < nchunks);
+        if (NS >= 2 && c + 1 < nchunks) body(c + 1, std::integral_constant<int, 2 % NS>{}, FF{}, c + 2 < nchunks, c + 2 + NS < nchunks);
+        if (NS >= 3 && c + 2 < nchunks) body(c + 2, std::integral_constant<int, 3 % NS>{}, FF{}, c + 3 < nchunks, c + 3 + NS < nchunks);
+    }
 }
 
 }  // namespace dz

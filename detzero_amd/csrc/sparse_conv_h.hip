@@ -24,7 +24,7 @@ struct SpConvHArgs {
     unsigned int in_bytes, w_bytes;
 };
 
-template <class T, class M>
+template <class T, class M, int NS>
 __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
     const int ntiles = (m + T::BP - 1) / T::BP;
     const int kchunks = a.cin / T::KC;
     const int n0 = blockIdx.y * T::BC;          // channel tile (cout_pad may be split over blockIdx.y)
-    const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t crsrc = make_rsrc(a.w, a.w_bytes);
+    const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes);
+    const srsrc_t crsrc = make_srsrc(a.w, a.w_bytes);
     unsigned int cvoff[T::C_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < T::C_PER_THREAD; ++i) {
@@ -77,10 +77,9 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
 
         const int nchunks = __popc(taps) * kchunks;
         if (nchunks > 0) {
-            HStage<T> st;
             unsigned int rem = taps;
             int tap = __ffs((int)rem) - 1, kc = 0;
-            auto issue = [&]() {
+            auto issue = [&](HStage<T> &st) {
                 unsigned int pvoff[T::P_PER_THREAD];
 #pragma unroll
                 for (int i = 0; i < T::P_PER_THREAD; ++i) {
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
             auto advance = [&]() {
                 if (++kc == kchunks) { kc = 0; rem &= rem - 1; tap = __ffs((int)rem) - 1; }
             };
-            hgemm_pipeline<T, M>(nchunks, smem, st, issue, advance, acc, wp, wc, lane, tid);
+            hgemm_pipeline<T, M, NS>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
         }
 
         // accumulator of a 32x32 fragment: row = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
@@ -145,12 +144,12 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
     }
 }
 
-template <class T, class M>
+template <class T, class M, int NS>
 static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
     constexpr int LDS = T::LDS_BYTES + KVOL_MAX_H * T::BP * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", LDS);
             return DZ_ERR_HIP;
@@ -160,7 +159,7 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
     int grid = ceil_div(a.cap, T::BP);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_spconv_h<T, M>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_spconv_h<T, M, NS>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -174,16 +173,16 @@ static int tune(const char *name, int dflt) {
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
-    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M>(a, stream);
-    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M>(a, stream);
+    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 2>(a, stream);
+    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 2>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
-        if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M>(a, stream);
-        return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M>(a, stream);
+        if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
+        return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 2>(a, stream);
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
-        if (t128 == 1) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M>(a, stream);
-        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M>(a, stream);
-        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M>(a, stream);
+        if (t128 == 1) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
+        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
+        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
