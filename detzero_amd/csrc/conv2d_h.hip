@@ -19,9 +19,16 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wp = wid / T::WC, wc = wid % T::WC;
     const int ntn = p.cout_pad / T::BC;           // channel tiles per group
-    const int grp = blockIdx.y / ntn;
-    const int n0 = (blockIdx.y % ntn) * T::BC;
-    const long row0 = (long)blockIdx.x * T::BP;
+    // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (each XCD has its own L2), so remap the
+    // linear id bijectively such that every XCD walks one CONTIGUOUS band of the image, channel tiles of a pixel
+    // tile adjacent: neighbouring tiles share their halo rows and taps in that XCD's L2 instead of re-fetching them
+    const int nty = ntn * p.groups;
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int by = lid % nty;
+    const int grp = by / ntn;
+    const int n0 = (by % ntn) * T::BC;
+    const long row0 = (long)(lid / nty) * T::BP;
 
     for (int r = tid; r < T::BP; r += 256) {
         const long mrow = row0 + r;
@@ -79,11 +86,13 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const unsigned int tap_bytes = (unsigned int)((long)p.cout_pad * p.cin * 4);
     unsigned int tap_base = 0;
     auto issue = [&](HStage<T> &st) { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
+    // chunk order: channel chunk outermost, then ky, kx innermost - the kx taps of one image row re-read the same
+    // cache lines shifted by one pixel, back to back, while they are still in the CU's L1
     auto advance = [&]() {
-        if (++kc == kchunks) {
-            kc = 0;
-            tap_base += tap_bytes;
-            if (++kx == p.kw) { kx = 0; ++ky; }
+        tap_base += tap_bytes;
+        if (++kx == p.kw) {
+            kx = 0;
+            if (++ky == p.kh) { ky = 0; ++kc; tap_base = 0; }
         }
         padd = (unsigned int)(((ky * p.in_wp + kx) * p.in_cstride + kc * T::KC) * 4);
         cadd = tap_base + (unsigned int)(kc * T::KC * 4);
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
 template <class T, class M, bool OUT_F32, int NS>
 static int launch_conv_h(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
     const long m_total = (long)p.batch * p.ho * p.wo;
-    dim3 grid(ceil_div(m_total, T::BP), (p.cout_pad / T::BC) * p.groups);
+    dim3 grid(ceil_div(m_total, T::BP) * (p.cout_pad / T::BC) * p.groups);
     const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
     if (in_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) {
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);

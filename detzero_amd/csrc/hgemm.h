@@ -212,6 +212,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
     constexpr int REST2 = MFMA_N - NLD;
     constexpr int PER2 = (REST2 / NST) > 0 ? (REST2 / NST) : 1;
 
+    static_assert(NS >= 1 && NS <= 4, "1..4 register stages");
     HStage<T> st[NS];
     issue(st[0]);
     wait_hstage<T, 0>(st[0]);
@@ -272,12 +273,14 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
         body(c, std::integral_constant<int, 1 % NS>{}, TT{}, true, true);
         if (NS >= 2) body(c + 1, std::integral_constant<int, 2 % NS>{}, TT{}, true, true);
         if (NS >= 3) body(c + 2, std::integral_constant<int, 3 % NS>{}, TT{}, true, true);
+        if (NS >= 4) body(c + 3, std::integral_constant<int, 4 % NS>{}, TT{}, true, true);
     }
     // tail (c is a multiple of NS): same stage rotation, run-time predicates
     for (; c < nchunks; c += NS) {
         body(c, std::integral_constant<int, 1 % NS>{}, FF{}, c + 1 < nchunks, c + 1 + NS < nchunks);
         if (NS >= 2 && c + 1 < nchunks) body(c + 1, std::integral_constant<int, 2 % NS>{}, FF{}, c + 2 < nchunks, c + 2 + NS < nchunks);
         if (NS >= 3 && c + 2 < nchunks) body(c + 2, std::integral_constant<int, 3 % NS>{}, FF{}, c + 3 < nchunks, c + 3 + NS < nchunks);
+        if (NS >= 4 && c + 3 < nchunks) body(c + 3, std::integral_constant<int, 4 % NS>{}, FF{}, c + 4 < nchunks, c + 4 + NS < nchunks);
     }
 }
 

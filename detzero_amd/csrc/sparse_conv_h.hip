@@ -51,7 +51,16 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
     }
     const unsigned int tap_bytes = (unsigned int)(a.cout_pad * a.cin * 4);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (private L2 each).  Tiles are dealt to the XCDs
+    // in runs of XRUN consecutive (spatially sorted) row tiles: a run shares its gathered neighbour rows in one L2,
+    // while the round-robin of runs keeps the eight XCDs evenly loaded (whole contiguous eighths were measured slower:
+    // tile cost follows the local point density)
+    constexpr int XRUN = 16;
+    const int xcd = blockIdx.x & 7;
+    for (int t = blockIdx.x >> 3;; t += gridDim.x >> 3) {
+        const int tile = ((t / XRUN) * 8 + xcd) * XRUN + t % XRUN;
+        if ((t / XRUN) * 8 * XRUN >= ntiles) break;
+        if (tile >= ntiles) continue;
         const int row0 = tile * T::BP;
         if (tid == 0) mask_s = 0u;
         __syncthreads();
@@ -94,8 +103,12 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
                 load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
                                (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
             };
+            // chunk order: channel chunk outermost, taps innermost - neighbouring taps gather mostly the same input
+            // rows, so their KC-channel slices are re-read back to back while they are still in the CU's L1
             auto advance = [&]() {
-                if (++kc == kchunks) { kc = 0; rem &= rem - 1; tap = __ffs((int)rem) - 1; }
+                rem &= rem - 1;
+                if (rem == 0u) { rem = taps; ++kc; }
+                tap = __ffs((int)rem) - 1;
             };
             hgemm_pipeline<T, M, NS>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
         }
@@ -158,7 +171,8 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
     }
     int grid = ceil_div(a.cap, T::BP);
     if (grid > 2048) grid = 2048;
-    if (grid < 1) grid = 1;
+    grid = (grid + 7) & ~7;            // a multiple of 8: see the XCD schedule in the kernel
+    if (grid < 8) grid = 8;
     hipLaunchKernelGGL((k_spconv_h<T, M, NS>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
@@ -173,16 +187,17 @@ static int tune(const char *name, int dflt) {
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
-    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 2>(a, stream);
-    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 2>(a, stream);
+    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4>(a, stream);
+    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
-        if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
-        return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 2>(a, stream);
+        if (t64 == 1) return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 3>(a, stream);
+        if (t64 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
+        return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
-        if (t128 == 1) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
-        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
-        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
+        if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
+        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
+        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream);
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
@@ -219,7 +234,7 @@ const char *dz_spconv_variant_split(int cin, int cout) {
     const int cout_pad = cout < 32 ? 32 : cout;
     if (cin == 16 && cout_pad == 32) return "k_spconv_h<128x32x16>";
     if (cin == 32 && cout_pad == 32) return "k_spconv_h<128x32x32>";
-    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<128x64x32>";
+    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<64x64x32>";
     if ((cin == 64 || cin == 128) && cout_pad == 128) return "k_spconv_h<64x128x32>";
     return "none";
 }
