@@ -189,6 +189,7 @@ class FramePipeline:
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
         self._iota = None
+        self._streams = []
 
     def _voxelize(self, frames):
         """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
@@ -199,21 +200,35 @@ class FramePipeline:
         if self.dynamic:
             pb = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p], dim=1) for i, p in enumerate(frames)], dim=0)
             return ops.voxelize_dynamic_nosync(pb.contiguous(), rng, info.voxel_size, nb, xy_range_mask=True)
-        feats, coords = [], []
+        feats, coords = [None] * nb, [None] * nb
         d_n = None
-        for i, p in enumerate(frames):
-            # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
-            voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(p, rng, info.voxel_size, info.max_points_per_voxel,
-                                                              info.max_voxels[self.mode], xy_range_mask=True)
-            feats.append(ops.mean_vfe(voxels, nump, d_m=d_n))
-            if nb == 1:
-                bcol = zyx.new_zeros((zyx.shape[0], 1))
-            else:
-                cap = zyx.shape[0]
-                if self._iota is None or self._iota.shape[0] < cap or self._iota.device != zyx.device:
-                    self._iota = torch.arange(cap, dtype=torch.int32, device=zyx.device)
-                bcol = torch.where(self._iota[:cap] < d_n, i, -1).to(torch.int32)[:, None]
-            coords.append(torch.cat([bcol, zyx], dim=1))
+        dev = frames[0].device
+        main = torch.cuda.current_stream(dev)
+        cap = int(min(info.max_voxels[self.mode], max(max(p.shape[0] for p in frames), 1)))
+        if nb > 1:
+            if len(self._streams) < nb:
+                self._streams += [torch.cuda.Stream(device=dev) for _ in range(nb - len(self._streams))]
+            if self._iota is None or self._iota.shape[0] < cap or self._iota.device != dev:
+                self._iota = torch.arange(cap, dtype=torch.int32, device=dev)
+            for st in self._streams[:nb]:          # fork: frames are independent until the batch index is attached,
+                st.wait_stream(main)               # so they are voxelized on parallel streams (parallel branches of a
+        for i, p in enumerate(frames):             # captured graph): each is a chain of ~15 launches too small to fill the chip
+            st = self._streams[i] if nb > 1 else main
+            with torch.cuda.stream(st):
+                # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
+                voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(p, rng, info.voxel_size, info.max_points_per_voxel,
+                                                                  info.max_voxels[self.mode], xy_range_mask=True)
+                feats[i] = ops.mean_vfe(voxels, nump, d_m=d_n)
+                if nb == 1:
+                    bcol = zyx.new_zeros((zyx.shape[0], 1))
+                else:
+                    bcol = torch.where(self._iota[:zyx.shape[0]] < d_n, i, -1).to(torch.int32)[:, None]
+                coords[i] = torch.cat([bcol, zyx], dim=1)
+        if nb > 1:
+            for i, st in enumerate(self._streams[:nb]):      # join
+                main.wait_stream(st)
+                feats[i].record_stream(main)
+                coords[i].record_stream(main)
         if nb == 1:
             return feats[0], coords[0].contiguous(), d_n
         return torch.cat(feats, dim=0), torch.cat(coords, dim=0).contiguous(), None
@@ -230,14 +245,11 @@ class FramePipeline:
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
         concat = m.backbone2d.run(bev, nb)
         head, h, w = self.head.run_convs(concat, nb)
-        outs, cnts = [], []
-        for boxes, scores, labels, keep, d_nk in self.head.decode_nosync(head, h, w):
-            packed = torch.cat([boxes, scores[:, None], (labels + 1).float()[:, None]], dim=1).contiguous()
-            outs.append(ops.gather_rows(packed, keep, d_nk, self.post_max))
-            cnts.append(d_nk)
+        boxes, scores, labels, keep, d_nk = self.head.decode_batched_nosync(head, h, w)
+        out = ops.pack_detections(boxes, scores, labels, keep, d_nk, self.post_max)
         if single:
-            return outs[0], cnts[0]
-        return torch.stack(outs, dim=0), torch.cat(cnts, dim=0)
+            return out[0], d_nk
+        return out, d_nk
 
 
 def synth_detector(voxel_size, seed=0):

@@ -157,7 +157,10 @@ __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__r
 constexpr int NMS_ROWS_PER_WAVE = 2;     // 500 candidates -> ~1150 independent wavefronts
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, const int *__restrict__ d_n, int n_cap,
                                                  float thr, unsigned long long *__restrict__ mask, int col_blocks) {
-    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    // batch item = blockIdx.z: boxes (B,n_cap,7), d_n (B), mask (B,n_cap,col_blocks)
+    boxes += (size_t)blockIdx.z * n_cap * 7;
+    mask += (size_t)blockIdx.z * n_cap * col_blocks;
+    const int n = d_n ? min(d_n[blockIdx.z], n_cap) : n_cap;
     const int cb = blockIdx.x;
     const int rb = blockIdx.y / (64 / NMS_ROWS_PER_WAVE), part = blockIdx.y % (64 / NMS_ROWS_PER_WAVE);
     const int row0 = rb * 64 + part * NMS_ROWS_PER_WAVE;
@@ -198,7 +201,11 @@ __global__ __launch_bounds__(256) void k_nms_sweep(const unsigned long long *__r
                                                    int n_cap, int col_blocks, int post_max, int *__restrict__ keep,
                                                    int *__restrict__ d_num_keep) {
     extern __shared__ unsigned long long rows[];   // 64 x col_blocks
-    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    // batch item = blockIdx.x: mask (B,n_cap,col_blocks), keep (B,n_cap), d_num_keep (B)
+    mask += (size_t)blockIdx.x * n_cap * col_blocks;
+    keep += (size_t)blockIdx.x * n_cap;
+    d_num_keep += blockIdx.x;
+    const int n = d_n ? min(d_n[blockIdx.x], n_cap) : n_cap;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     unsigned long long remv = 0ull;   // lane l of wave 0 owns column block l
     int nk = 0;
@@ -221,6 +228,23 @@ __global__ __launch_bounds__(256) void k_nms_sweep(const unsigned long long *__r
         __syncthreads();
     }
     if (threadIdx.x == 0) *d_num_keep = nk;
+}
+
+// out[b][j] = [box(7) | score | label+1] of candidate keep[b][j] for j < min(num_keep[b], post_max), zeros after
+// (model_nms_utils.py:22-25 selection + the 1-based labels of center_head.py:356)
+__global__ void k_pack_detections(const float *__restrict__ boxes, const float *__restrict__ scores, const int *__restrict__ labels,
+                                  const int *__restrict__ keep, const int *__restrict__ d_num_keep, int k, int post_max,
+                                  float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= post_max * 9) return;
+    const int j = idx / 9, c = idx % 9;
+    float v = 0.f;
+    if (j < min(d_num_keep[b], post_max) && j < k) {
+        const int src = keep[(size_t)b * k + j];
+        v = c < 7 ? boxes[((size_t)b * k + src) * 7 + c] : (c == 7 ? scores[(size_t)b * k + src] : (float)(labels[(size_t)b * k + src] + 1));
+    }
+    out[((size_t)b * post_max + j) * 9 + c] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -548,20 +572,39 @@ size_t dz_nms_workspace_bytes(int n_cap) {
     return align_up((size_t)(n_cap > 0 ? n_cap : 1) * (cb > 0 ? cb : 1) * sizeof(unsigned long long), 256);
 }
 
-int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, int post_max, int *keep, int *d_num_keep,
-                   void *ws, size_t ws_bytes, void *stream_) {
+int dz_nms_rotated_batched(const float *boxes, const int *d_n, int batch, int n_cap, float thresh, int post_max, int *keep,
+                           int *d_num_keep, void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(keep && d_num_keep && n_cap >= 0 && post_max >= 0, "dz_nms_rotated: bad argument");
-    if (n_cap == 0) return fill_u32(d_num_keep, 0u, 1, stream);
+    DZ_CHECK_ARG(keep && d_num_keep && n_cap >= 0 && post_max >= 0 && batch >= 0, "dz_nms_rotated: bad argument");
+    if (batch == 0) return DZ_OK;
+    if (n_cap == 0) return fill_u32(d_num_keep, 0u, (size_t)batch, stream);
     DZ_CHECK_ARG(boxes && ws, "dz_nms_rotated: null pointer");
     DZ_CHECK_ARG(n_cap <= 4096, "dz_nms_rotated: n_cap %d > 4096 (NMS_PRE_MAXSIZE of the reference configs)", n_cap);
-    if (ws_bytes < dz_nms_workspace_bytes(n_cap)) { set_error("dz_nms_rotated: workspace too small"); return DZ_ERR_WORKSPACE; }
+    DZ_CHECK_ARG(batch <= 65535, "dz_nms_rotated: batch %d > 65535", batch);
+    if (ws_bytes < (size_t)batch * dz_nms_workspace_bytes(n_cap)) { set_error("dz_nms_rotated: workspace too small"); return DZ_ERR_WORKSPACE; }
     const int cb = (n_cap + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
-    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb * (64 / NMS_ROWS_PER_WAVE)), dim3(64), 0, stream, boxes, d_n, n_cap, thresh,
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb * (64 / NMS_ROWS_PER_WAVE), batch), dim3(64), 0, stream, boxes, d_n, n_cap, thresh,
                        mask, cb);
-    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(256), (size_t)64 * cb * sizeof(unsigned long long), stream, mask, d_n,
+    hipLaunchKernelGGL(k_nms_sweep, dim3(batch), dim3(256), (size_t)64 * cb * sizeof(unsigned long long), stream, mask, d_n,
                        n_cap, cb, post_max, keep, d_num_keep);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, int post_max, int *keep, int *d_num_keep,
+                   void *ws, size_t ws_bytes, void *stream_) {
+    return dz_nms_rotated_batched(boxes, d_n, 1, n_cap, thresh, post_max, keep, d_num_keep, ws, ws_bytes, stream_);
+}
+
+int dz_pack_detections(const float *boxes, const float *scores, const int *labels, const int *keep, const int *d_num_keep,
+                       int batch, int k, int post_max, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(batch >= 0 && k >= 0 && post_max >= 0, "dz_pack_detections: bad sizes");
+    if (batch == 0 || post_max == 0) return DZ_OK;
+    DZ_CHECK_ARG(out && d_num_keep && (k == 0 || (boxes && scores && labels && keep)), "dz_pack_detections: null pointer");
+    hipLaunchKernelGGL(k_pack_detections, dim3(ceil_div(post_max * 9, 256), batch), dim3(256), 0, stream, boxes, scores, labels,
+                       keep, d_num_keep, k, post_max, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -296,8 +296,33 @@ class VoxelResBackBone8x(_Cached):
         lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
         rank = lvl1.build_from_coords(voxel_coords, d_n)
         mm = self.math
+        # The whole index pyramid (output sets, bitmaps, neighbour tables of every stage) depends only on the voxel
+        # coordinates, not on features: it is built on a side stream while the convolutions of the earlier stages run
+        # on the main stream (inside a captured graph this becomes a parallel branch; the small index kernels fill the
+        # tails of the conv launches).  Events order each stage's tables before its first use.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        side.wait_stream(main)
+        steps = []          # (down neighbour table or None, same-level table or None, level, ready event)
+        with torch.cuda.stream(side):
+            nbr1 = lvl1.neighbors_to(lvl1, K3, S1, P1)
+            steps.append((None, nbr1, lvl1, side.record_event()))
+            level = lvl1
+            for name in ('conv2', 'conv3', 'conv4', 'conv_out'):
+                dp = p[name]['down'] if name != 'conv_out' else p[name]
+                nxt = level.downsample(dp['k'], dp['s'], dp['p'])
+                nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
+                nbr_s = nxt.neighbors_to(nxt, K3, S1, P1) if name != 'conv_out' else None
+                steps.append((nbr_d, nbr_s, nxt, side.record_event()))
+                level = nxt
+        for nbr_d, nbr_s, lvl, _ in steps:      # tensors born on the side stream are consumed on the main stream
+            for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
+                if t is not None:
+                    t.record_stream(main)
+
         x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=mm)
-        nbr = lvl1.neighbors_to(lvl1, K3, S1, P1)
+        main.wait_event(steps[0][3])
+        nbr = steps[0][1]
         ci = p['conv_input']
         x = ops.spconv_forward(x, nbr, lvl1, self._w(ci), ci['scale'], ci['shift'], None, True, math=mm)
         for bp in p['conv1']:
@@ -306,20 +331,26 @@ class VoxelResBackBone8x(_Cached):
         level = lvl1
         for i, name in enumerate(('conv2', 'conv3', 'conv4')):
             dp = p[name]['down']
-            nxt = level.downsample(dp['k'], dp['s'], dp['p'])
-            nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
+            nbr_d, nbr, nxt, ev = steps[i + 1]
+            main.wait_event(ev)
             x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
-            nbr = nxt.neighbors_to(nxt, K3, S1, P1)
             for bp in p[name]['blocks']:
                 x = self._res_block(x, nbr, nxt, bp)
             out['x_conv%d' % (i + 2)] = (x, nxt)
             level = nxt
         dp = p['conv_out']
-        nxt = level.downsample(dp['k'], dp['s'], dp['p'])
-        nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
+        nbr_d, _, nxt, ev = steps[4]
+        main.wait_event(ev)
         x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
         out['encoded'] = (x, nxt)
         return out
+
+    def _side_stream(self, dev):
+        s = getattr(self, '_side', None)
+        if s is None or s.device != torch.device(dev):
+            s = torch.cuda.Stream(device=dev)
+            object.__setattr__(self, '_side', s)
+        return s
 
     def forward(self, batch_dict):
         _inference_only(self)
@@ -666,24 +697,27 @@ class CenterHead(_Cached):
                    g_cout=p['final']['g_cout'], g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
         return head, h, w
 
-    def decode_nosync(self, head, h, w):
+    def decode_batched_nosync(self, head, h, w):
+        """head (B,H*W,12) -> boxes (B,K,7), scores (B,K), labels (B,K) i32 (0-based), keep (B,K) i32, d_nk (B,) i32:
+        top-K decode and rotated NMS of all frames in one launch sequence, counts stay on the device."""
         post = self.model_cfg.POST_PROCESSING
         nms = post.NMS_CONFIG
         if nms.NMS_TYPE != 'nms_gpu':
             raise DetZeroHipError('CenterHead: NMS_TYPE %s not supported (nms_gpu only)' % nms.NMS_TYPE)
         k = post.MAX_OBJ_PER_SAMPLE
+        # candidates come out in descending score order and K <= NMS_PRE_MAXSIZE, so the reference's
+        # topk(pre_max) + sort (model_nms_utils.py:15-20) is the identity here
+        if k > nms.NMS_PRE_MAXSIZE:
+            raise DetZeroHipError('MAX_OBJ_PER_SAMPLE > NMS_PRE_MAXSIZE is not supported')
         boxes, scores, labels, counts = ops.centerhead_decode(
             head, h, w, len(self.class_names_each_head[0]), k, post.SCORE_THRESH, post.POST_CENTER_LIMIT_RANGE,
             self.point_cloud_range, self.voxel_size, self.feature_map_stride, use_iou=self.iou_weight > 0)
-        outs = []
-        for b in range(head.shape[0]):
-            # candidates are already in descending score order and K <= NMS_PRE_MAXSIZE, so the
-            # reference's topk(pre_max) + sort (model_nms_utils.py:15-20) is the identity here
-            if k > nms.NMS_PRE_MAXSIZE:
-                raise DetZeroHipError('MAX_OBJ_PER_SAMPLE > NMS_PRE_MAXSIZE is not supported')
-            keep, d_nk = ops.nms_rotated_nosync(boxes[b], counts[b:b + 1], nms.NMS_THRESH, nms.NMS_POST_MAXSIZE)
-            outs.append((boxes[b], scores[b], labels[b], keep, d_nk))
-        return outs
+        keep, d_nk = ops.nms_rotated_batched_nosync(boxes, counts, nms.NMS_THRESH, nms.NMS_POST_MAXSIZE)
+        return boxes, scores, labels, keep, d_nk
+
+    def decode_nosync(self, head, h, w):
+        boxes, scores, labels, keep, d_nk = self.decode_batched_nosync(head, h, w)
+        return [(boxes[b], scores[b], labels[b], keep[b], d_nk[b:b + 1]) for b in range(head.shape[0])]
 
     def generate_predicted_boxes(self, head, h, w):
         mapping = self.class_id_mapping_each_head[0].to(head.device)

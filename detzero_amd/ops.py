@@ -417,6 +417,32 @@ def nms_rotated_nosync(boxes_sorted, d_n, thresh, post_max):
     return keep, d_nk
 
 
+def nms_rotated_batched_nosync(boxes_sorted, d_n, thresh, post_max):
+    """boxes_sorted (B,n_cap,7) descending score per item, d_n (B,) -> keep (B,n_cap) i32, d_num_keep (B,) i32."""
+    lib = L.load()
+    L.require_cuda(boxes_sorted, d_n)
+    b, n_cap = boxes_sorted.shape[0], boxes_sorted.shape[1]
+    keep = torch.zeros((b, max(n_cap, 1)), dtype=torch.int32, device=boxes_sorted.device)
+    d_nk = torch.zeros((b,), dtype=torch.int32, device=boxes_sorted.device)
+    ws = _ws(b * lib.dz_nms_workspace_bytes(n_cap))
+    rc = lib.dz_nms_rotated_batched(L.ptr(boxes_sorted), L.ptr(d_n), b, n_cap, float(thresh), int(post_max), L.ptr(keep),
+                                    L.ptr(d_nk), L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_nms_rotated_batched')
+    return keep, d_nk
+
+
+def pack_detections(boxes, scores, labels, keep, d_nk, post_max):
+    """(B,K,7),(B,K),(B,K) i32, keep (B,K) i32, d_nk (B,) -> (B,post_max,9) [box7|score|label+1], zero rows after."""
+    lib = L.load()
+    L.require_cuda(boxes, scores, labels, keep, d_nk)
+    b, k = boxes.shape[0], boxes.shape[1]
+    out = torch.empty((b, post_max, 9), dtype=torch.float32, device=boxes.device)
+    rc = lib.dz_pack_detections(L.ptr(boxes), L.ptr(scores), L.ptr(labels), L.ptr(keep), L.ptr(d_nk), b, k, int(post_max),
+                                L.ptr(out), L.stream())
+    L.check(rc, 'dz_pack_detections')
+    return out
+
+
 def boxes_pairwise(a, b, iou):
     lib = L.load()
     L.require_cuda(a, b)

@@ -204,6 +204,14 @@ int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, i
 size_t dz_nms_workspace_bytes(int n_cap);
 int dz_nms_rotated(const float *boxes, const int *d_n, int n_cap, float thresh, int post_max, int *keep,
                    int *d_num_keep, void *ws, size_t ws_bytes, void *stream);
+/* the same for `batch` frames in one launch pair: boxes (batch,n_cap,7), d_n (batch), keep (batch,n_cap),
+ * d_num_keep (batch); ws >= batch * dz_nms_workspace_bytes(n_cap) */
+int dz_nms_rotated_batched(const float *boxes, const int *d_n, int batch, int n_cap, float thresh, int post_max,
+                           int *keep, int *d_num_keep, void *ws, size_t ws_bytes, void *stream);
+/* final selection of model_nms_utils.py:22-25 / center_head.py:350-360 as one gather:
+ * out (batch, post_max, 9) rows [x,y,z,dx,dy,dz,heading,score,label(1-based)] of the kept candidates, zeros after */
+int dz_pack_detections(const float *boxes, const float *scores, const int *labels, const int *keep,
+                       const int *d_num_keep, int batch, int k, int post_max, float *out, void *stream);
 
 /* iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d_nms.cpp:60-111) : (na,nb) f32 */
 int dz_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out, void *stream);
