@@ -63,6 +63,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=4, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
     ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2'],
                     help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores')
+    ap.add_argument('--overlap', action='store_true',
+                    help='two-stage streaming pipeline (StreamingDetector) instead of one graph per step; measured slower on MI355X')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
@@ -111,50 +113,67 @@ def main():
     # warm-up (also primes the caching allocator and builds the kernel-layout weights)
     use_graph = not args.no_graph
     graph = None
+    streamer = None
     g_out = g_n = None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for i in range(max(W, 3)):
-            load_inputs(i)
-            g_out, g_n = pipe(static_in)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph_note = 'hipGraph replay'
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g_out, g_n = pipe(static_in)
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # capture is an optimisation, not a requirement
-            graph = None
-            graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
-            torch.cuda.synchronize()
+    if args.overlap:
+        from detzero_amd.centerpoint import StreamingDetector
+        streamer = StreamingDetector(pipe, frames[:B], use_graph=use_graph, warmup=max(W, 3))
+        graph_note = streamer.graph_note
     else:
-        graph_note = 'eager launches'
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(max(W, 3)):
+                load_inputs(i)
+                g_out, g_n = pipe(static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph_note = 'hipGraph replay'
+        if use_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    g_out, g_n = pipe(static_in)
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:  # capture is an optimisation, not a requirement
+                graph = None
+                graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
+                torch.cuda.synchronize()
+        else:
+            graph_note = 'eager launches'
+
+    def batch_of(i):
+        return [frames[(i * B + j) % n_distinct] for j in range(B)]
 
     def step(i):
+        """One step = one batch through the whole path.  Streaming mode: stage A of batch i is enqueued together with
+        stage B of batch i-1 (whose results land in slot i-1); exactly one A and one B per call."""
         nonlocal g_out, g_n
+        if streamer is not None:
+            prev = streamer.feed(batch_of(i))
+            if prev is not None:
+                results[(i - 1) % K].copy_(prev[0], non_blocking=True)
+                counts[(i - 1) % K].copy_(prev[1], non_blocking=True)
+            return
         load_inputs(i)
         if graph is not None:
             graph.replay()
         else:
             g_out, g_n = pipe(static_in)
-        results[i].copy_(g_out, non_blocking=True)
-        counts[i].copy_(g_n, non_blocking=True)
+        results[i % K].copy_(g_out, non_blocking=True)
+        counts[i % K].copy_(g_n, non_blocking=True)
 
     log('launch mode:', graph_note)
-    for i in range(W):
-        step(i % K)
+    for i in range(W + 1):            # streaming mode: primes the pipeline (the first feed has no stage B)
+        step(i)
     torch.cuda.synchronize()
     log('warm-up done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
+    for i in range(W + 1, W + 1 + K):
         step(i)
     if world > 1:
         all_b, all_c = fp.gather_frame_boxes(results.view(K * B, post_max, 9), counts.view(K * B))
@@ -183,7 +202,7 @@ def main():
                                    '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
                                    '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'parallelism': 'frame-parallel x%d' % world,
-                       'launch': graph_note, 'math': args.math, 'weights': 'seeded random init (no checkpoints offline)',
+                       'launch': graph_note, 'math': args.math, 'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded random init (no checkpoints offline)',
                        'mean_boxes_per_frame': round(n_boxes, 1)},
         }
 

@@ -189,9 +189,13 @@ class FramePipeline:
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
         self._iota = None
-        self._streams = []
+        self._streams = {}
 
-    def _voxelize(self, frames):
+    def _ensure_iota(self, cap, dev):
+        if self._iota is None or self._iota.shape[0] < cap or self._iota.device != dev:
+            self._iota = torch.arange(cap, dtype=torch.int32, device=dev)
+
+    def _voxelize(self, frames, cid=0):
         """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
         voxel count carry b = -1 and are ignored by the index build (no host sync, capacity-sized)."""
         info = self.info
@@ -206,14 +210,14 @@ class FramePipeline:
         main = torch.cuda.current_stream(dev)
         cap = int(min(info.max_voxels[self.mode], max(max(p.shape[0] for p in frames), 1)))
         if nb > 1:
-            if len(self._streams) < nb:
-                self._streams += [torch.cuda.Stream(device=dev) for _ in range(nb - len(self._streams))]
-            if self._iota is None or self._iota.shape[0] < cap or self._iota.device != dev:
-                self._iota = torch.arange(cap, dtype=torch.int32, device=dev)
-            for st in self._streams[:nb]:          # fork: frames are independent until the batch index is attached,
+            streams = self._streams.setdefault(cid, [])
+            if len(streams) < nb:
+                streams += [torch.cuda.Stream(device=dev) for _ in range(nb - len(streams))]
+            self._ensure_iota(cap, dev)
+            for st in streams[:nb]:                # fork: frames are independent until the batch index is attached,
                 st.wait_stream(main)               # so they are voxelized on parallel streams (parallel branches of a
         for i, p in enumerate(frames):             # captured graph): each is a chain of ~15 launches too small to fill the chip
-            st = self._streams[i] if nb > 1 else main
+            st = streams[i] if nb > 1 else main
             with torch.cuda.stream(st):
                 # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
                 voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(p, rng, info.voxel_size, info.max_points_per_voxel,
@@ -225,7 +229,7 @@ class FramePipeline:
                     bcol = torch.where(self._iota[:zyx.shape[0]] < d_n, i, -1).to(torch.int32)[:, None]
                 coords[i] = torch.cat([bcol, zyx], dim=1)
         if nb > 1:
-            for i, st in enumerate(self._streams[:nb]):      # join
+            for i, st in enumerate(streams[:nb]):            # join
                 main.wait_stream(st)
                 feats[i].record_stream(main)
                 coords[i].record_stream(main)
@@ -234,22 +238,129 @@ class FramePipeline:
         return torch.cat(feats, dim=0), torch.cat(coords, dim=0).contiguous(), None
 
     @torch.no_grad()
-    def __call__(self, points):
-        m = self.model
-        single = torch.is_tensor(points)
-        frames = [points] if single else list(points)
+    def prepare(self, frames, overlap=True):
+        """Stage A: everything that depends only on the points - voxelization, voxel features, the sparse index
+        pyramid of the backbone.  Returns an opaque dict for ``infer``."""
         nb = len(frames)
         feats, coords, d_n = self._voxelize(frames)
-        res = m.backbone3d.run(feats, coords, nb, d_n)
+        pyr = self.model.backbone3d.build_pyramid(feats, coords, nb, d_n, overlap=overlap)
+        pyr['nb'] = nb
+        return pyr
+
+    @torch.no_grad()
+    def infer(self, prep):
+        """Stage B: the 21 sparse convolutions, BEV backbone, head, top-K decode, NMS -> (boxes9 (B,K,9), counts (B,))."""
+        m = self.model
+        nb = prep['nb']
+        res = m.backbone3d.run_pyramid(prep)
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
         concat = m.backbone2d.run(bev, nb)
         head, h, w = self.head.run_convs(concat, nb)
         boxes, scores, labels, keep, d_nk = self.head.decode_batched_nosync(head, h, w)
-        out = ops.pack_detections(boxes, scores, labels, keep, d_nk, self.post_max)
-        if single:
-            return out[0], d_nk
-        return out, d_nk
+        return ops.pack_detections(boxes, scores, labels, keep, d_nk, self.post_max), d_nk
+
+    @torch.no_grad()
+    def __call__(self, points):
+        single = torch.is_tensor(points)
+        out, d_nk = self.infer(self.prepare([points] if single else list(points)))
+        return (out[0], d_nk) if single else (out, d_nk)
+
+
+class StreamingDetector:
+    """Two-stage software pipeline over a stream of equally shaped batches on one GPU.
+
+    Stage A (``FramePipeline.prepare``: input copy, voxelization, index pyramid - dozens of small launches that
+    cannot fill 256 CUs) of batch i+1 runs on its own stream WHILE stage B (``infer``: the convolutions, head, NMS)
+    of batch i runs; each stage is a captured hipGraph with static buffers, double buffered so that the two
+    batches in flight never share memory.  ``feed(frames)`` enqueues A(frames) and B(previous batch) and returns
+    the previous batch's (boxes9 (B,K,9), counts (B,)) - device tensors that stay valid until the call after
+    next - or None on the first call; ``flush()`` returns the last batch's.  Nothing here synchronises the host.
+    """
+
+    def __init__(self, pipe, example_frames, use_graph=True, warmup=3):
+        self.pipe = pipe
+        dev = example_frames[0].device
+        self.dev = dev
+        # stage A is a long chain of small launches: give its queue priority, otherwise its workgroups only get CU
+        # slots at the pace the convolution kernels of stage B retire theirs and the chain never catches up
+        self.s_a = torch.cuda.Stream(device=dev, priority=-1)
+        self.s_b = torch.cuda.Stream(device=dev)
+        self.slots = []
+        self.graph_note = 'hipGraph replay (stage A / stage B graphs, double buffered)' if use_graph else 'eager launches (two streams)'
+        cur = torch.cuda.current_stream(dev)
+        for k in range(2):
+            slot = {'in': [f.clone() for f in example_frames], 'ga': None, 'gb': None, 'prep': None, 'out': None,
+                    'a_done': torch.cuda.Event(), 'b_done': torch.cuda.Event()}
+            self.s_a.wait_stream(cur)
+            with torch.cuda.stream(self.s_a):
+                for _ in range(max(1, warmup)):          # primes allocator pools and kernel-layout weights
+                    prep = pipe.prepare(slot['in'], overlap=False)
+                    out = pipe.infer(prep)
+            cur.wait_stream(self.s_a)
+            torch.cuda.synchronize(dev)
+            if use_graph:
+                try:
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga):
+                        prep = pipe.prepare(slot['in'], overlap=False)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        out = pipe.infer(prep)
+                    ga.replay(); gb.replay()
+                    torch.cuda.synchronize(dev)
+                    slot['ga'], slot['gb'] = ga, gb
+                except Exception as e:  # capture is an optimisation, not a requirement
+                    self.graph_note = 'eager launches, two streams (graph capture failed: %s)' % str(e).split('\n')[0][:100]
+                    slot['ga'] = slot['gb'] = None
+                    torch.cuda.synchronize(dev)
+            slot['prep'], slot['out'] = prep, out
+            self.slots.append(slot)
+        self.n_fed = 0
+
+    def _stage_a(self, k, frames):
+        slot = self.slots[k]
+        with torch.cuda.stream(self.s_a):
+            self.s_a.wait_event(slot['b_done'])            # the previous user of this slot has consumed its buffers
+            for dst, src in zip(slot['in'], frames):
+                dst.copy_(src, non_blocking=True)
+            if slot['ga'] is not None:
+                slot['ga'].replay()
+            else:
+                self.s_b.synchronize()                     # eager fallback only: the old buffers of this slot go back to the allocator
+                slot['prep'] = self.pipe.prepare(slot['in'], overlap=False)
+            slot['a_done'].record(self.s_a)
+
+    def _stage_b(self, k):
+        slot = self.slots[k]
+        with torch.cuda.stream(self.s_b):
+            self.s_b.wait_event(slot['a_done'])
+            if slot['gb'] is not None:
+                slot['gb'].replay()
+            else:
+                slot['out'] = self.pipe.infer(slot['prep'])
+            slot['b_done'].record(self.s_b)
+        return slot['out']
+
+    def feed(self, frames):
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_a.wait_stream(cur)                          # the caller's frames are ready
+        self.s_b.wait_stream(cur)                          # ... and it has finished reading the results handed out before
+        k = self.n_fed & 1
+        prev = self._stage_b(k ^ 1) if self.n_fed > 0 else None
+        self._stage_a(k, frames)
+        self.n_fed += 1
+        if prev is not None:
+            cur.wait_stream(self.s_b)                      # results are consumed on the caller's stream
+        return prev
+
+    def flush(self):
+        if self.n_fed == 0:
+            return None
+        cur = torch.cuda.current_stream(self.dev)
+        out = self._stage_b((self.n_fed - 1) & 1)
+        cur.wait_stream(self.s_b)
+        return out
 
 
 def synth_detector(voxel_size, seed=0):

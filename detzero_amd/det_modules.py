@@ -288,41 +288,56 @@ class VoxelResBackBone8x(_Cached):
         y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
         return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
-    def run(self, voxel_features, voxel_coords, batch_size, d_n=None):
-        """Capacity-sized execution without host syncs.  Returns dict of (features, SparseLevel)."""
+    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0):
+        """Everything of the backbone that depends only on voxel COORDINATES: the level-1 index + feature scatter and
+        the output sets / bitmaps / neighbour tables of every stage.  Returns {'x': level-1 rows, 'steps': [...]}.
+
+        overlap=True builds the tables of the deeper stages on a side stream (inside a captured graph: a parallel
+        branch) so that they run under the convolutions of the earlier stages; events order each stage's tables
+        before their first use.  overlap=False keeps everything on the current stream (used when the whole
+        preparation stage is itself overlapped with the previous batch, see StreamingDetector)."""
         p = self.plan()
         n = voxel_features.shape[0]
         dev = voxel_features.device
         lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
         rank = lvl1.build_from_coords(voxel_coords, d_n)
-        mm = self.math
-        # The whole index pyramid (output sets, bitmaps, neighbour tables of every stage) depends only on the voxel
-        # coordinates, not on features: it is built on a side stream while the convolutions of the earlier stages run
-        # on the main stream (inside a captured graph this becomes a parallel branch; the small index kernels fill the
-        # tails of the conv launches).  Events order each stage's tables before its first use.
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev)
-        side.wait_stream(main)
-        steps = []          # (down neighbour table or None, same-level table or None, level, ready event)
+        side = self._side_stream(dev, side_key) if overlap else main
+        if overlap:
+            side.wait_stream(main)
+        steps = []          # (down neighbour table or None, same-level table or None, level, ready event or None)
         with torch.cuda.stream(side):
             nbr1 = lvl1.neighbors_to(lvl1, K3, S1, P1)
-            steps.append((None, nbr1, lvl1, side.record_event()))
+            steps.append((None, nbr1, lvl1, side.record_event() if overlap else None))
             level = lvl1
             for name in ('conv2', 'conv3', 'conv4', 'conv_out'):
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
                 nxt = level.downsample(dp['k'], dp['s'], dp['p'])
                 nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
                 nbr_s = nxt.neighbors_to(nxt, K3, S1, P1) if name != 'conv_out' else None
-                steps.append((nbr_d, nbr_s, nxt, side.record_event()))
+                steps.append((nbr_d, nbr_s, nxt, side.record_event() if overlap else None))
                 level = nxt
-        for nbr_d, nbr_s, lvl, _ in steps:      # tensors born on the side stream are consumed on the main stream
-            for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
-                if t is not None:
-                    t.record_stream(main)
+        if overlap:
+            for nbr_d, nbr_s, lvl, _ in steps:      # tensors born on the side stream are consumed on the main stream
+                for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
+                    if t is not None:
+                        t.record_stream(main)
+        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
+        return {'x': x, 'steps': steps}
 
-        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=mm)
-        main.wait_event(steps[0][3])
-        nbr = steps[0][1]
+    def run_pyramid(self, pyr):
+        """The 21 sparse convolutions over a prepared pyramid.  Returns dict of (features, SparseLevel)."""
+        p = self.plan()
+        mm = self.math
+        steps = pyr['steps']
+        x = pyr['x']
+        main = torch.cuda.current_stream(x.device)
+
+        def ready(ev):
+            if ev is not None:
+                main.wait_event(ev)
+        _, nbr, lvl1, ev = steps[0]
+        ready(ev)
         ci = p['conv_input']
         x = ops.spconv_forward(x, nbr, lvl1, self._w(ci), ci['scale'], ci['shift'], None, True, math=mm)
         for bp in p['conv1']:
@@ -332,7 +347,7 @@ class VoxelResBackBone8x(_Cached):
         for i, name in enumerate(('conv2', 'conv3', 'conv4')):
             dp = p[name]['down']
             nbr_d, nbr, nxt, ev = steps[i + 1]
-            main.wait_event(ev)
+            ready(ev)
             x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
             for bp in p[name]['blocks']:
                 x = self._res_block(x, nbr, nxt, bp)
@@ -340,17 +355,21 @@ class VoxelResBackBone8x(_Cached):
             level = nxt
         dp = p['conv_out']
         nbr_d, _, nxt, ev = steps[4]
-        main.wait_event(ev)
+        ready(ev)
         x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
         out['encoded'] = (x, nxt)
         return out
 
-    def _side_stream(self, dev):
-        s = getattr(self, '_side', None)
-        if s is None or s.device != torch.device(dev):
-            s = torch.cuda.Stream(device=dev)
-            object.__setattr__(self, '_side', s)
-        return s
+    def run(self, voxel_features, voxel_coords, batch_size, d_n=None, side_key=0):
+        """Capacity-sized execution without host syncs.  Returns dict of (features, SparseLevel)."""
+        return self.run_pyramid(self.build_pyramid(voxel_features, voxel_coords, batch_size, d_n, True, side_key))
+
+    def _side_stream(self, dev, key=0):
+        pool = self.__dict__.setdefault('_side_streams', {})
+        k = (str(dev), key)
+        if k not in pool:
+            pool[k] = torch.cuda.Stream(device=dev)
+        return pool[k]
 
     def forward(self, batch_dict):
         _inference_only(self)

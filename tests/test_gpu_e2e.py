@@ -226,3 +226,32 @@ def test_batch_of_two_frames_matches_single_frames(small, device):
     annos = generate_prediction_dicts(batch, pred, info.class_names)
     assert len(annos) == 2 and annos[0]['boxes_lidar'].shape[1] == 7 and annos[1]['frame_id'] == 1
     assert set(annos[0]['name'].tolist()) <= set(info.class_names)
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_streaming_detector_equals_plain_pipeline(device, use_graph):
+    """Two-stage streaming executor (stage A of batch i+1 under stage B of batch i, double-buffered graphs):
+    every batch comes out bit-identical to the plain one-shot pipeline, in order."""
+    from detzero_amd.centerpoint import FramePipeline, StreamingDetector
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=2)
+    model = model.to(device)
+    pipe = FramePipeline(model, info)
+    n = 12000
+    batches = [[torch.from_numpy(masked_frame(10 * b + j, 20000)[:n].copy()).to(device) for j in range(2)] for b in range(5)]
+    ref = [pipe(b) for b in batches]
+    torch.cuda.synchronize()
+    sd = StreamingDetector(pipe, batches[0], use_graph=use_graph)
+    got = []
+    for b in batches:
+        r = sd.feed(b)
+        if r is not None:
+            got.append((r[0].clone(), r[1].clone()))
+    r = sd.flush()
+    got.append((r[0].clone(), r[1].clone()))
+    torch.cuda.synchronize()
+    assert len(got) == len(ref)
+    for (o, c), (ro, rc) in zip(got, ref):
+        assert torch.equal(c, rc)
+        for i in range(2):
+            k = int(rc[i].item())
+            assert k > 0 and torch.equal(o[i, :k], ro[i, :k])
