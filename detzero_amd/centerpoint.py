@@ -188,12 +188,7 @@ class FramePipeline:
         post = self.head.model_cfg.POST_PROCESSING
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
-        self._iota = None
         self._streams = {}
-
-    def _ensure_iota(self, cap, dev):
-        if self._iota is None or self._iota.shape[0] < cap or self._iota.device != dev:
-            self._iota = torch.arange(cap, dtype=torch.int32, device=dev)
 
     def _voxelize(self, frames, cid=0):
         """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
@@ -204,38 +199,31 @@ class FramePipeline:
         if self.dynamic:
             pb = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p], dim=1) for i, p in enumerate(frames)], dim=0)
             return ops.voxelize_dynamic_nosync(pb.contiguous(), rng, info.voxel_size, nb, xy_range_mask=True)
-        feats, coords = [None] * nb, [None] * nb
-        d_n = None
         dev = frames[0].device
         main = torch.cuda.current_stream(dev)
         cap = int(min(info.max_voxels[self.mode], max(max(p.shape[0] for p in frames), 1)))
+        c = frames[0].shape[1]
+        feats = torch.empty((nb * cap, c), dtype=torch.float32, device=dev)
+        coords = torch.full((nb * cap, 4), -1, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros((nb,), dtype=torch.int32, device=dev)
+        streams = [main]
         if nb > 1:
             streams = self._streams.setdefault(cid, [])
             if len(streams) < nb:
                 streams += [torch.cuda.Stream(device=dev) for _ in range(nb - len(streams))]
-            self._ensure_iota(cap, dev)
-            for st in streams[:nb]:                # fork: frames are independent until the batch index is attached,
-                st.wait_stream(main)               # so they are voxelized on parallel streams (parallel branches of a
-        for i, p in enumerate(frames):             # captured graph): each is a chain of ~15 launches too small to fill the chip
-            st = streams[i] if nb > 1 else main
-            with torch.cuda.stream(st):
-                # the xy range mask of data_processor.py:24-37 is applied inside the voxelizer kernel
-                voxels, zyx, nump, d_n = ops.voxelize_hard_nosync(p, rng, info.voxel_size, info.max_points_per_voxel,
-                                                                  info.max_voxels[self.mode], xy_range_mask=True)
-                feats[i] = ops.mean_vfe(voxels, nump, d_m=d_n)
-                if nb == 1:
-                    bcol = zyx.new_zeros((zyx.shape[0], 1))
-                else:
-                    bcol = torch.where(self._iota[:zyx.shape[0]] < d_n, i, -1).to(torch.int32)[:, None]
-                coords[i] = torch.cat([bcol, zyx], dim=1)
+            for st in streams[:nb]:                # fork: frames are independent, so they are voxelized on parallel
+                st.wait_stream(main)               # streams (parallel branches of a captured graph) - each is a chain
+        for i, p in enumerate(frames):             # of ~17 launches too small to fill the chip on its own
+            with torch.cuda.stream(streams[i]):
+                # fused voxelizer + MeanVFE writing row block i of the batch buffers; the xy range mask of
+                # data_processor.py:24-37 is applied inside the kernel
+                ops.voxelize_hard_mean_into(p, rng, info.voxel_size, info.max_points_per_voxel, info.max_voxels[self.mode], i,
+                                            feats[i * cap:(i + 1) * cap], coords[i * cap:(i + 1) * cap], d_ns[i:i + 1],
+                                            xy_range_mask=True)
         if nb > 1:
-            for i, st in enumerate(streams[:nb]):            # join
+            for st in streams[:nb]:                # join
                 main.wait_stream(st)
-                feats[i].record_stream(main)
-                coords[i].record_stream(main)
-        if nb == 1:
-            return feats[0], coords[0].contiguous(), d_n
-        return torch.cat(feats, dim=0), torch.cat(coords, dim=0).contiguous(), None
+        return feats, coords, None
 
     @torch.no_grad()
     def prepare(self, frames, overlap=True):

@@ -96,8 +96,6 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *ld
 //   mode 1: key = ((b*GX+x)*GY+y)*GZ+z -> coords [b,z,y,x] (dims = GX,GY,GZ)   (DynamicMeanVFE order)
 //   mode -1: no coordinates
 struct ScanDims { int d0, d1, d2; };
-constexpr int SCAN_WORDS_PER_THREAD = 8;
-constexpr int SCAN_CHUNK = 256 * SCAN_WORDS_PER_THREAD;
 // device fill (32-bit pattern) as a plain kernel: no memset nodes, so whole frames capture into a hipGraph
 // as kernels only
 int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream);

@@ -44,36 +44,40 @@ int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------
 // bitmap scan
 // ------------------------------------------------------------------------------------------
+// WPT = bitmap words per thread (a workgroup covers 256 * WPT words).  Large, mostly empty bitmaps use WPT = 4
+// (fewer partial sums); small / dense ones WPT = 1: the coordinate emission walks the set bits of a thread's words
+// serially, so a dense level needs many threads rather than long per-thread chains.
+template <int WPT>
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *__restrict__ bitmap, size_t nwords,
                                                      uint32_t *__restrict__ partial) {
     __shared__ uint32_t lds[4];
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_WORDS_PER_THREAD;
+    const size_t base = (size_t)blockIdx.x * (256 * WPT) + (size_t)threadIdx.x * WPT;
     uint32_t s = 0;
-    if (base + SCAN_WORDS_PER_THREAD <= nwords) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(bitmap + base);
-        const uint4 b = *reinterpret_cast<const uint4 *>(bitmap + base + 4);
-        s = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) +
-            __popc(b.z) + __popc(b.w);
-    } else {
-        for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j)
-            if (base + j < nwords) s += __popc(bitmap[base + j]);
-    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j)
+        if (base + j < nwords) s += __popc(bitmap[base + j]);
     uint32_t total;
     block_excl_scan_256(s, lds, total);
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of `partial` in place, total -> d_total
+// single block: exclusive scan of `partial` in place (8 entries per thread per trip), total -> d_total
 __global__ __launch_bounds__(256) void k_scan_partials(uint32_t *__restrict__ partial, int nblocks,
                                                        int *__restrict__ d_total) {
     __shared__ uint32_t lds[4];
     uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? partial[i] : 0u;
+    for (int base = 0; base < nblocks; base += 2048) {
+        const int i0 = base + threadIdx.x * 8;
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < nblocks) ? partial[i0 + j] : 0u; s += v[j]; }
         uint32_t total;
-        const uint32_t ex = block_excl_scan_256(v, lds, total);
-        if (i < nblocks) partial[i] = carry + ex;
+        uint32_t run = carry + block_excl_scan_256(s, lds, total);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i0 + j < nblocks) partial[i0 + j] = run;
+            run += v[j];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) *d_total = (int)carry;
@@ -91,57 +95,44 @@ __device__ __forceinline__ uint32_t fast_divmod(uint32_t n, const FastDiv f, uin
 }
 struct ScanDecode { FastDiv d0, d1, d2; };
 
-template <int MODE>
+template <int MODE, int WPT>
 __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ bitmap, size_t nwords,
                                                    const uint32_t *__restrict__ partial,
                                                    uint32_t *__restrict__ prefix, ScanDecode dec,
                                                    int *__restrict__ coords_out, int cap_out) {
+    constexpr int CHUNK = 256 * WPT;
     __shared__ uint32_t lds[4];
-    __shared__ __attribute__((aligned(16))) uint32_t w_s[SCAN_CHUNK];
-    __shared__ __attribute__((aligned(16))) uint32_t p_s[SCAN_CHUNK];
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_WORDS_PER_THREAD;
-    uint32_t wv[SCAN_WORDS_PER_THREAD];
-    const bool full = base + SCAN_WORDS_PER_THREAD <= nwords;      // nwords is a multiple of 8: all or nothing
-    if (full) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(bitmap + base);
-        const uint4 b = *reinterpret_cast<const uint4 *>(bitmap + base + 4);
-        wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w; wv[4] = b.x; wv[5] = b.y; wv[6] = b.z; wv[7] = b.w;
-    } else {
+    __shared__ __attribute__((aligned(16))) uint32_t w_s[CHUNK];
+    __shared__ __attribute__((aligned(16))) uint32_t p_s[CHUNK];
+    const size_t base = (size_t)blockIdx.x * CHUNK + (size_t)threadIdx.x * WPT;
+    uint32_t wv[WPT];
 #pragma unroll
-        for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) wv[j] = (base + j < nwords) ? bitmap[base + j] : 0u;
-    }
+    for (int j = 0; j < WPT; ++j) wv[j] = (base + j < nwords) ? bitmap[base + j] : 0u;
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) s += __popc(wv[j]);
+    for (int j = 0; j < WPT; ++j) s += __popc(wv[j]);
     uint32_t total;
     uint32_t run = block_excl_scan_256(s, lds, total) + partial[blockIdx.x];
-    uint32_t pv[SCAN_WORDS_PER_THREAD];
+    uint32_t pv[WPT];
 #pragma unroll
-    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) { pv[j] = run; run += __popc(wv[j]); }
-    if (full) {
-        *reinterpret_cast<uint4 *>(prefix + base) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-        *reinterpret_cast<uint4 *>(prefix + base + 4) = make_uint4(pv[4], pv[5], pv[6], pv[7]);
-    } else {
+    for (int j = 0; j < WPT; ++j) { pv[j] = run; run += __popc(wv[j]); }
 #pragma unroll
-        for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) if (base + j < nwords) prefix[base + j] = pv[j];
-    }
+    for (int j = 0; j < WPT; ++j)
+        if (base + j < nwords) prefix[base + j] = pv[j];
     if (MODE < 0 || total == 0) return;
     // coordinate emission: words are re-distributed round-robin over the threads (dense clusters of
-    // set bits are consecutive words; 8 consecutive words per thread serialised them on one lane)
-    uint32_t *wl = w_s + threadIdx.x * SCAN_WORDS_PER_THREAD, *pl = p_s + threadIdx.x * SCAN_WORDS_PER_THREAD;
-    *reinterpret_cast<uint4 *>(wl) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-    *reinterpret_cast<uint4 *>(wl + 4) = make_uint4(wv[4], wv[5], wv[6], wv[7]);
-    *reinterpret_cast<uint4 *>(pl) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-    *reinterpret_cast<uint4 *>(pl + 4) = make_uint4(pv[4], pv[5], pv[6], pv[7]);
+    // set bits are consecutive words; consecutive words per thread serialised them on one lane)
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) { w_s[threadIdx.x * WPT + j] = wv[j]; p_s[threadIdx.x * WPT + j] = pv[j]; }
     __syncthreads();
 #pragma unroll 1
-    for (int j = 0; j < SCAN_WORDS_PER_THREAD; ++j) {
+    for (int j = 0; j < WPT; ++j) {
         const int idx = threadIdx.x + 256 * j;
         uint32_t word = w_s[idx];
         if (!word) continue;
         uint32_t r = p_s[idx];
         // decode the word's first cell once (3 divisions), then walk the bits with carries only
-        const uint32_t key0 = (uint32_t)(((size_t)blockIdx.x * SCAN_CHUNK + idx) << 5);
+        const uint32_t key0 = (uint32_t)(((size_t)blockIdx.x * CHUNK + idx) << 5);
         uint32_t c2, c1, c0;
         const uint32_t t1 = fast_divmod(key0, dec.d2, c2);
         const uint32_t t0 = fast_divmod(t1, dec.d1, c1);
@@ -168,8 +159,25 @@ __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ 
 }
 
 size_t bitmap_scan_workspace_bytes(size_t nwords) {
-    const size_t nblocks = (nwords + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const size_t nblocks = (nwords + 255) / 256;          // the finest chunking (WPT = 1)
     return align_up(nblocks * sizeof(uint32_t), 256);
+}
+
+template <int WPT>
+static void launch_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode, const ScanDecode &dec,
+                        int *coords_out, int cap_out, uint32_t *partial, hipStream_t stream) {
+    const int nblocks = (int)((nwords + 256 * WPT - 1) / (256 * WPT));
+    hipLaunchKernelGGL(k_scan_reduce<WPT>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_scan_down<0, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_scan_down<1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
+    else
+        hipLaunchKernelGGL((k_scan_down<-1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
 }
 
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
@@ -179,23 +187,15 @@ int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_
         set_error("bitmap_scan: workspace %zu < %zu", ws_bytes, bitmap_scan_workspace_bytes(nwords));
         return DZ_ERR_WORKSPACE;
     }
-    const int nblocks = (int)((nwords + SCAN_CHUNK - 1) / SCAN_CHUNK);
     uint32_t *partial = reinterpret_cast<uint32_t *>(ws);
     ScanDecode dec;
     dec.d0 = FastDiv{(uint32_t)(dims.d0 > 0 ? dims.d0 : 1), 1.0 / (double)(dims.d0 > 0 ? dims.d0 : 1)};
     dec.d1 = FastDiv{(uint32_t)(dims.d1 > 0 ? dims.d1 : 1), 1.0 / (double)(dims.d1 > 0 ? dims.d1 : 1)};
     dec.d2 = FastDiv{(uint32_t)(dims.d2 > 0 ? dims.d2 : 1), 1.0 / (double)(dims.d2 > 0 ? dims.d2 : 1)};
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_scan_down<0>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dec, coords_out, cap_out);
-    else if (mode == 1)
-        hipLaunchKernelGGL(k_scan_down<1>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dec, coords_out, cap_out);
+    if (nwords <= ((size_t)1 << 21))
+        launch_scan<1>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream);
     else
-        hipLaunchKernelGGL(k_scan_down<-1>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial,
-                           prefix, dec, coords_out, cap_out);
+        launch_scan<4>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -240,34 +240,44 @@ struct ConvGeom {
 };
 
 // every active input marks the outputs whose window contains it
+// per dimension: the (at most KMAX) output coordinates fed by input coordinate c: w = (c + p - t) / s for the taps
+// t congruent to (c + p) mod s
+__device__ __forceinline__ int outs_of(int c, int k, int s, int p, int od, int (&w)[3]) {
+    int n = 0;
+    const int cp = c + p;
+    for (int t = cp % s; t < k && t <= cp; t += s) {
+        const int o = (cp - t) / s;
+        if (o < od && n < 3) w[n++] = o;
+    }
+    return n;
+}
+
 __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__restrict__ d_m_in, int cap_in,
                                ConvGeom g, uint32_t *__restrict__ bitmap_out) {
     const int m = min(*d_m_in, cap_in);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
-        for (int tz = 0; tz < g.k[0]; ++tz) {
-            const int nz = c.y + g.p[0] - tz;
-            if (nz < 0 || nz % g.s[0]) continue;
-            const int wz = nz / g.s[0];
-            if (wz >= g.od) continue;
-            for (int ty = 0; ty < g.k[1]; ++ty) {
-                const int ny = c.z + g.p[1] - ty;
-                if (ny < 0 || ny % g.s[1]) continue;
-                const int wy = ny / g.s[1];
-                if (wy >= g.oh) continue;
-                for (int tx = 0; tx < g.k[2]; ++tx) {
-                    const int nx = c.w + g.p[2] - tx;
-                    if (nx < 0 || nx % g.s[2]) continue;
-                    const int wx = nx / g.s[2];
-                    if (wx >= g.ow) continue;
-                    const uint32_t key = (uint32_t)(((c.x * g.od + wz) * g.oh + wy) * g.ow + wx);
-                    // ~8 inputs feed every output: test before the atomic (a stale read only costs a
-                    // redundant atomicOr)
-                    const uint32_t bit = 1u << (key & 31u);
-                    if (!(__builtin_nontemporal_load(&bitmap_out[key >> 5]) & bit)) atomicOr(&bitmap_out[key >> 5], bit);
+        int wz[3], wy[3], wx[3];
+        const int nz = outs_of(c.y, g.k[0], g.s[0], g.p[0], g.od, wz);
+        const int ny = outs_of(c.z, g.k[1], g.s[1], g.p[1], g.oh, wy);
+        const int nx = outs_of(c.w, g.k[2], g.s[2], g.p[2], g.ow, wx);
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < ny; ++b) {
+                const uint32_t rowkey = (uint32_t)(((c.x * g.od + wz[a]) * g.oh + wy[b]) * g.ow);
+                // the x candidates of one row are adjacent cells: usually one bitmap word
+                uint32_t word_idx = 0xFFFFFFFFu, bits = 0u;
+                for (int e = 0; e < nx; ++e) {
+                    const uint32_t key = rowkey + (uint32_t)wx[e];
+                    if ((key >> 5) != word_idx) {
+                        // ~8 inputs feed every output: test before the atomic (a stale read only costs a redundant atomicOr)
+                        if (bits && (__builtin_nontemporal_load(&bitmap_out[word_idx]) & bits) != bits) atomicOr(&bitmap_out[word_idx], bits);
+                        word_idx = key >> 5;
+                        bits = 0u;
+                    }
+                    bits |= 1u << (key & 31u);
                 }
+                if (bits && (__builtin_nontemporal_load(&bitmap_out[word_idx]) & bits) != bits) atomicOr(&bitmap_out[word_idx], bits);
             }
-        }
     }
 }
 

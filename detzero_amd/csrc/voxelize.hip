@@ -110,6 +110,39 @@ __global__ void k_hard_emit(const float *__restrict__ pts, int c, const int *__r
     }
 }
 
+// Fused emit + MeanVFE (vfe.py:58-83 on the voxels of data_processor.py:47-95) for the batched frame pipeline:
+// one thread per (voxel, channel) writes the mean of the voxel's (<= max_points) first points straight into the
+// voxel's first-appearance row of a batch buffer, and [batch_index, z, y, x] into the coordinate buffer; the
+// (max_voxels, max_points, C) tensor of the reference never exists.  Same summation order as k_mean_vfe.
+__global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int *__restrict__ mins, int cap,
+                                 int max_points, int max_voxels, const int *__restrict__ d_m,
+                                 const int *__restrict__ canon_coords, const uint32_t *__restrict__ pt_bitmap,
+                                 const uint32_t *__restrict__ pt_prefix, int batch_index, float *__restrict__ feats,
+                                 int c_stride, int *__restrict__ coords_bzyx, int *__restrict__ d_num_voxels) {
+    const int m = min(*d_m, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_num_voxels = min(m, max_voxels);
+    const long total = (long)m * c_stride;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx / c_stride), ch = (int)(idx % c_stride);
+        const int row = bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)mins[v]);
+        if (row >= max_voxels) continue;
+        float sum = 0.f;
+        int cnt = 0;
+        for (int q = 0; q < max_points; ++q) {
+            const int pi = mins[(size_t)q * cap + v];
+            if (pi != 0x7f7f7f7f) {
+                ++cnt;
+                if (ch < c) sum = __fadd_rn(sum, pts[(size_t)pi * c + ch]);
+            }
+        }
+        feats[(size_t)row * c_stride + ch] = ch < c ? __fdiv_rn(sum, fmaxf((float)cnt, 1.0f)) : 0.f;
+        if (ch == 0) {
+            const int4 cc = reinterpret_cast<const int4 *>(canon_coords)[v];  // [b,z,y,x]
+            reinterpret_cast<int4 *>(coords_bzyx)[row] = make_int4(batch_index, cc.y, cc.z, cc.w);
+        }
+    }
+}
+
 // ---- MeanVFE ---------------------------------------------------------------------------------
 __global__ void k_mean_vfe(const float *__restrict__ voxels, const int *__restrict__ num_points,
                            const int *__restrict__ d_m, int cap, int max_points, int c, float *__restrict__ out,
@@ -221,12 +254,11 @@ size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_p
     return carve_hard(nullptr, n, dz_index_words(1, gz, gy, gx), max_points).total;
 }
 
-int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
-                     const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels, int *coords_zyx,
-                     int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1, "dz_voxelize_hard: bad sizes");
-    DZ_CHECK_ARG(voxels && coords_zyx && num_points && d_num_voxels && ws, "dz_voxelize_hard: null pointer");
+// shared driver of the two emit flavours: feats != nullptr selects the fused emit + mean
+static int voxelize_hard_impl(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
+                              const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels,
+                              int *coords_zyx, int *num_points, int batch_index, float *feats, int c_stride, int *coords_bzyx,
+                              int *d_num_voxels, void *ws, size_t ws_bytes, hipStream_t stream) {
     VoxGeom g;
     DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_hard: bad geometry");
     const size_t cells = (size_t)g.g[0] * g.g[1] * g.g[2];
@@ -257,11 +289,34 @@ int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, c
     rc = bitmap_scan(w.pt_bitmap, pt_words, w.pt_prefix, d_num_voxels, -1, ScanDims{1, 1, 1}, nullptr, 0, w.scan_ws,
                      w.scan_ws_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hard_emit, dim3(stream_grid((long)cap * max_points, 256)), dim3(256), 0, stream, points, c,
-                       w.mins, cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, voxels,
-                       coords_zyx, num_points, d_num_voxels);
+    if (feats)
+        hipLaunchKernelGGL(k_hard_emit_mean, dim3(stream_grid((long)cap * c_stride, 256)), dim3(256), 0, stream, points, c, w.mins,
+                           cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, batch_index, feats,
+                           c_stride, coords_bzyx, d_num_voxels);
+    else
+        hipLaunchKernelGGL(k_hard_emit, dim3(stream_grid((long)cap * max_points, 256)), dim3(256), 0, stream, points, c,
+                           w.mins, cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, voxels,
+                           coords_zyx, num_points, d_num_voxels);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
+}
+
+int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
+                     const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels, int *coords_zyx,
+                     int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes, void *stream_) {
+    DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1, "dz_voxelize_hard: bad sizes");
+    DZ_CHECK_ARG(voxels && coords_zyx && num_points && d_num_voxels && ws, "dz_voxelize_hard: null pointer");
+    return voxelize_hard_impl(points, n, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels, voxels, coords_zyx,
+                              num_points, 0, nullptr, 0, nullptr, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
+                          const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int batch_index, float *feats,
+                          int c_stride, int *coords_bzyx, int *d_num_voxels, void *ws, size_t ws_bytes, void *stream_) {
+    DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1 && c_stride >= c, "dz_voxelize_hard_mean: bad sizes");
+    DZ_CHECK_ARG(feats && coords_bzyx && d_num_voxels && ws, "dz_voxelize_hard_mean: null pointer");
+    return voxelize_hard_impl(points, n, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels, nullptr, nullptr,
+                              nullptr, batch_index, feats, c_stride, coords_bzyx, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int cap, int max_points, int c, float *out,

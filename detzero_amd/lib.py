@@ -48,6 +48,8 @@ _SIGS = {
     'dz_voxelize_hard_workspace_bytes': (c_size_t, [c_int] * 5),
     'dz_voxelize_hard': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dz_voxelize_hard_mean': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dz_mean_vfe': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_voxelize_dynamic_workspace_bytes': (c_size_t, [c_int] * 7),
     'dz_voxelize_dynamic_mean': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -52,6 +52,22 @@ def voxelize_hard_nosync(points, pc_range, voxel_size, max_points, max_voxels, x
     return voxels, coords, nump, d_num
 
 
+def voxelize_hard_mean_into(points, pc_range, voxel_size, max_points, max_voxels, batch_index, feats, coords, d_num,
+                            xy_range_mask=False):
+    """Fused hard voxelizer + MeanVFE writing into caller-owned slices: feats (cap, C') f32, coords (cap,4) i32
+    [b,z,y,x] (pre-filled with -1 by the caller), d_num (1,) i32.  cap = feats.shape[0]."""
+    lib = L.load()
+    L.require_cuda(points, feats, coords, d_num)
+    n, c = points.shape
+    grid = grid_size_of(pc_range, voxel_size)
+    cap = feats.shape[0]
+    ws = _ws(lib.dz_voxelize_hard_workspace_bytes(n, int(grid[0]), int(grid[1]), int(grid[2]), max_points))
+    rc = lib.dz_voxelize_hard_mean(L.ptr(points), n, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid), 1 if xy_range_mask else 0,
+                                   max_points, int(min(max_voxels, cap)), int(batch_index), L.ptr(feats), feats.shape[1],
+                                   L.ptr(coords), L.ptr(d_num), L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_voxelize_hard_mean')
+
+
 def voxelize_hard(points, pc_range, voxel_size, max_points, max_voxels):
     voxels, coords, nump, d_num = voxelize_hard_nosync(points, pc_range, voxel_size, max_points, max_voxels)
     m = int(d_num.item())

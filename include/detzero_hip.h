@@ -53,6 +53,14 @@ int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, c
                      const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels,
                      int *coords_zyx, int *num_points, int *d_num_voxels, void *ws, size_t ws_bytes,
                      void *stream);
+/* dz_voxelize_hard + MeanVFE (vfe.py:58-83) fused for batched pipelines: row r < *d_num_voxels of `feats`
+ * (row stride c_stride >= c, extra channels zero) receives the mean of voxel r's first <= max_points points, and
+ * coords_bzyx row r = [batch_index, z, y, x]; rows beyond the count are left untouched (callers pre-fill the
+ * coordinate rows with -1 so that dz_index_from_coords ignores them).  Same workspace as dz_voxelize_hard. */
+int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
+                          const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int batch_index,
+                          float *feats, int c_stride, int *coords_bzyx, int *d_num_voxels, void *ws, size_t ws_bytes,
+                          void *stream);
 
 /* MeanVFE.forward — detection/detzero_det/models/centerpoint_modules/vfe.py:66-83.
  * out (m, c_out_stride) f32: columns [0,c) = sum over slots / max(num_points,1); columns
