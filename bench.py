@@ -47,6 +47,29 @@ def usable_cores():
     return max(1, n)
 
 
+def pmc_traffic(kernel, math):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC pass (profiles/*_pmc_traffic.json,
+    written by tools/gpu_round.sh full from separate FETCH_SIZE / WRITE_SIZE passes over this same command):
+    FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 (x2, MI355X_MICROARCH.md section HBM); WRITE_SIZE is
+    taken as reported.  None when no profile of this kernel is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        tag = {'f16x2': '[F16]', 'bf16x2': '[BF16]'}.get(math, '')
+        ent = d.get(kernel + tag) or d.get(kernel.replace('>', ' >'))
+        if not ent or 'FETCH_SIZE' not in ent:
+            return None
+        rd = 2.0 * 1024.0 * ent['FETCH_SIZE']['per_call']
+        wr = 1024.0 * ent.get('WRITE_SIZE', {'per_call': 0.0})['per_call']
+        return {'read_bytes': round(rd), 'write_bytes': round(wr), 'bytes': round(rd + wr), 'source': os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def log(*a):
     print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
@@ -235,7 +258,7 @@ def main():
             peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
             out['roofline'] = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
                                'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                               'traffic': None,
+                               'traffic': pmc_traffic(top['kernel'], args.math),
                                'flop_per_launch': round(a['flops'] / a['launches'], 1),
                                'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
                                'note': ('split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s '

@@ -24,13 +24,13 @@ fi
 echo "==== rocprofv3 kernel-trace (eager, 20 steps)"
 rm -rf gpurun_out/prof/trace
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/trace_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-python tools/rocpd_summary.py gpurun_out/prof/trace/bench_results.db | head -32
+python tools/rocpd_summary.py gpurun_out/prof/trace/bench_results.db > gpurun_out/prof/trace_summary.txt; head -32 gpurun_out/prof/trace_summary.txt
 if [ "$MODE" = "full" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
 echo "==== rocprofv3 pmc $c"
 rm -rf gpurun_out/prof/pmc_$c
 cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$c -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_${c}_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-python tools/rocpd_summary.py gpurun_out/prof/pmc_$c/bench_results.db | sed -n '/PMC/,$p' | head -12
+python tools/rocpd_summary.py gpurun_out/prof/pmc_$c/bench_results.db --json gpurun_out/prof/pmc_$c.json | sed -n '/PMC/,$p' > gpurun_out/prof/pmc_${c}_summary.txt; head -12 gpurun_out/prof/pmc_${c}_summary.txt
 done
 fi
 find gpurun_out/prof -size +20M -delete

@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 (rocpd sqlite) result: per-kernel launch count / total / average duration, and
-PMC counter sums per kernel when present.  usage: python tools/rocpd_summary.py <results.db> [--steps N]"""
+PMC counter sums per kernel when present.
+usage: python tools/rocpd_summary.py <results.db> [--json out.json]   (--json: per-kernel per-call counter values)"""
+import json
 import re
 import sqlite3
 import sys
@@ -9,6 +11,7 @@ def short(name):
     name = re.sub(r'\(.*', '', name)
     name = name.replace('void ', '').replace('dz::', '')
     name = re.sub(r'TileCfg<(\d+), (\d+), (\d+), \d+, \d+>', r'\1x\2x\3', name)
+    name = re.sub(r'<HTile<(\d+), (\d+), (\d+), \d+, \d+>, Math(\w+?)(, \w+)*>', r'<\1x\2x\3>[\4]', name)
     return name[:90]
 
 
@@ -40,8 +43,14 @@ def main():
                 a[0] += 1
                 a[1] += float(r[vi])
             print('\n# PMC counters (sum over dispatches / per dispatch)')
-            for (k, c), (n, v) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:40]:
+            for (k, c), (n, v) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:60]:
                 print('%-80s %-14s calls %6d sum %16.1f per_call %14.1f' % (k, c, n, v, v / n))
+            if '--json' in sys.argv:
+                out = {}
+                for (k, c), (n, v) in agg2.items():
+                    out.setdefault(k.strip(), {})[c] = {'calls': n, 'per_call': v / n}
+                with open(sys.argv[sys.argv.index('--json') + 1], 'w') as f:
+                    json.dump(out, f, indent=1, sort_keys=True)
     except Exception as ex:  # noqa
         print('no counters:', ex)
 
