@@ -88,6 +88,7 @@ def parse():
                     help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores')
     ap.add_argument('--overlap', action='store_true',
                     help='two-stage streaming pipeline (StreamingDetector) instead of one graph per step; measured slower on MI355X')
+    ap.add_argument('--no-calibrate', action='store_true', help='keep worst-case level capacities (limits the batch to ~4 frames)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
@@ -124,6 +125,9 @@ def main():
     n_distinct = max(4, B + 1)
     frames = [torch.from_numpy(synth_waymo_frame(1000 * rank + i, args.points)).to(dev) for i in range(n_distinct)]
     static_in = [frames[j].clone() for j in range(B)]
+    if not args.no_calibrate:
+        caps = pipe.calibrate(frames)           # row capacities of the deep sparse levels from the sample frames (x1.5)
+        log('calibrated level capacities per frame:', caps)
     K, W = args.steps, args.warmup
     post_max = pipe.post_max
     results = torch.zeros((K, B, post_max, 9), dtype=torch.float32, device=dev)
@@ -209,6 +213,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if pipe.last_overflow is not None and bool(pipe.last_overflow.item()):
+        raise SystemExit('bench: a sparse level overflowed its calibrated capacity - rerun with --no-calibrate')
     n_boxes = counts.float().mean().item()
     log('timed region: %d steps x %d frames in %.3f s' % (K, B, dt))
 

@@ -189,6 +189,8 @@ class FramePipeline:
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
         self._streams = {}
+        self.level_caps = None        # per-frame row capacities of the strided stages (None = worst case)
+        self.last_overflow = None
 
     def _voxelize(self, frames, cid=0):
         """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
@@ -231,15 +233,32 @@ class FramePipeline:
         pyramid of the backbone.  Returns an opaque dict for ``infer``."""
         nb = len(frames)
         feats, coords, d_n = self._voxelize(frames)
-        pyr = self.model.backbone3d.build_pyramid(feats, coords, nb, d_n, overlap=overlap)
+        caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
+        pyr = self.model.backbone3d.build_pyramid(feats, coords, nb, d_n, overlap=overlap, caps=caps)
         pyr['nb'] = nb
         return pyr
+
+    @torch.no_grad()
+    def calibrate(self, frames, margin=1.5):
+        """Measure the active-site counts of the strided backbone stages on sample frames (one host sync) and size
+        the per-frame row capacities to `margin` x the largest count seen; afterwards buffers grow with B x that
+        instead of the worst case.  Frames that later exceed a capacity lose rows; `prepare(...)['overflow']` /
+        `self.last_overflow` (device bool) tells.  Call before graph capture."""
+        self.level_caps = None
+        best = [0, 0, 0, 0]
+        for f in frames:
+            pyr = self.prepare([f], overlap=False)
+            for i, st in enumerate(pyr['steps'][1:]):
+                best[i] = max(best[i], st[2].num_active())
+        self.level_caps = [int(margin * b) + 4096 for b in best]
+        return self.level_caps
 
     @torch.no_grad()
     def infer(self, prep):
         """Stage B: the 21 sparse convolutions, BEV backbone, head, top-K decode, NMS -> (boxes9 (B,K,9), counts (B,))."""
         m = self.model
         nb = prep['nb']
+        self.last_overflow = prep.get('overflow', None)
         res = m.backbone3d.run_pyramid(prep)
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)

@@ -197,6 +197,7 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
         if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
         if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
+        if (t128 == 3) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
         return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream);
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);

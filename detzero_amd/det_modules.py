@@ -288,14 +288,19 @@ class VoxelResBackBone8x(_Cached):
         y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
         return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
-    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0):
+    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None):
         """Everything of the backbone that depends only on voxel COORDINATES: the level-1 index + feature scatter and
         the output sets / bitmaps / neighbour tables of every stage.  Returns {'x': level-1 rows, 'steps': [...]}.
 
         overlap=True builds the tables of the deeper stages on a side stream (inside a captured graph: a parallel
         branch) so that they run under the convolutions of the earlier stages; events order each stage's tables
         before their first use.  overlap=False keeps everything on the current stream (used when the whole
-        preparation stage is itself overlapped with the previous batch, see StreamingDetector)."""
+        preparation stage is itself overlapped with the previous batch, see StreamingDetector).
+
+        caps: optional row capacities of the 4 strided stages (conv2, conv3, conv4, conv_out).  The default is the
+        worst case (min(cells, 8 x inputs)), which is safe but grows with the batch; calibrated capacities
+        (FramePipeline.calibrate) keep large batches inside the 2 GiB buffer-addressing window.  Rows beyond a
+        capacity are DROPPED by the kernels; pyr['overflow'] (device bool) reports it."""
         p = self.plan()
         n = voxel_features.shape[0]
         dev = voxel_features.device
@@ -310,11 +315,21 @@ class VoxelResBackBone8x(_Cached):
             nbr1 = lvl1.neighbors_to(lvl1, K3, S1, P1)
             steps.append((None, nbr1, lvl1, side.record_event() if overlap else None))
             level = lvl1
-            for name in ('conv2', 'conv3', 'conv4', 'conv_out'):
+            overflow = None
+            for li, name in enumerate(('conv2', 'conv3', 'conv4', 'conv_out')):
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
-                nxt = level.downsample(dp['k'], dp['s'], dp['p'])
+                nxt = level.downsample(dp['k'], dp['s'], dp['p'], cap=None if caps is None else int(caps[li]))
                 nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
                 nbr_s = nxt.neighbors_to(nxt, K3, S1, P1) if name != 'conv_out' else None
+                if name == 'conv_out' and caps is not None:
+                    # overflow flag of the calibrated capacities (same stream as the index build: it is covered by
+                    # the last stage's event, so the main stream does not wait for the whole pyramid up front)
+                    lv = [st[2] for st in steps[1:]] + [nxt]
+                    key = (tuple(l.cap for l in lv), str(dev))
+                    cache = self.__dict__.setdefault('_cap_limits', {})
+                    if key not in cache:    # created on the first (eager, warm-up) call: no H2D copy inside a graph capture
+                        cache[key] = torch.tensor(key[0], dtype=torch.int32, device=dev)
+                    overflow = (torch.cat([l.d_m for l in lv]) > cache[key]).any()
                 steps.append((nbr_d, nbr_s, nxt, side.record_event() if overlap else None))
                 level = nxt
         if overlap:
@@ -322,8 +337,13 @@ class VoxelResBackBone8x(_Cached):
                 for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
                     if t is not None:
                         t.record_stream(main)
+            if overflow is not None:
+                overflow.record_stream(main)
         x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
-        return {'x': x, 'steps': steps}
+        pyr = {'x': x, 'steps': steps}
+        if overflow is not None:
+            pyr['overflow'] = overflow
+        return pyr
 
     def run_pyramid(self, pyr):
         """The 21 sparse convolutions over a prepared pyramid.  Returns dict of (features, SparseLevel)."""

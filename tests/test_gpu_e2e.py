@@ -255,3 +255,25 @@ def test_streaming_detector_equals_plain_pipeline(device, use_graph):
         for i in range(2):
             k = int(rc[i].item())
             assert k > 0 and torch.equal(o[i, :k], ro[i, :k])
+
+
+def test_calibrated_capacities_and_overflow_flag(small, device):
+    """Calibrated (measured x1.5) row capacities of the deep sparse levels give bit-identical detections to the
+    worst-case capacities and report no overflow; absurdly small capacities raise the device-side overflow flag."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, pts, ref = small
+    frames = [torch.from_numpy(pts).to(device), torch.from_numpy(masked_frame(11, 9000)).to(device)]
+    plain = FramePipeline(model, info)
+    o0, n0 = plain(frames)
+    assert plain.last_overflow is None
+    cal = FramePipeline(model, info)
+    caps = cal.calibrate(frames)
+    assert len(caps) == 4 and all(c > 4096 for c in caps)
+    o1, n1 = cal(frames)
+    assert torch.equal(n0, n1) and not bool(cal.last_overflow.item())
+    for i in range(2):
+        k = int(n0[i].item())
+        assert torch.equal(o0[i, :k], o1[i, :k])
+    cal.level_caps = [64, 64, 64, 64]
+    cal(frames)
+    assert bool(cal.last_overflow.item())
