@@ -80,10 +80,10 @@ _T0 = time.perf_counter()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
-    ap.add_argument('--batch', type=int, default=4, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
+    ap.add_argument('--batch', type=int, default=16, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
     ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2'],
                     help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores')
     ap.add_argument('--overlap', action='store_true',

@@ -239,7 +239,8 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
         const int cur = c & 1;
         const v4u *Pc = Ps0 + cur * T::PS_U4 + poff, *Cc = Cs0 + cur * T::CS_U4 + coff;
         const v4u *Pn = Ps0 + (cur ^ 1) * T::PS_U4 + poff, *Cn = Cs0 + (cur ^ 1) * T::CS_U4 + coff;
-        // ---- phase 1
+        // ---- phase 1: memory instructions first, MFMAs behind them (sched_barrier pins the order: without it the
+        // scheduler hoists the MFMAs above the staging and the LDS-write latency lands in front of the barrier)
         if (Q == 2) load_hfrag<T>(f1, Pc, Cc, 1);
         if (ALL) {
             wait_hstage<T, (NS - 1) * NST>(st[S]);     // steady state: the NS-1 younger stages stay in flight
@@ -248,21 +249,17 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
             wait_hstage<T, 0>(st[S]);                  // tail: fewer stages may be in flight - drain
             store_hstage<T>(st[S], Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
         }
+        __builtin_amdgcn_sched_barrier(0);
         mma_hfrag<T, M>(f0, acc);
-        if (ALL) {
-            if (Q == 2) interleave_hint<0x100, NLDH, 1>();
-            interleave_hint<0x200, NST, PER1>();
-        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- phase 2
         if (ALL || has1) load_hfrag<T>(f0, Pn, Cn, 0);
         if (ALL || has2) { advance(); issue(st[S]); }
         if (Q == 2) {
+            __builtin_amdgcn_sched_barrier(0);
             mma_hfrag<T, M>(f1, acc);
-            if (ALL) {
-                interleave_hint<0x100, NLDH, 1>();
-                interleave_hint<0x020, NST, PER2>();
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     using TT = std::integral_constant<bool, true>;

@@ -33,6 +33,7 @@ def main():
     pipe = FramePipeline(model, info, math=args.math)
     mm = ops.math_id(args.math)
     frames = [torch.from_numpy(synth_waymo_frame(i, args.points)).to(dev) for i in range(args.batch)]
+    pipe.calibrate(frames[:4])
     feats, coords, d_n = pipe._voxelize(frames)
 
     calls = []
@@ -44,7 +45,7 @@ def main():
     ops.spconv_forward = spy
     import detzero_amd.det_modules as dm
     dm.ops.spconv_forward = spy
-    model.backbone3d.run(feats, coords, args.batch, d_n)
+    model.backbone3d.run_pyramid(model.backbone3d.build_pyramid(feats, coords, args.batch, d_n, caps=[c * args.batch for c in pipe.level_caps]))
     ops.spconv_forward = real
     dm.ops.spconv_forward = real
     torch.cuda.synchronize()

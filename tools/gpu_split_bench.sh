@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/split
 for m in ${@:-f32 f16x2 bf16x2}; do
   echo "==== bench --math $m --batch 4"
-  timeout 400 python bench.py --steps 40 --warmup 5 --batch 4 --math $m --no-cpu-baseline 2> gpurun_out/split/$m.err > gpurun_out/split/$m.json || tail -5 gpurun_out/split/$m.err
+  timeout 400 python bench.py --steps 40 --warmup 5 --batch ${BATCH:-4} --math $m --no-cpu-baseline 2> gpurun_out/split/$m.err > gpurun_out/split/$m.json || tail -5 gpurun_out/split/$m.err
   python - $m <<'PY'
 import json, sys
 m = sys.argv[1]
@@ -19,4 +19,4 @@ except Exception as e:
     print('no bench json', e)
 PY
 done
-echo "==== per-layer sparse (f16x2)"; timeout 300 python tools/bench_spconv.py --batch 4 --math f16x2 2>&1 | tail -23
+echo "==== per-layer sparse (f16x2)"; timeout 300 python tools/bench_spconv.py --batch ${BATCH:-4} --math f16x2 2>&1 | tail -23
