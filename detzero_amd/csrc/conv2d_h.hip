@@ -9,6 +9,10 @@
 
 namespace dz {
 
+// conv3x3_h.hip: 3x3 stride-1 layers with enough tiles run on the image-tile-resident kernel
+int conv3x3_h_variant(const dz_conv2d_desc &p);
+int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_bytes, hipStream_t stream);
+
 template <class T, class M, bool OUT_F32, int NS>
 __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total, unsigned int in_bytes, unsigned int w_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -234,11 +238,17 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
                  "dz_conv2d_forward_split: output leaves the output image");
     if ((long)d->batch * d->ho * d->wo == 0) return DZ_OK;
     const size_t w_bytes = (size_t)d->groups * d->kh * d->kw * d->cout_pad * d->cin * sizeof(float);
+    if (conv3x3_h_variant(*d)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);
     if (math == DZ_MATH_F16X2)
         return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);
     return out_f32 ? conv2d_h_dispatch<MathBF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathBF16, false>(*d, w_bytes, stream);
 }
 
-const char *dz_conv2d_variant_split(const dz_conv2d_desc *d) { return d ? kConvHVariantName[conv2d_h_select(*d)] : "none"; }
+const char *dz_conv2d_variant_split(const dz_conv2d_desc *d) {
+    if (!d) return "none";
+    const int bc = conv3x3_h_variant(*d);
+    if (bc) return bc == 128 ? "k_conv3x3_h<8x32x128>" : "k_conv3x3_h<8x32x64>";
+    return kConvHVariantName[conv2d_h_select(*d)];
+}
 
 }  // extern "C"

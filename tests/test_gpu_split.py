@@ -193,3 +193,58 @@ def test_full_size_split_equals_f32_pipeline(device):
         nm, worst = match_boxes(a[:, :7], a[:, 7], b[:, :7], b[:, 7], tol=1e-3)
         assert n32 > 50 and abs(n - n32) <= 2 and nm >= n32 - 2, (name, n, n32, nm, worst)
     set_math(model, 'f32')
+
+
+@pytest.mark.parametrize('name,mid', MODES)
+@pytest.mark.parametrize('cin,cout,h,w,out_f32', [(64, 128, 188, 188, False), (32, 64, 122, 200, False), (64, 64, 201, 97, True)])
+def test_conv3x3_resident_tile_kernel_vs_torch(device, name, mid, cin, cout, h, w, out_f32):
+    """conv3x3_h.hip (image-tile-resident input, 512-thread workgroups): ragged image sizes, channel offsets inside wider
+    buffers, both channel-tile widths, pair16 and fp32 outputs - against torch's fp32 conv2d."""
+    import ctypes
+    import torch.nn.functional as F
+    from detzero_amd import lib as L, ops
+    from detzero_amd.det_modules import conv_layer
+    b = 4
+    gen = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn((b, cin, h, w), generator=gen)
+    wt = torch.randn((cout, cin, 3, 3), generator=gen) / (3.0 * cin ** 0.5)
+    scale = torch.rand((cout,), generator=gen) + 0.5
+    shift = torch.randn((cout,), generator=gen) * 0.1
+    ref = torch.relu(F.conv2d(x, wt, None, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    # input lives at channel offset 8 of a wider zero-bordered channel-last buffer, output at offset 16 of another
+    cs_in, cs_out = cin + 24, cout + 32
+    xin = torch.zeros((b, h + 2, w + 2, cs_in))
+    xin[:, 1:-1, 1:-1, 8:8 + cin] = x.permute(0, 2, 3, 1)
+    xin[..., :8] = 7.0; xin[..., 8 + cin:] = -3.0                       # neighbours in the buffer must not leak in
+    xin_d = ops.pair16_from_f32(xin.to(device), cs_in, mid)
+    w_taps = wt.permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous().to(device)
+    w_split = ops.pack_weight_split(w_taps, mid)
+    out = torch.zeros((b, h + 2, w + 2, cs_out), dtype=torch.float32, device=device)
+    kw = dict(cin=cin, in_cstride=cs_in, in_coff=8, ksize=3, stride=1, in_off=0, out_cstride=cs_out, out_coff=16, out_d=(1, 1),
+              ho=h, wo=w, batch=b, g_cout=[cout])
+    d = L.Conv2dDesc()          # the dispatcher must pick the resident-tile kernel for this shape
+    d.batch, d.ho, d.wo, d.kh, d.kw, d.stride, d.groups, d.cin, d.cout_pad = b, h, w, 3, 3, 1, 1, cin, cout
+    assert L.load().dz_conv2d_variant_split(ctypes.byref(d)).decode().startswith('k_conv3x3_h')
+    conv_layer(xin_d, (h + 2, w + 2), w_split, scale.to(device), shift.to(device), True, out, (h + 2, w + 2), math=mid,
+               out_f32=out_f32, **kw)
+    plain = out if out_f32 else ops.pair16_to_f32(out, mid)
+    got = plain[:, 1:-1, 1:-1, 16:16 + cout].permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(got, ref, rtol=TOL[mid], atol=TOL[mid])
+    assert float(plain[..., :16].abs().max()) == 0 and float(plain[..., 16 + cout:].abs().max()) == 0      # nothing outside its channels
+    assert float(plain[:, 0].abs().max()) == 0 and float(plain[:, :, -1].abs().max()) == 0                 # border untouched
+
+
+def test_full_size_batch_split_equals_f32_pipeline(device):
+    """4 full-size frames in one pass (the dense layers then run on the resident-tile 3x3 kernel): f16x2 boxes within
+    1e-3 of the fp32-MFMA engine, frame by frame."""
+    from detzero_amd.centerpoint import FramePipeline, set_math
+    model, cfg, info = make_model(VOXEL_SIZE_01, seed=1)
+    model = model.to(device)
+    frames = [torch.from_numpy(masked_frame(i, 160000)).to(device) for i in range(4)]
+    o32, n32 = FramePipeline(model, info, math='f32')(frames)
+    o16, n16 = FramePipeline(model, info, math='f16x2')(frames)
+    for i in range(4):
+        a, b = o32[i, :int(n32[i])].cpu().numpy(), o16[i, :int(n16[i])].cpu().numpy()
+        nm, worst = match_boxes(a[:, :7], a[:, 7], b[:, :7], b[:, 7], tol=1e-3)
+        assert a.shape[0] > 50 and abs(a.shape[0] - b.shape[0]) <= 2 and nm >= a.shape[0] - 2, (i, a.shape, b.shape, nm, worst)
+    set_math(model, 'f32')
