@@ -124,7 +124,8 @@ def main():
     B = max(1, args.batch)
     n_distinct = max(4, B + 1)
     frames = [torch.from_numpy(synth_waymo_frame(1000 * rank + i, args.points)).to(dev) for i in range(n_distinct)]
-    static_in = [frames[j].clone() for j in range(B)]
+    pool = torch.stack(frames + frames[:B], dim=0)          # (n_distinct + B, N, C): every window of B frames is contiguous
+    static_in = pool[:B].clone()                            # (B, N, C) static input of the captured graph
     if not args.no_calibrate:
         caps = pipe.calibrate(frames)           # row capacities of the deep sparse levels from the sample frames (x1.5)
         log('calibrated level capacities per frame:', caps)
@@ -134,8 +135,8 @@ def main():
     counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
 
     def load_inputs(i):
-        for j in range(B):
-            static_in[j].copy_(frames[(i * B + j) % n_distinct], non_blocking=True)
+        o = (i * B) % n_distinct
+        static_in.copy_(pool[o:o + B], non_blocking=True)   # one device-to-device copy of the B frames of this step
 
     # warm-up (also primes the caching allocator and builds the kernel-layout weights)
     use_graph = not args.no_graph
@@ -144,7 +145,7 @@ def main():
     g_out = g_n = None
     if args.overlap:
         from detzero_amd.centerpoint import StreamingDetector
-        streamer = StreamingDetector(pipe, frames[:B], use_graph=use_graph, warmup=max(W, 3))
+        streamer = StreamingDetector(pipe, frames[:B], use_graph=use_graph, warmup=max(W, 3))   # (per-frame input slots)
         graph_note = streamer.graph_note
     else:
         side = torch.cuda.Stream()

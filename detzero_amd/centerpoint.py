@@ -166,6 +166,14 @@ def set_math(model, mode):
     return model
 
 
+class _StackedFrames(list):
+    """List view of a (B,N,C) tensor of equally long frames that remembers the backing tensor (no re-concatenation)."""
+
+    def __init__(self, tensor):
+        super().__init__(tensor.unbind(0))
+        self.tensor = tensor
+
+
 class FramePipeline:
     """Sync-free detector step on one GPU over a batch of frames (reference eval batches frames the same way:
     tools/test.py builds the loader with OPTIMIZATION.BATCH_SIZE_PER_GPU, collate_batch stacks the voxels with
@@ -205,6 +213,15 @@ class FramePipeline:
         main = torch.cuda.current_stream(dev)
         cap = int(min(info.max_voxels[self.mode], max(max(p.shape[0] for p in frames), 1)))
         c = frames[0].shape[1]
+        if nb > 1 and all(p.shape[0] == frames[0].shape[0] for p in frames):
+            # equally long frames: ONE launch chain voxelizes the whole batch (the frame index extends the voxel key)
+            if isinstance(frames, _StackedFrames):
+                pts = frames.tensor.reshape(-1, c)
+            else:
+                pts = torch.cat(list(frames), dim=0)
+            feats, coords, _ = ops.voxelize_hard_mean_batched(pts, nb, rng, info.voxel_size, info.max_points_per_voxel,
+                                                              info.max_voxels[self.mode], cap, xy_range_mask=True)
+            return feats, coords, None
         feats = torch.empty((nb * cap, c), dtype=torch.float32, device=dev)
         coords = torch.full((nb * cap, 4), -1, dtype=torch.int32, device=dev)
         d_ns = torch.zeros((nb,), dtype=torch.int32, device=dev)
@@ -269,8 +286,15 @@ class FramePipeline:
 
     @torch.no_grad()
     def __call__(self, points):
-        single = torch.is_tensor(points)
-        out, d_nk = self.infer(self.prepare([points] if single else list(points)))
+        """points: (N,C) tensor = one frame; list of (N_i,C) tensors or a (B,N,C) tensor = a batch."""
+        single = torch.is_tensor(points) and points.dim() == 2
+        if single:
+            frames = [points]
+        elif torch.is_tensor(points):
+            frames = _StackedFrames(points.contiguous())
+        else:
+            frames = points if isinstance(points, _StackedFrames) else list(points)
+        out, d_nk = self.infer(self.prepare(frames))
         return (out[0], d_nk) if single else (out, d_nk)
 
 

@@ -37,15 +37,16 @@ __device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &g, in
 
 // ---- hard voxelization ---------------------------------------------------------------------
 // key (z-major) per point + occupancy bit
-__global__ void k_hard_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, uint32_t *__restrict__ keys,
-                            uint32_t *__restrict__ bitmap) {
+// (n_per = points per frame of a batch of equally long frames stored back to back; the frame index extends the key)
+__global__ void k_hard_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, int n_per, uint32_t cells,
+                            uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *p = pts + (size_t)i * c;
         const float xyz[3] = {p[0], p[1], p[2]};
         int cx, cy, cz;
         uint32_t key = KEY_INVALID;
         if (voxel_coord(xyz, g, cx, cy, cz)) {
-            key = (uint32_t)((cz * g.g[1] + cy) * g.g[0] + cx);
+            key = (uint32_t)(i / n_per) * cells + (uint32_t)((cz * g.g[1] + cy) * g.g[0] + cx);
             atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
         }
         keys[i] = key;
@@ -117,15 +118,27 @@ __global__ void k_hard_emit(const float *__restrict__ pts, int c, const int *__r
 __global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int *__restrict__ mins, int cap,
                                  int max_points, int max_voxels, const int *__restrict__ d_m,
                                  const int *__restrict__ canon_coords, const uint32_t *__restrict__ pt_bitmap,
-                                 const uint32_t *__restrict__ pt_prefix, int batch_index, float *__restrict__ feats,
-                                 int c_stride, int *__restrict__ coords_bzyx, int *__restrict__ d_num_voxels) {
+                                 const uint32_t *__restrict__ pt_prefix, int batch_index, int batch, int n_per, int cap_frame,
+                                 float *__restrict__ feats, int c_stride, int *__restrict__ coords_bzyx,
+                                 int *__restrict__ d_num_voxels) {
+    // batch frames stored back to back (n_per points each): the first-appearance rank is global (frame-major); frame f's
+    // voxels are the ranks [R_f, R_f+1) with R_f = number of first points below point index f*n_per, and go to rows
+    // f*cap_frame + (rank - R_f) of the batch buffers, cut at max_voxels per frame
     const int m = min(*d_m, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d_num_voxels = min(m, max_voxels);
+    if (blockIdx.x == 0 && (int)threadIdx.x < batch) {
+        const int f = threadIdx.x;
+        const int lo = bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)f * (uint32_t)n_per);
+        const int hi = f + 1 < batch ? bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)(f + 1) * (uint32_t)n_per) : m;
+        d_num_voxels[f] = min(hi - lo, max_voxels);
+    }
     const long total = (long)m * c_stride;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int v = (int)(idx / c_stride), ch = (int)(idx % c_stride);
-        const int row = bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)mins[v]);
-        if (row >= max_voxels) continue;
+        const int4 cc = reinterpret_cast<const int4 *>(canon_coords)[v];  // [frame,z,y,x]
+        const int rank = bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)mins[v]) -
+                         bitmap_rank(pt_bitmap, pt_prefix, (uint32_t)cc.x * (uint32_t)n_per);
+        if (rank >= max_voxels) continue;
+        const size_t row = (size_t)cc.x * cap_frame + rank;
         float sum = 0.f;
         int cnt = 0;
         for (int q = 0; q < max_points; ++q) {
@@ -135,11 +148,8 @@ __global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int
                 if (ch < c) sum = __fadd_rn(sum, pts[(size_t)pi * c + ch]);
             }
         }
-        feats[(size_t)row * c_stride + ch] = ch < c ? __fdiv_rn(sum, fmaxf((float)cnt, 1.0f)) : 0.f;
-        if (ch == 0) {
-            const int4 cc = reinterpret_cast<const int4 *>(canon_coords)[v];  // [b,z,y,x]
-            reinterpret_cast<int4 *>(coords_bzyx)[row] = make_int4(batch_index, cc.y, cc.z, cc.w);
-        }
+        feats[row * c_stride + ch] = ch < c ? __fdiv_rn(sum, fmaxf((float)cnt, 1.0f)) : 0.f;
+        if (ch == 0) reinterpret_cast<int4 *>(coords_bzyx)[row] = make_int4(batch_index + cc.x, cc.y, cc.z, cc.w);
     }
 }
 
@@ -257,15 +267,17 @@ size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_p
 // shared driver of the two emit flavours: feats != nullptr selects the fused emit + mean
 static int voxelize_hard_impl(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
                               const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, float *voxels,
-                              int *coords_zyx, int *num_points, int batch_index, float *feats, int c_stride, int *coords_bzyx,
-                              int *d_num_voxels, void *ws, size_t ws_bytes, hipStream_t stream) {
+                              int *coords_zyx, int *num_points, int batch_index, int batch, int cap_frame, float *feats,
+                              int c_stride, int *coords_bzyx, int *d_num_voxels, void *ws, size_t ws_bytes, hipStream_t stream) {
+    // n = points of ALL `batch` frames (equally long, back to back)
     VoxGeom g;
     DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_hard: bad geometry");
     const size_t cells = (size_t)g.g[0] * g.g[1] * g.g[2];
-    if (cells >= 0xFFFFFFFFull) { set_error("dz_voxelize_hard: grid too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
-    if (n == 0) return fill_u32(d_num_voxels, 0u, 1, stream);
+    if (cells * (size_t)batch >= 0xFFFFFFFFull) { set_error("dz_voxelize_hard: grid x batch too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
+    if (n == 0) return fill_u32(d_num_voxels, 0u, (size_t)batch, stream);
     DZ_CHECK_ARG(points, "dz_voxelize_hard: null points");
-    const size_t nwords = dz_index_words(1, g.g[2], g.g[1], g.g[0]);
+    const int n_per = n / batch;
+    const size_t nwords = dz_index_words(batch, g.g[2], g.g[1], g.g[0]);
     HardWs w = carve_hard(ws, n, nwords, max_points);
     if (ws_bytes < w.total) { set_error("dz_voxelize_hard: workspace %zu < %zu", ws_bytes, w.total); return DZ_ERR_WORKSPACE; }
     const size_t pt_words = align_up(((size_t)n + 31) / 32, 8);
@@ -276,7 +288,7 @@ static int voxelize_hard_impl(const float *points, int n, int c, const float *h_
     if (!rc) rc = fill_u32(w.mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
     if (rc) return rc;
     const int grid_n = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_hard_keys, dim3(grid_n), dim3(256), 0, stream, points, n, c, g, w.keys, w.bitmap);
+    hipLaunchKernelGGL(k_hard_keys, dim3(grid_n), dim3(256), 0, stream, points, n, c, g, n_per, (uint32_t)cells, w.keys, w.bitmap);
     rc = bitmap_scan(w.bitmap, nwords, w.prefix, w.d_m, 0, ScanDims{g.g[2], g.g[1], g.g[0]}, w.canon_coords, cap,
                          w.scan_ws, w.scan_ws_bytes, stream);
     if (rc) return rc;
@@ -291,8 +303,8 @@ static int voxelize_hard_impl(const float *points, int n, int c, const float *h_
     if (rc) return rc;
     if (feats)
         hipLaunchKernelGGL(k_hard_emit_mean, dim3(stream_grid((long)cap * c_stride, 256)), dim3(256), 0, stream, points, c, w.mins,
-                           cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, batch_index, feats,
-                           c_stride, coords_bzyx, d_num_voxels);
+                           cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, batch_index, batch, n_per,
+                           cap_frame, feats, c_stride, coords_bzyx, d_num_voxels);
     else
         hipLaunchKernelGGL(k_hard_emit, dim3(stream_grid((long)cap * max_points, 256)), dim3(256), 0, stream, points, c,
                            w.mins, cap, max_points, max_voxels, w.d_m, w.canon_coords, w.pt_bitmap, w.pt_prefix, voxels,
@@ -307,7 +319,7 @@ int dz_voxelize_hard(const float *points, int n, int c, const float *h_range6, c
     DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1, "dz_voxelize_hard: bad sizes");
     DZ_CHECK_ARG(voxels && coords_zyx && num_points && d_num_voxels && ws, "dz_voxelize_hard: null pointer");
     return voxelize_hard_impl(points, n, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels, voxels, coords_zyx,
-                              num_points, 0, nullptr, 0, nullptr, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
+                              num_points, 0, 1, 0, nullptr, 0, nullptr, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_range6, const float *h_vsize3,
@@ -316,7 +328,27 @@ int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_rang
     DZ_CHECK_ARG(n >= 0 && c >= 3 && max_points >= 1 && max_voxels >= 1 && c_stride >= c, "dz_voxelize_hard_mean: bad sizes");
     DZ_CHECK_ARG(feats && coords_bzyx && d_num_voxels && ws, "dz_voxelize_hard_mean: null pointer");
     return voxelize_hard_impl(points, n, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels, nullptr, nullptr,
-                              nullptr, batch_index, feats, c_stride, coords_bzyx, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
+                              nullptr, batch_index, 1, 0, feats, c_stride, coords_bzyx, d_num_voxels, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+size_t dz_voxelize_hard_batched_workspace_bytes(int n_per_frame, int batch, int gx, int gy, int gz, int max_points) {
+    const long n = (long)(n_per_frame < 1 ? 1 : n_per_frame) * (batch < 1 ? 1 : batch);
+    return carve_hard(nullptr, (int)n, dz_index_words(batch < 1 ? 1 : batch, gz, gy, gx), max_points).total;
+}
+
+int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batch, int c, const float *h_range6,
+                                  const float *h_vsize3, const int *h_grid3, int xy_range_mask, int max_points, int max_voxels,
+                                  float *feats, int c_stride, int *coords_bzyx, int cap_per_frame, int *d_num_voxels, void *ws,
+                                  size_t ws_bytes, void *stream_) {
+    DZ_CHECK_ARG(n_per_frame >= 0 && batch >= 1 && batch <= 256 && c >= 3 && max_points >= 1 && max_voxels >= 1 && c_stride >= c,
+                 "dz_voxelize_hard_mean_batched: bad sizes");
+    DZ_CHECK_ARG((long)n_per_frame * batch < 0x7FFFFFFFl, "dz_voxelize_hard_mean_batched: too many points");
+    DZ_CHECK_ARG(cap_per_frame >= (max_voxels < n_per_frame ? max_voxels : n_per_frame),
+                 "dz_voxelize_hard_mean_batched: cap_per_frame below min(max_voxels, points per frame)");
+    DZ_CHECK_ARG(feats && coords_bzyx && d_num_voxels && ws, "dz_voxelize_hard_mean_batched: null pointer");
+    return voxelize_hard_impl(points, n_per_frame * batch, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels,
+                              nullptr, nullptr, nullptr, 0, batch, cap_per_frame, feats, c_stride, coords_bzyx, d_num_voxels, ws,
+                              ws_bytes, (hipStream_t)stream_);
 }
 
 int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int cap, int max_points, int c, float *out,

@@ -68,6 +68,27 @@ def voxelize_hard_mean_into(points, pc_range, voxel_size, max_points, max_voxels
     L.check(rc, 'dz_voxelize_hard_mean')
 
 
+def voxelize_hard_mean_batched(points, batch, pc_range, voxel_size, max_points, max_voxels, cap_per_frame, xy_range_mask=False):
+    """points (batch*n, C): `batch` equally long frames back to back -> feats (batch*cap, C), coords (batch*cap,4) i32
+    [b,z,y,x] with b = -1 on unused rows, d_num (batch,) i32 - one launch chain for the whole batch."""
+    lib = L.load()
+    L.require_cuda(points)
+    n_tot, c = points.shape
+    n_per = n_tot // batch
+    assert n_per * batch == n_tot
+    grid = grid_size_of(pc_range, voxel_size)
+    dev = points.device
+    feats = torch.empty((batch * cap_per_frame, c), dtype=torch.float32, device=dev)
+    coords = torch.full((batch * cap_per_frame, 4), -1, dtype=torch.int32, device=dev)
+    d_num = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    ws = _ws(lib.dz_voxelize_hard_batched_workspace_bytes(n_per, batch, int(grid[0]), int(grid[1]), int(grid[2]), max_points))
+    rc = lib.dz_voxelize_hard_mean_batched(L.ptr(points), n_per, batch, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid),
+                                           1 if xy_range_mask else 0, max_points, int(max_voxels), L.ptr(feats), c, L.ptr(coords),
+                                           int(cap_per_frame), L.ptr(d_num), L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_voxelize_hard_mean_batched')
+    return feats, coords, d_num
+
+
 def voxelize_hard(points, pc_range, voxel_size, max_points, max_voxels):
     voxels, coords, nump, d_num = voxelize_hard_nosync(points, pc_range, voxel_size, max_points, max_voxels)
     m = int(d_num.item())

@@ -61,6 +61,14 @@ int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_rang
                           const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int batch_index,
                           float *feats, int c_stride, int *coords_bzyx, int *d_num_voxels, void *ws, size_t ws_bytes,
                           void *stream);
+/* the same for `batch` equally long frames stored back to back (points (batch*n_per_frame, c)) in ONE launch chain:
+ * frame f's voxels (first-appearance order within the frame, cut at max_voxels) go to rows f*cap_per_frame + r of
+ * feats / coords_bzyx with batch index f; d_num_voxels (batch) receives the per-frame counts. */
+size_t dz_voxelize_hard_batched_workspace_bytes(int n_per_frame, int batch, int gx, int gy, int gz, int max_points);
+int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batch, int c, const float *h_range6,
+                                  const float *h_vsize3, const int *h_grid3, int xy_range_mask, int max_points,
+                                  int max_voxels, float *feats, int c_stride, int *coords_bzyx, int cap_per_frame,
+                                  int *d_num_voxels, void *ws, size_t ws_bytes, void *stream);
 
 /* MeanVFE.forward — detection/detzero_det/models/centerpoint_modules/vfe.py:66-83.
  * out (m, c_out_stride) f32: columns [0,c) = sum over slots / max(num_points,1); columns

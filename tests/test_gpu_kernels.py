@@ -425,3 +425,29 @@ def test_mha_core_vs_torch(device, b, lq, lk, heads, masked):
         s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(b, lq, e).float()
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('max_voxels', [200000, 3000])
+def test_voxelize_hard_mean_batched_equals_per_frame(device, max_voxels):
+    """One launch chain over B equally long frames == B single-frame calls, bit for bit (features, [b,z,y,x] rows in
+    first-appearance order, per-frame counts), including the per-frame max_voxels cut; and the single-frame fused
+    call == dz_voxelize_hard + dz_mean_vfe."""
+    from detzero_amd import ops
+    n, b = 30000, 3
+    frames = [_t(synth_waymo_frame(40 + i, n), device) for i in range(b)]
+    cap = min(max_voxels, n)
+    feats, coords, d_num = ops.voxelize_hard_mean_batched(torch.cat(frames, 0), b, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, max_voxels,
+                                                          cap, xy_range_mask=True)
+    for i, f in enumerate(frames):
+        fi = torch.empty((cap, 5), dtype=torch.float32, device=device)
+        ci = torch.full((cap, 4), -1, dtype=torch.int32, device=device)
+        di = torch.zeros((1,), dtype=torch.int32, device=device)
+        ops.voxelize_hard_mean_into(f, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, max_voxels, i, fi, ci, di, xy_range_mask=True)
+        m = int(di.item())
+        assert m == int(d_num[i].item()) and 0 < m <= max_voxels
+        assert torch.equal(coords[i * cap:i * cap + m], ci[:m]) and torch.equal(feats[i * cap:i * cap + m], fi[:m])
+        assert bool((coords[i * cap + m:(i + 1) * cap, 0] == -1).all())
+        # fused == unfused reference-shaped path
+        vox, zyx, nump, dn = ops.voxelize_hard_nosync(f, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, max_voxels, xy_range_mask=True)
+        mean = ops.mean_vfe(vox, nump, d_m=dn)
+        assert int(dn.item()) == m and torch.equal(mean[:m], fi[:m]) and torch.equal(zyx[:m], ci[:m, 1:])
