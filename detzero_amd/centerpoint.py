@@ -249,9 +249,21 @@ class FramePipeline:
         """Stage A: everything that depends only on the points - voxelization, voxel features, the sparse index
         pyramid of the backbone.  Returns an opaque dict for ``infer``."""
         nb = len(frames)
-        feats, coords, d_n = self._voxelize(frames)
         caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
-        pyr = self.model.backbone3d.build_pyramid(feats, coords, nb, d_n, overlap=overlap, caps=caps)
+        bb = self.model.backbone3d
+        n0 = frames[0].shape[0]
+        if (not self.dynamic and nb > 1 and n0 <= self.info.max_voxels[self.mode] and all(p.shape[0] == n0 for p in frames)):
+            # equally long frames that cannot overflow max_voxels: voxelize straight into the level-1 index (one launch
+            # chain for the whole batch; no voxel list, no first-appearance ordering, no separate index build / scatter)
+            c = frames[0].shape[1]
+            pts = frames.tensor.reshape(-1, c) if isinstance(frames, _StackedFrames) else torch.cat(list(frames), dim=0)
+            lvl1, x = ops.voxelize_to_level(pts, nb, self.info.point_cloud_range, self.info.voxel_size,
+                                            self.info.max_points_per_voxel, self.info.max_voxels[self.mode], bb.sparse_shape,
+                                            bb.CIN_PAD, math=bb.math, xy_range_mask=True)
+            pyr = bb.build_pyramid(x, None, nb, None, overlap=overlap, caps=caps, level1=lvl1)
+        else:
+            feats, coords, d_n = self._voxelize(frames)
+            pyr = bb.build_pyramid(feats, coords, nb, d_n, overlap=overlap, caps=caps)
         pyr['nb'] = nb
         return pyr
 

@@ -11,7 +11,7 @@
 //   3. a second bitmap over POINT indices marks each voxel's first point; its scan is the
 //      first-appearance rank, which is the output row (and the max_voxels cut-off).
 // All kernels stream the point buffer with coalesced loads; the bitmaps live in L2/Infinity Cache.
-#include "common.h"
+#include "hgemm.h"
 
 namespace dz {
 
@@ -150,6 +150,68 @@ __global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int
         }
         feats[row * c_stride + ch] = ch < c ? __fdiv_rn(sum, fmaxf((float)cnt, 1.0f)) : 0.f;
         if (ch == 0) reinterpret_cast<int4 *>(coords_bzyx)[row] = make_int4(batch_index + cc.x, cc.y, cc.z, cc.w);
+    }
+}
+
+// ---- voxelize straight into the level-1 sparse index (batched frame pipeline) ---------------------------------
+// When a frame cannot exceed max_voxels (points per frame <= max_voxels), no voxel is ever dropped, so the occupancy
+// bitmap of the hard voxelizer IS the level-1 index of the sparse backbone: keys are laid out in the LEVEL's geometry
+// ((b*D + z)*H + y)*W + x, the scan writes the level's prefix / canonical coordinates / count, and the voxel means go
+// to the voxel's canonical row directly (zero-padded to the backbone's input width, optionally as pair16).  The
+// first-appearance ordering, the voxel list, dz_index_from_coords and dz_scatter_rows all disappear.
+__global__ void k_level_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, int n_per, int level_d,
+                             uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *p = pts + (size_t)i * c;
+        const float xyz[3] = {p[0], p[1], p[2]};
+        int cx, cy, cz;
+        uint32_t key = KEY_INVALID;
+        if (voxel_coord(xyz, g, cx, cy, cz)) {
+            key = (uint32_t)((((i / n_per) * level_d + cz) * g.g[1] + cy) * g.g[0] + cx);
+            atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+        }
+        keys[i] = key;
+    }
+}
+
+// one thread per (voxel row, group of 8 output channels)
+template <int MATH>
+__global__ void k_level_emit_mean(const float *__restrict__ pts, int c, const int *__restrict__ mins, int cap, int max_points,
+                                  const int *__restrict__ d_m, float *__restrict__ feats, int c_dst) {
+    const int m = min(*d_m, cap);
+    const int groups = c_dst / 8;
+    const long total = (long)m * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx / groups), gq = (int)(idx % groups);
+        float sum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+        int cnt = 0;
+        for (int q = 0; q < max_points; ++q) {
+            const int pi = mins[(size_t)q * cap + v];
+            if (pi != 0x7f7f7f7f) {
+                ++cnt;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (gq * 8 + e < c) sum[e] = __fadd_rn(sum[e], pts[(size_t)pi * c + gq * 8 + e]);
+            }
+        }
+        const float nrm = fmaxf((float)cnt, 1.0f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = gq * 8 + e < c ? __fdiv_rn(sum[e], nrm) : 0.f;
+        float *dst = feats + ((size_t)v * c_dst + gq * 8);
+        if (MATH == 0) {
+            reinterpret_cast<float4 *>(dst)[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            reinterpret_cast<float4 *>(dst)[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+        } else {
+            using M = typename std::conditional<MATH == 1, MathF16, MathBF16>::type;
+            const float a[4] = {sum[0], sum[1], sum[2], sum[3]}, b[4] = {sum[4], sum[5], sum[6], sum[7]};
+            uint2 h0, l0, h1, l1;
+            split4<M>(a, h0, l0);
+            split4<M>(b, h1, l1);
+            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
     }
 }
 
@@ -349,6 +411,73 @@ int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batc
     return voxelize_hard_impl(points, n_per_frame * batch, c, h_range6, h_vsize3, h_grid3, xy_range_mask, max_points, max_voxels,
                               nullptr, nullptr, nullptr, 0, batch, cap_per_frame, feats, c_stride, coords_bzyx, d_num_voxels, ws,
                               ws_bytes, (hipStream_t)stream_);
+}
+
+static size_t level_ws_layout(long n, int max_points, int cap, size_t nwords, size_t *o_min, size_t *o_sw, size_t *sw_bytes) {
+    size_t off = align_up((size_t)(n < 1 ? 1 : n) * 4, 256);                 // keys first
+    *o_min = off;
+    off += align_up((size_t)max_points * (cap < 1 ? 1 : cap) * 4, 256);
+    *sw_bytes = bitmap_scan_workspace_bytes(nwords);
+    *o_sw = off;
+    off += align_up(*sw_bytes, 256);
+    return off;
+}
+
+size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w) {
+    size_t a, b, c;
+    return level_ws_layout((long)n_per_frame * batch, max_points, cap, dz_index_words(batch, d, h, w), &a, &b, &c);
+}
+
+int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c, const float *h_range6, const float *h_vsize3,
+                         const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int level_d, uint32_t *bitmap,
+                         uint32_t *prefix, int *coords_out, int *d_m, int cap, float *feats, int c_dst, int math, void *ws,
+                         size_t ws_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n_per_frame >= 0 && batch >= 1 && c >= 3 && max_points >= 1 && c_dst >= c && c_dst % 8 == 0,
+                 "dz_voxelize_to_level: bad sizes");
+    DZ_CHECK_ARG(math >= 0 && math <= 2, "dz_voxelize_to_level: bad math mode %d", math);
+    DZ_CHECK_ARG(bitmap && prefix && coords_out && d_m && feats && ws, "dz_voxelize_to_level: null pointer");
+    VoxGeom g;
+    DZ_CHECK_ARG(make_geom(h_range6, h_vsize3, h_grid3, xy_range_mask, g), "dz_voxelize_to_level: bad geometry");
+    DZ_CHECK_ARG(level_d >= g.g[2], "dz_voxelize_to_level: level depth %d below the voxel grid's %d", level_d, g.g[2]);
+    if (n_per_frame > max_voxels) {
+        set_error("dz_voxelize_to_level: %d points per frame could exceed max_voxels %d - use dz_voxelize_hard_mean_batched",
+                  n_per_frame, max_voxels);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    const long n = (long)n_per_frame * batch;
+    DZ_CHECK_ARG(n < 0x7FFFFFFFl && cap >= (n < 1 ? 1 : 0), "dz_voxelize_to_level: too many points");
+    const size_t cells = (size_t)batch * level_d * g.g[1] * g.g[0];
+    if (cells >= 0xFFFFFFFFull) { set_error("dz_voxelize_to_level: grid x batch too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
+    const size_t nwords = dz_index_words(batch, level_d, g.g[1], g.g[0]);
+    size_t o_min, o_sw, sw_bytes;
+    const size_t need = level_ws_layout(n, max_points, cap, nwords, &o_min, &o_sw, &sw_bytes);
+    if (ws_bytes < need) { set_error("dz_voxelize_to_level: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }
+    uint32_t *keys = (uint32_t *)ws;
+    int *mins = (int *)((char *)ws + o_min);
+    int rc = fill_u32(bitmap, 0u, nwords, stream);
+    if (!rc) rc = fill_u32(mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
+    if (rc) return rc;
+    if (n == 0) return bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw,
+                                   sw_bytes, stream);
+    DZ_CHECK_ARG(points, "dz_voxelize_to_level: null points");
+    const int grid_n = stream_grid(n, 256);
+    hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, level_d, keys, bitmap);
+    rc = bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw, sw_bytes,
+                     stream);
+    if (rc) return rc;
+    for (int r = 0; r < max_points; ++r)
+        hipLaunchKernelGGL(k_hard_round, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix,
+                           r == 0 ? (const int *)nullptr : mins + (size_t)(r - 1) * cap, mins + (size_t)r * cap);
+    const dim3 ge(stream_grid((long)cap * (c_dst / 8), 256));
+    if (math == 0)
+        hipLaunchKernelGGL(k_level_emit_mean<0>, ge, dim3(256), 0, stream, points, c, mins, cap, max_points, d_m, feats, c_dst);
+    else if (math == 1)
+        hipLaunchKernelGGL(k_level_emit_mean<1>, ge, dim3(256), 0, stream, points, c, mins, cap, max_points, d_m, feats, c_dst);
+    else
+        hipLaunchKernelGGL(k_level_emit_mean<2>, ge, dim3(256), 0, stream, points, c, mins, cap, max_points, d_m, feats, c_dst);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
 }
 
 int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int cap, int max_points, int c, float *out,

@@ -288,7 +288,7 @@ class VoxelResBackBone8x(_Cached):
         y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
         return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
-    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None):
+    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None, level1=None):
         """Everything of the backbone that depends only on voxel COORDINATES: the level-1 index + feature scatter and
         the output sets / bitmaps / neighbour tables of every stage.  Returns {'x': level-1 rows, 'steps': [...]}.
 
@@ -302,10 +302,14 @@ class VoxelResBackBone8x(_Cached):
         (FramePipeline.calibrate) keep large batches inside the 2 GiB buffer-addressing window.  Rows beyond a
         capacity are DROPPED by the kernels; pyr['overflow'] (device bool) reports it."""
         p = self.plan()
-        n = voxel_features.shape[0]
         dev = voxel_features.device
-        lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
-        rank = lvl1.build_from_coords(voxel_coords, d_n)
+        if level1 is None:
+            n = voxel_features.shape[0]
+            lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
+            rank = lvl1.build_from_coords(voxel_coords, d_n)
+        else:
+            # ops.voxelize_to_level already produced the level-1 index and its feature rows (voxel_features = those rows)
+            lvl1, rank = level1, None
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev, side_key) if overlap else main
         if overlap:
@@ -339,7 +343,7 @@ class VoxelResBackBone8x(_Cached):
                         t.record_stream(main)
             if overflow is not None:
                 overflow.record_stream(main)
-        x = ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
+        x = voxel_features if level1 is not None else ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
         pyr = {'x': x, 'steps': steps}
         if overflow is not None:
             pyr['overflow'] = overflow

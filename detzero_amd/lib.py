@@ -53,6 +53,9 @@ _SIGS = {
     'dz_voxelize_hard_batched_workspace_bytes': (c_size_t, [c_int] * 6),
     'dz_voxelize_hard_mean_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                               c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dz_voxelize_to_level_workspace_bytes': (c_size_t, [c_int] * 7),
+    'dz_voxelize_to_level': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'dz_mean_vfe': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_voxelize_dynamic_workspace_bytes': (c_size_t, [c_int] * 7),
     'dz_voxelize_dynamic_mean': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -89,6 +89,28 @@ def voxelize_hard_mean_batched(points, batch, pc_range, voxel_size, max_points, 
     return feats, coords, d_num
 
 
+def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxels, level_shape, c_dst, math=0, xy_range_mask=False):
+    """points (batch*n, C), equally long frames back to back, n <= max_voxels -> (SparseLevel of the frames' voxels, level-1
+    feature rows (cap, c_dst) fp32 or pair16): hard voxelizer + MeanVFE + sparse-tensor construction in one launch chain."""
+    lib = L.load()
+    L.require_cuda(points)
+    n_tot, c = points.shape
+    n_per = n_tot // batch
+    assert n_per * batch == n_tot
+    grid = grid_size_of(pc_range, voxel_size)
+    assert [int(level_shape[1]), int(level_shape[2])] == [int(grid[1]), int(grid[0])], (level_shape, grid)
+    cap = batch * max(min(int(max_voxels), n_per), 1)
+    lvl = SparseLevel(batch, level_shape, cap, points.device)
+    feats = torch.empty((cap, c_dst), dtype=torch.float32, device=points.device)
+    ws = _ws(lib.dz_voxelize_to_level_workspace_bytes(n_per, batch, max_points, cap, *lvl.shape))
+    rc = lib.dz_voxelize_to_level(L.ptr(points), n_per, batch, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid),
+                                  1 if xy_range_mask else 0, max_points, int(max_voxels), lvl.shape[0], L.ptr(lvl.bitmap),
+                                  L.ptr(lvl.prefix), L.ptr(lvl.coords), L.ptr(lvl.d_m), cap, L.ptr(feats), c_dst, int(math),
+                                  L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_voxelize_to_level')
+    return lvl, feats
+
+
 def voxelize_hard(points, pc_range, voxel_size, max_points, max_voxels):
     voxels, coords, nump, d_num = voxelize_hard_nosync(points, pc_range, voxel_size, max_points, max_voxels)
     m = int(d_num.item())

@@ -69,6 +69,17 @@ int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batc
                                   const float *h_vsize3, const int *h_grid3, int xy_range_mask, int max_points,
                                   int max_voxels, float *feats, int c_stride, int *coords_bzyx, int cap_per_frame,
                                   int *d_num_voxels, void *ws, size_t ws_bytes, void *stream);
+/* Voxelize a batch straight into the level-1 sparse index of the backbone (data_processor.py:61-91 + vfe.py:66-83 +
+ * the SparseConvTensor construction of backbone3d.py:302-307 in one chain): fills the level's bitmap / prefix /
+ * canonical coordinates / count (the arrays dz_index_from_coords would produce for the frames' voxels, level shape
+ * (level_d, gy, gx)) and writes every voxel's mean to its canonical row of `feats` (cap, c_dst), channels >= c zero,
+ * fp32 (math 0) or pair16.  Valid only when a frame cannot exceed max_voxels (n_per_frame <= max_voxels; otherwise
+ * DZ_ERR_UNSUPPORTED: the first-appearance cut of the reference needs dz_voxelize_hard_mean_batched). */
+size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w);
+int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c, const float *h_range6,
+                         const float *h_vsize3, const int *h_grid3, int xy_range_mask, int max_points, int max_voxels,
+                         int level_d, uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap, float *feats,
+                         int c_dst, int math, void *ws, size_t ws_bytes, void *stream);
 
 /* MeanVFE.forward — detection/detzero_det/models/centerpoint_modules/vfe.py:66-83.
  * out (m, c_out_stride) f32: columns [0,c) = sum over slots / max(num_points,1); columns

@@ -277,3 +277,21 @@ def test_calibrated_capacities_and_overflow_flag(small, device):
     cal.level_caps = [64, 64, 64, 64]
     cal(frames)
     assert bool(cal.last_overflow.item())
+
+
+@pytest.mark.parametrize('math', ['f32', 'f16x2'])
+def test_stacked_equal_length_batch_equals_single_frames(device, math):
+    """A (B,N,C) tensor of equally long frames takes the fused route (voxelize straight into the level-1 index, one
+    launch chain for the batch); every frame's detections equal the single-frame pipeline's bit for bit."""
+    from detzero_amd.centerpoint import FramePipeline, set_math
+    from detzero_amd.synth import synth_waymo_frame
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
+    model = model.to(device)
+    pipe = FramePipeline(model, info, math=math)
+    stack = torch.stack([torch.from_numpy(synth_waymo_frame(70 + i, 20000)) for i in range(3)]).to(device)
+    out, cnt = pipe(stack)
+    for i in range(3):
+        o1, n1 = pipe(stack[i])
+        n = int(n1.item())
+        assert n > 0 and int(cnt[i].item()) == n and torch.equal(out[i, :n], o1[:n])
+    set_math(model, 'f32')

@@ -451,3 +451,25 @@ def test_voxelize_hard_mean_batched_equals_per_frame(device, max_voxels):
         vox, zyx, nump, dn = ops.voxelize_hard_nosync(f, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, max_voxels, xy_range_mask=True)
         mean = ops.mean_vfe(vox, nump, d_m=dn)
         assert int(dn.item()) == m and torch.equal(mean[:m], fi[:m]) and torch.equal(zyx[:m], ci[:m, 1:])
+
+
+@pytest.mark.parametrize('math', [0, 1])
+def test_voxelize_to_level_equals_voxelize_index_scatter(device, math):
+    """The fused batch voxelizer -> level-1 index equals hard voxelizer + MeanVFE + dz_index_from_coords + dz_scatter_rows
+    bit for bit: same bitmap, prefix, canonical coordinates, count and feature rows (fp32 and pair16)."""
+    from detzero_amd import ops
+    n, b = 30000, 3
+    frames = [_t(synth_waymo_frame(50 + i, n), device) for i in range(b)]
+    shape = [41, 752, 752]                           # VOXEL_SIZE_02 grid (752,752,40) + 1 in z
+    lvl, x = ops.voxelize_to_level(torch.cat(frames, 0), b, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000, shape, 16, math=math,
+                                   xy_range_mask=True)
+    feats, coords, d_num = ops.voxelize_hard_mean_batched(torch.cat(frames, 0), b, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000, n,
+                                                          xy_range_mask=True)
+    ref = ops.SparseLevel(b, shape, b * n, device)
+    rank = ref.build_from_coords(coords)
+    xr = ops.scatter_rows(feats, rank, 16, ref.cap, None, math=math)
+    m = ref.num_active()
+    assert lvl.num_active() == m == int(d_num.sum().item()) and m > 10000
+    assert torch.equal(lvl.bitmap, ref.bitmap) and torch.equal(lvl.prefix, ref.prefix)
+    assert torch.equal(lvl.coords[:m], ref.coords[:m])
+    assert torch.equal(x[:m].view(torch.int32), xr[:m].view(torch.int32))
