@@ -48,32 +48,47 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wp = wid >> 1, wc = wid & 1;                                   // image-row pair, channel half
-    // XCD-aware order (see conv2d_h.hip): contiguous band of tiles per XCD, channel tiles of a pixel tile adjacent
+    // Persistent workgroups, XCD-aware: the dispatcher places workgroup b on XCD b % 8 (own L2 each); XCD k walks the k-th
+    // contiguous eighth of the pixel tiles, its workgroups side by side (neighbouring tiles share halo rows in that L2).
+    // A workgroup keeps ONE channel tile (its weight stream simply wraps around from tile to tile) and the load pipeline
+    // never drains between tiles: the next tile's input is prefetched during the last channel chunk of the current one.
     const int nty = p.cout_pad / BC;
-    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int n0 = (lid % nty) * BC;
-    int rest = lid / nty;
-    const int tx = rest % tiles_x; rest /= tiles_x;
-    const int tyt = rest % tiles_y;
-    const int b = rest / tiles_y;
-    const int x0 = tx * C3_TW, y0 = tyt * C3_TH;
+    const int npx = p.batch * tiles_x * tiles_y;                 // pixel tiles
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, nj = gridDim.x >> 3;      // gridDim.x is a multiple of 8
+    const int n0 = (jloc % nty) * BC;
+    const int per_xcd = (npx + 7) >> 3;
+    const int band_lo = xcd * per_xcd, band_hi = min(npx, band_lo + per_xcd);
+    const int tstep = nj / nty;                                   // workgroups of this XCD that share my channel tile
+    int tile = band_lo + jloc / nty;
+    if (tstep == 0 || tile >= band_hi) return;
 
     const srsrc_t prsrc = make_srsrc(p.in, in_bytes);
     const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
-    // input pieces of the tile: pixel (y0 + in_off + ry, x0 + in_off + rx) of the padded image, rx < 34, ry < 10
-    unsigned int pvoff[C3_PXPT];
+    int x0, y0, b;
+    auto tile_origin = [&](int t, int &ox, int &oy, int &ob) {
+        ox = (t % tiles_x) * C3_TW;
+        oy = ((t / tiles_x) % tiles_y) * C3_TH;
+        ob = t / (tiles_x * tiles_y);
+    };
+    // input pieces of a tile: pixel (y0 + in_off + ry, x0 + in_off + rx) of the padded image, rx < 34, ry < 10
+    auto tile_offsets = [&](int t, unsigned int (&off)[C3_PXPT]) {
+        int ox, oy, ob;
+        tile_origin(t, ox, oy, ob);
 #pragma unroll
-    for (int i = 0; i < C3_PXPT; ++i) {
-        const int idx = tid + i * C3_THREADS;
-        pvoff[i] = OOB_OFFSET;
-        if (idx < C3_PX_PIECES) {
-            const int r = idx / (C3_KC / 4), q = idx % (C3_KC / 4);
-            const int iy = y0 + p.in_off + r / C3_PXW, ix = x0 + p.in_off + r % C3_PXW;
-            if (iy < p.in_hp && ix < p.in_wp)
-                pvoff[i] = (unsigned int)((((long)(b * p.in_hp + iy) * p.in_wp + ix) * p.in_cstride + p.in_coff + q * 4) * 4);
+        for (int i = 0; i < C3_PXPT; ++i) {
+            const int idx = tid + i * C3_THREADS;
+            off[i] = OOB_OFFSET;
+            if (idx < C3_PX_PIECES) {
+                const int r = idx / (C3_KC / 4), q = idx % (C3_KC / 4);
+                const int iy = oy + p.in_off + r / C3_PXW, ix = ox + p.in_off + r % C3_PXW;
+                if (iy < p.in_hp && ix < p.in_wp)
+                    off[i] = (unsigned int)((((long)(ob * p.in_hp + iy) * p.in_wp + ix) * p.in_cstride + p.in_coff + q * 4) * 4);
+            }
         }
-    }
+    };
+    unsigned int pvoff[C3_PXPT], pvoff_next[C3_PXPT];
+    tile_offsets(tile, pvoff);
+    bool has_next = tile + tstep < band_hi;
     unsigned int cvoff[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -87,18 +102,23 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     v4u wst[C3_NS][WPT];          // weight stages: chunk j lives in stage j % 3 == tap % 3
     v4u pst[C3_PXPT];             // input tile of the next channel chunk
     auto issue_w = [&](v4u (&st)[WPT], int chunk) {
-        // chunk = kc * 9 + tap; past the end: out-of-range offsets (zeros come back, nothing is fetched, counts stay uniform)
+        // chunk = kc * 9 + tap of the current tile; past its end the stream wraps to the next tile's chunks (same
+        // weights), or - after the last tile - to out-of-range offsets (zeros come back, nothing is fetched; the
+        // per-wave load counts stay uniform)
+        if (chunk >= nchunks) chunk = has_next ? chunk - nchunks : -1;
         const int kc = chunk / 9, tap = chunk - kc * 9;
-        const unsigned int add = chunk < nchunks ? (unsigned int)tap * tap_bytes + (unsigned int)(kc * C3_KC * 4) : OOB_OFFSET;
+        const unsigned int add = chunk >= 0 ? (unsigned int)tap * tap_bytes + (unsigned int)(kc * C3_KC * 4) : OOB_OFFSET;
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[i]) : "v"(cvoff[i] + add), "s"(crsrc));
     };
     auto issue_px = [&](int kc) {
-        const unsigned int add = kc < nk ? (unsigned int)(kc * C3_KC * 4) : OOB_OFFSET;
+        // input tile of channel chunk kc; kc == nk: chunk 0 of the next tile
 #pragma unroll
-        for (int i = 0; i < C3_PXPT; ++i)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pst[i]) : "v"(pvoff[i] + add), "s"(prsrc));
+        for (int i = 0; i < C3_PXPT; ++i) {
+            const unsigned int off = kc < nk ? pvoff[i] + (unsigned int)(kc * C3_KC * 4) : (has_next ? pvoff_next[i] : OOB_OFFSET);
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc));
+        }
     };
     auto own_w = [&](v4u (&st)[WPT]) {
 #pragma unroll
@@ -173,12 +193,15 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     Frag f0, f1;
     load_frag(f0, 0, 0, 0);
 
-    for (int kc = 0; kc < nk; ++kc) {
+    int kcg = 0;                                                 // channel chunks done so far, over all tiles (LDS buffer parity)
+    for (;;) {
+    if (has_next) tile_offsets(tile + tstep, pvoff_next);
+    for (int kc = 0; kc < nk; ++kc, ++kcg) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             constexpr int NW2 = 2 * WPT;                         // two younger weight stages stay in flight
             const int cur = t & 1;                               // 9 taps: the buffer parity flips every chunk, and
-            const int buf = (kc & 1) ? (cur ^ 1) : cur;          // every channel chunk (9 is odd)
+            const int buf = (kcg & 1) ? (cur ^ 1) : cur;         // every channel chunk (9 is odd)
             const int c = kc * 9 + t;
             // ---- phase 1: k-step-1 fragments, weights of chunk c+1 to the other LDS buffer, MFMAs of k-step 0
             load_frag(f1, t, buf, 1);
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
             interleave_hint<0x100, 2 * (2 + CT), 1>();
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)");      // drain the dummy tail loads before the epilogue's own memory traffic
+    tile_origin(tile, x0, y0, b);
 
     // ---- epilogue: 32x32 accumulator: pixel column = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
     const int h = lane >> 5;
@@ -247,6 +270,20 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
             }
         }
     }
+    // ---- next tile: its first input chunk is already in LDS, its first weight slices are in flight
+    if (!has_next) break;
+    tile += tstep;
+#pragma unroll
+    for (int i = 0; i < C3_PXPT; ++i) pvoff[i] = pvoff_next[i];
+    has_next = tile + tstep < band_hi;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)");      // nothing of this file's asm loads may stay in flight at exit
 }
 
 template <int BC, class M, bool OUT_F32>
@@ -267,7 +304,12 @@ static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream
         }
         attr_set = true;
     }
-    const long grid = (long)p.batch * tiles_x * tiles_y * (p.cout_pad / BC);
+    // persistent: one 512-thread workgroup per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
+    // workgroups of every channel tile
+    const int nty = p.cout_pad / BC;
+    int per_xcd = 32 / nty * nty;
+    if (per_xcd < nty) per_xcd = nty;
+    const long grid = 8L * per_xcd;
     hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32>), dim3((unsigned int)grid), dim3(C3_THREADS), C::LDS_BYTES, stream, p, tiles_x,
                        tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes);
     DZ_LAUNCH_CHECK();
