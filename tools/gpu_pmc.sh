@@ -11,4 +11,4 @@ cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/gpu
 tail -3 gpurun_out/prof/pmc_${TAG}_stdout.txt
 python tools/rocpd_summary.py gpurun_out/prof/pmc_$TAG/bench_results.db | sed -n '/PMC/,$p' > gpurun_out/prof/pmc_${TAG}_summary.txt
 grep -E "k_spconv|k_conv2d" gpurun_out/prof/pmc_${TAG}_summary.txt | head -80
-find gpurun_out/prof -size +20M -delete
+find gpurun_out/prof -name "*.db" -delete

@@ -33,4 +33,4 @@ cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpu
 python tools/rocpd_summary.py gpurun_out/prof/pmc_$c/bench_results.db --json gpurun_out/prof/pmc_$c.json | sed -n '/PMC/,$p' > gpurun_out/prof/pmc_${c}_summary.txt; head -12 gpurun_out/prof/pmc_${c}_summary.txt
 done
 fi
-find gpurun_out/prof -size +20M -delete
+find gpurun_out/prof -name "*.db" -delete

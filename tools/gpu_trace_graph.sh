@@ -7,4 +7,4 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/p
 tail -2 gpurun_out/prof/traceg_stdout.txt | cut -c1-200
 python tools/trace_timeline.py gpurun_out/prof/traceg/bench_results.db 2 > gpurun_out/prof/traceg_timeline.txt
 tail -1 gpurun_out/prof/traceg_timeline.txt
-find gpurun_out/prof -size +20M -delete
+find gpurun_out/prof -name "*.db" -delete

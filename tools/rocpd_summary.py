@@ -12,6 +12,7 @@ def short(name):
     name = name.replace('void ', '').replace('dz::', '')
     name = re.sub(r'TileCfg<(\d+), (\d+), (\d+), \d+, \d+>', r'\1x\2x\3', name)
     name = re.sub(r'<HTile<(\d+), (\d+), (\d+), \d+, \d+>, Math(\w+?)(, \w+)*>', r'<\1x\2x\3>[\4]', name)
+    name = re.sub(r'k_conv3x3_h<(\d+), Math(\w+?), \w+>', r'k_conv3x3_h<8x32x\1>[\2]', name)
     return name[:90]
 
 
