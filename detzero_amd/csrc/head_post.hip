@@ -541,11 +541,114 @@ __global__ __launch_bounds__(256) void k_points_in_boxes(const float *__restrict
     }
 }
 
+// ---- object crop with compaction (daemon/prepare_object_data.py:250-273,310) -------------------------------------
+// The reference builds the dense (T, M) int mask, copies it to the host and boolean-indexes the point array once per
+// object.  Here the mask is a BITMAP (T rows of M bits, one __ballot per wavefront and box), the bitmap scan of
+// sparse_index.hip ranks its set bits in (box, point) order - exactly the order of `[pts[mask[i]] for i in boxes]` -
+// and one gather writes every object's points back to back; per-object offsets are the ranks at the row starts.
+__global__ __launch_bounds__(256) void k_points_in_boxes_bits(const float *__restrict__ boxes, const float *__restrict__ pts,
+                                                              int t, int m, int row_words, uint32_t *__restrict__ bitmap) {
+    __shared__ float sb[64 * 9];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < m) { x = pts[(size_t)i * 3]; y = pts[(size_t)i * 3 + 1]; z = pts[(size_t)i * 3 + 2]; }
+    for (int base = 0; base < t; base += 64) {
+        const int nb = min(64, t - base);
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const float *q = boxes + (size_t)(base + threadIdx.x) * 7;
+            float *d = sb + threadIdx.x * 9;
+            for (int j = 0; j < 7; ++j) d[j] = q[j];
+            d[7] = cosf(-q[6]);
+            d[8] = sinf(-q[6]);
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const float *q = sb + k * 9;
+            bool in = false;
+            if (i < m && !((double)fabsf(z - q[2]) > (double)q[5] / 2.0)) {       // same test as k_points_in_boxes
+                const float sx = x - q[0], sy = y - q[1];
+                const float lx = sx * q[7] + sy * (-q[8]);
+                const float ly = sx * q[8] + sy * q[7];
+                in = ((double)fabsf(lx) < (double)q[3] / 2.0 + (double)1e-5f) && ((double)fabsf(ly) < (double)q[4] / 2.0 + (double)1e-5f);
+            }
+            const unsigned long long bits = __ballot(in);
+            if (lane == 0) {
+                uint32_t *w = bitmap + (size_t)(base + k) * row_words + (i >> 5);
+                w[0] = (uint32_t)bits;
+                w[1] = (uint32_t)(bits >> 32);
+            }
+        }
+    }
+}
+
+// one thread per (kept point, payload word)
+__global__ void k_crop_gather(const int *__restrict__ pairs, const int *__restrict__ d_total, int cap, const uint32_t *__restrict__ payload,
+                              int words, uint32_t *__restrict__ out, int *__restrict__ out_index, const uint32_t *__restrict__ prefix,
+                              int t, int row_words, int *__restrict__ offsets) {
+    const int total = min(*d_total, cap);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid <= t) offsets[gid] = gid < t ? (int)prefix[(size_t)gid * row_words] : *d_total;
+    for (long idx = gid; idx < (long)total * words; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / words), wq = (int)(idx % words);
+        const int pt = pairs[(size_t)r * 4 + 3];                 // [box, 0, 0, point]
+        out[idx] = payload[(size_t)pt * words + wq];
+        if (wq == 0 && out_index) out_index[r] = pt;
+    }
+}
+
 }  // namespace dz
 
 using namespace dz;
 
 extern "C" {
+
+static size_t crop_layout(int m, int t, int cap, size_t *o_pf, size_t *o_pairs, size_t *o_sw, size_t *sw_bytes, int *row_words) {
+    const int rw = (int)align_up(((size_t)(m < 1 ? 1 : m) + 31) / 32, 8);          // 256-bit rows: rows stay word aligned
+    *row_words = rw;
+    const size_t nwords = (size_t)(t < 1 ? 1 : t) * rw;
+    size_t off = align_up(nwords * 4, 256);
+    *o_pf = off; off += align_up(nwords * 4, 256);
+    *o_pairs = off; off += align_up((size_t)(cap < 1 ? 1 : cap) * 16, 256);
+    *sw_bytes = bitmap_scan_workspace_bytes(nwords);
+    *o_sw = off; off += align_up(*sw_bytes, 256);
+    return off;
+}
+
+size_t dz_crop_points_workspace_bytes(int m, int t, int cap) {
+    size_t a, b, c, d; int rw;
+    return crop_layout(m, t, cap, &a, &b, &c, &d, &rw);
+}
+
+int dz_crop_points_in_boxes(const float *xyz, int m, const float *boxes, int t, const void *payload, int payload_words, void *out,
+                            int *out_index, int *offsets, int *d_total, int cap, void *ws, size_t ws_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(m >= 0 && t >= 0 && cap >= 0 && payload_words >= 1, "dz_crop_points_in_boxes: bad sizes");
+    DZ_CHECK_ARG(offsets && d_total && ws, "dz_crop_points_in_boxes: null pointer");
+    DZ_CHECK_ARG((size_t)t * (((size_t)m + 255) / 256 * 256) < 0xFFFFFFFFull, "dz_crop_points_in_boxes: boxes x points exceed 2^32 mask bits");
+    size_t o_pf, o_pairs, o_sw, sw_bytes; int rw;
+    const size_t need = crop_layout(m, t, cap, &o_pf, &o_pairs, &o_sw, &sw_bytes, &rw);
+    if (ws_bytes < need) { set_error("dz_crop_points_in_boxes: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }
+    if (t == 0 || m == 0) {
+        int rc = fill_u32(offsets, 0u, (size_t)t + 1, stream);
+        return rc ? rc : fill_u32(d_total, 0u, 1, stream);
+    }
+    DZ_CHECK_ARG(xyz && boxes && payload && out, "dz_crop_points_in_boxes: null pointer");
+    uint32_t *bitmap = (uint32_t *)ws, *prefix = (uint32_t *)((char *)ws + o_pf);
+    int *pairs = (int *)((char *)ws + o_pairs);
+    const size_t nwords = (size_t)t * rw;
+    int rc = fill_u32(bitmap, 0u, nwords, stream);                      // words past the last point block of a row stay 0
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_points_in_boxes_bits, dim3(ceil_div(m, 256)), dim3(256), 0, stream, boxes, xyz, t, m, rw, bitmap);
+    rc = bitmap_scan(bitmap, nwords, prefix, d_total, 0, ScanDims{1, 1, rw * 32}, pairs, cap, (char *)ws + o_sw, sw_bytes, stream);
+    if (rc) return rc;
+    const long work = (long)cap * payload_words > t + 1 ? (long)cap * payload_words : t + 1;
+    hipLaunchKernelGGL(k_crop_gather, dim3(stream_grid(work, 256)), dim3(256), 0, stream, pairs, d_total, cap, (const uint32_t *)payload,
+                       payload_words, (uint32_t *)out, out_index, prefix, t, rw, offsets);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
 
 int dz_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -524,6 +524,26 @@ def points_in_boxes_v2(points, boxes):
     return mask
 
 
+def crop_points_in_boxes_nosync(xyz, boxes, payload, cap):
+    """xyz (M,3) f32, boxes (T,7) f32, payload (M,W) any 4-byte-multiple dtype -> (out (cap,W) payload dtype, index (cap,) i32,
+    offsets (T+1,) i32, d_total (1,) i32): the rows of the points inside box 0, then box 1, ... (ascending point index)."""
+    lib = L.load()
+    L.require_cuda(xyz, boxes, payload)
+    m, t = xyz.shape[0], boxes.shape[0]
+    words = payload.shape[1] * payload.element_size() // 4
+    assert payload.shape[0] == m and payload.shape[1] * payload.element_size() % 4 == 0
+    dev = xyz.device
+    out = torch.empty((max(cap, 1), payload.shape[1]), dtype=payload.dtype, device=dev)
+    index = torch.empty((max(cap, 1),), dtype=torch.int32, device=dev)
+    offsets = torch.zeros((t + 1,), dtype=torch.int32, device=dev)
+    d_total = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = _ws(lib.dz_crop_points_workspace_bytes(m, t, cap))
+    rc = lib.dz_crop_points_in_boxes(L.ptr(xyz), m, L.ptr(boxes), t, L.ptr(payload), words, L.ptr(out), L.ptr(index), L.ptr(offsets),
+                                     L.ptr(d_total), cap, L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_crop_points_in_boxes')
+    return out, index, offsets, d_total
+
+
 def mha_core(q, k, v, key_padding_mask, heads, scale):
     """q (B,Lq,E), k/v (B,Lk,E), mask (B,Lk) bool/uint8 or None -> (B,Lq,E)."""
     lib = L.load()

@@ -255,6 +255,17 @@ int dz_gather_rows(const float *src, const int *idx, const int *d_n, int n_cap, 
  * roiaware_pool3d_kernel.cu:352-374): mask (B,T,M) i32, 1 where point m is inside box t. */
 int dz_points_in_boxes_v2(const float *boxes, const float *pts, int batch, int t, int m, int *mask,
                           void *stream);
+/* Object crop with compaction - the consumer side of points_in_boxes_gpu_v2 in daemon/prepare_object_data.py:250-273,310
+ * (`obj_pts = pts[obj_pts_mask[idx, :]]` per object) without the dense (T, M) mask or its D2H copy.
+ *   xyz (m,3) f32: point coordinates used for the inside test (same test as dz_points_in_boxes_v2);
+ *   boxes (t,7) f32 (already enlarged by the caller); payload (m, payload_words) 32-bit words: the rows to gather
+ *   (e.g. 4 float64 = 8 words); out (cap, payload_words): the kept rows of box 0, then box 1, ... each in ascending
+ *   point order; out_index (cap) i32 or NULL: source point of every kept row; offsets (t+1) i32: row range of each
+ *   box; *d_total: number of kept rows (rows beyond cap are dropped, compare with cap). */
+size_t dz_crop_points_workspace_bytes(int m, int t, int cap);
+int dz_crop_points_in_boxes(const float *xyz, int m, const float *boxes, int t, const void *payload, int payload_words,
+                            void *out, int *out_index, int *offsets, int *d_total, int cap, void *ws, size_t ws_bytes,
+                            void *stream);
 
 /* multi_head_attention_forward core (refining/detzero_refine/models/transformer/
  * multi_head_attention.py:207-288): q (B,Lq,E), k,v (B,Lk,E) already projected, E = heads*32;
