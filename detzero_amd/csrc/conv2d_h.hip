@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     unsigned int padd = 0, cadd = 0;
     const unsigned int tap_bytes = (unsigned int)((long)p.cout_pad * p.cin * 4);
     unsigned int tap_base = 0;
-    auto issue = [&](HStage<T> &st) { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
+    auto issue = [&](HStage<T> &st, auto) { load_hstage<T>(st, prsrc, pvoff, padd, crsrc, cvoff, cadd); };
     // chunk order: channel chunk outermost, then ky, kx innermost - the kx taps of one image row re-read the same
     // cache lines shifted by one pixel, back to back, while they are still in the CU's L1
     auto advance = [&]() {

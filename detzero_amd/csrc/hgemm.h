@@ -196,7 +196,10 @@ __device__ __forceinline__ void store_hstage(const HStage<T> &st, v4u *__restric
 //   barrier
 //   phase 2 = MFMAs of k-step 1 || LDS reads of chunk c+1 || global loads of chunk c+1+NS into the stage just freed
 // `issue(stage)` loads the chunk the caller's iterator points at, `advance()` moves the iterator (chunk order).
-template <class T, class M, int NS, class Issue, class Advance>
+// `issue(stage, slot)` loads the chunk the caller's iterator points at (slot = std::integral_constant<int, chunk % NS>, the
+// static index of `stage`); it may issue EXTRA further loads AFTER the stage's NST ones in every call (the sparse conv's
+// neighbour-list prefetch) - the vmcnt bookkeeping below accounts for them.
+template <class T, class M, int NS, int EXTRA = 0, class Issue, class Advance>
 __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ smem, Issue &&issue, Advance &&advance,
                                                f32x16 (&acc)[T::CT][T::PT], int wp, int wc, int lane, int tid) {
     v4u *const Ps0 = smem, *const Cs0 = smem + 2 * T::PS_U4;          // [2][PS], [2][CS]
@@ -214,7 +217,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
 
     static_assert(NS >= 1 && NS <= 4, "1..4 register stages");
     HStage<T> st[NS];
-    issue(st[0]);
+    issue(st[0], std::integral_constant<int, 0>{});
     wait_hstage<T, 0>(st[0]);
     store_hstage<T>(st[0], Ps0, Cs0, tid);
     __syncthreads();
@@ -222,13 +225,21 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
     // compiler's s_waitcnt vmcnt(N) bookkeeping knows exactly NS stages are in flight at the loop header (with
     // conditional prefetches it falls back to vmcnt(0) there, which serialises the pipeline again)
     const bool steady = nchunks > 2 * NS;
+    auto issue_at = [&](auto j_t) {
+        constexpr int S = decltype(j_t)::value % NS;
+        advance();
+        issue(st[S], std::integral_constant<int, S>{});
+    };
     if (steady) {
-#pragma unroll
-        for (int j = 1; j <= NS; ++j) { advance(); issue(st[j % NS]); }
+        issue_at(std::integral_constant<int, 1>{});
+        if (NS >= 2) issue_at(std::integral_constant<int, 2>{});
+        if (NS >= 3) issue_at(std::integral_constant<int, 3>{});
+        if (NS >= 4) issue_at(std::integral_constant<int, 4>{});
     } else {
-#pragma unroll
-        for (int j = 1; j <= NS; ++j)
-            if (j < nchunks) { advance(); issue(st[j % NS]); }
+        if (1 < nchunks) issue_at(std::integral_constant<int, 1>{});
+        if (NS >= 2 && 2 < nchunks) issue_at(std::integral_constant<int, 2>{});
+        if (NS >= 3 && 3 < nchunks) issue_at(std::integral_constant<int, 3>{});
+        if (NS >= 4 && 4 < nchunks) issue_at(std::integral_constant<int, 4>{});
     }
     HFrag<T> f0, f1;
     load_hfrag<T>(f0, Ps0 + poff, Cs0 + coff, 0);
@@ -243,7 +254,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
         // scheduler hoists the MFMAs above the staging and the LDS-write latency lands in front of the barrier)
         if (Q == 2) load_hfrag<T>(f1, Pc, Cc, 1);
         if (ALL) {
-            wait_hstage<T, (NS - 1) * NST>(st[S]);     // steady state: the NS-1 younger stages stay in flight
+            wait_hstage<T, (NS - 1) * (NST + EXTRA) + EXTRA>(st[S]);     // steady state: the NS-1 younger stages stay in flight
             store_hstage<T>(st[S], Ps0 + (cur ^ 1) * T::PS_U4, Cs0 + (cur ^ 1) * T::CS_U4, tid);
         } else if (has1) {
             wait_hstage<T, 0>(st[S]);                  // tail: fewer stages may be in flight - drain
@@ -255,7 +266,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
         __syncthreads();
         // ---- phase 2
         if (ALL || has1) load_hfrag<T>(f0, Pn, Cn, 0);
-        if (ALL || has2) { advance(); issue(st[S]); }
+        if (ALL || has2) { advance(); issue(st[S], std::integral_constant<int, S>{}); }
         if (Q == 2) {
             __builtin_amdgcn_sched_barrier(0);
             mma_hfrag<T, M>(f1, acc);

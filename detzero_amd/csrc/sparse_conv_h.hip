@@ -14,6 +14,7 @@ constexpr int KVOL_MAX_H = 27;
 struct SpConvHArgs {
     const float *in;        // pair16 rows
     const int *nbr;
+    const uint32_t *tile_masks;  // per-64-row tap masks (dz_build_neighbors) or null
     const int *d_m_out;
     const float *w;         // (kvol, cout_pad, cin) pair16
     const float *scale;
@@ -21,15 +22,22 @@ struct SpConvHArgs {
     const float *residual;  // pair16 rows or null
     float *out;             // pair16 rows
     int cin, cout, cout_pad, kvol, cap, relu;
-    unsigned int in_bytes, w_bytes;
+    unsigned int in_bytes, w_bytes, nbr_bytes;
 };
 
-template <class T, class M, int NS>
-__global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
+// GN = false: the tile's slice of the neighbour table is staged in LDS and scanned for its tap mask first.
+// GN = true (tile_masks given): no table in LDS and no per-tile scan - the tap mask comes precomputed and each
+// thread fetches the neighbour index of the rows it gathers straight from the table, NS chunks ahead of the gather
+// that uses it (a register ring, filled by EXTRA loads behind every stage's loads; see hgemm_pipeline).  Less LDS per
+// workgroup = more resident workgroups for the small-channel levels, and the tile prologue disappears.
+template <class T, class M, int NS, bool GN, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_spconv_h(SpConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
-    int *const nbr_s = reinterpret_cast<int *>(smem + T::LDS_U4);       // [kvol][BP]
+    int *const nbr_s = reinterpret_cast<int *>(smem + T::LDS_U4);       // [kvol][BP]   (GN = false only)
     __shared__ unsigned int mask_s;
+    constexpr int P = T::P_PER_THREAD;
+    constexpr int NST = T::P_PER_THREAD + T::C_PER_THREAD;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wp = wid / T::WC, wc = wid % T::WC;
@@ -39,6 +47,7 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
     const int n0 = blockIdx.y * T::BC;          // channel tile (cout_pad may be split over blockIdx.y)
     const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes);
     const srsrc_t crsrc = make_srsrc(a.w, a.w_bytes);
+    const srsrc_t nrsrc = make_srsrc(a.nbr, a.nbr_bytes);
     unsigned int cvoff[T::C_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < T::C_PER_THREAD; ++i) {
@@ -50,6 +59,7 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
         }
     }
     const unsigned int tap_bytes = (unsigned int)(a.cout_pad * a.cin * 4);
+    const unsigned int nbr_tap_bytes = (unsigned int)a.cap * 4u;
 
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (private L2 each).  Tiles are dealt to the XCDs
     // in runs of XRUN consecutive (spatially sorted) row tiles: a run shares its gathered neighbour rows in one L2,
@@ -62,19 +72,27 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
         if ((t / XRUN) * 8 * XRUN >= ntiles) break;
         if (tile >= ntiles) continue;
         const int row0 = tile * T::BP;
-        if (tid == 0) mask_s = 0u;
-        __syncthreads();
-        unsigned int local = 0u;
-        for (int idx = tid; idx < a.kvol * T::BP; idx += 256) {
-            const int k = idx / T::BP, r = idx % T::BP;
-            const int row = row0 + r;
-            const int v = (row < m) ? a.nbr[(size_t)k * a.cap + row] : -1;
-            nbr_s[idx] = v;
-            if (v >= 0) local |= 1u << k;
+        unsigned int taps;
+        if constexpr (GN) {
+            taps = 0u;
+#pragma unroll
+            for (int i = 0; i < T::BP / 64; ++i) taps |= a.tile_masks[tile * (T::BP / 64) + i];
+            taps = __builtin_amdgcn_readfirstlane(taps);
+        } else {
+            if (tid == 0) mask_s = 0u;
+            __syncthreads();
+            unsigned int local = 0u;
+            for (int idx = tid; idx < a.kvol * T::BP; idx += 256) {
+                const int k = idx / T::BP, r = idx % T::BP;
+                const int row = row0 + r;
+                const int v = (row < m) ? a.nbr[(size_t)k * a.cap + row] : -1;
+                nbr_s[idx] = v;
+                if (v >= 0) local |= 1u << k;
+            }
+            if (local) atomicOr(&mask_s, local);
+            __syncthreads();
+            taps = mask_s;
         }
-        if (local) atomicOr(&mask_s, local);
-        __syncthreads();
-        const unsigned int taps = mask_s;
 
         f32x16 acc[T::CT][T::PT];
 #pragma unroll
@@ -88,21 +106,6 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
         if (nchunks > 0) {
             unsigned int rem = taps;
             int tap = __ffs((int)rem) - 1, kc = 0;
-            auto issue = [&](HStage<T> &st) {
-                unsigned int pvoff[T::P_PER_THREAD];
-#pragma unroll
-                for (int i = 0; i < T::P_PER_THREAD; ++i) {
-                    const int idx = tid + i * T::THREADS;
-                    pvoff[i] = OOB_OFFSET;
-                    if (T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) {
-                        const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
-                        const int rb = nbr_s[tap * T::BP + rr];
-                        pvoff[i] = rb >= 0 ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
-                    }
-                }
-                load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
-                               (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
-            };
             // chunk order: channel chunk outermost, taps innermost - neighbouring taps gather mostly the same input
             // rows, so their KC-channel slices are re-read back to back while they are still in the CU's L1
             auto advance = [&]() {
@@ -110,7 +113,70 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
                 if (rem == 0u) { rem = taps; ++kc; }
                 tap = __ffs((int)rem) - 1;
             };
-            hgemm_pipeline<T, M, NS>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
+            if constexpr (GN) {
+                // neighbour-index ring: slot s holds the indices of the chunk that will be gathered into stage s next
+                int nb[NS][P];
+                unsigned int nvoff[P];          // byte offset of this thread's rows in one tap of the table
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const int idx = tid + i * T::THREADS;
+                    const int row = row0 + idx / (T::KC / 4);
+                    nvoff[i] = ((T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) && row < m) ? (unsigned int)row * 4u : OOB_OFFSET;
+                }
+                unsigned int rem_a = taps;                  // tap iterator of the ring: NS chunks ahead of (rem, tap)
+                int tap_a = __ffs((int)rem_a) - 1;
+                auto fetch_nbr = [&](int (&dst)[P]) {
+                    const unsigned int toff = (unsigned int)tap_a * nbr_tap_bytes;
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+                        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst[i]) : "v"(nvoff[i] == OOB_OFFSET ? OOB_OFFSET : nvoff[i] + toff), "s"(nrsrc));
+                    rem_a &= rem_a - 1;
+                    if (rem_a == 0u) rem_a = taps;          // keeps cycling past the last chunk: those fetches are never used
+                    tap_a = __ffs((int)rem_a) - 1;
+                };
+#pragma unroll
+                for (int s = 0; s < NS; ++s) fetch_nbr(nb[s]);
+                asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) asm volatile("" : "+v"(nb[s][i]));
+                auto issue = [&](HStage<T> &st, auto s_t) {
+                    constexpr int S = decltype(s_t)::value;
+                    // the fetch into slot S was issued NS calls ago, right behind that call's stage loads
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * (NST + P)));
+                    unsigned int pvoff[P];
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        asm volatile("" : "+v"(nb[S][i]));
+                        const int q = (tid + i * T::THREADS) % (T::KC / 4);
+                        const int rb = nb[S][i];
+                        pvoff[i] = (nvoff[i] != OOB_OFFSET && rb >= 0) ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
+                    }
+                    load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
+                                   (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
+                    fetch_nbr(nb[S]);
+                };
+                hgemm_pipeline<T, M, NS, P>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
+                __syncthreads();          // the next tile's first stage overwrites LDS buffer 0
+            } else {
+                auto issue = [&](HStage<T> &st, auto) {
+                    unsigned int pvoff[P];
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        const int idx = tid + i * T::THREADS;
+                        pvoff[i] = OOB_OFFSET;
+                        if (T::P_PIECES % T::THREADS == 0 || idx < T::P_PIECES) {
+                            const int rr = idx / (T::KC / 4), q = idx % (T::KC / 4);
+                            const int rb = nbr_s[tap * T::BP + rr];
+                            pvoff[i] = rb >= 0 ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
+                        }
+                    }
+                    load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
+                                   (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
+                };
+                hgemm_pipeline<T, M, NS>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
+            }
         }
 
         // accumulator of a 32x32 fragment: row = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
@@ -153,16 +219,22 @@ __global__ __launch_bounds__(256) void k_spconv_h(SpConvHArgs a) {
                 }
             }
         }
-        __syncthreads();  // nbr_s / mask_s are rewritten by the next tile
+        if constexpr (!GN) __syncthreads();  // nbr_s / mask_s are rewritten by the next tile
     }
 }
 
-template <class T, class M, int NS>
-static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
-    constexpr int LDS = T::LDS_BYTES + KVOL_MAX_H * T::BP * 4;
+// development knob: DZ_TUNE_<name>=<int> in the environment overrides a tile choice (read once)
+static int tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <class T, class M, int NS, bool GN, int OCC>
+static int launch_spconv_h_impl(const SpConvHArgs &a, hipStream_t stream) {
+    constexpr int LDS = T::LDS_BYTES + (GN ? 0 : KVOL_MAX_H * T::BP * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS, GN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", LDS);
             return DZ_ERR_HIP;
@@ -173,32 +245,37 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream) {
     if (grid > 2048) grid = 2048;
     grid = (grid + 7) & ~7;            // a multiple of 8: see the XCD schedule in the kernel
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((k_spconv_h<T, M, NS>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_spconv_h<T, M, NS, GN, OCC>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
-// development knob: DZ_TUNE_<name>=<int> in the environment overrides a tile choice (read once)
-static int tune(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
+// NS / NSG: register stages of the LDS-table and of the register-ring variant (the ring costs registers: one stage
+// less where the extra registers would cost a resident wave)
+// OCC / OCCG: the resident waves per SIMD the register allocation has to leave room for
+template <class T, class M, int NS, int NSG = NS, int OCC = 1, int OCCG = OCC>
+static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream, bool ring_ok = true) {
+    static const int no_gn = tune("DZ_TUNE_SPCONV_NOGN", 0);
+    if (a.tile_masks && a.nbr_bytes && !no_gn && ring_ok) return launch_spconv_h_impl<T, M, NSG, true, OCCG>(a, stream);
+    return launch_spconv_h_impl<T, M, NS, false, OCC>(a, stream);
 }
 
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
-    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4>(a, stream);
-    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3>(a, stream);
+    if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4, 3, 4, 5>(a, stream);
+    if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
         if (t64 == 1) return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 3>(a, stream);
         if (t64 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
-        return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
+        return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
         if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
         if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
         if (t128 == 3) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
-        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream);
+        // 128 -> 128 with all 27 taps runs at 2 waves/SIMD either way and measured 2-3 % faster with the LDS table
+        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
@@ -210,9 +287,9 @@ using namespace dz;
 
 extern "C" {
 
-int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, int kvol, int cap_out, const int *d_m_out,
-                            const float *w, const float *scale, const float *shift, const float *residual, int relu,
-                            float *out, int cout, int math, void *stream_) {
+int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, const uint32_t *tile_masks, int kvol, int cap_out,
+                            const int *d_m_out, const float *w, const float *scale, const float *shift, const float *residual,
+                            int relu, float *out, int cout, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(in && nbr && d_m_out && w && out, "dz_spconv_forward_split: null pointer");
     DZ_CHECK_ARG(kvol >= 1 && kvol <= KVOL_MAX_H, "dz_spconv_forward_split: kvol %d not in [1,27]", kvol);
@@ -226,8 +303,10 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
         set_error("dz_spconv_forward_split: input of %zu bytes exceeds the 2 GiB buffer-addressing limit", in_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
-    SpConvHArgs a{in, nbr, d_m_out, w, scale, shift, residual, out, cin, cout, cout_pad, kvol, cap_out, relu,
-                  (unsigned int)in_bytes, (unsigned int)w_bytes};
+    // the table is addressed through a buffer descriptor when it fits its 2 GiB window (else: staged through LDS)
+    const size_t nbr_bytes = (size_t)kvol * cap_out * sizeof(int);
+    SpConvHArgs a{in, nbr, tile_masks, d_m_out, w, scale, shift, residual, out, cin, cout, cout_pad, kvol, cap_out, relu,
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, nbr_bytes < 0x80000000ull ? (unsigned int)nbr_bytes : 0u};
     return math == DZ_MATH_F16X2 ? spconv_h_dispatch<MathF16>(a, stream) : spconv_h_dispatch<MathBF16>(a, stream);
 }
 

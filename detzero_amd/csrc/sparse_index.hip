@@ -292,26 +292,41 @@ __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__
                                                          const int *__restrict__ d_m_out, int cap_out,
                                                          const uint32_t *__restrict__ bitmap_in,
                                                          const uint32_t *__restrict__ prefix_in, int B, int D,
-                                                         int H, int W, ConvGeom g, int *__restrict__ nbr) {
+                                                         int H, int W, ConvGeom g, int *__restrict__ nbr,
+                                                         uint32_t *__restrict__ tile_masks) {
+    // tile_masks (optional): word o/64 collects, for 64 consecutive output rows, the kernel taps that have at least
+    // one neighbour - what the conv kernels need to skip empty taps without scanning the table again
     const int m = min(*d_m_out, cap_out);
     const int rows = g.k[0] * g.k[1];
-    const long total = (long)m * rows;
+    // rows padded to whole 64-row groups: a wavefront then works on ONE group (its lanes share the mask word)
+    const int m_pad = (m + 63) & ~63;
+    const long total = (long)m_pad * rows;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(idx % m);
-        const int zy = (int)(idx / m);
+        const int o = (int)(idx % m_pad);
+        const int zy = (int)(idx / m_pad);
         const int tz = zy / g.k[1], ty = zy % g.k[1];
-        const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
-        const int uz = c.y * g.s[0] - g.p[0] + tz;
-        const int uy = c.z * g.s[1] - g.p[1] + ty;
-        const bool row_ok = (unsigned)uz < (unsigned)D && (unsigned)uy < (unsigned)H;
-        const int base_x = c.w * g.s[2] - g.p[2];
-        const uint32_t row_key = (uint32_t)(((c.x * D + uz) * H + uy) * W);
-        for (int tx = 0; tx < g.k[2]; ++tx) {
-            const int ux = base_x + tx;
-            int v = -1;
-            if (row_ok && (unsigned)ux < (unsigned)W) v = bitmap_find(bitmap_in, prefix_in, row_key + (uint32_t)ux);
-            nbr[(size_t)((tz * g.k[1] + ty) * g.k[2] + tx) * cap_out + o] = v;
+        uint32_t bits = 0u;
+        if (o < m) {
+            const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
+            const int uz = c.y * g.s[0] - g.p[0] + tz;
+            const int uy = c.z * g.s[1] - g.p[1] + ty;
+            const bool row_ok = (unsigned)uz < (unsigned)D && (unsigned)uy < (unsigned)H;
+            const int base_x = c.w * g.s[2] - g.p[2];
+            const uint32_t row_key = (uint32_t)(((c.x * D + uz) * H + uy) * W);
+            for (int tx = 0; tx < g.k[2]; ++tx) {
+                const int ux = base_x + tx;
+                int v = -1;
+                if (row_ok && (unsigned)ux < (unsigned)W) v = bitmap_find(bitmap_in, prefix_in, row_key + (uint32_t)ux);
+                const int tap = (tz * g.k[1] + ty) * g.k[2] + tx;
+                nbr[(size_t)tap * cap_out + o] = v;
+                if (v >= 0) bits |= 1u << tap;
+            }
+        }
+        if (tile_masks) {       // uniform per launch; the loop bounds are wave-uniform too (total is a multiple of 64)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, d, 64);
+            if ((threadIdx.x & 63) == 0 && bits) atomicOr(&tile_masks[o >> 6], bits);
         }
     }
 }
@@ -436,15 +451,19 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
 
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
                        const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3, const int *h_s3,
-                       const int *h_p3, int *nbr, void *stream_) {
+                       const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(coords_out && d_m_out && bitmap_in && prefix_in && nbr, "dz_build_neighbors: null argument");
     ConvGeom g;
     DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_build_neighbors: bad kernel/stride/padding");
     if (cap_out == 0) return DZ_OK;
+    if (tile_masks) {
+        const int rc = fill_u32(tile_masks, 0u, (size_t)cap_out / 64 + 1, stream);
+        if (rc) return rc;
+    }
     const long work = (long)cap_out * g.k[0] * g.k[1];
     hipLaunchKernelGGL(k_build_neighbors, dim3(stream_grid(work, 256)), dim3(256), 0, stream, coords_out, d_m_out,
-                       cap_out, bitmap_in, prefix_in, b, d, h, w, g, nbr);
+                       cap_out, bitmap_in, prefix_in, b, d, h, w, g, nbr, tile_masks);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -341,6 +341,8 @@ class VoxelResBackBone8x(_Cached):
                 for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
                     if t is not None:
                         t.record_stream(main)
+                        if getattr(t, 'tile_masks', None) is not None:
+                            t.tile_masks.record_stream(main)
             if overflow is not None:
                 overflow.record_stream(main)
         x = voxel_features if level1 is not None else ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)

@@ -68,7 +68,7 @@ _SIGS = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                     c_void_p]),
     'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_spconv_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p, c_int, c_void_p]),
@@ -80,7 +80,7 @@ _SIGS = {
     'dz_pair16_from_f32': (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_pair16_to_f32': (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_void_p]),
     'dz_scatter_rows_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
-    'dz_spconv_forward_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+    'dz_spconv_forward_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),

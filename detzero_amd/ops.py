@@ -215,10 +215,12 @@ class SparseLevel:
         lib = L.load()
         kvol = k[0] * k[1] * k[2]
         nbr = torch.empty((kvol, max(out_level.cap, 1)), dtype=torch.int32, device=self.coords.device)
+        masks = torch.empty((max(out_level.cap, 1) // 64 + 1,), dtype=torch.int32, device=self.coords.device)
         rc = lib.dz_build_neighbors(L.ptr(out_level.coords), L.ptr(out_level.d_m), out_level.cap,
                                     L.ptr(self.bitmap), L.ptr(self.prefix), self.batch, *self.shape, L.i3(k),
-                                    L.i3(s), L.i3(p), L.ptr(nbr), L.stream())
+                                    L.i3(s), L.i3(p), L.ptr(nbr), L.ptr(masks), L.stream())
         L.check(rc, 'dz_build_neighbors')
+        nbr.tile_masks = masks        # per-64-row tap masks ride along with the table (consumed by spconv_forward)
         return nbr
 
 
@@ -262,7 +264,8 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
 
     def launch():
         if math:
-            rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m),
+            rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(getattr(nbr, 'tile_masks', None)),
+                                             kvol, cap, L.ptr(out_level.d_m),
                                              L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0,
                                              L.ptr(out), cout, int(math), L.stream())
         else:
