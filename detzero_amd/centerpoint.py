@@ -198,6 +198,7 @@ class FramePipeline:
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE
         self._streams = {}
         self.level_caps = None        # per-frame row capacities of the strided stages (None = worst case)
+        self._ws = {}                 # zero-bordered activation images of the dense stage, reused across steps
         self.last_overflow = None
 
     def _voxelize(self, frames, cid=0):
@@ -291,8 +292,9 @@ class FramePipeline:
         res = m.backbone3d.run_pyramid(prep)
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
-        concat = m.backbone2d.run(bev, nb)
-        head, h, w = self.head.run_convs(concat, nb)
+        with cp_modules.workspace(self._ws):
+            concat = m.backbone2d.run(bev, nb)
+            head, h, w = self.head.run_convs(concat, nb)
         boxes, scores, labels, keep, d_nk = self.head.decode_batched_nosync(head, h, w)
         return ops.pack_detections(boxes, scores, labels, keep, d_nk, self.post_max), d_nk
 

@@ -74,11 +74,11 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 &hi, uint2 &lo
     lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
-// BP pixels (MFMA N side) x BC output channels (MFMA M side), KC channels of one tap per chunk, 4 waves as WP x WC
+// BP pixels (MFMA N side) x BC output channels (MFMA M side), KC channels of one tap per chunk, 4 or 8 waves as WP x WC
 template <int BP_, int BC_, int KC_, int WP_, int WC_>
 struct HTile {
     static constexpr int BP = BP_, BC = BC_, KC = KC_, WP = WP_, WC = WC_;
-    static constexpr int THREADS = 256;
+    static constexpr int THREADS = 64 * WP_ * WC_;
     static constexpr int PT = BP / (32 * WP);             // 32-pixel fragments per wave
     static constexpr int CT = BC / (32 * WC);             // 32-channel fragments per wave
     static constexpr int ROW_U4 = KC / 4 + 1;             // LDS row stride in 16-byte units (+1: conflict-free ds_read_b128)
@@ -90,7 +90,7 @@ struct HTile {
     static constexpr int CS_U4 = BC * ROW_U4;
     static constexpr int LDS_U4 = 2 * (PS_U4 + CS_U4);    // double buffered
     static constexpr int LDS_BYTES = LDS_U4 * 16;
-    static_assert(WP * WC == 4, "4 waves per workgroup");
+    static_assert(WP * WC == 4 || WP * WC == 8, "4 or 8 waves per workgroup");
     static_assert(BP % (32 * WP) == 0 && BC % (32 * WC) == 0, "tile must split into 32x32 fragments");
     static_assert(KC == 16 || KC == 32, "KC is one or two 16-deep MFMA steps");
 };
@@ -206,14 +206,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
     constexpr int Q = T::KC / 16;
     const int poff = (wp * T::PT * 32 + (lane & 31)) * T::ROW_U4 + (lane >> 5) * 2;
     const int coff = (wc * T::CT * 32 + (lane & 31)) * T::ROW_U4 + (lane >> 5) * 2;
-    constexpr int MFMA_N = 3 * T::PT * T::CT;                       // MFMAs per k-step
-    constexpr int NLD = 2 * (T::PT + T::CT);                        // LDS reads per k-step
-    constexpr int NLDH = NLD < MFMA_N ? NLD : MFMA_N;
     constexpr int NST = T::P_PER_THREAD + T::C_PER_THREAD;          // staging loads / stores per chunk
-    constexpr int REST1 = MFMA_N - (Q == 2 ? NLD : 0);
-    constexpr int PER1 = (REST1 / NST) > 0 ? (REST1 / NST) : 1;
-    constexpr int REST2 = MFMA_N - NLD;
-    constexpr int PER2 = (REST2 / NST) > 0 ? (REST2 / NST) : 1;
 
     static_assert(NS >= 1 && NS <= 4, "1..4 register stages");
     HStage<T> st[NS];

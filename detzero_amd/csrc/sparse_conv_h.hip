@@ -31,7 +31,7 @@ struct SpConvHArgs {
 // that uses it (a register ring, filled by EXTRA loads behind every stage's loads; see hgemm_pipeline).  Less LDS per
 // workgroup = more resident workgroups for the small-channel levels, and the tile prologue disappears.
 template <class T, class M, int NS, bool GN, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void k_spconv_h(SpConvHArgs a) {
+__global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void k_spconv_h(SpConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
     int *const nbr_s = reinterpret_cast<int *>(smem + T::LDS_U4);       // [kvol][BP]   (GN = false only)
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     // tile cost follows the local point density)
     constexpr int XRUN = 16;
     const int xcd = blockIdx.x & 7;
+    // (a ticket counter per XCD instead of this static deal was measured: the ticket's round trip per tile costs more
+    // than the idle tails it removes)
     for (int t = blockIdx.x >> 3;; t += gridDim.x >> 3) {
         const int tile = ((t / XRUN) * 8 + xcd) * XRUN + t % XRUN;
         if ((t / XRUN) * 8 * XRUN >= ntiles) break;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
             if (tid == 0) mask_s = 0u;
             __syncthreads();
             unsigned int local = 0u;
-            for (int idx = tid; idx < a.kvol * T::BP; idx += 256) {
+            for (int idx = tid; idx < a.kvol * T::BP; idx += T::THREADS) {
                 const int k = idx / T::BP, r = idx % T::BP;
                 const int row = row0 + r;
                 const int v = (row < m) ? a.nbr[(size_t)k * a.cap + row] : -1;
@@ -245,7 +247,7 @@ static int launch_spconv_h_impl(const SpConvHArgs &a, hipStream_t stream) {
     if (grid > 2048) grid = 2048;
     grid = (grid + 7) & ~7;            // a multiple of 8: see the XCD schedule in the kernel
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((k_spconv_h<T, M, NS, GN, OCC>), dim3(grid, a.cout_pad / T::BC), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_spconv_h<T, M, NS, GN, OCC>), dim3(grid, a.cout_pad / T::BC), dim3(T::THREADS), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -267,15 +269,18 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
         if (t64 == 1) return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 3>(a, stream);
+        if (t64 == 3) return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
         if (t64 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
-        return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);
+        if (t64 == 5) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);
+        return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);          // 8 waves of 32 x 32
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
         if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
         if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
         if (t128 == 3) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
-        // 128 -> 128 with all 27 taps runs at 2 waves/SIMD either way and measured 2-3 % faster with the LDS table
-        return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));
+        if (t128 == 5) return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 4, 4, 2, 2>(a, stream);
+        if (t128 == 6) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));
+        return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);        // 8 waves of 32 x 64
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
@@ -314,8 +319,8 @@ const char *dz_spconv_variant_split(int cin, int cout) {
     const int cout_pad = cout < 32 ? 32 : cout;
     if (cin == 16 && cout_pad == 32) return "k_spconv_h<128x32x16>";
     if (cin == 32 && cout_pad == 32) return "k_spconv_h<128x32x32>";
-    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<64x64x32>";
-    if ((cin == 64 || cin == 128) && cout_pad == 128) return "k_spconv_h<64x128x32>";
+    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<128x64x32>";
+    if ((cin == 64 || cin == 128) && cout_pad == 128) return "k_spconv_h<128x128x32>";
     return "none";
 }
 

@@ -449,6 +449,8 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
     return DZ_OK;
 }
 
+int dz_tile_masks_words(int cap_out) { return cap_out < 0 ? 0 : tile_masks_words(cap_out); }
+
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
                        const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3, const int *h_s3,
                        const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream_) {
@@ -458,7 +460,7 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
     DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_build_neighbors: bad kernel/stride/padding");
     if (cap_out == 0) return DZ_OK;
     if (tile_masks) {
-        const int rc = fill_u32(tile_masks, 0u, (size_t)cap_out / 64 + 1, stream);
+        const int rc = fill_u32(tile_masks, 0u, (size_t)tile_masks_words(cap_out), stream);
         if (rc) return rc;
     }
     const long work = (long)cap_out * g.k[0] * g.k[1];

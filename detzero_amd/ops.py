@@ -215,7 +215,7 @@ class SparseLevel:
         lib = L.load()
         kvol = k[0] * k[1] * k[2]
         nbr = torch.empty((kvol, max(out_level.cap, 1)), dtype=torch.int32, device=self.coords.device)
-        masks = torch.empty((max(out_level.cap, 1) // 64 + 1,), dtype=torch.int32, device=self.coords.device)
+        masks = torch.empty((lib.dz_tile_masks_words(max(out_level.cap, 1)),), dtype=torch.int32, device=self.coords.device)
         rc = lib.dz_build_neighbors(L.ptr(out_level.coords), L.ptr(out_level.d_m), out_level.cap,
                                     L.ptr(self.bitmap), L.ptr(self.prefix), self.batch, *self.shape, L.i3(k),
                                     L.i3(s), L.i3(p), L.ptr(nbr), L.ptr(masks), L.stream())

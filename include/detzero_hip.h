@@ -126,7 +126,9 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
                        const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3,
                        const int *h_s3, const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream);
-/* tile_masks (cap_out/64 + 1 words, or NULL): bit t of word o/64 = some row of the 64-row group has a neighbour at tap t. */
+/* tile_masks (dz_tile_masks_words(cap_out) words, 16-byte aligned, or NULL): bit t of word o/64 = some row of the 64-row
+ * group o/64 has a neighbour at tap t (what the conv kernels need to skip empty taps without scanning the table). */
+int dz_tile_masks_words(int cap_out);
 
 /* dst[rank[i]][0:c_src] = src[i][0:c_src]; dst[rank[i]][c_src:c_dst] = 0 (rows with rank<0 skipped) */
 int dz_scatter_rows(const float *src, const int *rank, const int *d_n, int n_cap, int c_src, float *dst,
@@ -202,7 +204,7 @@ int dz_scatter_rows_split(const float *src, const int *rank, const int *d_n, int
 int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, const uint32_t *tile_masks, int kvol,
                             int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
                             const float *residual, int relu, float *out, int cout, int math, void *stream);
-/* tile_masks: the per-64-row tap masks of dz_build_neighbors (NULL: the kernel scans the table itself, slower). */
+/* tile_masks: the buffer dz_build_neighbors filled for this table (NULL: the kernel scans the table itself, slower). */
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);
