@@ -67,6 +67,13 @@ _SIGS = {
     'dz_index_downsample': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                     c_void_p]),
+    'dz_grm_feature_channels': (c_int, [c_int]),
+    'dz_grm_encode_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'dz_prm_feature_channels': (c_int, [c_void_p, c_int]),
+    'dz_prm_encode_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     'dz_tile_masks_words': (c_int, [c_int]),
     'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -142,3 +142,31 @@ def synth_state_dict(shapes, seed=0):
             t = (rng.standard_normal(shape) / np.sqrt(max(fan_in, 1))).astype(np.float32)
         out[key] = torch.from_numpy(t)
     return out
+
+
+def synth_object_track(seed, n_frames, name='Vehicle', pts_lo=0, pts_hi=600, origin=(12000.0, -3400.0, 40.0)):
+    """One tracked object as the crop step stores it (daemon/prepare_object_data.py:274-313): global-frame boxes (T,7)
+    float64 with headings that leave [-pi, pi), scores (T,), and per frame an (n_i,4) float64 array
+    [x,y,z (global), tanh(intensity)] of points scattered in the enlarged box; n_i in [pts_lo, pts_hi] with a few
+    empty frames.  Global coordinates are kilometres from the origin, as in Waymo's world frame."""
+    rng = np.random.default_rng(seed)
+    size = {'Vehicle': (4.6, 2.0, 1.7), 'Pedestrian': (0.9, 0.8, 1.8), 'Cyclist': (1.8, 0.8, 1.7)}[name]
+    size = np.asarray(size) * rng.uniform(0.9, 1.2, size=3)
+    yaw0 = rng.uniform(-np.pi, np.pi)
+    speed = rng.uniform(0.0, 1.5)
+    boxes = np.zeros((n_frames, 7), dtype=np.float64)
+    pos = np.asarray(origin, dtype=np.float64) + rng.uniform(-50, 50, size=3) * [1, 1, 0.02]
+    yaw = yaw0
+    pts = []
+    for t in range(n_frames):
+        yaw += rng.normal(0, 0.03)
+        pos = pos + speed * np.array([np.cos(yaw), np.sin(yaw), 0.0]) + rng.normal(0, 0.02, size=3)
+        wrap = rng.choice([0.0, 0.0, 0.0, 2 * np.pi, -2 * np.pi])
+        boxes[t] = [pos[0], pos[1], pos[2], *(size * rng.uniform(0.97, 1.03, size=3)), yaw + wrap]
+        n = 0 if rng.random() < 0.08 else int(rng.integers(pts_lo, pts_hi + 1))
+        local = rng.uniform(-0.55, 0.55, size=(n, 3)) * boxes[t, 3:6]
+        c, s = np.cos(boxes[t, 6]), np.sin(boxes[t, 6])
+        xyz = np.stack([local[:, 0] * c - local[:, 1] * s, local[:, 0] * s + local[:, 1] * c, local[:, 2]], axis=1) + boxes[t, :3]
+        pts.append(np.concatenate([xyz, np.tanh(rng.uniform(0, 3, size=(n, 1)))], axis=1))
+    score = rng.uniform(0.05, 0.99, size=n_frames)
+    return {'boxes_global': boxes, 'score': score, 'pts': pts, 'name': name}

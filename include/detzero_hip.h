@@ -293,6 +293,46 @@ int dz_group_max(const float *x, int groups, int len, int c, float *out, void *s
 int dz_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c,
                      float eps, int do_norm, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Object features: cropped object points -> inputs of the refining models.
+ * Replaces, for inference, WaymoGeometryDataset.extract_track_feature
+ * (refining/detzero_refine/datasets/waymo/waymo_geometry_dataset.py:73-131) and WaymoPositionDataset.extract_track_feature
+ * (waymo_position_dataset.py:66-155) with their helpers (refining/detzero_refine/utils/data_utils.py:6-113,
+ * utils/detzero_utils/box_utils.py:28-53), batched over objects.
+ *
+ * Common inputs (device): pts (P,4) float64 [x,y,z global, intensity] of all boxes, object-major then frame order;
+ * box_offsets (F+1) first point of every box; traj (F,7) float64 global boxes; score (F) float64;
+ * obj_box_offsets (B+1) first box of every object.  WHICH points survive the fixed-size selection is the caller's
+ * (data_utils.py:12-30 draws with Python's random.sample): index lists, -1 = zero row.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define DZ_GRM_XYZ 1
+#define DZ_GRM_INTENSITY 2
+#define DZ_GRM_P2S 4
+#define DZ_GRM_SCORE 8
+int dz_grm_feature_channels(int encoding);           /* channels of a memory row for these flags (order: xyz, intensity, p2s, score) */
+/* mem_idx (B,mem_n): index into the object's concatenated points; query_box (B,q_max): box id in [0,F) or -1 (padding);
+ * query_idx (B,q_max,q_n): index into that box's points.  memory (B,mem_n,channels) and query (B,q_max,q_n,4) float32:
+ * points in the frame of their own box (waymo_geometry_dataset.py:75, data_utils.py:62-71). */
+int dz_grm_encode_points(const double *pts, const int *box_offsets, const double *traj, const double *score,
+                         const int *obj_box_offsets, const int *mem_idx, int mem_n, const int *query_box, const int *query_idx,
+                         int q_max, int q_n, int batch, int encoding, float *memory, float *query, void *stream);
+
+#define DZ_PRM_XYZ 0
+#define DZ_PRM_INTENSITY 1
+#define DZ_PRM_P2CO 2
+#define DZ_PRM_SCORE 3
+#define DZ_PRM_CLASS 4
+int dz_prm_feature_channels(const int *h_encoding, int n_enc);   /* channels of a row for this (host) list of codes, -1 if invalid */
+/* q_idx (F,q_n) / m_idx (F,m_n): per box, index into its points.  Outputs: query (B,box_max,q_n,channels), memory
+ * (B,box_max,m_n,channels), traj_local (B,box_max,7) and padding_mask (B,box_max) float32, init_box (B,7) float64 - points
+ * and boxes in the frame of the object's middle box (waymo_position_dataset.py:72-78, data_utils.py:74-113), boxes past
+ * an object's own are zero with mask 1.  anchors: scratch of B*box_max*27 + 2*B doubles.  obj_cls (B) 1-based, may be
+ * NULL without the 'class' feature. */
+int dz_prm_encode_points(const double *pts, const int *box_offsets, const double *traj, const double *score,
+                         const int *obj_box_offsets, const int *obj_cls, const int *q_idx, const int *m_idx, int q_n, int m_n,
+                         int batch, int box_max, const int *h_encoding, int n_enc, float *query, float *memory,
+                         float *traj_local, float *padding_mask, double *init_box, double *anchors, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
