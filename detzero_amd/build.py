@@ -14,6 +14,7 @@ OBJDIR = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libdetzero_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+FLAGS += os.environ.get('DZ_HIPCC_FLAGS', '').split()      # development only (e.g. -DDZ_SPCONV_DIAG: tools/gpu_diag.sh)
 
 
 def _sources():

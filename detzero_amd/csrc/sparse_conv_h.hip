@@ -30,7 +30,7 @@ struct SpConvHArgs {
 // thread fetches the neighbour index of the rows it gathers straight from the table, NS chunks ahead of the gather
 // that uses it (a register ring, filled by EXTRA loads behind every stage's loads; see hgemm_pipeline).  Less LDS per
 // workgroup = more resident workgroups for the small-channel levels, and the tile prologue disappears.
-template <class T, class M, int NS, bool GN, int OCC>
+template <class T, class M, int NS, bool GN, int OCC, int DIAG = 0>
 __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void k_spconv_h(SpConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
                 auto issue = [&](HStage<T> &st, auto s_t) {
                     constexpr int S = decltype(s_t)::value;
                     // the fetch into slot S was issued NS calls ago, right behind that call's stage loads
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * (NST + P)));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * (NST + (DIAG == 7 ? 0 : P))));
                     unsigned int pvoff[P];
 #pragma unroll
                     for (int i = 0; i < P; ++i) {
@@ -155,11 +155,18 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
                         const int rb = nb[S][i];
                         pvoff[i] = (nvoff[i] != OOB_OFFSET && rb >= 0) ? (unsigned int)rb * (unsigned int)(a.cin * 4) + (unsigned int)(q * 16) : OOB_OFFSET;
                     }
-                    load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cvoff,
+                    if constexpr (DIAG == 8) {      // gathers out of range: instructions issued, nothing fetched
+#pragma unroll
+                        for (int i = 0; i < P; ++i) pvoff[i] = OOB_OFFSET;
+                    }
+                    unsigned int cv2[T::C_PER_THREAD];
+#pragma unroll
+                    for (int i = 0; i < T::C_PER_THREAD; ++i) cv2[i] = DIAG == 9 ? OOB_OFFSET : cvoff[i];
+                    load_hstage<T>(st, prsrc, pvoff, (unsigned int)(kc * T::KC * 4), crsrc, cv2,
                                    (unsigned int)tap * tap_bytes + (unsigned int)(kc * T::KC * 4));
-                    fetch_nbr(nb[S]);
+                    if constexpr (DIAG != 7) fetch_nbr(nb[S]);
                 };
-                hgemm_pipeline<T, M, NS, P>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
+                hgemm_pipeline<T, M, NS, DIAG == 7 ? 0 : P, DIAG, (T::THREADS == 512)>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
                 __syncthreads();          // the next tile's first stage overwrites LDS buffer 0
             } else {
                 auto issue = [&](HStage<T> &st, auto) {
@@ -231,12 +238,12 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <class T, class M, int NS, bool GN, int OCC>
+template <class T, class M, int NS, bool GN, int OCC, int DIAG = 0>
 static int launch_spconv_h_impl(const SpConvHArgs &a, hipStream_t stream) {
     constexpr int LDS = T::LDS_BYTES + (GN ? 0 : KVOL_MAX_H * T::BP * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS, GN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS, GN, OCC, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", LDS);
             return DZ_ERR_HIP;
@@ -247,7 +254,7 @@ static int launch_spconv_h_impl(const SpConvHArgs &a, hipStream_t stream) {
     if (grid > 2048) grid = 2048;
     grid = (grid + 7) & ~7;            // a multiple of 8: see the XCD schedule in the kernel
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((k_spconv_h<T, M, NS, GN, OCC>), dim3(grid, a.cout_pad / T::BC), dim3(T::THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((k_spconv_h<T, M, NS, GN, OCC, DIAG>), dim3(grid, a.cout_pad / T::BC), dim3(T::THREADS), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -270,6 +277,8 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
         if (t64 == 1) return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 3>(a, stream);
         if (t64 == 3) return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
+        if (t64 == 6) return launch_spconv_h<HTile<256, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);       // 8 waves of 64 x 32
+        if (t64 == 7) return launch_spconv_h<HTile<256, 64, 32, 4, 2>, M, 3, 3, 3, 3>(a, stream);
         if (t64 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
         if (t64 == 5) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);
         return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);          // 8 waves of 32 x 32
@@ -279,6 +288,21 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
         if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
         if (t128 == 3) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
         if (t128 == 5) return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 4, 4, 2, 2>(a, stream);
+#ifdef DZ_SPCONV_DIAG
+        if (t128 >= 11 && t128 <= 19 && a.tile_masks && a.nbr_bytes) {
+            using DT = HTile<128, 128, 32, 4, 2>;
+            if (t128 == 11) return launch_spconv_h_impl<DT, M, 3, true, 2, 1>(a, stream);
+            if (t128 == 12) return launch_spconv_h_impl<DT, M, 3, true, 2, 2>(a, stream);
+            if (t128 == 13) return launch_spconv_h_impl<DT, M, 3, true, 2, 3>(a, stream);
+            if (t128 == 14) return launch_spconv_h_impl<DT, M, 3, true, 2, 4>(a, stream);
+            if (t128 == 16) return launch_spconv_h_impl<DT, M, 3, true, 2, 6>(a, stream);
+            if (t128 == 17) return launch_spconv_h_impl<DT, M, 3, true, 2, 7>(a, stream);
+            if (t128 == 18) return launch_spconv_h_impl<DT, M, 3, true, 2, 8>(a, stream);
+            return launch_spconv_h_impl<DT, M, 3, true, 2, 9>(a, stream);
+        }
+#endif
+        if (t128 == 7) return launch_spconv_h<HTile<256, 128, 32, 4, 2>, M, 2, 2, 2, 2>(a, stream);     // 8 waves of 64 x 64
+        if (t128 == 8) return launch_spconv_h<HTile<256, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
         if (t128 == 6) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));
         return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);        // 8 waves of 32 x 64
     }
