@@ -333,6 +333,34 @@ int dz_prm_encode_points(const double *pts, const int *box_offsets, const double
                          int batch, int box_max, const int *h_encoding, int n_enc, float *query, float *memory,
                          float *traj_local, float *padding_mask, double *init_box, double *anchors, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Test-time augmentation: point transforms of the augmented copies
+ * (detection/detzero_det/datasets/augmentor/test_time_augmentor.py:32-83), restore of their boxes
+ * (detection/detzero_det/models/centerpoint.py:165-203) and weighted box fusion
+ * (detection/detzero_det/utils/ensemble_utils/wbf_3d.py:10-203 as called by ensemble.py:7-33), all on the device.
+ * Operations: host arrays of codes + one float parameter each (angle in radians / scale factor, 0 otherwise).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define DZ_TTA_ORIGINAL 0
+#define DZ_TTA_FLIP_X 1
+#define DZ_TTA_FLIP_Y 2
+#define DZ_TTA_FLIP_XY 3
+#define DZ_TTA_ROT 4
+#define DZ_TTA_SCALE 5
+/* points (n,c) -> out (n_ops, n, c): copy i = points under operation i (columns >= 3 copied). */
+int dz_tta_augment_points(const float *points, int n, int c, const int *h_kind, const float *h_param, int n_ops, float *out,
+                          void *stream);
+/* boxes (frames, n_ops, m, dim >= 7) in place: rows of copy i back to the original frame (columns >= 7 untouched). */
+int dz_tta_restore_boxes(float *boxes, int frames, int n_ops, int m, int dim, const int *h_kind, const float *h_param, void *stream);
+size_t dz_wbf_workspace_bytes(int frames, int cand);
+/* weighted_boxes_fusion_3d with iou_type '3d' per frame: boxes (frames, cand, 7) float32, scores (frames, cand), labels
+ * (frames, cand) in 1..3 (0 = padding); candidate c belongs to model c / per_model (weights: device doubles per model or NULL
+ * = 1; weight_sum = their sum).  conf_max: 0 'avg', 1 'max'.  Outputs sorted by fused score: out_boxes (frames, cand, 7) and
+ * out_scores (frames, cand) float64 as in the reference, out_labels, out_count (frames). */
+int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, int frames, int cand, int per_model,
+                   const double *weights, int n_models, const double *h_iou_thr3, const double *h_skip_thr3, double weight_sum,
+                   int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_count, void *ws,
+                   size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
