@@ -162,3 +162,46 @@ def prm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_n
     L.check(rc, 'dz_prm_encode_points')
     return {'pos_query_points': query, 'pos_memory_points': memory, 'pos_trajectory': traj_local, 'padding_mask': mask,
             'pos_init_box': init_box, 'box_num': list(packed.box_num), 'obj_cls': packed.classes, 'batch_size': b}
+
+
+def crm_selection(packed, query_pts_num=256, rng=random):
+    """Host side of waymo_confidence_dataset.py:106-111: one draw per box.  (F, q_n) int32."""
+    q_idx = np.full((max(sum(packed.box_num), 1), query_pts_num), -1, dtype=np.int32)
+    k = 0
+    for counts in packed.counts:
+        for n in counts:
+            _draw(n, query_pts_num, q_idx[k], rng)
+            k += 1
+    return q_idx
+
+
+def crm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_num=200, query_pts_num=256, rng=random, device=None):
+    """Batch of tracks -> {'conf_points' (B,query_num,q_n,C) float32 device tensor, 'conf_score' (B,query_num) float64 numpy
+    (padded with -1), 'box_num', 'batch_size'} - the collated CRM input (waymo_confidence_dataset.py:59-162; the per-point
+    encoding is the PRM query encoding, same kernel)."""
+    if any(e not in PRM_CODES or e == 'class' for e in encoding):
+        raise L.DetZeroHipError('CRM encoding %r (supported on the device: xyz, intensity, p2co, score)' % (list(encoding),))
+    packed = tracks if isinstance(tracks, PackedTracks) else PackedTracks(tracks, device)
+    if max(packed.box_num, default=0) > query_num:
+        raise L.DetZeroHipError('object track with %d boxes exceeds QUERY_NUM = %d' % (max(packed.box_num), query_num))
+    dev, b = packed.device, packed.batch
+    q_idx = crm_selection(packed, query_pts_num, rng)
+    codes = np.asarray([PRM_CODES[e] for e in encoding], dtype=np.int32)
+    lib = L.load()
+    ch = lib.dz_prm_feature_channels(codes.ctypes.data, len(codes))
+    points = torch.empty((b, query_num, query_pts_num, ch), dtype=torch.float32, device=dev)
+    traj_local = torch.empty((b, query_num, 7), dtype=torch.float32, device=dev)
+    mask = torch.empty((b, query_num), dtype=torch.float32, device=dev)
+    init_box = torch.empty((b, 7), dtype=torch.float64, device=dev)
+    scratch = torch.empty((b * query_num * 27 + 2 * b,), dtype=torch.float64, device=dev)
+    d_q = torch.from_numpy(q_idx).to(dev)
+    with torch.cuda.device(dev):
+        rc = lib.dz_prm_encode_points(L.ptr(packed.pts), L.ptr(packed.box_offsets), L.ptr(packed.traj), L.ptr(packed.score),
+                                      L.ptr(packed.obj_box_offsets), None, L.ptr(d_q), None, query_pts_num, 0, b, query_num,
+                                      codes.ctypes.data, len(codes), L.ptr(points), None, L.ptr(traj_local), L.ptr(mask),
+                                      L.ptr(init_box), L.ptr(scratch), L.stream())
+    L.check(rc, 'dz_prm_encode_points')
+    score = np.full((b, query_num), -1.0)
+    for i, sc in enumerate(packed.scores):
+        score[i, :len(sc)] = sc
+    return {'conf_points': points, 'conf_score': score, 'box_num': list(packed.box_num), 'batch_size': b}

@@ -465,4 +465,70 @@ class PositionTransformer(_Cached):
         return data_dict
 
 
-__all__ = {'GeometryTransformer': GeometryTransformer, 'PositionTransformer': PositionTransformer}
+# ------------------------------------------------------------------------------------------------
+# CRM
+# ------------------------------------------------------------------------------------------------
+class ConfidencePointnet(_Cached):
+    """refining/detzero_refine/models/modules/confidence_pointnet.py:9-116 (inference): two nested PointNets - points of a
+    box (encoder, max, concat, encoder, max), then boxes of a track (MLP, max, concat, MLP) - and two sigmoid heads;
+    `pred_score = sqrt(score_reg * iou_reg)` per box.  Same module tree / state_dict as the reference.  Like the reference
+    it does not mask the padded boxes: their zero rows take part in the max over the track."""
+
+    def __init__(self, model_cfg, query_point_dims=None, memory_point_dims=None):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.query_point_dims = query_point_dims
+        self.embed_dims = model_cfg.get('EMBED_DIMS', 256)
+        e = self.embed_dims
+        self.pts_encoder_1 = make_conv_layers(model_cfg.ENCODER_MLP, query_point_dims, e, output_use_norm=True)
+        self.pts_encoder_2 = make_conv_layers([], e + model_cfg.ENCODER_MLP[1], e, output_use_norm=True)
+        self.pts_mlp = make_fc_layers(model_cfg.REGRESSION_MLP, e, e, output_use_norm=True)
+        self.regression_mlp = make_fc_layers(model_cfg.REGRESSION_MLP, e * 2, e, output_use_norm=True)
+        self.heads = nn.ModuleDict()
+        self.preds_dict = {}
+        self.score_thresh = model_cfg.get('SCORE_THRESH', [0.25, 0.5])
+        self.tasks = {'score_reg': 1, 'iou_reg': 1}
+        for task in self.tasks:
+            self.heads[task] = make_fc_layers([int(e / 2)], e, self.tasks[task], output_use_norm=False)
+
+    def plan(self):
+        if self._plan is None:
+            if len(list(self.pts_mlp)) < 6:
+                raise DetZeroHipError('ConfidencePointnet: REGRESSION_MLP must have at least one hidden layer (the reference taps pts_mlp[5])')
+            reg = _stack_plan(self.regression_mlp)
+            first = list(self.regression_mlp)[0]
+            w = first.weight.detach().float().reshape(first.weight.shape[0], first.weight.shape[1]).t().contiguous()     # (2E, C1)
+            e = self.embed_dims
+            reg[0]['w'] = w[e:].contiguous()                       # cat([pooled, tapped]) (confidence_pointnet.py:104-105): tapped rows
+            self._plan = {
+                'points': _PointNetPlan(self.pts_encoder_1, self.pts_encoder_2, self.query_point_dims, pooled_first=True),
+                'boxes': _stack_plan(self.pts_mlp),
+                'reg': reg, 'reg_w_pool': w[:e].contiguous(),
+                'ones': torch.ones(w.shape[1], device=w.device), 'zeros': torch.zeros(w.shape[1], device=w.device),
+                'heads': {k: _stack_plan(v) for k, v in self.heads.items()},
+            }
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        _inference_only(self)
+        p = self.plan()
+        pts = data_dict['conf_points'].float()
+        b, nb, npts, c = pts.shape
+        feat = p['points'].forward(pts.reshape(b * nb * npts, c), b * nb, npts)              # (B*nb*npts, E)
+        box = ops.group_max(feat, b * nb, npts)                                              # (B*nb, E)
+        box, outs = _run_stack(box, p['boxes'])
+        tapped = outs[1]                                                                     # pts_mlp[5]
+        pooled = ops.group_max(box, b, nb)                                                   # (B, E)
+        gshift = ops.linear(pooled, p['reg_w_pool'], p['ones'], p['zeros'], False, p['reg_w_pool'].shape[1])
+        l0 = p['reg'][0]
+        y = ops.linear(tapped, l0['w'], l0['scale'], l0['shift'], l0['relu'], l0['cout'], group_shift=gshift, group_rows=nb)
+        y, _ = _run_stack(y, p['reg'][1:])
+        preds = {k: torch.sigmoid(_run_stack(y, layers)[0].view(b, nb, -1)) for k, layers in p['heads'].items()}
+        self.preds_dict = preds
+        data_dict['pred_score'] = torch.sqrt(preds['score_reg'].squeeze(2) * preds['iou_reg'].squeeze(2))
+        return data_dict
+
+
+__all__ = {'GeometryTransformer': GeometryTransformer, 'PositionTransformer': PositionTransformer,
+           'ConfidencePointnet': ConfidencePointnet}

@@ -4,13 +4,15 @@ scope):
 
   GRM  refining/detzero_refine/datasets/waymo/waymo_geometry_dataset.py:26-155 (extract_track_feature)
   PRM  refining/detzero_refine/datasets/waymo/waymo_position_dataset.py:31-184 (extract_track_feature)
+  CRM  refining/detzero_refine/datasets/waymo/waymo_confidence_dataset.py:59-162 (extract_track_feature)
   helpers  refining/detzero_refine/utils/data_utils.py:6-10 (rotate_yaw), :12-30 (sample_points), :33-42
            (limit_heading_range), :62-71 (local_coords_transform), :74-113 (init_coords_transform);
            utils/detzero_utils/box_utils.py:28-53 (boxes_to_corners_3d, float32 through torch),
            common_utils.py:220-244 (rotate_points_along_z)
   batch    refining/detzero_refine/datasets/dataset.py:207-258 (collate_batch: zero padding of the GRM queries)
 
-Pinned by tests/golden/refine_feat_golden.npz, which tests/golden/gen_refine_feat_golden.py produced by running the
+Pinned by tests/golden/refine_feat_golden.npz (GRM, PRM) and crm_golden.npz (CRM), which tests/golden/gen_refine_feat_golden.py /
+gen_crm_golden.py produced by running the
 reference's own dataset classes on seeded synthetic tracks (same Python `random` stream: sample_points draws with
 random.sample, so the oracle draws the same subsets when seeded identically).
 
@@ -179,3 +181,48 @@ def prm_batch(objs):
     out['box_num'] = [o['box_num'] for o in objs]
     out['batch_size'] = len(objs)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ CRM
+def crm_object(track, encoding=('xyz', 'intensity', 'p2co', 'score'), query_num=200, query_pts_num=256, rng=random):
+    """Inference-time conf_* entries of one object (waymo_confidence_dataset.py:82-160): the PRM query-point encoding in
+    the frame of the middle box (one draw per box), plus 'box_pos'; scores padded with -1."""
+    traj = np.array(track['boxes_global'], dtype=np.float64, copy=True)[:, :7]
+    score = np.asarray(track['score'])
+    t = traj.shape[0]
+    init = traj[t // 2].copy()
+    init[6] = wrap_heading(init[[6]])[0]
+    rot = yaw_matrix(init[6]).T
+    pts = []
+    for p in track['pts']:
+        q = np.array(p, dtype=np.float64, copy=True)
+        q[:, :3] = (q[:, :3] - init[:3]) @ rot
+        pts.append(q)
+    traj[:, 6] = wrap_heading(traj[:, 6])
+    traj[:, :3] = (traj[:, :3] - init[:3]) @ rot
+    traj[:, 6] -= init[6]
+    traj[:, 6] = wrap_heading(traj[:, 6])
+    qs = np.stack([take_padded(q, draw_subset(q.shape[0], query_pts_num, rng), query_pts_num) for q in pts])
+    cols = []
+    for e in encoding:
+        if e == 'xyz':
+            cols.append(qs[:, :, :3])
+        elif e == 'intensity':
+            cols.append(qs[:, :, [3]])
+        elif e == 'p2co':
+            anchor = np.concatenate([corners_f32(traj).reshape(t, -1), traj[:, :3]], axis=-1)
+            cols.append(np.tile(qs[:, :, :3], (1, 1, 9)) - anchor[:, None, :])
+        elif e == 'box_pos':
+            cols.append(np.tile(np.concatenate([traj[:, :3], traj[:, 6:7]], axis=-1)[:, None, :], (1, query_pts_num, 1)))
+        elif e == 'score':
+            cols.append(np.tile(score[:, None, None], (1, query_pts_num, 1)))
+        else:
+            raise NotImplementedError(e)
+    feat = np.concatenate(cols, axis=2)
+    feat = np.concatenate([feat, np.zeros((query_num - t, query_pts_num, feat.shape[2]))], axis=0)
+    return {'conf_points': feat, 'conf_score': np.concatenate((score, np.full(query_num - t, -1))), 'box_num': t}
+
+
+def crm_batch(objs):
+    return {'conf_points': np.stack([o['conf_points'] for o in objs]), 'conf_score': np.stack([o['conf_score'] for o in objs]),
+            'box_num': [o['box_num'] for o in objs], 'batch_size': len(objs)}

@@ -171,3 +171,75 @@ def test_features_feed_the_refining_models(device):
     b = prm({k: torch.from_numpy(ref[k]).to(device) for k in ('pos_query_points', 'pos_memory_points', 'pos_trajectory', 'padding_mask')})['batch_box_preds']
     valid = torch.from_numpy(ref['padding_mask']) == 0
     torch.testing.assert_close(a.cpu()[valid], b.cpu()[valid], rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ CRM
+@pytest.fixture(scope='module')
+def gc(golden_dir):
+    return np.load(os.path.join(golden_dir, 'crm_golden.npz'))
+
+
+def _crm_spec():
+    import gen_crm_golden
+    return gen_crm_golden.CRM_TRACKS, gen_crm_golden.CCFG
+
+
+def test_oracle_crm_features_equal_reference(gc):
+    spec, _ = _crm_spec()
+    objs = []
+    for (seed, *_), tr in zip(spec, _tracks(spec)):
+        random.seed(3000 + seed)
+        objs.append(oracle_feat.crm_object(tr))
+    batch = oracle_feat.crm_batch(objs)
+    assert batch['box_num'] == gc['feat_box_num'].tolist()
+    np.testing.assert_array_equal(batch['conf_score'], gc['feat_conf_score'])
+    np.testing.assert_allclose(batch['conf_points'].astype(np.float32), gc['feat_conf_points'], rtol=0, atol=1e-6)      # p2co corners: 1 ulp, see PRM
+
+
+def test_crm_state_dict_identical_to_reference_manifest(gc):
+    from detzero_amd.config import AttrDict
+    from detzero_amd.refine_modules import ConfidencePointnet
+    _, cfg = _crm_spec()
+    crm = ConfidencePointnet(AttrDict(cfg), query_point_dims=32, memory_point_dims=32)
+    mine = {k: str(tuple(v.shape)) for k, v in crm.state_dict().items()}
+    assert list(mine) == gc['crm_keys'].tolist()
+    assert list(mine.values()) == gc['crm_shapes'].tolist()
+
+
+@pytest.mark.gpu
+def test_crm_model_matches_reference(device, gc):
+    from detzero_amd.config import AttrDict
+    from detzero_amd.refine_modules import ConfidencePointnet
+    _, cfg = _crm_spec()
+    crm = ConfidencePointnet(AttrDict(cfg), query_point_dims=32, memory_point_dims=32).eval()
+    crm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in crm.state_dict().items()}, seed=7), strict=True)
+    crm = crm.to(device)
+    res = crm({'conf_points': torch.from_numpy(gc['crm_in_conf_points']).to(device)})
+    torch.testing.assert_close(crm.preds_dict['score_reg'].cpu(), torch.from_numpy(gc['crm_score_reg']), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(crm.preds_dict['iou_reg'].cpu(), torch.from_numpy(gc['crm_iou_reg']), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(res['pred_score'].cpu(), torch.from_numpy(gc['crm_pred_score']), rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_crm_features_match_reference_and_feed_the_model(device, gc):
+    from detzero_amd import object_features as of
+    from detzero_amd.config import AttrDict
+    from detzero_amd.refine_modules import ConfidencePointnet
+    spec, cfg = _crm_spec()
+    tracks = _tracks(spec)
+    for i, ((seed, *_), tr) in enumerate(zip(spec, tracks)):
+        random.seed(3000 + seed)
+        out = of.crm_features([tr], device=device)
+        assert out['box_num'] == [int(gc['feat_box_num'][i])]
+        np.testing.assert_array_equal(out['conf_score'][0], gc['feat_conf_score'][i])
+        _close(out['conf_points'][0], gc['feat_conf_points'][i], atol=3e-5)
+    crm = ConfidencePointnet(AttrDict(cfg), query_point_dims=32, memory_point_dims=32).eval()
+    crm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in crm.state_dict().items()}, seed=7), strict=True)
+    crm = crm.to(device)
+    random.seed(8)
+    feats = of.crm_features(tracks, device=device)
+    a = crm({'conf_points': feats['conf_points']})['pred_score']
+    b = crm({'conf_points': torch.from_numpy(gc['feat_conf_points']).to(device)})['pred_score']
+    assert a.shape == (3, 200) and torch.isfinite(a).all()
+    # different draws of the over-full boxes -> slightly different scores; same inputs elsewhere
+    assert (a - b).abs().max() < 0.2
