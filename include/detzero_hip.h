@@ -361,6 +361,16 @@ int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, i
                    int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_count, void *ws,
                    size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Frame assembly from stored sweeps (DatasetTemplate.merge_sweeps, detection/detzero_det/datasets/dataset.py:164-195):
+ * raw (n_total,6) float32 rows [x,y,z,intensity,elongation,NLZ] of n_sweeps sweeps back to back (host offsets,
+ * n_sweeps+1 entries); h_transforms: per sweep rows 0..2 of inv(pose_current) @ pose_sweep (12 doubles, row-major);
+ * h_time_offsets: seconds.  out (n_total,6) float32 receives the rows with NLZ == -1 in their stored order as
+ * [x',y',z',tanh(intensity),elongation,time offset]; *d_count their number. */
+size_t dz_merge_sweeps_workspace_bytes(int n_total);
+int dz_merge_sweeps(const float *raw, int n_total, const int *h_sweep_offsets, const double *h_transforms, const double *h_time_offsets,
+                    int n_sweeps, float *out, int *d_count, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
