@@ -123,7 +123,10 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
                 for (int e = 0; e < 4; ++e) {
                     const float sc = p.scale ? p.scale[grp * p.cout_pad + col + e] : 1.f;
                     const float sh = p.shift ? p.shift[grp * p.cout_pad + col + e] : 0.f;
-                    v[e] = fmaf(acc[ct][pt][4 * j + e], sc, sh);
+                    float a = acc[ct][pt][4 * j + e];
+                    // per-row-group addend of the PointNet concat (linear layers: output pixel index = row)
+                    if (p.group_shift) a += p.group_shift[(size_t)(op / p.group_rows) * p.cout_pad + col + e];
+                    v[e] = fmaf(a, sc, sh);
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (OUT_F32) {
@@ -220,7 +223,9 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
     DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward_split: null pointer");
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_conv2d_forward_split: math %d is not a split mode", math);
     DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward_split: groups %d not in [1,8]", d->groups);
-    DZ_CHECK_ARG(!d->group_shift, "dz_conv2d_forward_split: group_shift is only available in the fp32 engine");
+    DZ_CHECK_ARG(!d->group_shift || (d->group_rows >= 1 && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->batch == 1 && d->ho == 1 &&
+                                     d->out_hp == 1 && d->out_sx == 1 && d->out_dx == 0),
+                 "dz_conv2d_forward_split: group_shift is for linear layers (1x1, one image row = the rows), group_rows >= 1");
     DZ_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->cin >= 32, "dz_conv2d_forward_split: bad kernel/cin");
     DZ_CHECK_ARG(d->in_cstride % 8 == 0 && d->in_coff % 8 == 0 && d->cin % 8 == 0,
                  "dz_conv2d_forward_split: input channel stride / offset must be multiples of the 8-channel pair16 group");
@@ -242,6 +247,34 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
     if (math == DZ_MATH_F16X2)
         return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);
     return out_f32 ? conv2d_h_dispatch<MathBF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathBF16, false>(*d, w_bytes, stream);
+}
+
+int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
+                            const float *shift, const float *group_shift, int group_rows, int relu, float *y, int y_stride, int math,
+                            int out_f32, void *stream_) {
+    DZ_CHECK_ARG(rows >= 0 && x_stride >= cin && y_stride >= cout && cin % 32 == 0 && cout_pad % 32 == 0 && cout <= cout_pad,
+                 "dz_linear_forward_split: bad sizes (cin and cout_pad in multiples of 32)");
+    if (group_rows < 1) group_rows = 1;
+    // the rows are fetched through 32-bit buffer offsets: at most ~2 GiB of them per launch
+    long max_rows = (long)(0x7FF00000ull / ((size_t)x_stride * sizeof(float)));
+    if (group_shift) max_rows = max_rows / group_rows * group_rows;
+    DZ_CHECK_ARG(max_rows >= 1, "dz_linear_forward_split: one row group exceeds the 2 GiB addressing window");
+    for (long r0 = 0; r0 < rows; r0 += max_rows) {
+        const int n = (int)((rows - r0) < max_rows ? (rows - r0) : max_rows);
+        dz_conv2d_desc d = {};
+        d.in = x + (size_t)r0 * x_stride; d.out = y + (size_t)r0 * y_stride; d.w = w; d.scale = scale; d.shift = shift;
+        d.batch = 1; d.ho = 1; d.wo = n;
+        d.in_hp = 1; d.in_wp = n; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin;
+        d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
+        d.out_hp = 1; d.out_wp = n; d.out_cstride = y_stride; d.out_coff = 0;
+        d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
+        d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
+        d.group_shift = group_shift ? group_shift + (size_t)(r0 / group_rows) * cout_pad : nullptr;
+        d.group_rows = group_rows;
+        const int rc = dz_conv2d_forward_split(&d, math, out_f32, stream_);
+        if (rc) return rc;
+    }
+    return DZ_OK;
 }
 
 const char *dz_conv2d_variant_split(const dz_conv2d_desc *d) {

@@ -81,6 +81,8 @@ _SIGS = {
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dz_merge_sweeps_workspace_bytes': (c_size_t, [c_int]),
     'dz_merge_sweeps': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dz_linear_forward_split': (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dz_tile_masks_words': (c_int, [c_int]),
     'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -419,6 +419,25 @@ def linear(x, w, scale, shift, relu, cout, out=None, group_shift=None, group_row
     return out
 
 
+def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shift=None, group_rows=0):
+    """dz_linear_forward_split: x (rows, >= cin words) pair16 @ w (cout_pad, cin) pair16 -> (rows, cout) fp32 when out_f32,
+    else (rows, cout) pair16 (cout % 32 == 0 so that the result can feed the next layer)."""
+    lib = L.load()
+    L.require_cuda(x, w, scale, shift, group_shift)
+    rows = x.shape[0]
+    cout_pad, cin = w.shape
+    if not out_f32 and cout % 32:
+        raise L.DetZeroHipError('linear_split: a pair16 result needs cout %% 32 == 0 (got %d)' % cout)
+    if group_shift is not None and group_shift.shape[1] != cout_pad:
+        raise L.DetZeroHipError('linear_split: group_shift rows must be cout_pad = %d wide' % cout_pad)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    rc = lib.dz_linear_forward_split(L.ptr(x), rows, cin, x.stride(0), L.ptr(w), cout, cout_pad, L.ptr(scale), L.ptr(shift),
+                                     L.ptr(group_shift), int(group_rows), 1 if relu else 0, L.ptr(out), out.stride(0), int(math),
+                                     1 if out_f32 else 0, L.stream())
+    L.check(rc, 'dz_linear_forward_split')
+    return out
+
+
 def group_max(x, groups, length):
     """x (groups*length, c) -> (groups, c) max over each group's rows."""
     lib = L.load()

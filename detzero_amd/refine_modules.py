@@ -16,6 +16,8 @@ Execution (all tensors channel-last, one row per point / query):
   * attention = in-projections (``dz_linear_forward``) + ``dz_mha_core`` (scores never leave registers) +
     out-projection; residual + LayerNorm = ``dz_add_layernorm``.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -202,9 +204,72 @@ def _stack_plan(seq, cin_pad=None):
     return layers
 
 
-def _run_stack(x, layers, upto=None):
+# Arithmetic of the refiner's big MLP stacks: 0 = fp32 matrix cores (default), 1 / 2 = split-precision pairs on the 16-bit
+# matrix cores (csrc/hgemm.h) - set by the model's forward from its `math` (set_math).  Only stacks with many
+# rows switch (the conversion pass has to pay), and only when every hidden width is a multiple of 32.
+_REFINE_MATH = [0]
+SPLIT_MIN_ROWS = 2048
+
+
+@contextlib.contextmanager
+def _math_mode(m):
+    prev = _REFINE_MATH[0]
+    _REFINE_MATH[0] = int(m)
+    try:
+        yield
+    finally:
+        _REFINE_MATH[0] = prev
+
+
+def _with_math(fn):
+    """Model forward under the module's arithmetic (`set_math('f16x2')`; default fp32)."""
+    def wrapper(self, data_dict):
+        with _math_mode(self.math):
+            return fn(self, data_dict)
+    return wrapper
+
+
+def _r32(n):
+    return (n + 31) // 32 * 32
+
+
+def _split_w(l, m, key='w'):
+    """pair16 weights (cout_pad32, cin_pad32) of a layer dict, packed once per math mode; also scale / shift of that width."""
+    ck = '%s_split%d' % (key, m)
+    if ck not in l:
+        w = l[key]
+        ci, co = w.shape
+        wp = w.new_zeros((_r32(ci), _r32(co)))
+        wp[:ci, :co] = w
+        l[ck] = ops.pack_weight_split(wp, m)
+        if 'scale32' not in l:
+            l['scale32'], l['shift32'] = _vec(l['scale'], _r32(co), 1.0), _vec(l['shift'], _r32(co))
+    return l[ck]
+
+
+def _splittable(layers, rows):
+    return bool(_REFINE_MATH[0]) and rows >= SPLIT_MIN_ROWS and all(l['cout'] % 32 == 0 for l in layers[:-1])
+
+
+def _run_stack_split(xp, layers, keep_pair=False):
+    """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair."""
+    m = _REFINE_MATH[0]
     outs = []
-    for li, l in enumerate(layers if upto is None else layers[:upto]):
+    for li, l in enumerate(layers):
+        last = li == len(layers) - 1
+        w = _split_w(l, m)
+        xp = ops.linear_split(xp, w, l['scale32'], l['shift32'], l['relu'], l['cout'], m, out_f32=last and not keep_pair)
+        outs.append(xp)
+    return xp, outs
+
+
+def _run_stack(x, layers, upto=None):
+    layers = layers if upto is None else layers[:upto]
+    if _splittable(layers, x.shape[0]):
+        xp = ops.pair16_from_f32(x, c_dst=_r32(x.shape[1]), math=_REFINE_MATH[0])
+        return _run_stack_split(xp, layers)
+    outs = []
+    for li, l in enumerate(layers):
         x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
         outs.append(x)
     return x, outs
@@ -232,8 +297,18 @@ def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask):
     """rows are (B*L, E) channel-last.  multi_head_attention.py:199-288."""
     e = p['e']
     q = ops.linear(q_rows, p['wq'], p['one'], p['bq'], False, e)
-    k = ops.linear(k_rows, p['wk'], p['one'], p['bk'], False, e)
-    v = ops.linear(v_rows, p['wv'], p['one'], p['bv'], False, e)
+    m = _REFINE_MATH[0]
+    if m and k_rows is v_rows and k_rows.shape[0] >= SPLIT_MIN_ROWS and e % 32 == 0:
+        # key / value projections of a long memory: one conversion of the memory rows, two split GEMMs
+        if 'kv_split%d' % m not in p:
+            p['kv_split%d' % m] = (ops.pack_weight_split(p['wk'], m), ops.pack_weight_split(p['wv'], m))
+        wk, wv = p['kv_split%d' % m]
+        mp = ops.pair16_from_f32(k_rows, c_dst=e, math=m)
+        k = ops.linear_split(mp, wk, p['one'], p['bk'], False, e, m, out_f32=True)
+        v = ops.linear_split(mp, wv, p['one'], p['bv'], False, e, m, out_f32=True)
+    else:
+        k = ops.linear(k_rows, p['wk'], p['one'], p['bk'], False, e)
+        v = ops.linear(v_rows, p['wv'], p['one'], p['bv'], False, e)
     o = ops.mha_core(q.view(b, lq, e), k.view(b, lk, e), v.view(b, lk, e), key_padding_mask, p['heads'], p['scale'])
     return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
 
@@ -310,6 +385,20 @@ class _PointNetPlan:
         self.zeros = torch.zeros(w.shape[1], device=w.device)
 
     def forward(self, pts_rows, groups, length):
+        if _splittable(self.enc + self.mlp, pts_rows.shape[0]) and self.mlp[0]['cout'] % 32 == 0:
+            m = _REFINE_MATH[0]
+            xp = ops.pair16_from_f32(pts_rows, c_dst=_r32(self.cin_pad), math=m)
+            feat, outs = _run_stack_split(xp, self.enc)                               # feat fp32, the tapped layer pair16
+            pooled = ops.group_max(feat, groups, length)
+            gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])
+            l0 = self.mlp[0]
+            w0 = _split_w(l0, m)
+            only = len(self.mlp) == 1
+            y = ops.linear_split(outs[1], w0, l0['scale32'], l0['shift32'], l0['relu'], l0['cout'], m, out_f32=only,
+                                 group_shift=gshift, group_rows=length)
+            if not only:
+                y, _ = _run_stack_split(y, self.mlp[1:])
+            return y
         x = _pad_cols(pts_rows, self.cin_pad)
         feat, outs = _run_stack(x, self.enc)
         pooled = ops.group_max(feat, groups, length)                               # (G, Cpool)
@@ -355,6 +444,7 @@ class GeometryTransformer(_Cached):
         return self._plan
 
     @torch.no_grad()
+    @_with_math
     def forward(self, data_dict):
         _inference_only(self)
         p = self.plan()
@@ -430,6 +520,7 @@ class PositionTransformer(_Cached):
         return self._plan
 
     @torch.no_grad()
+    @_with_math
     def forward(self, data_dict):
         _inference_only(self)
         p = self.plan()
@@ -510,6 +601,7 @@ class ConfidencePointnet(_Cached):
         return self._plan
 
     @torch.no_grad()
+    @_with_math
     def forward(self, data_dict):
         _inference_only(self)
         p = self.plan()

@@ -212,6 +212,11 @@ int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m
  * (cout_pad % 32 == 0, cin % 32 == 0), desc->out pair16 or, with out_f32 != 0, plain fp32 (last head conv). */
 int dz_conv2d_forward_split(const dz_conv2d_desc *h_desc, int math, int out_f32, void *stream);
 const char *dz_conv2d_variant_split(const dz_conv2d_desc *h_desc);
+/* dz_linear_forward on pair16 rows: x (rows, x_stride words) pair16, w (cout_pad, cin) pair16 (cin, cout_pad % 32 == 0), y pair16
+ * rows or, with out_f32 != 0, fp32 rows; group_shift (row groups, cout_pad) fp32 as in dz_linear_forward. */
+int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
+                            const float *shift, const float *group_shift, int group_rows, int relu, float *y, int y_stride, int math,
+                            int out_f32, void *stream);
 const char *dz_spconv_variant_split(int cin, int cout);
 
 /* ---------------------------------------------------------------------------------------------

@@ -207,13 +207,14 @@ def test_crm_state_dict_identical_to_reference_manifest(gc):
 
 
 @pytest.mark.gpu
-def test_crm_model_matches_reference(device, gc):
+@pytest.mark.parametrize('math', ['f32', 'f16x2'])
+def test_crm_model_matches_reference(device, gc, math):
     from detzero_amd.config import AttrDict
     from detzero_amd.refine_modules import ConfidencePointnet
     _, cfg = _crm_spec()
     crm = ConfidencePointnet(AttrDict(cfg), query_point_dims=32, memory_point_dims=32).eval()
     crm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in crm.state_dict().items()}, seed=7), strict=True)
-    crm = crm.to(device)
+    crm = crm.to(device).set_math(math)
     res = crm({'conf_points': torch.from_numpy(gc['crm_in_conf_points']).to(device)})
     torch.testing.assert_close(crm.preds_dict['score_reg'].cpu(), torch.from_numpy(gc['crm_score_reg']), rtol=1e-3, atol=2e-4)
     torch.testing.assert_close(crm.preds_dict['iou_reg'].cpu(), torch.from_numpy(gc['crm_iou_reg']), rtol=1e-3, atol=2e-4)

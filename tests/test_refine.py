@@ -43,10 +43,13 @@ def test_state_dict_identical_to_reference_manifest(g):
 
 
 @pytest.mark.gpu
-def test_grm_matches_reference(device, g):
+@pytest.mark.parametrize('math', ['f32', 'f16x2', 'bf16x2'])
+def test_grm_matches_reference(device, g, math, monkeypatch):
+    from detzero_amd import refine_modules
+    monkeypatch.setattr(refine_modules, 'SPLIT_MIN_ROWS', 1)          # the fixture is small: force the split stacks on
     grm, _ = _models()
     grm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in grm.state_dict().items()}, seed=5), strict=True)
-    grm = grm.to(device)
+    grm = grm.to(device).set_math(math)
     data = {k[len('grm_in_'):]: torch.from_numpy(g[k]).to(device) for k in g.files if k.startswith('grm_in_')}
     res = grm(data)
     torch.testing.assert_close(res['memory'].cpu(), torch.from_numpy(g['grm_memory']), rtol=1e-3, atol=1e-4)
@@ -57,10 +60,13 @@ def test_grm_matches_reference(device, g):
 
 
 @pytest.mark.gpu
-def test_prm_matches_reference(device, g):
+@pytest.mark.parametrize('math', ['f32', 'f16x2', 'bf16x2'])
+def test_prm_matches_reference(device, g, math, monkeypatch):
+    from detzero_amd import refine_modules
+    monkeypatch.setattr(refine_modules, 'SPLIT_MIN_ROWS', 1)
     _, prm = _models()
     prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, seed=6), strict=True)
-    prm = prm.to(device)
+    prm = prm.to(device).set_math(math)
     data = {k[len('prm_in_'):]: torch.from_numpy(g[k]).to(device) for k in g.files if k.startswith('prm_in_')}
     res = prm(data)
     torch.testing.assert_close(res['query'].cpu(), torch.from_numpy(g['prm_query']), rtol=1e-3, atol=1e-4)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--objects', type=int, default=1024)
     ap.add_argument('--chunk', type=int, default=128, help='objects per forward (reference BATCH_SIZE_PER_GPU 128 / 96)')
     ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--math', default='f32', choices=['f32', 'f16x2', 'bf16x2'], help="arithmetic of the big MLP stacks (set_math)")
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     from detzero_amd import ops
@@ -41,7 +42,7 @@ def main():
     from detzero_amd.synth import synth_boxes, synth_state_dict, synth_waymo_frame
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from test_refine import GCFG, PCFG
-    out = {'metric': 'refiner objects/sec (GRM 3x256+4096 pts, PRM 200x256+200x48 pts)', 'dtype': 'f32', 'data': 'synthetic',
+    out = {'metric': 'refiner objects/sec (GRM 3x256+4096 pts, PRM 200x256+200x48 pts)', 'dtype': args.math, 'data': 'synthetic',
            'objects': args.objects, 'chunk': args.chunk}
     gen = torch.Generator().manual_seed(0)
     b = args.chunk
@@ -49,7 +50,7 @@ def main():
 
     grm = GeometryTransformer(GCFG, 11, 4).eval()
     grm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in grm.state_dict().items()}, 1))
-    grm = grm.to(dev)
+    grm = grm.to(dev).set_math(args.math)
     gd = {'geo_memory_points': torch.randn((b, 4096, 11), generator=gen).to(dev),
           'geo_query_points': torch.randn((b, 3, 256, 4), generator=gen).to(dev),
           'geo_query_boxes': torch.randn((b, 3, 7), generator=gen).to(dev), 'geo_query_num': torch.full((b,), 3)}
@@ -60,7 +61,7 @@ def main():
 
     prm = PositionTransformer(PCFG, 32, 32).eval()
     prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, 2))
-    prm = prm.to(dev)
+    prm = prm.to(dev).set_math(args.math)
     bp = min(b, 96)
     pchunks = max(args.objects // bp, 1)
     lens = torch.randint(5, 201, (bp,), generator=gen)
