@@ -241,6 +241,37 @@ __global__ __launch_bounds__(256) void k_prm_points(const double *__restrict__ p
     }
 }
 
+// ---- device-side draw of the fixed-size selections (the fast alternative to replaying Python's random.sample on the host) ----
+// Same distribution as sample_points (data_utils.py:12-30: a uniformly random k-subset in ascending order when n >= k, all rows
+// otherwise), different random stream: selection sampling (Knuth 3.4.2 S) driven by a counter-based generator, so that set s
+// of a call is a pure function of (seed, s) - reproducible, order-independent, restated bit for bit by oracle/object_features.py.
+__host__ __device__ inline uint32_t draw_hash(uint64_t seed, uint32_t set, uint32_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)set + 1) + (uint64_t)i * 0xD1B54A32D192ED03ull;     // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+__global__ __launch_bounds__(64) void k_draw_subsets(const int *__restrict__ counts, int n_sets, int k, uint64_t seed, int set0,
+                                                     int *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sets) return;
+    const int n = counts[s];
+    int *o = out + (size_t)s * k;
+    int sel = 0;
+    if (n < k) {
+        for (; sel < n; ++sel) o[sel] = sel;
+    } else {
+        for (int i = 0; i < n && sel < k; ++i) {
+            // keep row i with probability (k - sel) / (n - i): floor(r * (n - i) / 2^32) < k - sel
+            const uint32_t r = draw_hash(seed, (uint32_t)(set0 + s), (uint32_t)i);
+            if ((uint32_t)(((uint64_t)r * (uint32_t)(n - i)) >> 32) < (uint32_t)(k - sel)) o[sel++] = i;
+        }
+    }
+    for (; sel < k; ++sel) o[sel] = -1;
+}
+
 static int grm_channels(int enc) {
     return ((enc & GRM_XYZ) ? 3 : 0) + ((enc & GRM_INTENSITY) ? 1 : 0) + ((enc & GRM_P2S) ? 6 : 0) + ((enc & GRM_SCORE) ? 1 : 0);
 }
@@ -260,6 +291,16 @@ static int prm_channels(const int *codes, int n) {
 using namespace dz;
 
 extern "C" {
+
+int dz_draw_subsets(const int *counts, int n_sets, int k, unsigned long long seed, int first_set_id, int *out_idx, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n_sets >= 0 && k >= 1, "dz_draw_subsets: bad sizes");
+    if (n_sets == 0) return DZ_OK;
+    DZ_CHECK_ARG(counts && out_idx, "dz_draw_subsets: null pointer");
+    hipLaunchKernelGGL(k_draw_subsets, dim3(ceil_div(n_sets, 64)), dim3(64), 0, stream, counts, n_sets, k, (uint64_t)seed, first_set_id, out_idx);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
 
 int dz_grm_feature_channels(int encoding) { return grm_channels(encoding); }
 

@@ -67,6 +67,7 @@ _SIGS = {
     'dz_index_downsample': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                     c_void_p]),
+    'dz_draw_subsets': (c_int, [c_void_p, c_int, c_int, ctypes.c_ulonglong, c_int, c_void_p, c_void_p]),
     'dz_grm_feature_channels': (c_int, [c_int]),
     'dz_grm_encode_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

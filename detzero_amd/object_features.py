@@ -60,6 +60,29 @@ class PackedTracks:
         self.obj_cls = up(np.asarray(self.classes, dtype=np.int32))
 
 
+class DeviceDraw:
+    """Pass as `rng` to grm_features / prm_features / crm_features to draw the fixed-size selections on the device
+    (dz_draw_subsets): the distribution of sample_points, a counter-based stream keyed by (seed, set) instead of Python's
+    random - no host loop over the boxes, nothing uploaded.  Streams: 1 = GRM memory sets (one per object), 2 = GRM query
+    sets (object x query), 3 = PRM / CRM query sets (one per box), 4 = PRM memory sets (one per box)."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def stream_seed(self, stream):
+        return (self.seed ^ (0xA24BAED4963EE407 * stream)) & 0xFFFFFFFFFFFFFFFF
+
+    def draw(self, counts, k, stream, device):
+        """counts: per-set row counts (sequence or int32 tensor) -> (n_sets, k) int32 device tensor of kept rows / -1."""
+        c = counts if torch.is_tensor(counts) else torch.as_tensor(np.asarray(counts, dtype=np.int32))
+        c = c.to(device=device, dtype=torch.int32).contiguous()
+        out = torch.empty((max(c.numel(), 1), k), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            rc = L.load().dz_draw_subsets(L.ptr(c), c.numel(), k, self.stream_seed(stream), 0, L.ptr(out), L.stream())
+        L.check(rc, 'dz_draw_subsets')
+        return out
+
+
 def _draw(n, k, out, rng):
     """Row indices sample_points keeps (data_utils.py:12-30, replace=False) into out[:k]; the rest stays -1 (zero rows)."""
     if n >= k:
@@ -97,13 +120,27 @@ def grm_features(tracks, encoding=('xyz', 'intensity', 'p2s', 'score'), query_nu
     packed = tracks if isinstance(tracks, PackedTracks) else PackedTracks(tracks, device)
     dev = packed.device
     flags = sum(GRM_FLAGS[e] for e in set(encoding))
-    mem_idx, query_box, query_idx, qnum, orders = grm_selection(packed, query_num, query_pts_num, memory_pts_num, rng)
+    if isinstance(rng, DeviceDraw):
+        orders = [np.argsort(sc)[::-1][:query_num] for sc in packed.scores]
+        qnum = [len(o) for o in orders]
+        q_max = max(max(qnum, default=0), 1)
+        query_box = np.full((packed.batch, q_max), -1, dtype=np.int32)
+        qcounts = np.zeros((packed.batch, q_max), dtype=np.int32)
+        for i, o in enumerate(orders):
+            for q, f in enumerate(o):
+                query_box[i, q] = packed.obj_box_start[i] + int(f)
+                qcounts[i, q] = packed.counts[i][int(f)]
+        d_mem = rng.draw([sum(c) for c in packed.counts], memory_pts_num, 1, dev)
+        d_qi = rng.draw(qcounts.reshape(-1), query_pts_num, 2, dev)
+        d_qb = torch.from_numpy(query_box).to(dev)
+    else:
+        mem_idx, query_box, query_idx, qnum, orders = grm_selection(packed, query_num, query_pts_num, memory_pts_num, rng)
+        d_mem, d_qb, d_qi = (torch.from_numpy(a).to(dev) for a in (mem_idx, query_box, query_idx))
     b, q_max = packed.batch, query_box.shape[1]
     lib = L.load()
     cm = lib.dz_grm_feature_channels(flags)
     memory = torch.empty((b, memory_pts_num, cm), dtype=torch.float32, device=dev)
     query = torch.empty((b, q_max, query_pts_num, 4), dtype=torch.float32, device=dev)
-    d_mem, d_qb, d_qi = (torch.from_numpy(a).to(dev) for a in (mem_idx, query_box, query_idx))
     with torch.cuda.device(dev):
         rc = lib.dz_grm_encode_points(L.ptr(packed.pts), L.ptr(packed.box_offsets), L.ptr(packed.traj), L.ptr(packed.score),
                                       L.ptr(packed.obj_box_offsets), L.ptr(d_mem), memory_pts_num, L.ptr(d_qb), L.ptr(d_qi), q_max,
@@ -143,7 +180,12 @@ def prm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_n
         raise L.DetZeroHipError('object track with %d boxes exceeds QUERY_NUM = %d' % (max(packed.box_num), query_num))
     dev = packed.device
     b = packed.batch
-    q_idx, m_idx = prm_selection(packed, query_pts_num, memory_pts_num, rng)
+    if isinstance(rng, DeviceDraw):
+        flat = [n for counts in packed.counts for n in counts]
+        d_q, d_m = rng.draw(flat, query_pts_num, 3, dev), rng.draw(flat, memory_pts_num, 4, dev)
+    else:
+        q_idx, m_idx = prm_selection(packed, query_pts_num, memory_pts_num, rng)
+        d_q, d_m = torch.from_numpy(q_idx).to(dev), torch.from_numpy(m_idx).to(dev)
     codes = np.asarray([PRM_CODES[e] for e in encoding], dtype=np.int32)
     lib = L.load()
     ch = lib.dz_prm_feature_channels(codes.ctypes.data, len(codes))
@@ -153,7 +195,6 @@ def prm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_n
     mask = torch.empty((b, query_num), dtype=torch.float32, device=dev)
     init_box = torch.empty((b, 7), dtype=torch.float64, device=dev)
     scratch = torch.empty((b * query_num * 27 + 2 * b,), dtype=torch.float64, device=dev)
-    d_q, d_m = torch.from_numpy(q_idx).to(dev), torch.from_numpy(m_idx).to(dev)
     with torch.cuda.device(dev):
         rc = lib.dz_prm_encode_points(L.ptr(packed.pts), L.ptr(packed.box_offsets), L.ptr(packed.traj), L.ptr(packed.score),
                                       L.ptr(packed.obj_box_offsets), L.ptr(packed.obj_cls), L.ptr(d_q), L.ptr(d_m), query_pts_num,
@@ -185,7 +226,10 @@ def crm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_n
     if max(packed.box_num, default=0) > query_num:
         raise L.DetZeroHipError('object track with %d boxes exceeds QUERY_NUM = %d' % (max(packed.box_num), query_num))
     dev, b = packed.device, packed.batch
-    q_idx = crm_selection(packed, query_pts_num, rng)
+    if isinstance(rng, DeviceDraw):
+        d_q = rng.draw([n for counts in packed.counts for n in counts], query_pts_num, 3, dev)
+    else:
+        d_q = torch.from_numpy(crm_selection(packed, query_pts_num, rng)).to(dev)
     codes = np.asarray([PRM_CODES[e] for e in encoding], dtype=np.int32)
     lib = L.load()
     ch = lib.dz_prm_feature_channels(codes.ctypes.data, len(codes))
@@ -194,7 +238,6 @@ def crm_features(tracks, encoding=('xyz', 'intensity', 'p2co', 'score'), query_n
     mask = torch.empty((b, query_num), dtype=torch.float32, device=dev)
     init_box = torch.empty((b, 7), dtype=torch.float64, device=dev)
     scratch = torch.empty((b * query_num * 27 + 2 * b,), dtype=torch.float64, device=dev)
-    d_q = torch.from_numpy(q_idx).to(dev)
     with torch.cuda.device(dev):
         rc = lib.dz_prm_encode_points(L.ptr(packed.pts), L.ptr(packed.box_offsets), L.ptr(packed.traj), L.ptr(packed.score),
                                       L.ptr(packed.obj_box_offsets), None, L.ptr(d_q), None, query_pts_num, 0, b, query_num,

@@ -310,6 +310,10 @@ int dz_add_layernorm(const float *x, const float *y, const float *gamma, const f
  * obj_box_offsets (B+1) first box of every object.  WHICH points survive the fixed-size selection is the caller's
  * (data_utils.py:12-30 draws with Python's random.sample): index lists, -1 = zero row.
  * ------------------------------------------------------------------------------------------------------------------ */
+/* Device-side alternative to the host draw: set s of the call (global id first_set_id + s) keeps, of its counts[s] rows, a
+ * uniformly random k-subset in ascending order (all rows when counts[s] < k, padded with -1) - the distribution of
+ * sample_points, from a counter-based generator keyed by (seed, set id) instead of Python's random stream.  out_idx (n_sets,k). */
+int dz_draw_subsets(const int *counts, int n_sets, int k, unsigned long long seed, int first_set_id, int *out_idx, void *stream);
 #define DZ_GRM_XYZ 1
 #define DZ_GRM_INTENSITY 2
 #define DZ_GRM_P2S 4

@@ -226,3 +226,45 @@ def crm_object(track, encoding=('xyz', 'intensity', 'p2co', 'score'), query_num=
 def crm_batch(objs):
     return {'conf_points': np.stack([o['conf_points'] for o in objs]), 'conf_score': np.stack([o['conf_score'] for o in objs]),
             'box_num': [o['box_num'] for o in objs], 'batch_size': len(objs)}
+
+
+# ------------------------------------------------------------------------------------------------ device-side draw (restated)
+_M64 = (1 << 64) - 1
+
+
+def device_draw_hash(seed, set_id, i):
+    """csrc/object_features.hip draw_hash (splitmix64 finaliser of seed + C1 (set+1) + C2 i), upper 32 bits."""
+    z = (seed + 0x9E3779B97F4A7C15 * (set_id + 1) + i * 0xD1B54A32D192ED03) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    z ^= z >> 31
+    return z >> 32
+
+
+def device_draw_subset(n, k, seed, set_id):
+    """dz_draw_subsets for one set: selection sampling, row i kept when floor(r (n - i) / 2^32) < k - kept."""
+    if n < k:
+        return np.arange(n, dtype=np.int64)
+    out = []
+    for i in range(n):
+        if ((device_draw_hash(seed, set_id, i) * (n - i)) >> 32) < k - len(out):
+            out.append(i)
+            if len(out) == k:
+                break
+    return np.asarray(out, dtype=np.int64)
+
+
+def device_stream_seed(seed, stream):
+    return ((seed & _M64) ^ (0xA24BAED4963EE407 * stream)) & _M64
+
+
+class DeviceDrawReplay:
+    """Stand-in for `random` that replays the device draws in the order the oracle's *_object functions ask for them:
+    queue of (stream seed, set id) prepared by the caller, one per rng.sample call."""
+
+    def __init__(self, queue):
+        self.queue = list(queue)
+
+    def sample(self, population, k):
+        seed, set_id = self.queue.pop(0)
+        return [int(v) for v in device_draw_subset(len(population), k, seed, set_id)]

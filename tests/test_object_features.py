@@ -244,3 +244,67 @@ def test_crm_features_match_reference_and_feed_the_model(device, gc):
     assert a.shape == (3, 200) and torch.isfinite(a).all()
     # different draws of the over-full boxes -> slightly different scores; same inputs elsewhere
     assert (a - b).abs().max() < 0.2
+
+
+# ------------------------------------------------------------------------------------------------ device-side draw
+def test_device_draw_restatement_is_uniform_and_sorted():
+    n, k = 40, 10
+    hits = np.zeros(n)
+    for s in range(3000):
+        idx = oracle_feat.device_draw_subset(n, k, 99, s)
+        assert len(idx) == k and (np.diff(idx) > 0).all() and idx.min() >= 0 and idx.max() < n
+        hits[idx] += 1
+    assert abs(hits / 3000 - k / n).max() < 0.04                       # 5 sigma of a binomial(3000, 0.25) frequency
+    np.testing.assert_array_equal(oracle_feat.device_draw_subset(7, 10, 1, 0), np.arange(7))
+
+
+@pytest.mark.gpu
+def test_device_draw_matches_restatement(device):
+    from detzero_amd import object_features as of
+    counts = [0, 5, 47, 48, 49, 255, 256, 257, 1000, 5000, 48, 48]
+    for k, stream in ((48, 4), (256, 3)):
+        dd = of.DeviceDraw(seed=20260925)
+        got = dd.draw(counts, k, stream, device).cpu().numpy()
+        seed = oracle_feat.device_stream_seed(20260925, stream)
+        assert seed == dd.stream_seed(stream)
+        for s, n in enumerate(counts):
+            want = oracle_feat.device_draw_subset(n, k, seed, s)
+            np.testing.assert_array_equal(got[s, :len(want)], want)
+            assert (got[s, len(want):] == -1).all()
+
+
+@pytest.mark.gpu
+def test_features_with_device_draw_vs_oracle(device):
+    """rng=DeviceDraw: nothing drawn on the host; the result equals the oracle fed the same (restated) draws."""
+    from detzero_amd import object_features as of
+    tracks = _tracks(gen.GRM_TRACKS + [(15, 30, 'Vehicle', 300, 900)])
+    dd = of.DeviceDraw(seed=7)
+    out = of.grm_features(tracks, rng=dd, device=device)
+    q_max = max(out['geo_query_num'])
+    objs = []
+    for i, tr in enumerate(tracks):
+        queue = []
+        if sum(p.shape[0] for p in tr['pts']) >= 4096:
+            queue.append((oracle_feat.device_stream_seed(7, 1), i))
+        for q, f in enumerate(np.argsort(tr['score'])[::-1][:3]):
+            if tr['pts'][f].shape[0] >= 256:
+                queue.append((oracle_feat.device_stream_seed(7, 2), i * q_max + q))
+        objs.append(oracle_feat.grm_object(tr, rng=oracle_feat.DeviceDrawReplay(queue)))
+    ref = oracle_feat.grm_batch(objs)
+    for k in GRM_KEYS:
+        _close(out[k], ref[k], atol=2e-6)
+    tracks = _tracks(gen.PRM_TRACKS[:2] + [(24, 6, 'Vehicle', 300, 700)])
+    out = of.prm_features(tracks, rng=dd, device=device)
+    objs, f = [], 0
+    for tr in tracks:
+        queue = []
+        for p in tr['pts']:
+            if p.shape[0] >= 256:
+                queue.append((oracle_feat.device_stream_seed(7, 3), f))
+            if p.shape[0] >= 48:
+                queue.append((oracle_feat.device_stream_seed(7, 4), f))
+            f += 1
+        objs.append(oracle_feat.prm_object(tr, rng=oracle_feat.DeviceDrawReplay(queue)))
+    ref = oracle_feat.prm_batch(objs)
+    for k in PRM_KEYS:
+        _close(out[k], ref[k], atol=3e-5 if 'points' in k else 1e-5)

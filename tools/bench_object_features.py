@@ -39,7 +39,9 @@ def main():
     torch.cuda.synchronize()
     print('pack + H2D of %d objects, %d boxes, %d points: %.1f ms' % (a.objects, sum(packed.box_num), packed.pts.shape[0], (time.perf_counter() - t0) * 1e3))
     random.seed(0)
-    for name, fn in (('GRM', lambda: of.grm_features(packed)), ('PRM', lambda: of.prm_features(packed))):
+    dd = of.DeviceDraw(seed=1)
+    for name, fn in (('GRM', lambda: of.grm_features(packed)), ('PRM', lambda: of.prm_features(packed)),
+                     ('GRM device draw', lambda: of.grm_features(packed, rng=dd)), ('PRM device draw', lambda: of.prm_features(packed, rng=dd))):
         out, dev_ms, wall_ms = timed(fn)
         nbytes = sum(v.numel() * v.element_size() for v in out.values() if torch.is_tensor(v))
         print('%s features: %.1f MB out, wall %.1f ms per batch (host index drawing + H2D + kernels), stream %.2f ms' % (name, nbytes / 1e6, wall_ms, dev_ms))
