@@ -208,9 +208,8 @@ int orc_nms(const float *boxes, int n, float thr, long long *keep)
  * utils/detzero_utils/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-36,352-374.
  * mask: (T, M) int32, 1 where point m lies in box t (caller zero-fills).
  * ------------------------------------------------------------------------------------------ */
-void orc_points_in_boxes_v2(const float *boxes, int t, const float *pts, int m, int *mask)
+void orc_points_in_boxes_margin(const float *boxes, int t, const float *pts, int m, float MARGIN, int *mask)
 {
-    const float MARGIN = 1e-5f;
     for (int i = 0; i < m; ++i) {
         float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
         for (int k = 0; k < t; ++k) {
@@ -227,4 +226,12 @@ void orc_points_in_boxes_v2(const float *boxes, int t, const float *pts, int m, 
                 mask[(size_t)k * m + i] = 1;
         }
     }
+}
+
+/* the GPU kernel's margin (roiaware_pool3d_kernel.cu:26); the reference's host twin check_pt_in_box3d_cpu
+ * (roiaware_pool3d.cpp:255-267) is the same test with MARGIN = 1e-2 - that one can be compiled here and pins the formula
+ * (oracle/refbuild.py: points_in_boxes_cpu_reference == orc_points_in_boxes_margin(..., 1e-2f)) */
+void orc_points_in_boxes_v2(const float *boxes, int t, const float *pts, int m, int *mask)
+{
+    orc_points_in_boxes_margin(boxes, t, pts, m, 1e-5f, mask);
 }

@@ -76,6 +76,15 @@ def nms_sorted(boxes_sorted, thr):
     return keep[:nk].copy()
 
 
+def points_in_boxes_margin(points_xyz, boxes, margin):
+    p = np.ascontiguousarray(points_xyz[:, :3], np.float32)
+    b = np.ascontiguousarray(boxes[:, :7], np.float32)
+    mask = np.zeros((b.shape[0], p.shape[0]), np.int32)
+    lib().orc_points_in_boxes_margin(_p(b, ctypes.c_float), b.shape[0], _p(p, ctypes.c_float), p.shape[0], ctypes.c_float(margin),
+                                     _p(mask, ctypes.c_int))
+    return mask
+
+
 def points_in_boxes_v2(points_xyz, boxes):
     p = np.ascontiguousarray(points_xyz[:, :3], np.float32)
     b = np.ascontiguousarray(boxes[:, :7], np.float32)

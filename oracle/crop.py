@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure only): CPU restatement of the object crop of daemon/prepare_object_data.py:250-273,310.
-The inside test is oracle/c/oracle.c's restatement of roiaware_pool3d_kernel.cu:16-36,352-374 (parity unpinned, see
-DESIGN.md section 3); everything else is the reference's numpy, line for line in meaning."""
+The inside test is oracle/c/oracle.c's restatement of roiaware_pool3d_kernel.cu:16-36,352-374 (pinned on the reference's compiled
+host twin points_in_boxes_cpu); everything else is the reference's numpy, line for line in meaning."""
 import numpy as np
 
 from . import cref

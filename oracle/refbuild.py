@@ -38,6 +38,48 @@ def build(force=False):
     return _SO
 
 
+ROI_SRC_DIR = '/root/reference/utils/detzero_utils/ops/roiaware_pool3d/src'
+_ROI_SO = os.path.join(_HERE, '_ref', 'libroiaware_cpu_ref.so')
+
+
+def build_roiaware(force=False):
+    """The reference's roiaware_pool3d.cpp (host part: points_in_boxes_cpu) compiled the same way."""
+    if os.path.exists(_ROI_SO) and not force:
+        return _ROI_SO
+    if not os.path.isdir(ROI_SRC_DIR):
+        raise RuntimeError('reference sources not present and %s not prebuilt' % _ROI_SO)
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(os.path.dirname(_ROI_SO), exist_ok=True)
+    inc = ['-I' + p for p in cpp_extension.include_paths()]
+    inc += ['-I' + sysconfig.get_paths()['include'], '-I' + os.path.join(_HERE, 'ref_build', 'stubs'), '-I' + ROI_SRC_DIR]
+    libdir = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off', '-w',
+           '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc + \
+          [os.path.join(_HERE, 'ref_build', 'roiaware_cpu_wrap.cpp'), '-o', _ROI_SO, '-L' + libdir, '-Wl,-rpath,' + libdir,
+           '-ltorch', '-ltorch_cpu', '-lc10', '-ltorch_python']
+    subprocess.check_call(cmd)
+    return _ROI_SO
+
+
+_roi_lib = None
+
+
+def points_in_boxes_cpu_reference(points_xyz, boxes):
+    """(T,7) boxes, (M,3) points -> (T,M) int32 flags from the reference's points_in_boxes_cpu."""
+    global _roi_lib
+    if _roi_lib is None:
+        import torch  # noqa: F401
+        _roi_lib = ctypes.CDLL(build_roiaware())
+    p = np.ascontiguousarray(points_xyz[:, :3], np.float32)
+    b = np.ascontiguousarray(boxes[:, :7], np.float32)
+    out = np.zeros((b.shape[0], p.shape[0]), np.int32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    _roi_lib.ref_points_in_boxes_cpu(b.ctypes.data_as(fp), b.shape[0], p.ctypes.data_as(fp), p.shape[0],
+                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    return out
+
+
 _lib = None
 
 

@@ -76,6 +76,25 @@ def test_rotated_iou_against_live_reference_build():
     assert np.array_equal(keep, keep_ref)
 
 
+def test_points_in_boxes_against_live_reference_build():
+    """The inside test of oracle.c against the reference's own host implementation (roiaware_pool3d.cpp:248-295, compiled by
+    oracle/refbuild.py): identical flags when given the host twin's margin (1e-2); the GPU kernel's margin (1e-5,
+    roiaware_pool3d_kernel.cu:26), which the product follows, keeps a subset."""
+    from oracle import refbuild
+    if not os.path.isdir(refbuild.ROI_SRC_DIR) and not os.path.exists(refbuild._ROI_SO):
+        pytest.skip('reference sources / prebuilt oracle/_ref not present')
+    from detzero_amd.synth import synth_boxes, synth_waymo_frame
+    for seed, n, t in ((3, 60000, 80), (5, 5000, 7)):
+        pts = synth_waymo_frame(seed, n)[:, :3]
+        boxes = synth_boxes(seed + 2, t, 60.0)
+        boxes[:, 2] = np.random.default_rng(seed).uniform(-0.5, 1.5, t)
+        ref = refbuild.points_in_boxes_cpu_reference(pts, boxes)
+        assert ref.sum() > 0
+        assert np.array_equal(cref.points_in_boxes_margin(pts, boxes, 1e-2), ref)
+        tight = cref.points_in_boxes_v2(pts, boxes)
+        assert ((tight == 1) & (ref == 0)).sum() == 0 and tight.sum() <= ref.sum()
+
+
 def test_points_in_boxes_properties():
     from detzero_amd.synth import synth_boxes
     boxes = synth_boxes(5, 30)
