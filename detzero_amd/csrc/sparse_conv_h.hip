@@ -269,25 +269,19 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream, bool ring_o
     return launch_spconv_h_impl<T, M, NS, false, OCC>(a, stream);
 }
 
+// Tile choices (per launch at 16 frames, r01e; alternatives that were built and measured slower or equal are listed in
+// 64-row tiles with 4 waves - the r01d defaults, kept below as knob 1 -, 256-row tiles with 64 x 64 wave tiles,
+// 4 register stages, 128 x 128 with 4 waves).
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
     if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4, 3, 4, 5>(a, stream);
     if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
-        if (t64 == 1) return launch_spconv_h<HTile<128, 64, 32, 2, 2>, M, 3>(a, stream);
-        if (t64 == 3) return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
-        if (t64 == 6) return launch_spconv_h<HTile<256, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);       // 8 waves of 64 x 32
-        if (t64 == 7) return launch_spconv_h<HTile<256, 64, 32, 4, 2>, M, 3, 3, 3, 3>(a, stream);
-        if (t64 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 2>(a, stream);
-        if (t64 == 5) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);
-        return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);          // 8 waves of 32 x 32
+        if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);       // 4 waves of 32 x 32 (r01d)
+        return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);                    // 8 waves of 32 x 32
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
-        if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 2>(a, stream);
-        if (t128 == 2) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4>(a, stream);
-        if (t128 == 3) return launch_spconv_h<HTile<128, 128, 32, 2, 2>, M, 2>(a, stream);
-        if (t128 == 5) return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 4, 4, 2, 2>(a, stream);
 #ifdef DZ_SPCONV_DIAG
         if (t128 >= 11 && t128 <= 19 && a.tile_masks && a.nbr_bytes) {
             using DT = HTile<128, 128, 32, 4, 2>;
@@ -301,10 +295,8 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
             return launch_spconv_h_impl<DT, M, 3, true, 2, 9>(a, stream);
         }
 #endif
-        if (t128 == 7) return launch_spconv_h<HTile<256, 128, 32, 4, 2>, M, 2, 2, 2, 2>(a, stream);     // 8 waves of 64 x 64
-        if (t128 == 8) return launch_spconv_h<HTile<256, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
-        if (t128 == 6) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));
-        return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);        // 8 waves of 32 x 64
+        if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));   // 4 waves (r01d)
+        return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);                   // 8 waves of 32 x 64
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
