@@ -31,6 +31,8 @@ class PackedTracks:
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.device = dev
         self.batch = len(tracks)
+        if self.batch == 0:
+            raise L.DetZeroHipError('PackedTracks: empty batch of object tracks')
         self.counts = [[int(p.shape[0]) for p in t['pts']] for t in tracks]           # points per box, per object
         boxes = [np.asarray(t['boxes_global'], dtype=np.float64)[:, :7] for t in tracks]
         for t, b, c in zip(tracks, boxes, self.counts):

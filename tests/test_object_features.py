@@ -308,3 +308,19 @@ def test_features_with_device_draw_vs_oracle(device):
     ref = oracle_feat.prm_batch(objs)
     for k in PRM_KEYS:
         _close(out[k], ref[k], atol=3e-5 if 'points' in k else 1e-5)
+
+
+def test_host_side_errors():
+    from detzero_amd import object_features as of
+    from detzero_amd.lib import DetZeroHipError
+    cpu = torch.device('cpu')
+    with pytest.raises(DetZeroHipError):
+        of.PackedTracks([], device=cpu)
+    tr = synth_object_track(1, 3, 'Vehicle', 1, 5)
+    tr['score'] = tr['score'][:2]
+    with pytest.raises(DetZeroHipError):
+        of.PackedTracks([tr], device=cpu)
+    with pytest.raises(DetZeroHipError):
+        of.grm_features(of.PackedTracks([synth_object_track(2, 3, 'Vehicle', 1, 5)], device=cpu), encoding=('xyz', 'p2co'))
+    with pytest.raises(DetZeroHipError):
+        of.prm_features(of.PackedTracks([synth_object_track(3, 5, 'Vehicle', 1, 5)], device=cpu), query_num=4)
