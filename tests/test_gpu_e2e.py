@@ -295,3 +295,25 @@ def test_stacked_equal_length_batch_equals_single_frames(device, math):
         n = int(n1.item())
         assert n > 0 and int(cnt[i].item()) == n and torch.equal(out[i, :n], o1[:n])
     set_math(model, 'f32')
+
+
+@pytest.mark.parametrize('math', ['f32', 'f16x2'])
+def test_frame_without_points_in_range(small, device, math):
+    """A frame whose points all fall outside the range (an empty frame after the reference's range mask) next to a normal one:
+    no voxels, no sparse sites at any level, only what the head makes of an empty BEV map - and the neighbour frame's boxes are
+    the ones it gets alone."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, pts0, ref = small
+    pipe = FramePipeline(model, info, math=math)
+    f0 = torch.from_numpy(pts0).to(device)
+    far = f0.clone()
+    far[:, 0] += 1000.0
+    alone, n_alone = pipe([f0])
+    both, n_both = pipe([f0, far])
+    torch.cuda.synchronize()
+    k = int(n_alone[0])
+    assert int(n_both[0]) == k and k > 0
+    torch.testing.assert_close(both[0, :k], alone[0, :k], rtol=0, atol=1e-4)
+    empty_only, n_empty = pipe([far])
+    assert int(n_both[1]) == int(n_empty[0])
+    assert torch.isfinite(both[1]).all()
