@@ -41,13 +41,11 @@ def box_coords_transform(traj, init_box):
 
 def world_to_lidar(boxes, poses):
     """data_utils.py:45-57: global boxes (T,7) + the frames' poses (T,4,4) -> boxes in each frame's lidar coordinates."""
-    boxes, poses = np.stack(boxes, axis=0), np.stack(poses, axis=0)
-    r_t = np.linalg.inv(poses)
-    n = len(boxes)
-    centers = np.concatenate([boxes[:, :3], np.ones((n, 1))], axis=-1)
-    centers = np.einsum('ijk,ikm->ijm', centers[:, None, :], r_t.transpose(0, 2, 1)).reshape(n, -1)
-    heading = boxes[:, 6] + np.arctan2(r_t[:, 1, 0], r_t[:, 0, 0])
-    return np.concatenate([centers[:, :3], boxes[:, 3:6], heading[:, None]], axis=-1)
+    boxes, to_lidar = np.stack(boxes, axis=0), np.linalg.inv(np.stack(poses, axis=0))          # (T,7), (T,4,4) world -> lidar
+    homog = np.concatenate([boxes[:, :3], np.ones((len(boxes), 1))], axis=1)
+    centers = np.einsum('nk,nmk->nm', homog, to_lidar[:, :3, :])                                # row n: R_n c_n + t_n
+    heading = boxes[:, 6] + np.arctan2(to_lidar[:, 1, 0], to_lidar[:, 0, 0])
+    return np.concatenate([centers, boxes[:, 3:6], heading[:, None]], axis=1)
 
 
 def grm_revert_to_each_frame(pred_boxes, trajectories, poses):

@@ -23,7 +23,10 @@ def _check(tag, res, g):
                 if k in ('sequence_name', 'state', 'name'):
                     assert np.asarray(v).astype(str).tolist() == ref.tolist()
                 else:
-                    np.testing.assert_array_equal(np.asarray(v), ref, err_msg='%s %s %s' % (tag, obj, k))      # same numpy ops: bit for bit
+                    # float64 host arithmetic on coordinates of ~1e4 m: equal to the last few bits (the contraction order of the
+                    # pose product may differ from the reference's einsum)
+                    np.testing.assert_allclose(np.asarray(v, dtype=np.float64), ref.astype(np.float64), rtol=0, atol=1e-9,
+                                               err_msg='%s %s %s' % (tag, obj, k))
                 n += 1
     assert n == sum(1 for k in g.files if k.startswith(tag + '_'))
 
