@@ -115,16 +115,28 @@ __device__ __forceinline__ void load_hfrag(HFrag<T> &f, const v4u *__restrict__ 
     }
 }
 
-template <class T, class M>
+// TM (term-major): the three terms outermost, so that consecutive MFMAs go to different accumulators when a wave has more than
+// one (same bits: every accumulator still receives lo.hi, hi.lo, hi.hi in that order)
+template <class T, class M, bool TM = false>
 __device__ __forceinline__ void mma_hfrag(const HFrag<T> &f, f32x16 (&acc)[T::CT][T::PT]) {
+    if constexpr (TM) {
 #pragma unroll
-    for (int ct = 0; ct < T::CT; ++ct)
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int pt = 0; pt < T::PT; ++pt) {
-            acc[ct][pt] = M::mma(f.c_lo[ct], f.p_hi[pt], acc[ct][pt]);
-            acc[ct][pt] = M::mma(f.c_hi[ct], f.p_lo[pt], acc[ct][pt]);
-            acc[ct][pt] = M::mma(f.c_hi[ct], f.p_hi[pt], acc[ct][pt]);
-        }
+            for (int ct = 0; ct < T::CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < T::PT; ++pt)
+                    acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < T::CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < T::PT; ++pt) {
+                acc[ct][pt] = M::mma(f.c_lo[ct], f.p_hi[pt], acc[ct][pt]);
+                acc[ct][pt] = M::mma(f.c_hi[ct], f.p_lo[pt], acc[ct][pt]);
+                acc[ct][pt] = M::mma(f.c_hi[ct], f.p_hi[pt], acc[ct][pt]);
+            }
+    }
 }
 
 template <class T>
@@ -230,7 +242,7 @@ __device__ __forceinline__ void hgemm_pipeline(int nchunks, v4u *__restrict__ sm
         if constexpr (DIAG != 2) load_hfrag<T>(f, ps, cs, q);
     };
     auto do_mma = [&](HFrag<T> &f) {
-        if constexpr (DIAG == 1) keep_hfrag<T>(f); else mma_hfrag<T, M>(f, acc);
+        if constexpr (DIAG == 1) keep_hfrag<T>(f); else mma_hfrag<T, M, DIAG == 10>(f, acc);
     };
     do_issue(st[0], std::integral_constant<int, 0>{});
     if constexpr (DIAG != 4) wait_hstage<T, 0>(st[0]);

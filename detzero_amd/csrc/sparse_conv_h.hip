@@ -283,7 +283,7 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
 #ifdef DZ_SPCONV_DIAG
-        if (t128 >= 11 && t128 <= 19 && a.tile_masks && a.nbr_bytes) {
+        if (t128 >= 11 && t128 <= 20 && a.tile_masks && a.nbr_bytes) {
             using DT = HTile<128, 128, 32, 4, 2>;
             if (t128 == 11) return launch_spconv_h_impl<DT, M, 3, true, 2, 1>(a, stream);
             if (t128 == 12) return launch_spconv_h_impl<DT, M, 3, true, 2, 2>(a, stream);
@@ -292,6 +292,7 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
             if (t128 == 16) return launch_spconv_h_impl<DT, M, 3, true, 2, 6>(a, stream);
             if (t128 == 17) return launch_spconv_h_impl<DT, M, 3, true, 2, 7>(a, stream);
             if (t128 == 18) return launch_spconv_h_impl<DT, M, 3, true, 2, 8>(a, stream);
+            if (t128 == 20) return launch_spconv_h_impl<DT, M, 3, true, 2, 10>(a, stream);
             return launch_spconv_h_impl<DT, M, 3, true, 2, 9>(a, stream);
         }
 #endif
