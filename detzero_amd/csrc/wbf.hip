@@ -89,13 +89,13 @@ struct WbfParams {
 
 // workspace of one (frame, class) slot; `cap` = candidates per frame
 struct WbfSlot {
-    int *sel_idx, *order, *c_cnt, *c_first, *counts;      // counts: [0] selected, [1] clusters, [2] first candidate of the class
+    int *sel_idx, *order, *c_cnt, *c_first, *c_obj, *counts;     // counts: [0] selected, [1] clusters, [2] first candidate of the class
     double *sel_score, *c_conf, *c_score;
     float *c_acc, *c_fused;
 };
 
 __host__ __device__ inline size_t wbf_slot_bytes(int cap) {
-    return (size_t)cap * (4 * sizeof(int) + 3 * sizeof(double) + 14 * sizeof(float)) + 64;
+    return (size_t)cap * (5 * sizeof(int) + 3 * sizeof(double) + 14 * sizeof(float) + 4) + 64;      // (+4: keeps slots 8-byte aligned)
 }
 
 __device__ __forceinline__ WbfSlot wbf_slot(void *ws, int slot, int cap) {
@@ -109,6 +109,7 @@ __device__ __forceinline__ WbfSlot wbf_slot(void *ws, int slot, int cap) {
     s.order = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_cnt = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_first = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
+    s.c_obj = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_acc = reinterpret_cast<float *>(p); p += (size_t)cap * 7 * sizeof(float);
     s.c_fused = reinterpret_cast<float *>(p);
     return s;
@@ -162,7 +163,8 @@ constexpr int WBF_THREADS = 256;
 
 // the clustering loop of weighted_boxes_fusion_3d (wbf_3d.py:168-190) for one (frame, class)
 __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__restrict__ boxes, const float *__restrict__ scores,
-                                                             const double *__restrict__ weights, WbfParams p, void *ws) {
+                                                             const double *__restrict__ weights, const int *__restrict__ obj_ids,
+                                                             WbfParams p, void *ws) {
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const WbfSlot s = wbf_slot(ws, f * 3 + l, p.cand);
     __shared__ P2 cp_s[16 * WBF_THREADS];
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__rest
                 float *acc = s.c_acc + (size_t)ncl * 7, *fu = s.c_fused + (size_t)ncl * 7;
                 for (int k = 0; k < 7; ++k) { acc[k] = (float)(sj * (double)bj[k]); fu[k] = bj[k]; }
                 s.c_conf[ncl] = sj; s.c_cnt[ncl] = 1; s.c_first[ncl] = cand; s.c_score[ncl] = sj;
+                s.c_obj[ncl] = obj_ids ? obj_ids[(size_t)f * p.cand + cand] : -1;
                 ncl_s = ncl + 1;
             } else {                                                        // get_weighted_box (wbf_3d.py:53-96)
                 const int c = best_idx;
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__rest
                 const int first = s.c_first[c];
                 fu[6] = boxes[((size_t)f * p.cand + first) * 7 + 6];
                 s.c_conf[c] = conf; s.c_cnt[c] = cnt;
+                // object id (weighted_tracking_boxes_fusion_3d, wbf_3d.py:86-94): the most confident member that has one
+                if (obj_ids && s.c_obj[c] < 0) s.c_obj[c] = obj_ids[(size_t)f * p.cand + cand];
                 const double first_sc = (double)scores[(size_t)f * p.cand + first] * (weights ? weights[first / p.per_model] : 1.0);
                 s.c_score[c] = (double)(float)(p.conf_max ? first_sc : conf / cnt);
             }
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__rest
 
 // all classes of a frame, sorted by fused score (wbf_3d.py:198-203)
 __global__ __launch_bounds__(256) void k_wbf_emit(const float *__restrict__ boxes, WbfParams p, void *ws, double *__restrict__ out_boxes,
-                                                  double *__restrict__ out_scores, int *__restrict__ out_labels, int *__restrict__ out_count) {
+                                                  double *__restrict__ out_scores, int *__restrict__ out_labels, int *__restrict__ out_obj,
+                                                  int *__restrict__ out_count) {
     const int f = blockIdx.x;
     WbfSlot s[3];
     int ncl[3], first[3], pos0[3];
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(256) void k_wbf_emit(const float *__restrict__ boxe
         for (int k = 0; k < 7; ++k) ob[k] = (double)fu[k];
         out_scores[(size_t)f * p.cand + r] = sc;
         out_labels[(size_t)f * p.cand + r] = l + 1;
+        if (out_obj) out_obj[(size_t)f * p.cand + r] = s[l].c_obj[c];
     }
     if (threadIdx.x == 0) out_count[f] = total;
 }
@@ -340,10 +347,10 @@ size_t dz_wbf_workspace_bytes(int frames, int cand) {
     return (size_t)frames * 3 * wbf_slot_bytes(cand) + 256;
 }
 
-int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, int frames, int cand, int per_model,
+int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, const int *obj_ids, int frames, int cand, int per_model,
                    const double *weights, int n_models, const double *h_iou_thr3, const double *h_skip_thr3, double weight_sum,
-                   int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_count, void *ws,
-                   size_t ws_bytes, void *stream_) {
+                   int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_obj_ids,
+                   int *out_count, void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(frames >= 0 && cand >= 0 && per_model >= 1 && n_models >= 1 && (long)per_model * n_models >= cand,
                  "dz_wbf_fuse_3d: bad sizes (cand %d, %d models x %d)", cand, n_models, per_model);
@@ -361,8 +368,9 @@ int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, i
     for (int i = 0; i < 3; ++i) { p.iou_thr[i] = h_iou_thr3[i]; p.skip_thr[i] = h_skip_thr3[i]; }
     p.wsum = weight_sum;
     hipLaunchKernelGGL(k_wbf_rank, dim3(3, frames), dim3(256), 0, stream, scores, labels, weights, p, ws);
-    hipLaunchKernelGGL(k_wbf_cluster, dim3(3, frames), dim3(WBF_THREADS), 0, stream, boxes, scores, weights, p, ws);
-    hipLaunchKernelGGL(k_wbf_emit, dim3(frames), dim3(256), 0, stream, boxes, p, ws, out_boxes, out_scores, out_labels, out_count);
+    DZ_CHECK_ARG(!obj_ids == !out_obj_ids, "dz_wbf_fuse_3d: obj_ids and out_obj_ids go together");
+    hipLaunchKernelGGL(k_wbf_cluster, dim3(3, frames), dim3(WBF_THREADS), 0, stream, boxes, scores, weights, obj_ids, p, ws);
+    hipLaunchKernelGGL(k_wbf_emit, dim3(frames), dim3(256), 0, stream, boxes, p, ws, out_boxes, out_scores, out_labels, out_obj_ids, out_count);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

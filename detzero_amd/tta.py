@@ -100,11 +100,13 @@ def restore_boxes(boxes, op_names):
 
 
 def wbf_fuse_nosync(boxes, scores, labels, n_models, weights=None, iou_thr=IOU_THR, skip_box_thr=SKIP_BOX_THR, conf_type='avg',
-                    allows_overflow=False):
+                    allows_overflow=False, obj_ids=None):
     """boxes (F, cand, 7) float32, scores (F, cand) float32, labels (F, cand) int32 (0 = padding), candidates model-major
     (cand = n_models x per-model rows).  -> (boxes (F,cand,7) float64, scores (F,cand) float64, labels (F,cand) int32,
-    counts (F,) int32): the first counts[f] rows of frame f, sorted by fused score.  No host synchronisation."""
-    L.require_cuda(boxes, scores, labels)
+    counts (F,) int32): the first counts[f] rows of frame f, sorted by fused score.  No host synchronisation.
+    With obj_ids (F, cand) int32 the tracking variant (weighted_tracking_boxes_fusion_3d): a fifth result, the fused boxes'
+    object ids (F, cand) int32, sits before the counts."""
+    L.require_cuda(boxes, scores, labels, obj_ids)
     f, cand = scores.shape
     if cand % n_models:
         raise DetZeroHipError('wbf: %d candidates do not split into %d models' % (cand, n_models))
@@ -119,14 +121,15 @@ def wbf_fuse_nosync(boxes, scores, labels, n_models, weights=None, iou_thr=IOU_T
     osc = torch.empty((f, cand), dtype=torch.float64, device=dev)
     ol = torch.empty((f, cand), dtype=torch.int32, device=dev)
     oc = torch.empty((f,), dtype=torch.int32, device=dev)
+    oo = None if obj_ids is None else torch.empty((f, cand), dtype=torch.int32, device=dev)
     thr = np.asarray(iou_thr, dtype=np.float64)
     skip = np.asarray(skip_box_thr, dtype=np.float64)
     with torch.cuda.device(dev):
-        rc = lib.dz_wbf_fuse_3d(L.ptr(boxes), L.ptr(scores), L.ptr(labels), f, cand, cand // n_models, L.ptr(w), n_models,
+        rc = lib.dz_wbf_fuse_3d(L.ptr(boxes), L.ptr(scores), L.ptr(labels), L.ptr(obj_ids), f, cand, cand // n_models, L.ptr(w), n_models,
                                 thr.ctypes.data, skip.ctypes.data, wsum, 1 if conf_type == 'max' else 0, 1 if allows_overflow else 0,
-                                L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc), L.ptr(ws), ws.numel() * 8, L.stream())
+                                L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oo), L.ptr(oc), L.ptr(ws), ws.numel() * 8, L.stream())
     L.check(rc, 'dz_wbf_fuse_3d')
-    return ob, osc, ol, oc
+    return (ob, osc, ol, oc) if obj_ids is None else (ob, osc, ol, oo, oc)
 
 
 def wbf_online(boxes, scores, labels):
@@ -139,6 +142,18 @@ def wbf_online(boxes, scores, labels):
     ob, osc, ol, oc = wbf_fuse_nosync(b, s, la, t)
     k = int(oc.item())
     return ob[0, :k], osc[0, :k], ol[0, :k].long()
+
+
+def wbf_tracking_v1(boxes, scores, labels, obj_ids):
+    """ensemble.py:35-62 for ONE frame: as wbf_online, plus obj_ids (T, M[, 1]) -> (boxes, scores, labels, obj_ids (K,) int64)."""
+    t, m = boxes.shape[0], boxes.shape[1]
+    b = boxes[..., :7].float().reshape(1, t * m, 7).contiguous()
+    s = scores.float().reshape(1, t * m).contiguous()
+    la = labels.reshape(1, t * m).to(torch.int32).contiguous()
+    ids = obj_ids.reshape(1, t * m).to(torch.int32).contiguous()
+    ob, osc, ol, oo, oc = wbf_fuse_nosync(b, s, la, t, obj_ids=ids)
+    k = int(oc.item())
+    return ob[0, :k], osc[0, :k], ol[0, :k].long(), oo[0, :k].long()
 
 
 class TTAPipeline:

@@ -365,10 +365,12 @@ size_t dz_wbf_workspace_bytes(int frames, int cand);
  * (frames, cand) in 1..3 (0 = padding); candidate c belongs to model c / per_model (weights: device doubles per model or NULL
  * = 1; weight_sum = their sum).  conf_max: 0 'avg', 1 'max'.  Outputs sorted by fused score: out_boxes (frames, cand, 7) and
  * out_scores (frames, cand) float64 as in the reference, out_labels, out_count (frames). */
-int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, int frames, int cand, int per_model,
+int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, const int *obj_ids, int frames, int cand, int per_model,
                    const double *weights, int n_models, const double *h_iou_thr3, const double *h_skip_thr3, double weight_sum,
-                   int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_count, void *ws,
-                   size_t ws_bytes, void *stream);
+                   int conf_max, int allows_overflow, double *out_boxes, double *out_scores, int *out_labels, int *out_obj_ids,
+                   int *out_count, void *ws, size_t ws_bytes, void *stream);
+/* obj_ids / out_obj_ids (frames, cand), both or neither: weighted_tracking_boxes_fusion_3d (wbf_3d.py:205-265) - a fused box
+ * carries the object id of its most confident member that has one (>= 0), else -1. */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Frame assembly from stored sweeps (DatasetTemplate.merge_sweeps, detection/detzero_det/datasets/dataset.py:164-195):

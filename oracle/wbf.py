@@ -98,8 +98,8 @@ def iou3d_one_to_many(box, others):
 
 
 def _fused(members, conf_type):
-    """get_weighted_box (wbf_3d.py:53-96): rows [label, conf, x, y, z, dx, dy, dz, yaw]; float32 accumulator."""
-    out = np.zeros(9, dtype=np.float32)
+    """get_weighted_box (wbf_3d.py:53-96): rows [label, conf, (obj id,) x, y, z, dx, dy, dz, yaw]; float32 accumulator."""
+    out = np.zeros(len(members[0]), dtype=np.float32)
     conf, confs = 0, []
     for m in members:
         out[-7:] += m[1] * m[-7:]
@@ -109,14 +109,20 @@ def _fused(members, conf_type):
     out[1] = conf / len(members) if conf_type == 'avg' else np.array(confs).max()
     out[-7:] /= conf
     out[-1] = members[confs.index(max(confs))][-1]
+    if len(members[0]) > 9:                                                     # tracking rows: id of the most confident member that has one
+        ids = np.array([m[2] for m in members])[np.argsort(np.array(confs))[::-1]]
+        ids = ids[ids >= 0]
+        out[2] = ids[0] if len(ids) else -1
     return out
 
 
 def weighted_boxes_fusion_3d(boxes, scores, labels, weights=None, iou_thr=IOU_THR, skip_box_thr=SKIP_THR, conf_type='avg',
-                             allows_overflow=False):
+                             allows_overflow=False, obj_ids=None):
     """boxes (T, M, 7), scores (T, M[, 1]), labels (T, M[, 1]) of ONE frame (label 0 = padding) -> fused
-    (K,7) float64, (K,) float64, (K,) int, sorted by fused score (wbf_3d.py:118-203, iou_type '3d')."""
+    (K,7) float64, (K,) float64, (K,) int, sorted by fused score (wbf_3d.py:118-203, iou_type '3d').  With obj_ids
+    (T, M[, 1]): weighted_tracking_boxes_fusion_3d (wbf_3d.py:205-265), a fourth result (K,) int of object ids."""
     boxes = np.asarray(boxes)
+    ids_in = None if obj_ids is None else np.asarray(obj_ids).reshape(boxes.shape[0], -1)
     scores = np.asarray(scores).reshape(boxes.shape[0], -1)
     labels = np.asarray(labels).reshape(boxes.shape[0], -1)
     t = boxes.shape[0]
@@ -127,14 +133,15 @@ def weighted_boxes_fusion_3d(boxes, scores, labels, weights=None, iou_thr=IOU_TH
             lab = int(labels[i][j])
             if lab == 0:
                 continue
-            row = [lab, float(scores[i][j]) * weights[i]] + [float(v) for v in boxes[i][j][:7]]
+            row = [lab, float(scores[i][j]) * weights[i]] + ([] if ids_in is None else [int(ids_in[i][j])]) + [float(v) for v in boxes[i][j][:7]]
             per_label.setdefault(lab, []).append(row)
     for lab in per_label:
         arr = np.array(per_label[lab])
         arr = arr[arr[:, 1].argsort()[::-1]]
         per_label[lab] = arr[arr[:, 1] >= skip_box_thr[lab - 1]]
+    empty = (np.zeros((0, 7)), np.zeros((0,)), np.zeros((0,))) + (() if ids_in is None else (np.zeros((0,)),))
     if len(per_label) == 0:
-        return np.zeros((0, 7)), np.zeros((0,)), np.zeros((0,))
+        return empty
     overall = []
     for lab, cand in per_label.items():
         groups, fused = [], []
@@ -160,7 +167,9 @@ def weighted_boxes_fusion_3d(boxes, scores, labels, weights=None, iou_thr=IOU_TH
         if fused:
             overall.append(np.array(fused))
     if not overall:
-        return np.zeros((0, 7)), np.zeros((0,)), np.zeros((0,))
+        return empty
     overall = np.concatenate(overall, axis=0)
     overall = overall[overall[:, 1].argsort()[::-1]]
-    return overall[:, -7:], overall[:, 1], overall[:, 0].astype(int)
+    if ids_in is None:
+        return overall[:, -7:], overall[:, 1], overall[:, 0].astype(int)
+    return overall[:, 3:], overall[:, 1], overall[:, 0].astype(int), overall[:, 2].astype(int)

@@ -87,6 +87,7 @@ def import_reference():
         return ens.wbf_online(boxes, scores, labels)
     glb = {'torch': torch, 'np': np, 'common_utils': cu, 'wbf_online': wbf_online}
     exec(code, glb)
+    captured['wbf_tracking_v1'] = ens.wbf_tracking_v1
     return aug.TestTimeAugmentor, glb['test_time_augment'], captured
 
 
@@ -177,6 +178,16 @@ def main():
         out[tag + 'fused_scores'] = scores.numpy()
         out[tag + 'fused_labels'] = labels.numpy()
         print(tag, 'copies', len(ops), 'max boxes', m, '->', boxes.shape[0], 'fused')
+        if seed == FRAMES[1][0]:
+            # tracking variant (ensemble.py:35-62 -> wbf_3d.py:205-265) on the same restored boxes: object ids per candidate,
+            # -1 (no id) for a third of them
+            rng = np.random.default_rng(seed)
+            ids = np.where(rng.random(pl.shape) < 0.33, -1, rng.integers(0, 40, size=pl.shape)).astype(np.int64)
+            out[tag + 'obj_ids'] = ids
+            tb, ts, tl, ti = captured['wbf_tracking_v1'](captured['restored'].clone(), torch.from_numpy(ps)[..., None], torch.from_numpy(pl)[..., None],
+                                                         torch.from_numpy(ids)[..., None])
+            out[tag + 'trk_boxes'], out[tag + 'trk_scores'], out[tag + 'trk_labels'], out[tag + 'trk_ids'] = tb.numpy(), ts.numpy(), tl.numpy(), ti.numpy()
+            print(tag, 'tracking variant ->', tb.shape[0], 'fused,', int((ti >= 0).sum()), 'with an id')
     np.savez_compressed(os.path.join(HERE, 'tta_golden.npz'), **out)
     print('saved %d arrays, %d KiB' % (len(out), os.path.getsize(os.path.join(HERE, 'tta_golden.npz')) // 1024))
 

@@ -156,3 +156,29 @@ def test_tta_pipeline_end_to_end(device):
         np.testing.assert_allclose(mine[:, 2:8], ref[:, 2:8], rtol=0, atol=1e-4)
         # heading = the heading of the cluster's most confident member: with equal confidences (see above) either may be it
         assert (np.abs(mine[:, 8] - ref[:, 8]) > 1e-4).mean() < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ tracking variant (object ids)
+def test_oracle_tracking_fusion_equals_reference(g):
+    tag = 'f%d_' % gen.FRAMES[1][0]
+    b, s, l, ids = oracle_wbf.weighted_boxes_fusion_3d(g[tag + 'restored'], g[tag + 'pred_scores'], g[tag + 'pred_labels'], obj_ids=g[tag + 'obj_ids'])
+    np.testing.assert_array_equal(b, g[tag + 'trk_boxes'])
+    np.testing.assert_array_equal(s, g[tag + 'trk_scores'])
+    np.testing.assert_array_equal(l, g[tag + 'trk_labels'])
+    np.testing.assert_array_equal(ids, g[tag + 'trk_ids'])
+    assert (ids >= 0).sum() > 10 and (ids < 0).sum() > 0
+
+
+@pytest.mark.gpu
+def test_tracking_fusion_matches_reference(device, g):
+    """wbf_tracking_v1 (ensemble.py:35-62 -> weighted_tracking_boxes_fusion_3d): the fused boxes of wbf_online plus, per box, the
+    object id of its most confident member that has one."""
+    from detzero_amd import tta
+    tag = 'f%d_' % gen.FRAMES[1][0]
+    b, s, l, ids = tta.wbf_tracking_v1(torch.from_numpy(g[tag + 'restored']).to(device), torch.from_numpy(g[tag + 'pred_scores']).to(device)[..., None],
+                                       torch.from_numpy(g[tag + 'pred_labels']).to(device)[..., None], torch.from_numpy(g[tag + 'obj_ids']).to(device)[..., None])
+    assert ids.dtype == torch.int64 and b.shape[0] == g[tag + 'trk_boxes'].shape[0]
+    np.testing.assert_array_equal(l.cpu().numpy(), g[tag + 'trk_labels'])
+    np.testing.assert_array_equal(ids.cpu().numpy(), g[tag + 'trk_ids'])
+    np.testing.assert_allclose(s.cpu().numpy(), g[tag + 'trk_scores'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(b.cpu().numpy(), g[tag + 'trk_boxes'], rtol=0, atol=1e-6)
