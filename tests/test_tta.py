@@ -182,3 +182,18 @@ def test_tracking_fusion_matches_reference(device, g):
     np.testing.assert_array_equal(ids.cpu().numpy(), g[tag + 'trk_ids'])
     np.testing.assert_allclose(s.cpu().numpy(), g[tag + 'trk_scores'], rtol=0, atol=1e-7)
     np.testing.assert_allclose(b.cpu().numpy(), g[tag + 'trk_boxes'], rtol=0, atol=1e-6)
+
+
+def test_augmentor_config_forms_and_errors():
+    from detzero_amd.config import AttrDict
+    from detzero_amd.lib import DetZeroHipError
+    from detzero_amd.tta import TestTimeAugmentor, parse_op
+    cfg = AttrDict({'DISABLE_AUG_LIST': ['world_scaling'], 'AUG_CONFIG_LIST': [AttrDict(c) for c in gen.AUG_CONFIG]})
+    aug = TestTimeAugmentor(cfg)
+    assert len(aug.op_names) == 13 and not any('scale' in n for n in aug.op_names)
+    assert aug.kinds.dtype == np.int32 and aug.params.dtype == np.float32 and aug.kinds[0] == 0
+    for bad in ('tta_shear_1', 'flip_x', 'tta_flip_z', 'tta_rot'):
+        with pytest.raises((DetZeroHipError, ValueError)):
+            parse_op(bad)
+    with pytest.raises(DetZeroHipError):
+        TestTimeAugmentor([{'NAME': 'world_translation'}])
