@@ -408,14 +408,15 @@ class StreamingDetector:
         return out
 
 
-def synth_detector(voxel_size, seed=0):
-    """Seeded random-init CenterPoint of the reference architecture (there are no checkpoints offline):
+def synth_detector(voxel_size, seed=0, sweeps=1):
+    """Seeded random-init CenterPoint of the reference architecture (there are no checkpoints offline;
+    sweeps > 1: the multi-sweep configuration - DynamicMeanVFE on 6 point features, centerpoint_3sweeps.yaml):
     default inits, BatchNorm running statistics randomised so BN folding is exercised, final-conv biases
     of hm / dim / iou spread so that a few hundred boxes pass SCORE_THRESH and NMS has work to do
     (SURVEY.md §8d).  Returns (model on CPU in eval mode, cfg, dataset_info)."""
-    from .config import centerpoint_1sweep_cfg
-    cfg = centerpoint_1sweep_cfg(tuple(voxel_size))
-    info = SyntheticDatasetInfo(cfg)
+    from .config import centerpoint_1sweep_cfg, centerpoint_3sweeps_cfg
+    cfg = centerpoint_1sweep_cfg(tuple(voxel_size)) if sweeps == 1 else centerpoint_3sweeps_cfg(tuple(voxel_size))
+    info = SyntheticDatasetInfo(cfg, num_point_features=5 if sweeps == 1 else 6)
     torch.manual_seed(seed)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), info).eval()
     gen = torch.Generator().manual_seed(seed)

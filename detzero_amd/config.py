@@ -111,3 +111,18 @@ def centerpoint_1sweep_cfg(voxel_size=(0.1, 0.1, 0.15), max_voxels_test=200000):
                                 'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'waymo'},
         },
     })
+
+
+def centerpoint_3sweeps_cfg(voxel_size=(0.1, 0.1, 0.15)):
+    """VALUES of det_model_cfgs/centerpoint_3sweeps.yaml + det_dataset_cfgs/waymo_3sweeps.yaml read on the inference path:
+    the 1-sweep network with DynamicMeanVFE on 6 point features (x, y, z, intensity, elongation, offset), SWEEP_COUNT [-1, 1],
+    voxelization left to the model (transform_points_to_voxels_placeholder, centerpoint_3sweeps.yaml:15-16), 400k voxels at test."""
+    cfg = centerpoint_1sweep_cfg(voxel_size, max_voxels_test=400000)
+    cfg.DATA_CONFIG.SWEEP_COUNT = [-1, 1]
+    cfg.DATA_CONFIG.POINT_FEATURE_ENCODING = {
+        'encoding_type': 'absolute_coordinates_encoding',
+        'used_feature_list': ['x', 'y', 'z', 'intensity', 'elongation', 'offset'],
+        'src_feature_list': ['x', 'y', 'z', 'intensity', 'elongation', 'offset']}
+    cfg.DATA_CONFIG.DATA_PROCESSOR[2].NAME = 'transform_points_to_voxels_placeholder'
+    cfg.MODEL.VFE.NAME = 'DynamicMeanVFE'
+    return cfg

@@ -1,0 +1,202 @@
+"""GPU (MI355X): oracle parity AT the headline configuration itself - BASELINE.json configs[1], 160k points, 0.1 m voxels,
+grid 1504 x 1504 x 40, the full network - per stage and end to end, in every math mode and through both voxelizer routes of
+``FramePipeline`` (the stacked ``dz_voxelize_to_level`` chain that ``bench.py`` times, and the ragged per-frame route), plus
+the multi-sweep configuration of configs[4] (two merged sweeps, 320k points, 6 features, DynamicMeanVFE).
+
+The CPU oracle needs ~3 s per 160k frame, so it runs once per module.  Tolerances: active sets / coordinates bit-exact;
+sparse features 2e-3; dense maps 2e-3 (5e-3 in bf16x2, whose pairs carry 16 bits); final boxes and scores within the north
+star's 1e-3.  Reference: backbone3d.py:289-338, backbone2d.py:89-120, center_head.py:315-368,440-488.
+"""
+import numpy as np
+import pytest
+import torch
+
+from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
+from tests.util import cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
+
+pytestmark = pytest.mark.gpu
+MATHS = ['f32', 'f16x2', 'bf16x2']
+FEAT_TOL = {'f32': 2e-3, 'f16x2': 2e-3, 'bf16x2': 2e-3}
+MAP_TOL = {'f32': 2e-3, 'f16x2': 2e-3, 'bf16x2': 5e-3}
+N_FULL = 160000
+
+
+@pytest.fixture(scope='module')
+def full(device):
+    """Seed-0 detector at the headline configuration, a 160k and a 150k frame and their oracle runs."""
+    model, cfg, info = make_model(VOXEL_SIZE_01, seed=0)
+    sd = cpu_state_dict(model)
+    frames = [masked_frame(0, N_FULL), masked_frame(7, 150016)]      # different lengths: a ragged batch
+    refs = [oracle_detect(sd, p, info) for p in frames]
+    return model.to(device), cfg, info, frames, refs
+
+
+def _check_boxes(ref_final, boxes9, n, tag):
+    rb = ref_final[0]
+    n_ref = rb['pred_boxes'].shape[0]
+    assert n_ref > 50, (tag, n_ref)
+    got = boxes9[:n].cpu().numpy()
+    nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), got[:, :7], got[:, 7], tol=1e-3)
+    # a candidate sitting exactly on SCORE_THRESH / the NMS threshold may flip; everything else matches within 1e-3
+    assert abs(n - n_ref) <= 2 and nm >= n_ref - 2, (tag, n, n_ref, nm, worst)
+    lab = {tuple(np.round(b[:3], 2)): int(l) for b, l in zip(rb['pred_boxes'].numpy(), rb['pred_labels'].numpy())}
+    hits = sum(1 for g in got if lab.get(tuple(np.round(g[:3], 2)), int(g[8])) == int(g[8]))
+    assert hits >= n - 2, (tag, hits, n)
+    return worst
+
+
+def _check_sparse(res, ref, math, model, names=('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'encoded'), frame=0, nb=1):
+    """res: {name: (capacity-sized feature rows, SparseLevel)} of a batch; compares frame `frame` with the oracle."""
+    from detzero_amd import ops
+    mid = ops.math_id(math)
+    for name in names:
+        feats, lvl = res[name]
+        m = lvl.num_active()
+        coords = lvl.coords[:m].cpu().numpy()
+        rf, rc, rs = ref['backbone'][name]
+        sel = np.nonzero(coords[:, 0] == frame)[0]
+        assert lvl.shape == list(rs) and sel.size == rc.shape[0], (name, sel.size, rc.shape[0])
+        got_c = coords[sel].copy(); got_c[:, 0] = 0
+        assert np.array_equal(got_c, rc), name                                     # active set + canonical order: bit-exact
+        plain = ops.pair16_to_f32(feats[:m], mid) if mid else feats[:m]
+        torch.testing.assert_close(plain[torch.from_numpy(sel).to(plain.device)].cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math],
+                                   msg=lambda s: '%s [%s]: %s' % (name, math, s))
+
+
+@pytest.mark.parametrize('math', MATHS)
+def test_modules_stage_by_stage_160k(full, device, math):
+    """The plugin modules (reference registry names) on the 160k frame against the oracle: voxels bit-exact, x_conv1..4 and
+    the encoded tensor, spatial_features, spatial_features_2d, the six head maps, the final boxes."""
+    from detzero_amd.centerpoint import set_math
+    from tests.test_gpu_e2e import _batch_dict
+    model, cfg, info, frames, refs = full
+    ref = refs[0]
+    set_math(model, math)
+    bd = _batch_dict(model, cfg, info, frames[0], device)
+    assert np.array_equal(bd['voxels'].cpu().numpy(), ref['voxels'])
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy().astype(np.int32), ref['coords'])
+    assert np.array_equal(bd['voxel_num_points'].cpu().numpy().astype(np.int32), ref['num_points'])
+    bd = model.vfe(bd)
+    np.testing.assert_allclose(bd['voxel_features'].cpu().numpy(), ref['feats'], rtol=0, atol=1e-6)
+    bd = model.backbone3d(bd)
+    for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
+        t = bd['multi_scale_3d_features'][name]
+        rf, rc, rs = ref['backbone'][name]
+        assert t.spatial_shape == list(rs) and np.array_equal(t.indices.cpu().numpy(), rc), name
+        torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    t = bd['encoded_spconv_tensor']
+    rf, rc, rs = ref['backbone']['encoded']
+    assert np.array_equal(t.indices.cpu().numpy(), rc)
+    torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    bd = model.map_to_bev(bd)
+    torch.testing.assert_close(bd['spatial_features'].cpu(), ref['bev'], rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    bd = model.backbone2d(bd)
+    torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=MAP_TOL[math], atol=MAP_TOL[math])
+    bd = model.dense_head(bd)
+    pred = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for k, v in ref['pred'].items():
+        torch.testing.assert_close(pred[k].cpu(), v, rtol=MAP_TOL[math], atol=MAP_TOL[math])
+    got = bd['final_box_dicts'][0]
+    b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
+    _check_boxes(ref['final'], b9, b9.shape[0], 'modules/' + math)
+    set_math(model, 'f32')
+
+
+def _equalised(frames, device):
+    """Frames padded to one length with rows outside the point-cloud range (x = 1e6): the xy range mask of
+    data_processor.py:24-37 removes them inside the kernels, so the stacked route sees the same points."""
+    n = max(p.shape[0] for p in frames)
+    out = np.zeros((len(frames), n, frames[0].shape[1]), np.float32)
+    out[:, :, 0] = 1e6
+    for i, p in enumerate(frames):
+        out[i, :p.shape[0]] = p
+    return torch.from_numpy(out).to(device)
+
+
+@pytest.mark.parametrize('math', MATHS)
+@pytest.mark.parametrize('route', ['stacked', 'ragged'])
+def test_frame_pipeline_routes_160k(full, device, math, route):
+    """FramePipeline on a batch of two 160k frames through both voxelizer routes: sparse features of every stage and the final
+    boxes of BOTH frames against the oracle.  'stacked' is the route bench.py times (dz_voxelize_to_level on a (B,N,C) tensor);
+    'ragged' is what real Waymo frames take (different lengths, per-frame fused voxelizers on parallel streams)."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, frames, refs = full
+    pipe = FramePipeline(model, info, math=math)
+    if route == 'stacked':
+        inp = _equalised(frames, device)
+        assert inp.shape[1] <= info.max_voxels['test']
+    else:
+        inp = [torch.from_numpy(p).to(device) for p in frames]
+        assert inp[0].shape[0] != inp[1].shape[0]
+    from detzero_amd.centerpoint import _StackedFrames
+    fr = _StackedFrames(inp) if torch.is_tensor(inp) else inp
+    prep = pipe.prepare(fr)
+    res = model.backbone3d.run_pyramid(prep)
+    for i in range(2):
+        _check_sparse(res, refs[i], math, model, frame=i, nb=2)
+    out, cnt = pipe(inp)
+    worst = [_check_boxes(refs[i]['final'], out[i], int(cnt[i].item()), '%s/%s/frame%d' % (route, math, i)) for i in range(2)]
+    assert max(worst) <= 1e-3
+    from detzero_amd.centerpoint import set_math
+    set_math(model, 'f32')
+
+
+@pytest.mark.parametrize('math', ['f32', 'f16x2'])
+def test_calibrated_capacities_do_not_change_results(full, device, math):
+    """bench.py sizes the deep levels from sample frames (FramePipeline.calibrate); the boxes must not depend on it and the
+    overflow flag must stay clear on the calibration frames themselves."""
+    from detzero_amd.centerpoint import FramePipeline, set_math
+    model, cfg, info, frames, refs = full
+    pipe = FramePipeline(model, info, math=math)
+    inp = _equalised(frames, device)
+    pipe.calibrate([inp[0], inp[1]])
+    out, cnt = pipe(inp)
+    assert not bool(pipe.last_overflow.item())
+    for i in range(2):
+        _check_boxes(refs[i]['final'], out[i], int(cnt[i].item()), 'calibrated/%s/frame%d' % (math, i))
+    set_math(model, 'f32')
+
+
+@pytest.fixture(scope='module')
+def multisweep(device):
+    """configs[4] shape: two sweeps merged into one 320k-point frame with the time-offset column, the 6-feature
+    DynamicMeanVFE detector of centerpoint_3sweeps.yaml (400k voxels at test)."""
+    model, cfg, info = make_model(VOXEL_SIZE_01, seed=3, sweeps=3)
+    sd = cpu_state_dict(model)
+    merged = merge_two_sweeps(synth_waymo_frame(21, N_FULL), synth_waymo_frame(22, N_FULL))
+    from oracle.voxelize import mask_points_by_range
+    merged = merged[mask_points_by_range(merged, info.point_cloud_range)]
+    ref = oracle_detect(sd, merged, info, dynamic=True)
+    return model.to(device), cfg, info, merged, ref
+
+
+@pytest.mark.parametrize('math', MATHS)
+def test_multisweep_320k_dynamic_vfe(multisweep, device, math):
+    """6 point features, ~320k points, DynamicMeanVFE -> backbone -> head: voxel set bit-exact, voxel means 1e-5 (float atomics),
+    every sparse stage, the final boxes within 1e-3 - through the plugin modules and through FramePipeline(dynamic=True)."""
+    from detzero_amd.centerpoint import FramePipeline, set_math
+    model, cfg, info, merged, ref = multisweep
+    assert merged.shape[1] == 6 and merged.shape[0] > 300000
+    set_math(model, math)
+    pb = np.concatenate([np.zeros((merged.shape[0], 1), np.float32), merged], 1)
+    bd = {'points': torch.from_numpy(pb).to(device), 'batch_size': 1}
+    bd = model.vfe(bd)
+    # the reference emits voxels in ascending x-major merge-key order (vfe.py:128-143)
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), ref['coords'])
+    np.testing.assert_allclose(bd['voxel_features'].cpu().numpy(), ref['feats'], rtol=1e-5, atol=1e-5)
+    bd = model.backbone3d(bd)
+    for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
+        t = bd['multi_scale_3d_features'][name]
+        rf, rc, rs = ref['backbone'][name]
+        assert np.array_equal(t.indices.cpu().numpy(), rc), name
+        torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    for mod in (model.map_to_bev, model.backbone2d, model.dense_head):
+        bd = mod(bd)
+    torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=MAP_TOL[math], atol=MAP_TOL[math])
+    got = bd['final_box_dicts'][0]
+    b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
+    _check_boxes(ref['final'], b9, b9.shape[0], 'multisweep-modules/' + math)
+    pipe = FramePipeline(model, info, dynamic=True, math=math)
+    out, d_n = pipe(torch.from_numpy(merged).to(device))
+    _check_boxes(ref['final'], out, int(d_n.item()), 'multisweep-pipeline/' + math)
+    set_math(model, 'f32')
