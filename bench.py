@@ -10,9 +10,19 @@ CenterHead + decode + rotated NMS; the reference evaluates with BATCH_SIZE_PER_G
 way), frames already resident in HBM when the timed region starts.  --math f32 runs every convolution on
 the fp32 matrix cores (exact fp32); the default f16x2 carries every fp32 value as an (hi, lo) pair of fp16
 and evaluates products as three fp16 MFMAs with fp32 accumulation (csrc/hgemm.h: 22-bit significands, head
-maps within 5e-7 of the fp32 path, boxes within the 1e-3 the north star asks for - tests/test_gpu_split.py).  One process per GPU, frames sharded across GPUs (weak scaling); with N>1 the per-frame boxes are
-gathered to rank 0 with one RCCL all-gather at the end of the timed region.  value = frames/s over all GPUs.
-Prints ONE JSON line on rank 0.
+maps within 5e-7 of the fp32 path; boxes within the north star's 1e-3 of the CPU oracle ON THIS WORKLOAD -
+tests/test_gpu_full_parity.py).  One process per GPU, frames sharded across GPUs (weak scaling); with N>1 the
+per-frame boxes are gathered to rank 0 with one RCCL all-gather inside the timed region.
+value = frames/s over all GPUs.  Prints ONE JSON line on rank 0.
+
+Besides the headline the default single-GPU run measures, into the same JSON line (each a few seconds; --no-aux skips):
+  fp32       the same workload with every convolution in exact fp32 (--fp32-batch frames per step), with its own roofline
+  ref_batch  the headline arithmetic at the reference's BATCH_SIZE_PER_GPU = 8 (centerpoint_1sweep.yaml:88)
+  ragged     frames of 150k-180k points: padded to the slot capacity with out-of-range rows (the stacked route), and as a
+             ragged list (per-frame voxelizers on parallel streams)
+  with_h2d   frames start in pinned host memory; the H2D copy of step i+1 runs on a copy stream under step i
+  stages     voxelize / index pyramid / sparse backbone / dense / post-processing: time per step (each stage replayed as its
+             own hipGraph, serially), algorithmic bytes and HBM GB/s as a fraction of the 8 TB/s peak
 """
 import argparse
 import json
@@ -31,6 +41,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2516.6    # same guide: fp16 / bf16 MFMA dense (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
+REF_BATCH = 8                    # OPTIMIZATION.BATCH_SIZE_PER_GPU of centerpoint_1sweep.yaml:88
 
 
 def usable_cores():
@@ -80,7 +91,7 @@ _T0 = time.perf_counter()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=500, help='timed steps (default: ~10 s of GPU time at 16 frames per step)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
     ap.add_argument('--batch', type=int, default=16, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
@@ -93,7 +104,248 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
+    ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, with_h2d, stages)')
+    ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
+    ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
     return ap.parse_args()
+
+
+class Case:
+    """One configured pipeline over one batch shape: seeded detector, synthetic frames resident in HBM, calibrated level
+    capacities, and the step captured as a hipGraph over a static input.
+
+    lengths = None: every frame has `points` points (stacked (B,N,C) input, dz_voxelize_to_level route).
+    lengths = (lo, hi), mode 'padded': frames of lo..hi points padded with out-of-range rows to slots of hi rows (same route).
+    lengths = (lo, hi), mode 'list': slot j holds a frame of its own length L_j in lo..hi (ragged list route)."""
+
+    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0):
+        from detzero_amd.centerpoint import FramePipeline, synth_detector
+        from detzero_amd.synth import VOXEL_SIZE_01, synth_waymo_frame
+        self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
+        self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0)
+        self.model = self.model.to(dev)
+        self.pipe = FramePipeline(self.model, self.info, math=math)
+        B = self.B
+        self.n_distinct = n_distinct = max(4, B + 1)
+        rng = np.random.default_rng(77 + rank)
+        if lengths is None:
+            ns = [args.points] * n_distinct
+        elif mode == 'list':
+            # a captured graph replays fixed shapes: slot j always holds a frame of ITS length L_j; two groups of B frames alternate
+            slot_len = [int(v) for v in rng.integers(lengths[0], lengths[1] + 1, size=B)]
+            ns = slot_len + slot_len
+            self.n_distinct = n_distinct = 2 * B
+        else:
+            ns = [int(v) for v in rng.integers(lengths[0], lengths[1] + 1, size=n_distinct)]
+        self.host_frames = [synth_waymo_frame(seed_base + 1000 * rank + i, n) for i, n in enumerate(ns)]
+        self.mean_points = float(np.mean([f.shape[0] for f in self.host_frames]))
+        if mode == 'list':
+            self.frames = [torch.from_numpy(f).to(dev) for f in self.host_frames]
+            self.static_in = [self.frames[j].clone() for j in range(B)]
+            sample = self.frames[:n_distinct]
+        else:
+            cap = args.points if lengths is None else lengths[1]
+            padded = np.zeros((n_distinct, cap, self.host_frames[0].shape[1]), np.float32)
+            padded[:, :, 0] = 1e6                                        # rows outside POINT_CLOUD_RANGE: dropped by the xy mask
+            for i, f in enumerate(self.host_frames):
+                padded[i, :f.shape[0]] = f
+            self.host_pool = np.concatenate([padded, padded[:B]], axis=0)     # every window of B frames is contiguous
+            self.pool = torch.from_numpy(self.host_pool).to(dev)
+            self.static_in = self.pool[:B].clone()                       # (B, N, C) static input of the captured graph
+            sample = [self.pool[i] for i in range(n_distinct)]
+        self.caps = None
+        if not args.no_calibrate:
+            self.caps = self.pipe.calibrate(sample)       # row capacities of the deep sparse levels from the sample frames (x1.5)
+        self.graph = None
+        self.g_out = self.g_n = None
+        self.graph_note = 'eager launches'
+        self.results = self.counts = None
+
+    def load_inputs(self, i):
+        B = self.B
+        if self.mode == 'list':
+            for j in range(B):
+                self.static_in[j].copy_(self.frames[(i % 2) * B + j], non_blocking=True)
+        else:
+            o = (i * B) % self.n_distinct
+            self.static_in.copy_(self.pool[o:o + B], non_blocking=True)   # one device-to-device copy of the B frames of this step
+
+    def prepare(self, steps, warmup, use_graph=True):
+        K, B = steps, self.B
+        self.results = torch.zeros((K, B, self.pipe.post_max, 9), dtype=torch.float32, device=self.dev)
+        self.counts = torch.zeros((K, B), dtype=torch.int32, device=self.dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):        # warm-up (also primes the caching allocator and builds the kernel-layout weights)
+            for i in range(max(warmup, 3)):
+                self.load_inputs(i)
+                self.g_out, self.g_n = self.pipe(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.g_out, self.g_n = self.pipe(self.static_in)
+                self.graph.replay()
+                torch.cuda.synchronize()
+                self.graph_note = 'hipGraph replay'
+            except Exception as e:  # capture is an optimisation, not a requirement
+                self.graph = None
+                self.graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
+                torch.cuda.synchronize()
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.g_out, self.g_n = self.pipe(self.static_in)
+
+    def step(self, i):
+        """One step = one batch through the whole path: input copy, voxelize ... NMS, results into slot i % K."""
+        K = self.results.shape[0]
+        self.load_inputs(i)
+        self.run()
+        self.results[i % K].copy_(self.g_out, non_blocking=True)
+        self.counts[i % K].copy_(self.g_n, non_blocking=True)
+
+    def check_overflow(self):
+        if self.pipe.last_overflow is not None and bool(self.pipe.last_overflow.item()):
+            raise SystemExit('bench: a sparse level overflowed its calibrated capacity - rerun with --no-calibrate')
+
+    def time_steps(self, steps, warmup, step=None):
+        from detzero_amd import frame_parallel as fp
+        dt, _, _ = fp.timed_steps(step or self.step, steps, warmup, self.results, self.counts, sync=torch.cuda.synchronize)
+        self.check_overflow()
+        return dt
+
+    def aux_leg(self, seconds, step=None):
+        """Time ~`seconds` of steps (count chosen from a short probe).  Returns (frames/s, ms per step, steps)."""
+        if self.g_out is None:
+            self.prepare(8, 3, use_graph=not self.args.no_graph)
+        probe = self.time_steps(4, 2, step)
+        k = int(min(max(seconds / max(probe / 4, 1e-4), 8), 2000))
+        self.results = torch.zeros((k,) + tuple(self.results.shape[1:]), dtype=torch.float32, device=self.dev)
+        self.counts = torch.zeros((k, self.B), dtype=torch.int32, device=self.dev)
+        dt = self.time_steps(k, 2, step)
+        return k * self.B / dt, 1000.0 * dt / k, k
+
+    def kernel_profile(self, passes):
+        """HIP events around every conv launch, on the launch stream, over `passes` eager passes."""
+        from detzero_amd import ops
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+        try:
+            for i in range(passes):
+                self.load_inputs(i)
+                self.pipe(self.static_in)
+            agg = prof.summary()
+        finally:
+            ops.PROFILER = None
+        kern = []
+        for name, a in agg.items():
+            per = a['ms'] / a['launches']
+            kern.append({'kernel': name, 'launches_per_step': a['launches'] / passes,
+                         'avg_us': round(1000.0 * per, 2), 'ms_per_step': round(a['ms'] / passes, 4),
+                         'tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
+                         'algorithmic_gbs': round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)})
+        kern.sort(key=lambda r: -r['ms_per_step'])
+        roof = None
+        if kern:
+            top = kern[0]
+            a = agg[top['kernel']]
+            achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
+            split = '_h<' in top['kernel']
+            # split engine: three 16-bit MFMAs per algorithmic product -> algorithmic peak = f16 MFMA peak / 3
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
+                    'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                    'traffic': pmc_traffic(top['kernel'], self.math),
+                    'flop_per_launch': round(a['flops'] / a['launches'], 1),
+                    'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
+                    'note': ('split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s '
+                             'algorithmic; ' if split else 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; ')
+                            + 'algorithmic FLOP = 2*pixels*taps*Cin*Cout (dense) / 2*pairs*Cin*Cout (sparse); '
+                              'fraction of the fp32-MFMA peak: %.3f' % (achieved / PEAK_F32_MFMA_TFLOPS)}
+        return kern, roof, agg
+
+    def stage_profile(self, replays=10):
+        """Each stage of the step captured as its own hipGraph (index pyramid on the main stream, i.e. serial) and replayed in
+        order with HIP events in between.  Returns a list of {stage, ms_per_step, algorithmic_bytes, hbm_gbs, frac_of_hbm_peak}."""
+        from detzero_amd.centerpoint import _StackedFrames
+        pipe, B = self.pipe, self.B
+        frames = _StackedFrames(self.static_in) if torch.is_tensor(self.static_in) else self.static_in
+        self.load_inputs(0)
+        torch.cuda.synchronize()
+        graphs = []
+        state = {}
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            graphs.append(g)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            capture(lambda: state.__setitem__('vox', pipe.voxelize_stage(frames)))
+            capture(lambda: state.__setitem__('pyr', pipe.pyramid_stage(state['vox'], B, overlap=False)))
+            capture(lambda: state.__setitem__('res', pipe.backbone_stage(state['pyr'])))
+            capture(lambda: state.__setitem__('head', pipe.dense_stage(state['res'], B)))
+            capture(lambda: state.__setitem__('out', pipe.post_stage(*state['head'])))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        names = ['voxelize', 'index', 'sparse_backbone', 'dense', 'post']
+        ms = [0.0] * len(graphs)
+        for _ in range(replays + 1):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(graphs) + 1)]
+            ev[0].record()
+            for j, g in enumerate(graphs):
+                g.replay()
+                ev[j + 1].record()
+            torch.cuda.synchronize()
+            if _ > 0:
+                for j in range(len(graphs)):
+                    ms[j] += ev[j].elapsed_time(ev[j + 1]) / replays
+        # algorithmic bytes from the live counts (SURVEY.md 8d): voxelize = points read + voxel rows and coordinates written;
+        # index = per rulebook: output coordinates read + 8 B per (in, out) pair written; sparse backbone = sum over the 21 convs
+        # of in rows + out rows (+ residual) + weights + 8 B per pair
+        pyr = state['pyr']
+        steps = pyr['steps']                    # level li: (table of the strided conv INTO it, its submanifold table, SparseLevel, event)
+        n_pts = sum(int(f.shape[0]) for f in frames)
+        c_in = int(frames[0].shape[1])
+        level_m = [st[2].num_active() for st in steps]
+        vox_bytes = 4.0 * n_pts * c_in + level_m[0] * (4.0 * c_in + 16.0)
+        ch = list(self.model.backbone3d.channels) + [self.model.backbone3d.channels[-1]]     # channels of levels 0..4
+
+        def pairs_of(nbr, m):
+            return int((nbr[:, :m] >= 0).sum().item())
+
+        def conv(n_in, cin, m, cout, kvol, pairs, residual):
+            return 4.0 * (n_in * cin + m * cout * (2 if residual else 1) + kvol * cin * cout) + 8.0 * pairs
+        idx_bytes = conv_bytes = 0.0
+        for li, (nbr_d, nbr_s, lvl, _) in enumerate(steps):
+            m = level_m[li]
+            if nbr_d is not None:               # spconv2/3/4 and conv_out
+                pd = pairs_of(nbr_d, m)
+                idx_bytes += 16.0 * m + 8.0 * pd
+                conv_bytes += conv(level_m[li - 1], ch[li - 1], m, ch[li], nbr_d.shape[0], pd, False)
+            if nbr_s is not None:               # conv_input (level 0 only) + two residual blocks
+                ps = pairs_of(nbr_s, m)
+                idx_bytes += 16.0 * m + 8.0 * ps
+                if li == 0:
+                    conv_bytes += conv(m, c_in, m, ch[0], 27, ps, False)
+                for blk in range(2):
+                    conv_bytes += conv(m, ch[li], m, ch[li], 27, ps, False) + conv(m, ch[li], m, ch[li], 27, ps, True)
+        algo = {'voxelize': vox_bytes, 'index': idx_bytes, 'sparse_backbone': conv_bytes}
+        out = []
+        for nme, t in zip(names, ms):
+            rec = {'stage': nme, 'ms_per_step': round(t, 4), 'ms_per_frame': round(t / B, 4)}
+            if nme in algo:
+                gbs = algo[nme] / (t * 1e-3) / 1e9
+                rec.update({'algorithmic_bytes': round(algo[nme]), 'hbm_gbs': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)})
+            out.append(rec)
+        return out
 
 
 def main():
@@ -111,123 +363,52 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
-    from detzero_amd import ops
-    from detzero_amd.centerpoint import FramePipeline, synth_detector
-    from detzero_amd.synth import VOXEL_SIZE_01, synth_waymo_frame
     from detzero_amd import frame_parallel as fp
 
     torch.set_num_threads(min(usable_cores(), 32))
     log('rank', rank, 'of', world, 'usable host cores', usable_cores())
-    model, cfg, info = synth_detector(VOXEL_SIZE_01, seed=0)
-    model = model.to(dev)
-    pipe = FramePipeline(model, info, math=args.math)
-    B = max(1, args.batch)
-    n_distinct = max(4, B + 1)
-    frames = [torch.from_numpy(synth_waymo_frame(1000 * rank + i, args.points)).to(dev) for i in range(n_distinct)]
-    pool = torch.stack(frames + frames[:B], dim=0)          # (n_distinct + B, N, C): every window of B frames is contiguous
-    static_in = pool[:B].clone()                            # (B, N, C) static input of the captured graph
-    if not args.no_calibrate:
-        caps = pipe.calibrate(frames)           # row capacities of the deep sparse levels from the sample frames (x1.5)
-        log('calibrated level capacities per frame:', caps)
+    case = Case(args, dev, rank, args.math, args.batch)
+    if case.caps is not None:
+        log('calibrated level capacities per frame:', case.caps)
+    B = case.B
     K, W = args.steps, args.warmup
-    post_max = pipe.post_max
-    results = torch.zeros((K, B, post_max, 9), dtype=torch.float32, device=dev)
-    counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
-
-    def load_inputs(i):
-        o = (i * B) % n_distinct
-        static_in.copy_(pool[o:o + B], non_blocking=True)   # one device-to-device copy of the B frames of this step
-
-    # warm-up (also primes the caching allocator and builds the kernel-layout weights)
-    use_graph = not args.no_graph
-    graph = None
     streamer = None
-    g_out = g_n = None
     if args.overlap:
         from detzero_amd.centerpoint import StreamingDetector
-        streamer = StreamingDetector(pipe, frames[:B], use_graph=use_graph, warmup=max(W, 3))   # (per-frame input slots)
+        case.results = torch.zeros((K, B, case.pipe.post_max, 9), dtype=torch.float32, device=dev)
+        case.counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
+        frames = [case.pool[i] for i in range(case.n_distinct)]
+        streamer = StreamingDetector(case.pipe, frames[:B], use_graph=not args.no_graph, warmup=max(W, 3))   # (per-frame input slots)
         graph_note = streamer.graph_note
-    else:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for i in range(max(W, 3)):
-                load_inputs(i)
-                g_out, g_n = pipe(static_in)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph_note = 'hipGraph replay'
-        if use_graph:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    g_out, g_n = pipe(static_in)
-                graph.replay()
-                torch.cuda.synchronize()
-            except Exception as e:  # capture is an optimisation, not a requirement
-                graph = None
-                graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
-                torch.cuda.synchronize()
-        else:
-            graph_note = 'eager launches'
 
-    def batch_of(i):
-        return [frames[(i * B + j) % n_distinct] for j in range(B)]
-
-    def step(i):
-        """One step = one batch through the whole path.  Streaming mode: stage A of batch i is enqueued together with
-        stage B of batch i-1 (whose results land in slot i-1); exactly one A and one B per call."""
-        nonlocal g_out, g_n
-        if streamer is not None:
-            prev = streamer.feed(batch_of(i))
+        def step(i):
+            """Streaming mode: stage A of batch i is enqueued together with stage B of batch i-1 (whose results land in slot
+            i-1); exactly one A and one B per call."""
+            prev = streamer.feed([frames[(i * B + j) % case.n_distinct] for j in range(B)])
             if prev is not None:
-                results[(i - 1) % K].copy_(prev[0], non_blocking=True)
-                counts[(i - 1) % K].copy_(prev[1], non_blocking=True)
-            return
-        load_inputs(i)
-        if graph is not None:
-            graph.replay()
-        else:
-            g_out, g_n = pipe(static_in)
-        results[i % K].copy_(g_out, non_blocking=True)
-        counts[i % K].copy_(g_n, non_blocking=True)
-
+                case.results[(i - 1) % K].copy_(prev[0], non_blocking=True)
+                case.counts[(i - 1) % K].copy_(prev[1], non_blocking=True)
+    else:
+        case.prepare(K, W, use_graph=not args.no_graph)
+        graph_note = case.graph_note
+        step = case.step
     log('launch mode:', graph_note)
-    for i in range(W + 1):            # streaming mode: primes the pipeline (the first feed has no stage B)
-        step(i)
-    torch.cuda.synchronize()
-    log('warm-up done')
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W + 1, W + 1 + K):
-        step(i)
-    if world > 1:
-        all_b, all_c = fp.gather_frame_boxes(results.view(K * B, post_max, 9), counts.view(K * B))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if pipe.last_overflow is not None and bool(pipe.last_overflow.item()):
-        raise SystemExit('bench: a sparse level overflowed its calibrated capacity - rerun with --no-calibrate')
-    n_boxes = counts.float().mean().item()
+    # W + 1 untimed steps (streaming mode: the first feed has no stage B), then exactly K timed steps, barrier + synchronize on
+    # both sides, box gather inside the timed region, MAX over ranks
+    dt, all_b, all_c = fp.timed_steps(step, K, W + 1, case.results, case.counts, sync=torch.cuda.synchronize)
+    case.check_overflow()
+    n_boxes = case.counts.float().mean().item()
     log('timed region: %d steps x %d frames in %.3f s' % (K, B, dt))
 
     out = None
-    dtype_name = {'f32': 'f32', 'f16x2': 'f32 as f16 pairs (hi+lo, 22-bit significand; 3 f16 MFMA per product, f32 accumulate)',
-                  'bf16x2': 'f32 as bf16 pairs (hi+lo, 16-bit significand; 3 bf16 MFMA per product, f32 accumulate)'}[args.math]
+    dtype_names = {'f32': 'f32', 'f16x2': 'f32 as f16 pairs (hi+lo, 22-bit significand; 3 f16 MFMA per product, f32 accumulate)',
+                   'bf16x2': 'f32 as bf16 pairs (hi+lo, 16-bit significand; 3 bf16 MFMA per product, f32 accumulate)'}
     if rank == 0:
         value = world * K * B / dt
         out = {
             'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(value, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_names[args.math], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
                                    '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
                                    '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
@@ -237,59 +418,99 @@ def main():
         }
 
     # ---- roofline of the dominant kernel: HIP events around every conv launch, on the launch stream
-    if rank == 0:
-        prof = ops.LaunchProfiler()
-        ops.PROFILER = prof
-        stage_ms = {}
-        try:
-            for i in range(args.profile_frames):
-                load_inputs(i)
-                pipe(static_in)
-            agg = prof.summary()
-        finally:
-            ops.PROFILER = None
-        kern = []
-        for name, a in agg.items():
-            per = a['ms'] / a['launches']
-            kern.append({'kernel': name, 'launches_per_step': a['launches'] / args.profile_frames,
-                         'avg_us': round(1000.0 * per, 2), 'ms_per_step': round(a['ms'] / args.profile_frames, 4),
-                         'tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2),
-                         'algorithmic_gbs': round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1)})
-        kern.sort(key=lambda r: -r['ms_per_step'])
-        if kern:
-            top = kern[0]
-            a = agg[top['kernel']]
-            achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
-            split = '_h<' in top['kernel']
-            # split engine: three 16-bit MFMAs per algorithmic product -> algorithmic peak = f16 MFMA peak / 3
-            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-            out['roofline'] = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
-                               'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                               'traffic': pmc_traffic(top['kernel'], args.math),
-                               'flop_per_launch': round(a['flops'] / a['launches'], 1),
-                               'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
-                               'note': ('split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s '
-                                        'algorithmic; ' if split else 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; ')
-                                       + 'algorithmic FLOP = 2*pixels*taps*Cin*Cout (dense) / 2*pairs*Cin*Cout (sparse); '
-                                         'fraction of the fp32-MFMA peak: %.3f' % (achieved / PEAK_F32_MFMA_TFLOPS)}
+    if rank == 0 and args.profile_frames > 0:
+        kern, roof, _ = case.kernel_profile(args.profile_frames)
+        if roof:
+            out['roofline'] = roof
         out['kernels'] = kern
         log('per-kernel profile done')
         out['conv_ms_per_frame'] = round(sum(r['ms_per_step'] for r in kern) / B, 4)
+
+    # ---- auxiliary legs (single GPU only): what the headline does not show
+    if rank == 0 and world == 1 and not args.no_aux and streamer is None:
+        sec = args.aux_seconds
+        try:
+            out['stages'] = case.stage_profile()
+            log('stages:', [(s['stage'], s['ms_per_step']) for s in out['stages']])
+        except Exception as e:
+            out['stages'] = {'error': str(e).split('\n')[0][:200]}
+        # frames in pinned host memory: H2D of step i+1 on a copy stream under step i (double-buffered staging in HBM)
+        hpool = torch.from_numpy(case.host_pool).pin_memory()
+        stage = [torch.empty_like(case.static_in) for _ in range(2)]
+        copy_stream = torch.cuda.Stream()
+        ready = [torch.cuda.Event() for _ in range(2)]
+        free = [torch.cuda.Event() for _ in range(2)]
+        main_stream = torch.cuda.current_stream()
+        for e in free:
+            e.record(main_stream)
+        state = {'next': None}
+
+        def prefetch(i):
+            o = (i * B) % case.n_distinct
+            copy_stream.wait_event(free[i % 2])
+            with torch.cuda.stream(copy_stream):
+                stage[i % 2].copy_(hpool[o:o + B], non_blocking=True)
+                ready[i % 2].record(copy_stream)
+            state['next'] = i
+
+        def step_h2d(i):
+            if state['next'] != i:
+                prefetch(i)
+            main_stream.wait_event(ready[i % 2])
+            case.static_in.copy_(stage[i % 2], non_blocking=True)
+            free[i % 2].record(main_stream)
+            prefetch(i + 1)
+            case.run()
+            kk = case.results.shape[0]
+            case.results[i % kk].copy_(case.g_out, non_blocking=True)
+            case.counts[i % kk].copy_(case.g_n, non_blocking=True)
+        fps, ms, k = case.aux_leg(sec, step_h2d)
+        out['with_h2d'] = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(ms, 4), 'steps': k, 'frames_per_step': B,
+                           'math': args.math, 'h2d_bytes_per_step': int(hpool[:B].numel() * 4),
+                           'note': 'frames start in pinned host memory; the H2D copy of step i+1 (copy stream, double-buffered '
+                                   'staging) overlaps step i; never the headline value'}
+        log('with_h2d %.1f frames/s' % fps)
+        del hpool, stage
+
+        def leg(name, math, batch, lengths=None, mode='stacked', note=''):
+            c = Case(args, dev, rank, math, batch, lengths, mode, seed_base=500)
+            fps, ms, k = c.aux_leg(sec)
+            rec = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(ms, 4), 'steps': k, 'frames_per_step': c.B,
+                   'math': math, 'dtype': dtype_names[math], 'launch': c.graph_note, 'mean_points_per_frame': round(c.mean_points), 'note': note}
+            log('%s %.1f frames/s' % (name, fps))
+            return c, rec
+        c, rec = leg('fp32', 'f32', args.fp32_batch, note='every convolution on v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation')
+        if args.profile_frames > 0:
+            kern, roof, _ = c.kernel_profile(args.profile_frames)
+            rec['roofline'] = roof
+            rec['kernels'] = kern[:6]
+        out['fp32'] = rec
+        del c
+        c, out['ref_batch'] = leg('ref_batch', args.math, REF_BATCH, note='BATCH_SIZE_PER_GPU of centerpoint_1sweep.yaml:88')
+        del c
+        c, padded = leg('ragged/padded', args.math, B, (150000, 180000), 'padded',
+                        note='frames of 150k-180k points padded with out-of-range rows to 180k-row slots: stacked dz_voxelize_to_level route')
+        del c
+        c, lst = leg('ragged/list', args.math, B, (150000, 180000), 'list',
+                     note='slot j holds frames of its own length in 150k-180k: per-frame fused voxelizers on parallel streams')
+        del c
+        out['ragged'] = {'padded': padded, 'list': lst}
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests.util import cpu_state_dict, oracle_detect       # oracle = checker/baseline only
         cores = min(usable_cores(), 32)
         torch.set_num_threads(cores)
-        sd = cpu_state_dict(model)
-        pts = [f.cpu().numpy() for f in frames]
+        sd = cpu_state_dict(case.model)
+        pts = case.host_frames
         from oracle.voxelize import mask_points_by_range
         done, t_cpu = 0, 0.0
         while t_cpu < args.cpu_baseline_seconds and done < 8:
-            p = pts[done % n_distinct]
-            p = p[mask_points_by_range(p, info.point_cloud_range)]
+            p = pts[done % case.n_distinct]
+            p = p[mask_points_by_range(p, case.info.point_cloud_range)]
             t1 = time.perf_counter()
-            oracle_detect(sd, p, info)
+            oracle_detect(sd, p, case.info)
             t_cpu += time.perf_counter() - t1
             done += 1
         out['cpu_baseline'] = {'value': round(done / t_cpu, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',

@@ -246,27 +246,38 @@ class FramePipeline:
         return feats, coords, None
 
     @torch.no_grad()
-    def prepare(self, frames, overlap=True):
-        """Stage A: everything that depends only on the points - voxelization, voxel features, the sparse index
-        pyramid of the backbone.  Returns an opaque dict for ``infer``."""
+    def voxelize_stage(self, frames):
+        """Points -> voxels.  Equally long frames that cannot overflow max_voxels are voxelized straight into the level-1
+        sparse index (one launch chain for the whole batch; no voxel list, no first-appearance ordering, no separate index
+        build / scatter): returns ('level', SparseLevel, rows).  Otherwise ('voxels', features, coords, d_n)."""
         nb = len(frames)
-        caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
         bb = self.model.backbone3d
         n0 = frames[0].shape[0]
         if (not self.dynamic and nb > 1 and n0 <= self.info.max_voxels[self.mode] and all(p.shape[0] == n0 for p in frames)):
-            # equally long frames that cannot overflow max_voxels: voxelize straight into the level-1 index (one launch
-            # chain for the whole batch; no voxel list, no first-appearance ordering, no separate index build / scatter)
             c = frames[0].shape[1]
             pts = frames.tensor.reshape(-1, c) if isinstance(frames, _StackedFrames) else torch.cat(list(frames), dim=0)
             lvl1, x = ops.voxelize_to_level(pts, nb, self.info.point_cloud_range, self.info.voxel_size,
                                             self.info.max_points_per_voxel, self.info.max_voxels[self.mode], bb.sparse_shape,
                                             bb.CIN_PAD, math=bb.math, xy_range_mask=True)
-            pyr = bb.build_pyramid(x, None, nb, None, overlap=overlap, caps=caps, level1=lvl1)
+            return ('level', lvl1, x)
+        return ('voxels',) + tuple(self._voxelize(frames))
+
+    @torch.no_grad()
+    def pyramid_stage(self, vox, nb, overlap=True):
+        """Voxels -> the sparse index pyramid of the backbone (output sets, bitmaps, neighbour tables of every stage)."""
+        caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
+        bb = self.model.backbone3d
+        if vox[0] == 'level':
+            pyr = bb.build_pyramid(vox[2], None, nb, None, overlap=overlap, caps=caps, level1=vox[1])
         else:
-            feats, coords, d_n = self._voxelize(frames)
-            pyr = bb.build_pyramid(feats, coords, nb, d_n, overlap=overlap, caps=caps)
+            pyr = bb.build_pyramid(vox[1], vox[2], nb, vox[3], overlap=overlap, caps=caps)
         pyr['nb'] = nb
         return pyr
+
+    def prepare(self, frames, overlap=True):
+        """Stage A: everything that depends only on the points - voxelization, voxel features, the sparse index
+        pyramid of the backbone.  Returns an opaque dict for ``infer``."""
+        return self.pyramid_stage(self.voxelize_stage(frames), len(frames), overlap)
 
     @torch.no_grad()
     def calibrate(self, frames, margin=1.5):
@@ -284,19 +295,30 @@ class FramePipeline:
         return self.level_caps
 
     @torch.no_grad()
-    def infer(self, prep):
-        """Stage B: the 21 sparse convolutions, BEV backbone, head, top-K decode, NMS -> (boxes9 (B,K,9), counts (B,))."""
-        m = self.model
-        nb = prep['nb']
+    def backbone_stage(self, prep):
+        """The 21 sparse convolutions -> {name: (rows, SparseLevel)}."""
         self.last_overflow = prep.get('overflow', None)
-        res = m.backbone3d.run_pyramid(prep)
+        return self.model.backbone3d.run_pyramid(prep)
+
+    @torch.no_grad()
+    def dense_stage(self, res, nb):
+        """HeightCompression + BaseBEVBackbone + the CenterHead convolutions -> (head map (B,H*W,12), H, W)."""
+        m = self.model
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
         with cp_modules.workspace(self._ws):
             concat = m.backbone2d.run(bev, nb)
-            head, h, w = self.head.run_convs(concat, nb)
+            return self.head.run_convs(concat, nb)
+
+    @torch.no_grad()
+    def post_stage(self, head, h, w):
+        """Top-K decode, rotated NMS, packing -> (boxes9 (B,K,9), counts (B,))."""
         boxes, scores, labels, keep, d_nk = self.head.decode_batched_nosync(head, h, w)
         return ops.pack_detections(boxes, scores, labels, keep, d_nk, self.post_max), d_nk
+
+    def infer(self, prep):
+        """Stage B: the 21 sparse convolutions, BEV backbone, head, top-K decode, NMS -> (boxes9 (B,K,9), counts (B,))."""
+        return self.post_stage(*self.dense_stage(self.backbone_stage(prep), prep['nb']))
 
     @torch.no_grad()
     def __call__(self, points):

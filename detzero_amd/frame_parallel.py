@@ -39,8 +39,10 @@ def interleave_parts(parts, size):
 def gather_frame_boxes(boxes, counts, group=None, dst=0):
     """boxes (F,K,9) float32, counts (F,) int32 on every rank (same F) -> on ``dst``:
     (world,F,K,9), (world,F); ``None`` elsewhere.  One all_gather each for boxes and counts
-    (all_gather_into_tensor maps to a single RCCL ring all-gather; gather() is not implemented by
-    every backend build)."""
+    Why all-gather and not gather: the payload is 18 KB per frame (latency-bound either way); RCCL implements
+    all_gather_into_tensor as ONE ring collective over xGMI, whereas gather() is a group of point-to-point send/recv
+    pairs into rank 0 (W-1 transfers serialised on rank 0's links) that also needs per-rank output lists; the copies the
+    other ranks receive are simply dropped."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     f, k, c = boxes.shape
@@ -67,21 +69,31 @@ def boxes_to_annos(boxes9, count, class_names, frame_meta=None):
     return anno
 
 
-def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None):
-    """Run ``pipeline`` (points -> (boxes9 (K,9), count)) over this rank's shard of ``frames`` (a
-    list of device tensors or a callable index -> tensor), gather, and return on rank 0 the
-    list-of-dicts result in dataset order (what result.pkl holds); other ranks return None."""
+def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, batch=1):
+    """Run ``pipeline`` over this rank's shard of ``frames`` (a list of device tensors or a callable index -> tensor with a
+    ``num_frames`` attribute), gather, and return on rank 0 the list-of-dicts result in dataset order (what result.pkl
+    holds); other ranks return None.
+
+    batch = frames per pipeline call (the reference's BATCH_SIZE_PER_GPU).  batch == 1: ``pipeline(points) -> ((K,9), (1,))``;
+    batch > 1: ``pipeline([points, ...]) -> ((B,K,9), (B,))`` - the shard is walked in consecutive groups of ``batch`` frames
+    (sampler order is kept: only the grouping changes), the last group may be shorter."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(frames) if not callable(frames) else frames.num_frames
     mine = shard_indices(n, rank, world)
+    get = frames if callable(frames) else frames.__getitem__
     outs, cnts = [], []
-    for i in mine:
-        pts = frames(i) if callable(frames) else frames[i]
-        b, c = pipeline(pts)
-        outs.append(b)
-        cnts.append(c.reshape(1))
-    boxes = torch.stack(outs, dim=0)
+    if batch <= 1:
+        for i in mine:
+            b, c = pipeline(get(i))
+            outs.append(b[None])
+            cnts.append(c.reshape(1))
+    else:
+        for s0 in range(0, len(mine), batch):
+            b, c = pipeline([get(i) for i in mine[s0:s0 + batch]])
+            outs.append(b)
+            cnts.append(c.reshape(-1))
+    boxes = torch.cat(outs, dim=0)
     counts = torch.cat(cnts, dim=0).to(torch.int32)
     if world == 1:
         all_b, all_c = boxes[None], counts[None]
@@ -93,3 +105,36 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None):
     parts = [[(all_b[r, j], all_c[r, j]) for j in range(all_b.shape[1])] for r in range(world)]
     ordered = interleave_parts(parts, n)
     return [boxes_to_annos(b, c, class_names, metas[i] if metas else None) for i, (b, c) in enumerate(ordered)]
+
+
+def timed_steps(step, steps, warmup, results, counts, sync, group=None):
+    """The timed region of bench.py, shared with the CPU (gloo) test of the multi-GPU plumbing: ``warmup`` untimed calls of
+    ``step(i)``, then exactly ``steps`` timed calls bracketed by barrier + ``sync()`` on both sides; with more than one rank
+    the per-frame boxes in ``results`` (steps, B, K, 9) / ``counts`` (steps, B) are gathered inside the timed region
+    (the tracker needs them on rank 0) and the elapsed time is the MAX over ranks.
+    Returns (seconds, gathered boxes (world, steps*B, K, 9) or None, gathered counts or None) - gathered tensors on rank 0 only."""
+    import time
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    for i in range(warmup):
+        step(i)
+    sync()
+    if world > 1:
+        dist.barrier(group)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    all_b = all_c = None
+    if world > 1:
+        k, b = results.shape[0], results.shape[1]
+        all_b, all_c = gather_frame_boxes(results.view(k * b, results.shape[2], results.shape[3]), counts.view(k * b), group)
+    sync()
+    if world > 1:
+        dist.barrier(group)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=results.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dt = float(t.item())
+    return dt, all_b, all_c

@@ -101,6 +101,16 @@ class WaymoDetectionDataset(torch.utils.data.Dataset):
         self.sweep_count = dataset_cfg.get('SWEEP_COUNT', None) or [0, 0]
         self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
         self.point_feature_encoder = PointFeatureEncoder(dataset_cfg.POINT_FEATURE_ENCODING, point_cloud_range=self.point_cloud_range)
+        # dataset.py:41-50: the config-named processor queue (range mask, voxelization on the device or its placeholder);
+        # grid_size / voxel_size are what build_network reads from the dataset
+        self.tta = bool(dataset_cfg.get('TTA', False))
+        self.data_processor = None
+        self.grid_size = self.voxel_size = None
+        if dataset_cfg.get('DATA_PROCESSOR', None):
+            from .data_processor import DataProcessor
+            self.data_processor = DataProcessor(dataset_cfg.DATA_PROCESSOR, point_cloud_range=self.point_cloud_range, training=False,
+                                                num_point_features=self.point_feature_encoder.num_point_features)
+            self.grid_size, self.voxel_size = self.data_processor.grid_size, self.data_processor.voxel_size
         self.data_path = self.root_path + '/' + dataset_cfg.PROCESSED_DATA_TAG
         self.split = dataset_cfg.DATA_SPLIT[self.mode]
         self.infos = []
@@ -181,7 +191,18 @@ class WaymoDetectionDataset(torch.utils.data.Dataset):
             boxes = np.asarray(annos['gt_boxes_lidar'])[keep][sel]
             classes = np.array([self.class_names.index(n) + 1 for n in names[sel]], dtype=np.int32)
             data_dict['gt_boxes'] = np.concatenate((boxes, classes.reshape(-1, 1).astype(np.float32)), axis=1)
-        return self.point_feature_encoder.forward(data_dict)
+        data_dict = self.point_feature_encoder.forward(data_dict)
+        if self.data_processor is not None:               # dataset.py:249-251
+            data_dict = self.data_processor.forward(data_dict=data_dict)
+        return data_dict
+
+    def evaluation(self, det_annos, class_names, **kwargs):
+        """waymo_dataset.py:104-131.  Without ground truth in the infos the reference returns early; with it, it calls the
+        TensorFlow / waymo_open_dataset metrics, which are outside this backend (recall statistics come from the model's
+        generate_recall_record)."""
+        if not self.infos or 'annos' not in self.infos[0]:
+            return 'No ground-truth boxes for evaluation', {}
+        return 'Official Waymo metrics (waymo_open_dataset / TensorFlow) are not provided by the HIP backend', {}
 
     collate_batch = staticmethod(dataset_utils.collate_batch)
     generate_prediction_dicts = staticmethod(dataset_utils.generate_prediction_dicts)

@@ -102,6 +102,19 @@ def test_state_dict_layout_matches_reference():
     assert float(sd['dense_head.heads_list.0.hm.1.bias'][0]) == pytest.approx(-2.19)
 
 
+def test_state_dict_identical_to_reference_manifest():
+    """EVERY key and shape equals what the reference's own classes register for centerpoint_1sweep (tests/golden/det_manifest.json,
+    recorded by gen_det_manifest.py from backbone3d.py / backbone2d.py / center_head.py), and a strict load of it succeeds."""
+    import json
+    from detzero_amd.synth import synth_state_dict
+    model, cfg, info = _model()
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'det_manifest.json')))
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref, (sorted(set(mine) ^ set(ref))[:6], [(k, mine[k], ref[k]) for k in mine if k in ref and mine[k] != ref[k]][:4])
+    assert len(ref) == 288
+    model.load_state_dict(synth_state_dict({k: tuple(v) for k, v in ref.items()}, seed=2), strict=True)
+
+
 def test_registry_and_processor_names():
     from detzero_amd import det_modules
     from detzero_amd.data_processor import DataProcessor

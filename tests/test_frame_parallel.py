@@ -46,10 +46,34 @@ def _worker(rank, world, port, n_frames, q):
         b[:, 7] = 0.5
         b[:, 8] = 1 + (i % 3)
         return b, torch.tensor([i % 3 + 1], dtype=torch.int32)
+    def batched(frames):      # the same detector over a list of frames -> (B,K,9), (B,)
+        outs = [pipeline(p) for p in frames]
+        return torch.stack([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     res = fp.run_frame_parallel(pipeline, Frames(), ['Vehicle', 'Pedestrian', 'Cyclist'],
                                 metas=[{'frame_id': i} for i in range(n_frames)])
+    res_b = fp.run_frame_parallel(batched, Frames(), ['Vehicle', 'Pedestrian', 'Cyclist'],
+                                  metas=[{'frame_id': i} for i in range(n_frames)], batch=3)
+    # bench.py's multi-GPU structure: sharded steps, gather inside the timed region, MAX over ranks of the elapsed time
+    K, B = 3, 2
+    results = torch.zeros((K, B, 6, 9)); counts = torch.zeros((K, B), dtype=torch.int32)
+    calls = []
+
+    def step(i):
+        calls.append(i)
+        results[i % K, :, :, 0] = 100 * rank + i
+        counts[i % K] = rank + 1
+        if rank == 1 and i >= 2:
+            import time
+            time.sleep(0.05)          # the slow rank decides the time
+    dt, all_b, all_c = fp.timed_steps(step, K, 2, results, counts, sync=lambda: None)
     if rank == 0:
-        q.put([(r['frame_id'], r['boxes_lidar'].shape[0], float(r['boxes_lidar'][0, 0]), str(r['name'][0])) for r in res])
+        same = all(a['frame_id'] == b['frame_id'] and np.array_equal(a['boxes_lidar'], b['boxes_lidar']) and list(a['name']) == list(b['name'])
+                   for a, b in zip(res, res_b))
+        timed = (calls == [0, 1, 2, 3, 4], dt >= 0.15, tuple(all_b.shape) == (2, K * B, 6, 9), all_c[1].tolist() == [2] * (K * B),
+                 float(all_b[1, 0, 0, 0]) == 103.0, float(all_b[0, 0, 0, 0]) == 3.0)
+        q.put(([(r['frame_id'], r['boxes_lidar'].shape[0], float(r['boxes_lidar'][0, 0]), str(r['name'][0])) for r in res], same, timed))
+    else:
+        assert res_b is None and all_b is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,7 +86,9 @@ def test_gloo_world2_gather_and_order():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out, same, timed = q.get(timeout=120)
+    assert same, 'batched run differs from the frame-by-frame run'
+    assert all(timed), timed
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
