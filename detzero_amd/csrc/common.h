@@ -38,8 +38,8 @@ void set_error(const char *fmt, ...);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
-// words of a neighbour table's tile_masks buffer: one tap mask per 64 output rows (whole 16-byte units)
-static inline int tile_masks_words(int cap) { return (cap / 64 + 1 + 3) & ~3; }
+// words of a neighbour table's tile_masks buffer: one tap mask per 32 output rows (whole 16-byte units)
+static inline int tile_masks_words(int cap) { return (cap / 32 + 1 + 3) & ~3; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // persistent-grid size for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8

@@ -26,6 +26,7 @@
 namespace dz {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
 
@@ -33,6 +34,9 @@ struct MathF16 {
     static constexpr int ID = 1;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4v mma16(v4u a, v4u b, f32x4v c) {        // 16x16x32: lane = (row or column) & 15, k group = lane >> 4
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ void split(float v, unsigned int &hi, unsigned int &lo) {
         // saturate instead of overflowing to inf: |v| beyond the fp16 range keeps hi = +-65504 and the rest in lo
@@ -52,6 +56,9 @@ struct MathBF16 {
     static constexpr int ID = 2;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4v mma16(v4u a, v4u b, f32x4v c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ void split(float v, unsigned int &hi, unsigned int &lo) {
         const __bf16 h = (__bf16)v;

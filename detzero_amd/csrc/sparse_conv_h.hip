@@ -6,24 +6,11 @@
 #include <stdlib.h>
 
 #include "hgemm.h"
+#include "sparse_conv_w.h"
 
 namespace dz {
 
 constexpr int KVOL_MAX_H = 27;
-
-struct SpConvHArgs {
-    const float *in;        // pair16 rows
-    const int *nbr;
-    const uint32_t *tile_masks;  // per-64-row tap masks (dz_build_neighbors) or null
-    const int *d_m_out;
-    const float *w;         // (kvol, cout_pad, cin) pair16
-    const float *scale;
-    const float *shift;
-    const float *residual;  // pair16 rows or null
-    float *out;             // pair16 rows
-    int cin, cout, cout_pad, kvol, cap, relu;
-    unsigned int in_bytes, w_bytes, nbr_bytes;
-};
 
 // GN = false: the tile's slice of the neighbour table is staged in LDS and scanned for its tap mask first.
 // GN = true (tile_masks given): no table in LDS and no per-tile scan - the tap mask comes precomputed and each
@@ -78,7 +65,7 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
         if constexpr (GN) {
             taps = 0u;
 #pragma unroll
-            for (int i = 0; i < T::BP / 64; ++i) taps |= a.tile_masks[tile * (T::BP / 64) + i];
+            for (int i = 0; i < T::BP / 32; ++i) taps |= a.tile_masks[tile * (T::BP / 32) + i];
             taps = __builtin_amdgcn_readfirstlane(taps);
         } else {
             if (tid == 0) mask_s = 0u;
@@ -274,7 +261,13 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream, bool ring_o
 // 4 register stages, 128 x 128 with 4 waves).
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
-    static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0);
+    static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0), tw = tune("DZ_TUNE_SPCONV_W", 1);
+    // small-channel levels: wave-private tiles with all weights resident in LDS (sparse_conv_w.h)
+    if (tw && a.cout_pad == 32 && a.tile_masks && a.nbr_bytes) {
+        if (a.cin == 16 && a.cout == 16) return launch_spconv_w<16, 16, 4, M, 6, 3>(a, stream);
+        if (a.cin == 16 && a.cout == 32) return launch_spconv_w<16, 32, 3, M, 6, 3>(a, stream);
+        if (a.cin == 32 && a.cout == 32) return launch_spconv_w<32, 32, 2, M, 12, 3>(a, stream);
+    }
     if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4, 3, 4, 5>(a, stream);
     if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
@@ -328,12 +321,21 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
     // the table is addressed through a buffer descriptor when it fits its 2 GiB window (else: staged through LDS)
     const size_t nbr_bytes = (size_t)kvol * cap_out * sizeof(int);
     SpConvHArgs a{in, nbr, tile_masks, d_m_out, w, scale, shift, residual, out, cin, cout, cout_pad, kvol, cap_out, relu,
-                  (unsigned int)in_bytes, (unsigned int)w_bytes, nbr_bytes < 0x80000000ull ? (unsigned int)nbr_bytes : 0u};
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, nbr_bytes < 0x80000000ull ? (unsigned int)nbr_bytes : 0u,
+                  tile_masks ? (unsigned int)tile_masks_words(cap_out) * 4u : 0u, 0};
+#ifdef DZ_SPCONV_DIAG
+    a.diag = tune("DZ_TUNE_W_DIAG", 0);
+#endif
     return math == DZ_MATH_F16X2 ? spconv_h_dispatch<MathF16>(a, stream) : spconv_h_dispatch<MathBF16>(a, stream);
 }
 
 const char *dz_spconv_variant_split(int cin, int cout) {
     const int cout_pad = cout < 32 ? 32 : cout;
+    if (tune("DZ_TUNE_SPCONV_W", 1) && cout_pad == 32) {        // (needs the table's tile masks, which dz_build_neighbors always writes)
+        if (cin == 16 && cout == 16) return "k_spconv_w<16x16>";
+        if (cin == 16 && cout == 32) return "k_spconv_w<16x32>";
+        if (cin == 32 && cout == 32) return "k_spconv_w<32x32>";
+    }
     if (cin == 16 && cout_pad == 32) return "k_spconv_h<128x32x16>";
     if (cin == 32 && cout_pad == 32) return "k_spconv_h<128x32x32>";
     if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<128x64x32>";

@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__
                                                          const uint32_t *__restrict__ prefix_in, int B, int D,
                                                          int H, int W, ConvGeom g, int *__restrict__ nbr,
                                                          uint32_t *__restrict__ tile_masks) {
-    // tile_masks (optional): word o/64 collects, for 64 consecutive output rows, the kernel taps that have at least
-    // one neighbour - what the conv kernels need to skip empty taps without scanning the table again
+    // tile_masks (optional): word o/32 collects, for 32 consecutive output rows (the pixel side of one 32x32 MFMA fragment),
+    // the kernel taps that have at least one neighbour - what the conv kernels need to skip empty taps without scanning the
+    // table again
     const int m = min(*d_m_out, cap_out);
     const int rows = g.k[0] * g.k[1];
     // rows padded to whole 64-row groups: a wavefront then works on ONE group (its lanes share the mask word)
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__
         }
         if (tile_masks) {       // uniform per launch; the loop bounds are wave-uniform too (total is a multiple of 64)
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, d, 64);
-            if ((threadIdx.x & 63) == 0 && bits) atomicOr(&tile_masks[o >> 6], bits);
+            for (int d = 16; d >= 1; d >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, d, 64);
+            if ((threadIdx.x & 31) == 0 && bits) atomicOr(&tile_masks[o >> 5], bits);
         }
     }
 }

@@ -126,8 +126,8 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
                        const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3,
                        const int *h_s3, const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream);
-/* tile_masks (dz_tile_masks_words(cap_out) words, 16-byte aligned, or NULL): bit t of word o/64 = some row of the 64-row
- * group o/64 has a neighbour at tap t (what the conv kernels need to skip empty taps without scanning the table). */
+/* tile_masks (dz_tile_masks_words(cap_out) words, 16-byte aligned, or NULL): bit t of word o/32 = some row of the 32-row
+ * group o/32 has a neighbour at tap t (what the conv kernels need to skip empty taps without scanning the table). */
 int dz_tile_masks_words(int cap_out);
 
 /* dst[rank[i]][0:c_src] = src[i][0:c_src]; dst[rank[i]][c_src:c_dst] = 0 (rows with rank<0 skipped) */
