@@ -25,9 +25,7 @@ class CenterPoint(nn.Module):
         self.model_cfg = model_cfg
         self.num_class = num_class
         self.dataset = dataset
-        self.tta = getattr(self.dataset, 'tta', False)
-        if self.tta:
-            raise DetZeroHipError('TTA / weighted box fusion is out of scope of the HIP backend (SURVEY.md §8f)')
+        self.tta = getattr(self.dataset, 'tta', False)       # TTA: True in the dataset config -> copies, restore, weighted box fusion
         self.class_names = dataset.class_names
         self.register_buffer('global_step', torch.LongTensor(1).zero_())
         self.second_stage = model_cfg.SECOND_STAGE
@@ -81,15 +79,44 @@ class CenterPoint(nn.Module):
         return self.post_processing(batch_dict)
 
     def post_processing(self, batch_dict):
-        """centerpoint.py:283-296 (one-stage branch)."""
+        """centerpoint.py:283-307 (one-stage branch; with TTA the copies' boxes are restored and fused, :298-306)."""
         post_process_cfg = self.model_cfg.POST_PROCESSING
         pred_dicts = batch_dict['final_box_dicts']
         recall_dict = {}
         for index in range(batch_dict['batch_size']):
             recall_dict = self.generate_recall_record(
-                box_preds=pred_dicts[index]['pred_boxes'], recall_dict=recall_dict, batch_index=index,
+                box_preds=pred_dicts[index]['pred_boxes'], recall_dict=recall_dict, batch_index=0 if self.tta else index,
                 data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+        if self.tta:
+            boxes, scores, labels = self.test_time_augment(batch_dict, pred_dicts)
+            pred_dicts = [{'pred_boxes': boxes, 'pred_scores': scores, 'pred_labels': labels}]
         return pred_dicts, recall_dict
+
+    @staticmethod
+    def test_time_augment(data_dict, pred_dicts):
+        """centerpoint.py:131-208: the copies' boxes padded into one (frames, copies, rows, dim) tensor, restored to the original
+        coordinates in place (dz_tta_restore_boxes) and fused (dz_wbf_fuse_3d).  Like the reference (its ``boxes.squeeze(0)``)
+        this handles ONE frame per batch; ``data_dict['batch_size']`` becomes the number of frames."""
+        from . import tta
+        tta_ops = list(data_dict['tta_ops'])
+        tta_num = len(tta_ops)
+        bs = int(data_dict['batch_size'] // tta_num)
+        if bs != 1:
+            raise DetZeroHipError('TTA: one frame per batch (the reference squeezes the frame axis, centerpoint.py:205)')
+        max_num = max(max(len(x['pred_boxes']) for x in pred_dicts), 1)
+        ref = pred_dicts[0]['pred_boxes']
+        dim = ref.shape[-1]
+        boxes = torch.zeros((data_dict['batch_size'], max_num, dim), dtype=torch.float32, device=ref.device)
+        scores = torch.zeros((data_dict['batch_size'], max_num, 1), dtype=torch.float32, device=ref.device)
+        labels = torch.zeros((data_dict['batch_size'], max_num, 1), dtype=pred_dicts[0]['pred_labels'].dtype, device=ref.device)
+        for i, pred in enumerate(pred_dicts):
+            n = len(pred['pred_boxes'])
+            boxes[i, :n] = pred['pred_boxes']
+            scores[i, :n, 0] = pred['pred_scores']
+            labels[i, :n, 0] = pred['pred_labels']
+        boxes = tta.restore_boxes(boxes.reshape(bs, tta_num, max_num, dim), tta_ops)
+        data_dict['batch_size'] = bs
+        return tta.wbf_online(boxes[0], scores, labels)
 
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):

@@ -479,6 +479,41 @@ __global__ __launch_bounds__(256) void k_points_in_boxes_bits(const float *__res
     }
 }
 
+// points per box (roiaware_pool3d's points_in_boxes_num as tracking/.../data_processor.py:64-69 uses it): the bitmap kernel's
+// test, one popcount of the ballot per wavefront and box, one atomicAdd per wavefront that saw a point - no (T, M) mask at all
+__global__ __launch_bounds__(256) void k_points_in_boxes_count(const float *__restrict__ boxes, const float *__restrict__ pts,
+                                                               int t, int m, int *__restrict__ counts) {
+    __shared__ float sb[64 * 9];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < m) { x = pts[(size_t)i * 3]; y = pts[(size_t)i * 3 + 1]; z = pts[(size_t)i * 3 + 2]; }
+    for (int base = 0; base < t; base += 64) {
+        const int nb = min(64, t - base);
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const float *q = boxes + (size_t)(base + threadIdx.x) * 7;
+            float *d = sb + threadIdx.x * 9;
+            for (int j = 0; j < 7; ++j) d[j] = q[j];
+            d[7] = cosf(-q[6]);
+            d[8] = sinf(-q[6]);
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const float *q = sb + k * 9;
+            bool in = false;
+            if (i < m && !((double)fabsf(z - q[2]) > (double)q[5] / 2.0)) {       // same test as k_points_in_boxes
+                const float sx = x - q[0], sy = y - q[1];
+                const float lx = sx * q[7] + sy * (-q[8]);
+                const float ly = sx * q[8] + sy * q[7];
+                in = ((double)fabsf(lx) < (double)q[3] / 2.0 + (double)1e-5f) && ((double)fabsf(ly) < (double)q[4] / 2.0 + (double)1e-5f);
+            }
+            const unsigned long long bits = __ballot(in);
+            if (lane == 0 && bits) atomicAdd(&counts[base + k], __popcll(bits));
+        }
+    }
+}
+
 // one thread per (kept point, payload word)
 __global__ void k_crop_gather(const int *__restrict__ pairs, const int *__restrict__ d_total, int cap, const uint32_t *__restrict__ payload,
                               int words, uint32_t *__restrict__ out, int *__restrict__ out_index, const uint32_t *__restrict__ prefix,
@@ -661,6 +696,19 @@ int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, i
     for (int i = 0; i < 6; ++i) a.lim[i] = h_limit6[i];
     for (int i = 0; i < 3; ++i) { a.lo[i] = h_range6[i]; a.vs[i] = h_vsize3[i]; }
     hipLaunchKernelGGL(k_topk_decode, dim3(batch), dim3(TOPK_THREADS), 0, stream, a);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_points_in_boxes_count(const float *boxes, const float *pts, int t, int m, int *counts, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(t >= 0 && m >= 0, "dz_points_in_boxes_count: negative size");
+    if (t == 0) return DZ_OK;
+    DZ_CHECK_ARG(boxes && counts && (pts || m == 0), "dz_points_in_boxes_count: null pointer");
+    const int rc = fill_u32(counts, 0u, (size_t)t, stream);
+    if (rc) return rc;
+    if (m == 0) return DZ_OK;
+    hipLaunchKernelGGL(k_points_in_boxes_count, dim3(ceil_div(m, 256)), dim3(256), 0, stream, boxes, pts, t, m, counts);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -89,13 +89,13 @@ struct WbfParams {
 
 // workspace of one (frame, class) slot; `cap` = candidates per frame
 struct WbfSlot {
-    int *sel_idx, *order, *c_cnt, *c_first, *c_obj, *counts;     // counts: [0] selected, [1] clusters, [2] first candidate of the class
+    int *sel_idx, *order, *c_cnt, *c_first, *c_obj, *c_objc, *counts;     // c_objc: candidate lending the cluster its object id; counts: [0] selected, [1] clusters, [2] first candidate of the class
     double *sel_score, *c_conf, *c_score;
     float *c_acc, *c_fused;
 };
 
 __host__ __device__ inline size_t wbf_slot_bytes(int cap) {
-    return (size_t)cap * (5 * sizeof(int) + 3 * sizeof(double) + 14 * sizeof(float) + 4) + 64;      // (+4: keeps slots 8-byte aligned)
+    return (size_t)cap * (6 * sizeof(int) + 3 * sizeof(double) + 14 * sizeof(float)) + 64;      // (a multiple of 8: slots stay 8-byte aligned)
 }
 
 __device__ __forceinline__ WbfSlot wbf_slot(void *ws, int slot, int cap) {
@@ -110,6 +110,7 @@ __device__ __forceinline__ WbfSlot wbf_slot(void *ws, int slot, int cap) {
     s.c_cnt = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_first = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_obj = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
+    s.c_objc = reinterpret_cast<int *>(p); p += (size_t)cap * sizeof(int);
     s.c_acc = reinterpret_cast<float *>(p); p += (size_t)cap * 7 * sizeof(float);
     s.c_fused = reinterpret_cast<float *>(p);
     return s;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__rest
                 for (int k = 0; k < 7; ++k) { acc[k] = (float)(sj * (double)bj[k]); fu[k] = bj[k]; }
                 s.c_conf[ncl] = sj; s.c_cnt[ncl] = 1; s.c_first[ncl] = cand; s.c_score[ncl] = sj;
                 s.c_obj[ncl] = obj_ids ? obj_ids[(size_t)f * p.cand + cand] : -1;
+                s.c_objc[ncl] = cand;
                 ncl_s = ncl + 1;
             } else {                                                        // get_weighted_box (wbf_3d.py:53-96)
                 const int c = best_idx;
@@ -221,8 +223,16 @@ __global__ __launch_bounds__(WBF_THREADS) void k_wbf_cluster(const float *__rest
                 const int first = s.c_first[c];
                 fu[6] = boxes[((size_t)f * p.cand + first) * 7 + 6];
                 s.c_conf[c] = conf; s.c_cnt[c] = cnt;
-                // object id (weighted_tracking_boxes_fusion_3d, wbf_3d.py:86-94): the most confident member that has one
-                if (obj_ids && s.c_obj[c] < 0) s.c_obj[c] = obj_ids[(size_t)f * p.cand + cand];
+                // object id (weighted_tracking_boxes_fusion_3d, wbf_3d.py:86-94): the most confident member that has one; members
+                // are ordered by np.argsort(conf)[::-1], so among EQUAL confidences the member appended last wins
+                if (obj_ids) {
+                    const int id_new = obj_ids[(size_t)f * p.cand + cand];
+                    if (id_new >= 0) {
+                        const int holder = s.c_objc[c];
+                        const double holder_sc = (double)scores[(size_t)f * p.cand + holder] * (weights ? weights[holder / p.per_model] : 1.0);
+                        if (s.c_obj[c] < 0 || sj == holder_sc) { s.c_obj[c] = id_new; s.c_objc[c] = cand; }
+                    }
+                }
                 const double first_sc = (double)scores[(size_t)f * p.cand + first] * (weights ? weights[first / p.per_model] : 1.0);
                 s.c_score[c] = (double)(float)(p.conf_max ? first_sc : conf / cnt);
             }
@@ -362,13 +372,13 @@ int dz_wbf_fuse_3d(const float *boxes, const float *scores, const int *labels, c
         return DZ_OK;
     }
     DZ_CHECK_ARG(boxes && scores && labels && out_boxes && out_scores && out_labels && ws, "dz_wbf_fuse_3d: null pointer");
+    DZ_CHECK_ARG(!obj_ids == !out_obj_ids, "dz_wbf_fuse_3d: obj_ids and out_obj_ids go together");
     DZ_CHECK_ARG(ws_bytes >= dz_wbf_workspace_bytes(frames, cand) && ((uintptr_t)ws & 7u) == 0, "dz_wbf_fuse_3d: workspace too small or misaligned");
     WbfParams p;
     p.frames = frames; p.cand = cand; p.per_model = per_model; p.n_models = n_models; p.conf_max = conf_max; p.allows_overflow = allows_overflow;
     for (int i = 0; i < 3; ++i) { p.iou_thr[i] = h_iou_thr3[i]; p.skip_thr[i] = h_skip_thr3[i]; }
     p.wsum = weight_sum;
     hipLaunchKernelGGL(k_wbf_rank, dim3(3, frames), dim3(256), 0, stream, scores, labels, weights, p, ws);
-    DZ_CHECK_ARG(!obj_ids == !out_obj_ids, "dz_wbf_fuse_3d: obj_ids and out_obj_ids go together");
     hipLaunchKernelGGL(k_wbf_cluster, dim3(3, frames), dim3(WBF_THREADS), 0, stream, boxes, scores, weights, obj_ids, p, ws);
     hipLaunchKernelGGL(k_wbf_emit, dim3(frames), dim3(256), 0, stream, boxes, p, ws, out_boxes, out_scores, out_labels, out_obj_ids, out_count);
     DZ_LAUNCH_CHECK();

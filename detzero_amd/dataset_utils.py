@@ -9,12 +9,26 @@ import torch
 
 
 def collate_batch(batch_list, _unused=False):
-    """dataset.py:259-303 without the TTA branch (TTA is out of scope).  Values may be numpy arrays or
-    device tensors (a frame voxelized on the GPU stays there)."""
+    """dataset.py:259-303, TTA branch included: a sample that is a dict of copies ({'tta_original': ..., 'tta_flip_x': ...})
+    contributes the point / voxel arrays of every copy and the remaining keys of the original; ``tta_ops`` lists the copies
+    and ``batch_size`` counts frames x copies.  Values may be numpy arrays or device tensors (a frame voxelized on the GPU
+    stays there)."""
     data_dict = defaultdict(list)
+    tta = 'tta_original' in batch_list[0]
+    tta_ops = []
     for cur_sample in batch_list:
-        for key, val in cur_sample.items():
-            data_dict[key].append(val)
+        if tta:
+            tta_ops = list(cur_sample.keys())
+            data_dict['tta_ops'] = list(tta_ops)
+            for key in cur_sample['tta_original']:
+                if key in ['points', 'voxels', 'voxel_num_points', 'voxel_coords']:
+                    for tta_cfg in tta_ops:
+                        data_dict[key].append(cur_sample[tta_cfg][key])
+                else:
+                    data_dict[key].append(cur_sample['tta_original'][key])
+        else:
+            for key, val in cur_sample.items():
+                data_dict[key].append(val)
     batch_size = len(batch_list)
     ret = {}
 
@@ -38,12 +52,14 @@ def collate_batch(batch_list, _unused=False):
             for k in range(batch_size):
                 out[k, :len(val[k]), :] = val[k]
             ret[key] = out
+        elif key == 'tta_ops':
+            ret[key] = val
         else:
             try:
                 ret[key] = np.stack(val, axis=0)
             except Exception:
                 ret[key] = val
-    ret['batch_size'] = batch_size
+    ret['batch_size'] = batch_size if not tta else int(batch_size * len(tta_ops))
     return ret
 
 

@@ -118,6 +118,7 @@ _SIGS = {
     'dz_boxes_overlap_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_boxes_iou_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dz_points_in_boxes_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_points_in_boxes_v2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_crop_points_workspace_bytes': (c_size_t, [c_int] * 3),
     'dz_crop_points_in_boxes': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

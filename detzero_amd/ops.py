@@ -617,3 +617,41 @@ class LaunchProfiler:
 
 
 PROFILER = None
+
+
+# ------------------------------------------------------------------------------------------------
+# device guard: every wrapper above allocates its outputs / workspaces with the current device and launches on its current
+# stream, so each public entry runs under torch.cuda.device(<device of its first tensor argument>) - tensors living on a GPU
+# other than the current one (one process driving several GPUs) then get their kernels on their own device and stream
+# ------------------------------------------------------------------------------------------------
+def _guarded(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            if torch.is_tensor(a) and a.is_cuda:
+                dev = a.device
+                break
+            if isinstance(a, SparseLevel):
+                dev = a.coords.device
+                break
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def _install_guards():
+    import types
+    g = globals()
+    for name, obj in list(g.items()):
+        if isinstance(obj, types.FunctionType) and obj.__module__ == __name__ and not name.startswith('_') and name not in ('grid_size_of', 'math_id', 'pair16_pack', 'pair16_unpack'):
+            g[name] = _guarded(obj)
+    for name in ('build_from_coords', 'downsample', 'neighbors_to'):
+        setattr(SparseLevel, name, _guarded(getattr(SparseLevel, name)))
+
+
+_install_guards()

@@ -102,14 +102,23 @@ def bev_overlap_gpu(boxes_a, boxes_b):
 
 def points_in_boxes_num_gpu(points_xyz, boxes):
     """Number of points inside each box (roiaware_pool3d_utils.points_in_boxes_num_gpu as used at
-    data_processor.py:64-69): column sums of the dz_points_in_boxes_v2 mask."""
+    data_processor.py:64-69) -> (T,) int32 numpy: dz_points_in_boxes_count (per-wavefront popcounts + atomics into a (T,)
+    counter; the dense (T, M) mask of points_in_boxes_gpu_v2 is never built)."""
     import torch
-    from . import roiaware_pool3d_utils
-    dev = torch.device('cuda', torch.cuda.current_device())
-    p = torch.from_numpy(np.ascontiguousarray(points_xyz[:, :3], dtype=np.float32)).to(dev)[None]
-    b = torch.from_numpy(np.ascontiguousarray(boxes[:, :7], dtype=np.float32)).to(dev)[None]
-    mask = roiaware_pool3d_utils.points_in_boxes_gpu_v2(p, b)            # (1, T, M) int32
-    return mask[0].sum(dim=1).cpu().numpy()
+    from . import lib as L
+    t = boxes.shape[0]
+    if t == 0:
+        return np.zeros((0,), dtype=np.int32)
+    dev = points_xyz.device if torch.is_tensor(points_xyz) else torch.device('cuda', torch.cuda.current_device())
+    p = points_xyz if torch.is_tensor(points_xyz) else torch.from_numpy(np.ascontiguousarray(points_xyz[:, :3], dtype=np.float32))
+    b = boxes if torch.is_tensor(boxes) else torch.from_numpy(np.ascontiguousarray(boxes[:, :7], dtype=np.float32))
+    p = p[:, :3].to(dev, torch.float32).contiguous()
+    b = b[:, :7].to(dev, torch.float32).contiguous()
+    counts = torch.empty((t,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.load().dz_points_in_boxes_count(L.ptr(b), L.ptr(p), t, p.shape[0], L.ptr(counts), L.stream())
+    L.check(rc, 'dz_points_in_boxes_count')
+    return counts.cpu().numpy()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -113,6 +113,11 @@ def wbf_fuse_nosync(boxes, scores, labels, n_models, weights=None, iou_thr=IOU_T
     if conf_type not in ('avg', 'max'):
         conf_type = 'avg'                                    # wbf_3d.py:148-150
     dev = boxes.device
+    if weights is not None and len(weights) != n_models:
+        # wbf_3d.py:143-145: a weights list of the wrong length is replaced by all ones (the reference prints a warning)
+        import warnings
+        warnings.warn('wbf: %d weights for %d models - using equal weights' % (len(weights), n_models))
+        weights = None
     w = None if weights is None else torch.as_tensor(np.asarray(weights, dtype=np.float64)).to(dev)
     wsum = float(n_models) if weights is None else float(np.asarray(weights, dtype=np.float64).sum())
     lib = L.load()

@@ -104,6 +104,10 @@ class WaymoDetectionDataset(torch.utils.data.Dataset):
         # dataset.py:41-50: the config-named processor queue (range mask, voxelization on the device or its placeholder);
         # grid_size / voxel_size are what build_network reads from the dataset
         self.tta = bool(dataset_cfg.get('TTA', False))
+        self.test_time_augmentor = None
+        if self.tta:                                      # waymo_dataset.py:48-55 (init_tta)
+            from .tta import TestTimeAugmentor
+            self.test_time_augmentor = TestTimeAugmentor(dataset_cfg.TEST_TIME_AUGMENTOR, logger=logger)
         self.data_processor = None
         self.grid_size = self.voxel_size = None
         if dataset_cfg.get('DATA_PROCESSOR', None):
@@ -192,6 +196,11 @@ class WaymoDetectionDataset(torch.utils.data.Dataset):
             classes = np.array([self.class_names.index(n) + 1 for n in names[sel]], dtype=np.int32)
             data_dict['gt_boxes'] = np.concatenate((boxes, classes.reshape(-1, 1).astype(np.float32)), axis=1)
         data_dict = self.point_feature_encoder.forward(data_dict)
+        if self.tta:                                      # dataset.py:239-246: every copy goes through the processors
+            copies = self.test_time_augmentor.forward(data_dict)
+            if self.data_processor is not None:
+                copies = {k: self.data_processor.forward(data_dict=v) for k, v in copies.items()}
+            return copies
         if self.data_processor is not None:               # dataset.py:249-251
             data_dict = self.data_processor.forward(data_dict=data_dict)
         return data_dict

@@ -260,6 +260,11 @@ int dz_gather_rows(const float *src, const int *idx, const int *d_n, int n_cap, 
 /* ---------------------------------------------------------------------------------------------
  * Refining module, secondary kernel set
  * ------------------------------------------------------------------------------------------- */
+/* Points per box: counts[t] = number of points inside box t, the inside test of dz_points_in_boxes_v2, no (T, M) mask
+ * (roiaware_pool3d_utils.points_in_boxes_num_gpu -> points_in_boxes_num kernel, used by tracking/detzero_track/datasets/
+ * data_processor.py:64-69).  boxes (t,7) f32, pts (m,3) f32, counts (t,) i32 (overwritten). */
+int dz_points_in_boxes_count(const float *boxes, const float *pts, int t, int m, int *counts, void *stream);
+
 /* roiaware_pool3d_cuda.points_in_boxes_gpu_v2 (roiaware_pool3d.cpp:135-155,
  * roiaware_pool3d_kernel.cu:352-374): mask (B,T,M) i32, 1 where point m is inside box t. */
 int dz_points_in_boxes_v2(const float *boxes, const float *pts, int batch, int t, int m, int *mask,

@@ -35,6 +35,33 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c['unit'] == d['unit']
 
 
+def test_committed_bench_line_has_the_auxiliary_legs():
+    """Round 2: what the headline does not show rides in the same line - an exact-fp32 run with its own roofline, the
+    reference's batch size, ragged frames, host-resident frames, and per-stage HBM figures (north star: HBM GB/s on the scatter)."""
+    d, path = _newest_line()
+    if 'fp32' not in d:
+        import pytest
+        pytest.skip('line predates the auxiliary legs')
+    f = d['fp32']
+    assert f['math'] == 'f32' and f['dtype'] == 'f32' and f['value'] > 0 and f['unit'] == d['unit']
+    assert abs(f['value'] - f['frames_per_step'] * 1000.0 / f['ms_per_step']) / f['value'] < 1e-3
+    r = f['roofline']
+    assert r['bound'] == 'mfma' and abs(r['peak'] - 157.3) < 0.1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert d['ref_batch']['frames_per_step'] == 8 and d['ref_batch']['value'] > 0
+    for k in ('padded', 'list'):
+        leg = d['ragged'][k]
+        assert leg['value'] > 0 and 150000 <= leg['mean_points_per_frame'] <= 180000
+    h = d['with_h2d']
+    assert h['value'] > 0 and h['h2d_bytes_per_step'] == h['frames_per_step'] * 160000 * 5 * 4
+    assert h['value'] <= d['value'] * 1.05                                  # the H2D-inclusive rate is never the headline
+    stages = {s['stage']: s for s in d['stages']}
+    assert list(stages) == ['voxelize', 'index', 'sparse_backbone', 'dense', 'post']
+    for k in ('voxelize', 'index', 'sparse_backbone'):
+        s = stages[k]
+        assert s['algorithmic_bytes'] > 0 and abs(s['hbm_gbs'] - s['algorithmic_bytes'] / (s['ms_per_step'] * 1e-3) / 1e9) / s['hbm_gbs'] < 1e-2
+        assert abs(s['frac_of_hbm_peak'] - s['hbm_gbs'] / 8000.0) < 1e-3
+
+
 def test_bench_arguments():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0

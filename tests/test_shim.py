@@ -304,3 +304,50 @@ def test_generate_recall_record_on_planted_boxes(device):
     rec = CenterPoint.generate_recall_record(pred[:0], rec, 0, {'gt_boxes': gt_pad[None]}, [0.3, 0.5, 0.7])
     assert rec['gt'] == 20 and rec['rcnn_0.3'] == 8
     assert CenterPoint.generate_recall_record(pred, {}, 0, {}, [0.3]) == {}
+
+
+@pytest.mark.gpu
+def test_tta_through_the_plugin_surface(device, tmp_path):
+    """TTA: True in the dataset config (waymo_1sweep.yaml:31,48-58): the dataset emits the dict of augmented copies, collate_batch
+    stacks them as frames x copies, CenterPoint.post_processing restores and fuses them (centerpoint.py:131-208,298-306) - and
+    the result equals TTAPipeline over the same frame."""
+    shim.install()
+    from detzero_det.datasets import build_dataloader
+    from detzero_det.models import build_network
+    from detzero_amd import tta
+    from detzero_amd.centerpoint import FramePipeline, SyntheticDatasetInfo, synth_detector
+    from detzero_amd.synth import VOXEL_SIZE_02
+    root = str(tmp_path / 'waymo')
+    _write_dataset(root, n_frames=2, with_annos=False)
+    cfg = _dataset_cfg(root)
+    cfg.DATA_CONFIG.TTA = True
+    cfg.DATA_CONFIG.TEST_TIME_AUGMENTOR = AttrDict({'DISABLE_AUG_LIST': ['placeholder'], 'AUG_CONFIG_LIST': [
+        {'NAME': 'world_flip', 'ALONG_AXIS_LIST': ['x', 'y']}, {'NAME': 'world_rotation', 'ROT_ANGLE': [0, 0.39365818, -0.78539816]},
+        {'NAME': 'world_scaling', 'SCALE_RANGE': [0.95, 1.05]}]})
+    logger = logging.getLogger('shim-tta')
+    ds, loader, _ = build_dataloader(dataset_cfg=cfg.DATA_CONFIG, class_names=cfg.CLASS_NAMES, batch_size=1, dist=False, workers=0,
+                                     logger=logger, training=False)
+    assert ds.tta and ds.test_time_augmentor.op_names == ['tta_original', 'tta_flip_x', 'tta_flip_y', 'tta_rot_0.39365818', 'tta_rot_-0.78539816',
+                                                          'tta_scale_0.95', 'tta_scale_1.05']
+    ref_model, _, info = synth_detector(VOXEL_SIZE_02, seed=0)
+    model = build_network(model_cfg=cfg.MODEL, num_class=3, dataset=ds)
+    model.load_state_dict(ref_model.state_dict())
+    model.cuda().eval()
+    batch = next(iter(loader))
+    assert batch['batch_size'] == 7 and batch['tta_ops'][2] == 'tta_flip_y' and int(batch['voxel_coords'][:, 0].max()) == 6
+    from detzero_det.models import load_data_to_gpu
+    load_data_to_gpu(batch)
+    with torch.no_grad():
+        pred_dicts, _ = model(batch)
+    assert len(pred_dicts) == 1 and batch['batch_size'] == 1
+    got_b, got_s, got_l = pred_dicts[0]['pred_boxes'], pred_dicts[0]['pred_scores'], pred_dicts[0]['pred_labels']
+    assert got_b.shape[0] > 10 and got_b.dtype == torch.float64 and bool((got_s[:-1] >= got_s[1:]).all())
+    pipe = FramePipeline(ref_model.to(device), SyntheticDatasetInfo(cfg))
+    cfg.DATA_CONFIG.TTA = False
+    plain = type(ds)(cfg.DATA_CONFIG, cfg.CLASS_NAMES, root_path=root)
+    ob, osc, ol, oc = tta.TTAPipeline(pipe, ds.test_time_augmentor)(plain[0]['points'])
+    k = int(oc[0].item())
+    assert k == got_b.shape[0]
+    np.testing.assert_allclose(got_b.cpu().numpy(), ob[0, :k].cpu().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got_s.cpu().numpy(), osc[0, :k].cpu().numpy(), rtol=0, atol=1e-6)
+    assert torch.equal(got_l.cpu(), ol[0, :k].long().cpu())

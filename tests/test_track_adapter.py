@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 from detzero_amd import track_adapter as ta
@@ -106,4 +107,8 @@ def test_points_in_boxes_num(device):
     boxes = synth_boxes(3, 40, 50.0)
     got = ta.points_in_boxes_num_gpu(pts, boxes)
     ref = cref.points_in_boxes_v2(np.ascontiguousarray(pts, np.float32), boxes).sum(axis=1)
-    assert np.array_equal(got, ref) and got.sum() > 0
+    assert np.array_equal(got, ref) and got.sum() > 0 and got.dtype == np.int32           # the reference's kernel counts in int32
+    boxes = synth_boxes(4, 150, 60.0)                                                       # more than one 64-box chunk
+    got = ta.points_in_boxes_num_gpu(torch.from_numpy(pts).to(device), boxes)
+    assert np.array_equal(got, cref.points_in_boxes_v2(np.ascontiguousarray(pts, np.float32), boxes).sum(axis=1))
+    assert ta.points_in_boxes_num_gpu(pts, boxes[:0]).shape == (0,)

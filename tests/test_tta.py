@@ -184,6 +184,46 @@ def test_tracking_fusion_matches_reference(device, g):
     np.testing.assert_allclose(b.cpu().numpy(), g[tag + 'trk_boxes'], rtol=0, atol=1e-6)
 
 
+def _tie_case():
+    """Two models, three objects; members of a cluster with EQUAL confidences and different object ids."""
+    base = np.array([[10, 5, 1, 4, 2, 1.6, 0.3], [-20, 8, 1, 4.2, 1.9, 1.5, -1.0], [30, -12, 1, 0.8, 0.8, 1.7, 2.0]], np.float32)
+    boxes = np.stack([base, base + np.array([0.05, 0.02, 0, 0, 0, 0, 0.01], np.float32)])
+    scores = np.array([[0.8, 0.6, 0.5], [0.8, 0.6, 0.4]], np.float32)
+    labels = np.array([[1, 1, 2], [1, 1, 2]], np.int64)
+    ids = np.array([[5, -1, 9], [7, 3, 11]], np.int64)
+    return boxes, scores, labels, ids
+
+
+def test_oracle_tracking_tie_rule():
+    """get_weighted_box orders members by np.argsort(conf)[::-1] (wbf_3d.py:86-94): among equal confidences the member
+    appended LAST lends its id."""
+    boxes, scores, labels, ids = _tie_case()
+    b, s, l, out = oracle_wbf.weighted_boxes_fusion_3d(boxes, scores, labels, obj_ids=ids)
+    assert b.shape[0] == 3
+    order = np.argsort(-s)
+    assert out[order].tolist() == [5, 3, 9]
+
+
+@pytest.mark.gpu
+def test_tracking_fusion_tie_rule_on_device(device):
+    from detzero_amd import tta
+    boxes, scores, labels, ids = _tie_case()
+    rb, rs, rl, rid = oracle_wbf.weighted_boxes_fusion_3d(boxes, scores, labels, obj_ids=ids)
+    b, s, l, out = tta.wbf_tracking_v1(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device)[..., None],
+                                       torch.from_numpy(labels).to(device)[..., None], torch.from_numpy(ids).to(device)[..., None])
+    np.testing.assert_array_equal(out.cpu().numpy(), rid)
+    np.testing.assert_allclose(s.cpu().numpy(), rs, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(b.cpu().numpy()[:, :6], rb[:, :6], rtol=0, atol=1e-6)
+
+
+def test_wbf_weights_length_mismatch_falls_back_to_ones_like_the_reference():
+    """wbf_3d.py:143-145 resets a weights list of the wrong length to ones; the host wrapper must not hand it to the kernel."""
+    import inspect
+    from detzero_amd import tta
+    src = inspect.getsource(tta.wbf_fuse_nosync)
+    assert 'len(weights) != n_models' in src and 'weights = None' in src
+
+
 def test_augmentor_config_forms_and_errors():
     from detzero_amd.config import AttrDict
     from detzero_amd.lib import DetZeroHipError
