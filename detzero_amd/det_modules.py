@@ -672,7 +672,8 @@ class SeparateHead(nn.Module):
 class CenterHead(_Cached):
     """center_head.py:51-488, inference path: shared conv, six branches (batched into one 64->384
     conv and one grouped 384->12 conv), decode + rotated NMS on the device.
-    ``gt_boxes`` is not needed (the reference runs its CPU target assignment even in eval, :448)."""
+    ``gt_boxes`` is optional: the reference runs its CPU target assignment even in eval (:448-453) and needs the key;
+    here ``assign_targets`` runs when the batch carries it and fills ``forward_ret_dict['target_dicts']`` the same way."""
 
     COLS = {'center': (0, 2), 'center_z': (2, 1), 'dim': (3, 3), 'rot': (6, 2), 'iou': (8, 1), 'hm': (9, 3)}
 
@@ -770,6 +771,11 @@ class CenterHead(_Cached):
                    g_cout=p['final']['g_cout'], g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
         return head, h, w
 
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """center_head.py:202-260 (host-side, like the reference's)."""
+        from .target_assign import assign_targets
+        return assign_targets(self, gt_boxes, feature_map_size)
+
     def decode_batched_nosync(self, head, h, w):
         """head (B,H*W,12) -> boxes (B,K,7), scores (B,K), labels (B,K) i32 (0-based), keep (B,K) i32, d_nk (B,) i32:
         top-K decode and rotated NMS of all frames in one launch sequence, counts stay on the device."""
@@ -813,6 +819,8 @@ class CenterHead(_Cached):
             head, h, w = self.run_convs(concat, concat.shape[0])
             pred = {n: head.view(head.shape[0], h, w, 12)[..., o:o + c].permute(0, 3, 1, 2)
                     for n, (o, c) in self.COLS.items()}
+            if data_dict.get('gt_boxes', None) is not None:              # center_head.py:448-453
+                self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=(h, w))
             self.forward_ret_dict['pred_dicts'] = [pred]
             data_dict['final_box_dicts'] = self.generate_predicted_boxes(head, h, w)
         return data_dict
