@@ -193,6 +193,35 @@ def set_math(model, mode):
     return model
 
 
+F16_PAIR_SAFE_MAX = 3.0e4      # |activation| up to which fp16 pairs are used (fp16 saturates at 65504; interior layers get 2x headroom)
+
+
+@torch.no_grad()
+def activation_range(model, dataset_info, frames):
+    """Largest |activation| per stage of the detector on sample frames, measured on the exact-fp32 engine: the outputs of the
+    five sparse stages and the concatenated 2-D feature map.  Leaves the model in 'f32' math."""
+    pipe = FramePipeline(model, dataset_info, math='f32')
+    frames = list(frames)
+    out = {}
+    res = pipe.backbone_stage(pipe.prepare(frames))
+    for name, (feats, lvl) in res.items():
+        out[name] = float(feats[:max(lvl.num_active(), 1)].abs().max().item())
+    x, lvl = res['encoded']
+    bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=0)
+    out['spatial_features_2d'] = float(model.backbone2d.run(bev, len(frames)).abs().max().item())
+    return out
+
+
+def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX):
+    """Pick the split-precision mode for a checkpoint from a calibration pass: fp16 pairs (22-bit significands) while every
+    stage stays below `limit`, else bf16 pairs (16 bits, the full fp32 exponent range) - fp16 pairs SATURATE at +-65504 + lo,
+    so a network whose activations reach 1e5 must not run on them.  Returns (mode, per-stage maxima) and sets the mode."""
+    rng = activation_range(model, dataset_info, frames)
+    mode = prefer if max(rng.values()) <= limit else 'bf16x2'
+    set_math(model, mode)
+    return mode, rng
+
+
 class _StackedFrames(list):
     """List view of a (B,N,C) tensor of equally long frames that remembers the backing tensor (no re-concatenation)."""
 

@@ -248,3 +248,51 @@ def test_full_size_batch_split_equals_f32_pipeline(device):
         nm, worst = match_boxes(a[:, :7], a[:, 7], b[:, :7], b[:, 7], tol=1e-3)
         assert a.shape[0] > 50 and abs(a.shape[0] - b.shape[0]) <= 2 and nm >= a.shape[0] - 2, (i, a.shape, b.shape, nm, worst)
     set_math(model, 'f32')
+
+
+# ------------------------------------------------------------------------------------------------ range safety of the fp16 pairs
+def _scaled_model(device, gain):
+    """Seed-0 detector whose first BatchNorm gain is multiplied by `gain`: every later layer is positively homogeneous up to
+    its shifts, so all activations scale by ~gain (real checkpoints are not normalised to O(1) like the random-init ones)."""
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
+    with torch.no_grad():
+        model.backbone3d.conv_input[1].weight.mul_(gain)
+        model.backbone3d.conv_input[1].bias.mul_(gain)
+    return model.to(device), info
+
+
+def _stage_features(model, info, pts, math):
+    from detzero_amd import ops
+    from detzero_amd.centerpoint import FramePipeline
+    pipe = FramePipeline(model, info, math=math)
+    res = pipe.backbone_stage(pipe.prepare([pts]))
+    mid = ops.math_id(math)
+    out = {}
+    for name, (feats, lvl) in res.items():
+        m = lvl.num_active()
+        out[name] = (ops.pair16_to_f32(feats[:m], mid) if mid else feats[:m]).clone()
+    return out
+
+
+@pytest.mark.parametrize('gain,expect', [(300.0, 'f16x2'), (3.0e4, 'bf16x2')])
+def test_math_mode_selection_by_activation_range(device, gain, expect):
+    """Activations of 1e3..1e4 stay on fp16 pairs and keep ~1e-6 relative accuracy; activations beyond the fp16 range make
+    select_math fall over to bf16 pairs, which still track the fp32 engine to 2e-3 relative - while fp16 pairs there are
+    demonstrably wrong (saturated), which is exactly what the selection prevents."""
+    from detzero_amd.centerpoint import activation_range, select_math
+    model, info = _scaled_model(device, gain)
+    pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
+    mode, rng = select_math(model, info, [pts])
+    assert mode == expect, (mode, rng)
+    peak = max(rng.values())
+    assert (1e3 < peak < 3e4) if expect == 'f16x2' else peak > 65504, rng
+    ref = _stage_features(model, info, pts, 'f32')
+    got = _stage_features(model, info, pts, mode)
+    for name in ref:
+        scale = float(ref[name].abs().max())
+        err = float((got[name] - ref[name]).abs().max()) / scale
+        assert err < (2e-5 if mode == 'f16x2' else 2e-3), (name, err, scale)
+    if expect == 'bf16x2':
+        bad = _stage_features(model, info, pts, 'f16x2')
+        worst = max(float((bad[n] - ref[n]).abs().max()) / float(ref[n].abs().max()) for n in ref)
+        assert worst > 1e-2, worst

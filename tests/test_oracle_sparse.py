@@ -102,3 +102,54 @@ def test_backbone_shapes_and_bev():
     j = 0
     b, z, y, xx = oc[j]
     assert torch.equal(bev[0, z::2, y, xx], x[j])
+
+
+def test_all_nine_rulebooks_of_the_backbone_against_a_dense_lookup():
+    """The nine rulebooks of VoxelResBackBone8x on the 20k-point / 0.2 m configuration (backbone3d.py:243-280: subm1, res1,
+    spconv2, res2, spconv3, res3, spconv4 with padding (0,1,1), res4, and the (3,1,1)/(2,1,1) conv_out), each derived a second,
+    independent way: a DENSE index map (cell -> row + 1) read at out * stride - pad + tap for every output and tap, and output
+    sets from a ones-kernel dense conv3d.  The oracle's searchsorted-based tables must agree entry for entry."""
+    from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_02, synth_waymo_frame
+    from oracle import voxelize as ov
+    pts = synth_waymo_frame(0, 20000)
+    pts = pts[ov.mask_points_by_range(pts, POINT_CLOUD_RANGE)]
+    _, czyx, _ = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000)
+    coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    shape = [41, 752, 752]
+    coords = coords[osp.canonical_order(coords, shape)]
+    K3, S1, P1, S2 = (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 2, 2)
+    plan = [('subm1', None), ('res1', None), ('spconv2', (K3, S2, (1, 1, 1))), ('res2', None), ('spconv3', (K3, S2, (1, 1, 1))), ('res3', None),
+            ('spconv4', (K3, S2, (0, 1, 1))), ('res4', None), ('spconv_down2', ((3, 1, 1), (2, 1, 1), (0, 0, 0)))]
+
+    def dense_table(cin, sin, cout, k, s, p):
+        idx = np.zeros(sin, np.int32)
+        idx[cin[:, 1], cin[:, 2], cin[:, 3]] = np.arange(1, cin.shape[0] + 1)
+        tab = np.full((k[0] * k[1] * k[2], cout.shape[0]), -1, np.int32)
+        for tz in range(k[0]):
+            for ty in range(k[1]):
+                for tx in range(k[2]):
+                    u = cout[:, 1:].astype(np.int64) * np.array(s) - np.array(p) + np.array([tz, ty, tx])
+                    ok = np.all((u >= 0) & (u < np.array(sin)), axis=1)
+                    v = np.zeros(cout.shape[0], np.int32)
+                    v[ok] = idx[u[ok, 0], u[ok, 1], u[ok, 2]]
+                    tab[(tz * k[1] + ty) * k[2] + tx] = v - 1
+        return tab
+    checked = 0
+    for name, geom in plan:
+        if geom is None:
+            k, s, p, oc, oshape = K3, S1, P1, coords, shape
+        else:
+            k, s, p = geom
+            oc, oshape = osp.conv_out_coords(coords, shape, k, s, p)
+            occ = torch.zeros((1, 1, *shape))
+            occ[0, 0, coords[:, 1], coords[:, 2], coords[:, 3]] = 1
+            touched = F.conv3d(occ, torch.ones(1, 1, *k), stride=s, padding=p)[0, 0] > 0
+            got = torch.zeros_like(touched)
+            got[oc[:, 1], oc[:, 2], oc[:, 3]] = True
+            assert torch.equal(got, touched), name                       # output set = cells whose window holds an input
+            assert list(touched.shape) == list(oshape)
+        tab = osp.neighbor_table(coords, shape, oc, k, s, p)
+        assert np.array_equal(tab, dense_table(coords, shape, oc, k, s, p)), name
+        checked += 1
+        coords, shape = oc, list(oshape)
+    assert checked == 9 and shape == [2, 94, 94]
