@@ -29,8 +29,6 @@ class CenterPoint(nn.Module):
         self.class_names = dataset.class_names
         self.register_buffer('global_step', torch.LongTensor(1).zero_())
         self.second_stage = model_cfg.SECOND_STAGE
-        if self.second_stage:
-            raise DetZeroHipError('PDV second stage (ROI_HEAD) is out of scope of the HIP backend (SURVEY.md §8f)')
         self.module_list = self.build_networks()
 
     def build_networks(self):
@@ -62,7 +60,17 @@ class CenterPoint(nn.Module):
         self.add_module('map_to_bev', map_to_bev)
         self.add_module('backbone2d', backbone2d)
         self.add_module('dense_head', dense_head)
-        return [vfe, backbone3d, map_to_bev, backbone2d, dense_head]
+        module_list = [vfe, backbone3d, map_to_bev, backbone2d, dense_head]
+        if self.second_stage:                                # centerpoint.py:115-127
+            from .pdv_modules import PDVHead
+            roi_heads = {'PDVHead': PDVHead}
+            roi_head = roi_heads[self.model_cfg.ROI_HEAD.NAME](
+                model_cfg=self.model_cfg.ROI_HEAD, input_channels=backbone2d.num_bev_features,
+                num_class=self.num_class if not self.model_cfg.ROI_HEAD.CLASS_AGNOSTIC else 1,
+                grid_size=info['grid_size'], voxel_size=info['voxel_size'], point_cloud_range=info['point_cloud_range'])
+            self.add_module('roi_head', roi_head)
+            module_list.append(roi_head)
+        return module_list
 
     @property
     def mode(self):
@@ -81,12 +89,28 @@ class CenterPoint(nn.Module):
     def post_processing(self, batch_dict):
         """centerpoint.py:283-307 (one-stage branch; with TTA the copies' boxes are restored and fused, :298-306)."""
         post_process_cfg = self.model_cfg.POST_PROCESSING
-        pred_dicts = batch_dict['final_box_dicts']
         recall_dict = {}
-        for index in range(batch_dict['batch_size']):
-            recall_dict = self.generate_recall_record(
-                box_preds=pred_dicts[index]['pred_boxes'], recall_dict=recall_dict, batch_index=0 if self.tta else index,
-                data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+        if self.second_stage:                                # centerpoint.py:214-281 (the single-class-NMS branch of the PDV configs)
+            if post_process_cfg.get('NMS_CONFIG', {}).get('MULTI_CLASSES_NMS', False):
+                raise DetZeroHipError('post_processing: MULTI_CLASSES_NMS is not used by the DetZero configs and not provided')
+            pred_dicts = []
+            for index in range(batch_dict['batch_size']):
+                box_preds = batch_dict['batch_box_preds'][index]
+                cls_preds = batch_dict['batch_cls_preds'][index]                 # the predicted IoU
+                label_preds = batch_dict['roi_labels'][index]
+                scores = torch.sqrt(torch.sigmoid(cls_preds).reshape(-1) * batch_dict['roi_scores'][index].reshape(-1))
+                mask = (label_preds != 0).reshape(-1)
+                final_boxes, final_scores, final_labels = box_preds[mask, :], scores[mask], label_preds[mask]
+                recall_dict = self.generate_recall_record(
+                    box_preds=final_boxes if 'rois' not in batch_dict else box_preds, recall_dict=recall_dict,
+                    batch_index=0 if self.tta else index, data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+                pred_dicts.append({'pred_boxes': final_boxes, 'pred_scores': final_scores, 'pred_labels': final_labels})
+        else:
+            pred_dicts = batch_dict['final_box_dicts']
+            for index in range(batch_dict['batch_size']):
+                recall_dict = self.generate_recall_record(
+                    box_preds=pred_dicts[index]['pred_boxes'], recall_dict=recall_dict, batch_index=0 if self.tta else index,
+                    data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
         if self.tta:
             boxes, scores, labels = self.test_time_augment(batch_dict, pred_dicts)
             pred_dicts = [{'pred_boxes': boxes, 'pred_scores': scores, 'pred_labels': labels}]

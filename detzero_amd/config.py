@@ -126,3 +126,29 @@ def centerpoint_3sweeps_cfg(voxel_size=(0.1, 0.1, 0.15)):
     cfg.DATA_CONFIG.DATA_PROCESSOR[2].NAME = 'transform_points_to_voxels_placeholder'
     cfg.MODEL.VFE.NAME = 'DynamicMeanVFE'
     return cfg
+
+
+def centerpoint_pdv_cfg(voxel_size=(0.1, 0.1, 0.15)):
+    """VALUES of det_model_cfgs/centerpoint_pdv_3sweeps.yaml read on the inference path: the 3-sweep detector with SECOND_STAGE and
+    the PDVHead RoI head (voxel-centroid aggregation on x_conv3 / x_conv4, 6x6x6 RoI grid pooling with density features, one
+    attention layer, FC heads)."""
+    cfg = centerpoint_3sweeps_cfg(voxel_size)
+    cfg.MODEL.SECOND_STAGE = True
+    cfg.MODEL.ROI_HEAD = {
+        'NAME': 'PDVHead', 'CLASS_AGNOSTIC': True, 'SHARED_FC': [256, 256], 'CLS_FC': [256, 256], 'REG_FC': [256, 256], 'DP_RATIO': 0.3,
+        'NMS_CONFIG': {'TRAIN': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 9000, 'NMS_POST_MAXSIZE': 512, 'NMS_THRESH': 0.8},
+                       'TEST': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 1024, 'NMS_POST_MAXSIZE': 512, 'NMS_THRESH': 0.7}},
+        'VOXEL_AGGREGATION': {'NUM_FEATURES': [64, 128], 'FEATURE_LOCATIONS': ['x_conv3', 'x_conv4']},
+        'ROI_GRID_POOL': {
+            'FEATURE_LOCATIONS': ['x_conv3', 'x_conv4'], 'GRID_SIZE': 6,
+            'POOL_LAYERS': {'x_conv3': {'MLPS': [[32, 32], [32, 32]], 'POOL_RADIUS': [0.8, 1.2], 'NSAMPLE': [16, 16], 'POOL_METHOD': 'max_pool', 'USE_DENSITY': True},
+                            'x_conv4': {'MLPS': [[64, 64], [64, 64]], 'POOL_RADIUS': [1.2, 2.4], 'NSAMPLE': [16, 16], 'POOL_METHOD': 'max_pool', 'USE_DENSITY': True}},
+            'ATTENTION': {'ENABLED': True, 'NUM_FEATURES': 192, 'NUM_HEADS': 1, 'NUM_HIDDEN_FEATURES': 128, 'NUM_LAYERS': 1,
+                          'POSITIONAL_ENCODER': 'density_grid_points', 'MAX_NUM_BOXES': 20, 'DROPOUT': 0.1, 'COMBINE': True, 'MASK_EMPTY_POINTS': True}},
+        'TARGET_CONFIG': {'BOX_CODER': 'ResidualCoder', 'ROI_PER_IMAGE': 128, 'FG_RATIO': 0.5, 'SAMPLE_ROI_BY_EACH_CLASS': True, 'CLS_SCORE_TYPE': 'roi_iou',
+                          'CLS_FG_THRESH': 0.75, 'CLS_BG_THRESH': 0.25, 'CLS_BG_THRESH_LO': 0.1, 'HARD_BG_RATIO': 0.8, 'REG_FG_THRESH': 0.55},
+        'LOSS_CONFIG': {'CLS_LOSS': 'BinaryCrossEntropy', 'REG_LOSS': 'smooth-l1', 'CORNER_LOSS_REGULARIZATION': True,
+                        'LOSS_WEIGHTS': {'rcnn_cls_weight': 1.0, 'rcnn_reg_weight': 1.0, 'rcnn_corner_weight': 1.0, 'code_weights': [1.0] * 7}},
+    }
+    cfg.MODEL.POST_PROCESSING.NMS_CONFIG = {'MULTI_CLASSES_NMS': False, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}
+    return cfg

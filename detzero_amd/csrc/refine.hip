@@ -89,10 +89,11 @@ int dz_add_layernorm(const float *x, const float *y, const float *gamma, const f
     const dim3 grid(ceil_div(rows, 4));
     switch (c) {
         case 64: hipLaunchKernelGGL(k_add_layernorm<1>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
+        case 192: hipLaunchKernelGGL(k_add_layernorm<3>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
         case 128: hipLaunchKernelGGL(k_add_layernorm<2>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
         case 256: hipLaunchKernelGGL(k_add_layernorm<4>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
         case 512: hipLaunchKernelGGL(k_add_layernorm<8>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
-        default: set_error("dz_add_layernorm: c=%d not in {64,128,256,512}", c); return DZ_ERR_UNSUPPORTED;
+        default: set_error("dz_add_layernorm: c=%d not in {64,128,192,256,512}", c); return DZ_ERR_UNSUPPORTED;
     }
     DZ_LAUNCH_CHECK();
     return DZ_OK;

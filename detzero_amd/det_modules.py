@@ -822,8 +822,28 @@ class CenterHead(_Cached):
             if data_dict.get('gt_boxes', None) is not None:              # center_head.py:448-453
                 self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=(h, w))
             self.forward_ret_dict['pred_dicts'] = [pred]
-            data_dict['final_box_dicts'] = self.generate_predicted_boxes(head, h, w)
+            pred_dicts = self.generate_predicted_boxes(head, h, w)
+            data_dict['final_box_dicts'] = pred_dicts
+            if self.predict_boxes_when_training:         # second stage (center_head.py:461-486): first-stage boxes become the RoIs
+                rois, roi_scores, roi_labels = self.reorder_rois(data_dict['batch_size'], pred_dicts)
+                data_dict.update({'rois': rois, 'roi_scores': roi_scores, 'roi_labels': roi_labels, 'has_class_labels': True})
         return data_dict
+
+    @staticmethod
+    def reorder_rois(batch_size, pred_dicts):
+        """center_head.py:388-406 without ``roi_features`` (bilinear BEV samples at five box points: no DetZero second stage reads
+        them - PDVHead pools from x_conv3 / x_conv4): (B, max boxes, 7) RoIs padded with zero rows, scores, 1-based labels."""
+        num_max_rois = max(1, max(len(d['pred_boxes']) for d in pred_dicts))
+        ref = pred_dicts[0]['pred_boxes']
+        rois = ref.new_zeros((batch_size, num_max_rois, ref.shape[-1]))
+        roi_scores = ref.new_zeros((batch_size, num_max_rois))
+        roi_labels = ref.new_zeros((batch_size, num_max_rois)).long()
+        for b in range(batch_size):
+            n = len(pred_dicts[b]['pred_boxes'])
+            rois[b, :n] = pred_dicts[b]['pred_boxes']
+            roi_scores[b, :n] = pred_dicts[b]['pred_scores']
+            roi_labels[b, :n] = pred_dicts[b]['pred_labels']
+        return rois, roi_scores, roi_labels
 
 
 __all__ = {

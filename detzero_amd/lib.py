@@ -118,6 +118,16 @@ _SIGS = {
     'dz_boxes_overlap_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_boxes_iou_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dz_pdv_centroids_workspace_bytes': (c_size_t, [c_int] * 7),
+    'dz_pdv_voxel_centroids': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'dz_index_lookup': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_pdv_ball_query': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                  c_int, c_void_p, c_void_p, c_void_p]),
+    'dz_pdv_group_features': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_int, c_void_p]),
+    'dz_pdv_part_counts': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_attention_single_head': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'dz_points_in_boxes_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_points_in_boxes_v2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_crop_points_workspace_bytes': (c_size_t, [c_int] * 3),

@@ -1,0 +1,462 @@
+"""PDV second stage under the reference's module names, on the HIP kernels of csrc/pdv.hip.
+
+Mirror of /root/reference/detection/detzero_det/models/centerpoint_modules/pdv_head.py (``RoIHeadTemplate`` :17-267,
+``VoxelAggregationHead`` :269-575, ``PDVHead`` :594-637) with its helpers - ``voxel_aggregation_utils.py``, ``density_utils.py``,
+``attention_utils.py``, ``box_coder_utils.ResidualCoder``, ``pointnet2_stack.pointnet2_modules.StackSAModuleMSGAttention`` -
+for inference: same constructor arguments, ``batch_dict`` keys and ``state_dict()`` names / shapes (tests/test_pdv.py compares
+with the manifest recorded from the reference class), so ``centerpoint_pdv_*`` checkpoints load unchanged.
+
+Data flow of ``PDVHead.forward`` (eval):
+  points -> voxel centroids per feature location          dz_pdv_voxel_centroids  (bitmap + scan: no sort, (b,z,y,x) order)
+         -> rows of x_conv3 / x_conv4 under each centroid  dz_index_lookup         (the level's own bitmap: no dense hash table)
+  RoIs   -> 6x6x6 grid points                              (a few thousand floats: torch elementwise)
+         -> per location and radius: stacked ball query    dz_pdv_ball_query       (cell walk in index order instead of O(M x N))
+            grouping + KDE density + feature gather        dz_pdv_group_features
+            shared MLP, max over the samples               dz_linear_forward x2, dz_group_max
+  points x RoIs -> points per box part                     dz_pdv_part_counts
+  216 grid points per RoI -> one encoder layer              dz_linear_forward, dz_attention_single_head, dz_add_layernorm
+  -> shared FC / regression / confidence heads              dz_linear_forward
+  -> box decoding (ResidualCoder, a few flops per RoI)      torch elementwise
+Training paths (proposal target layer, losses) are out of scope, like everywhere in this backend.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import iou3d_nms_utils, ops
+from . import lib as L
+from .det_modules import _Cached
+from .lib import DetZeroHipError
+from .refine_modules import _mha_plan, _pad16, _run_stack, _stack_plan
+
+
+# ================================================================================================
+# parameter holders (names and shapes of the reference modules)
+# ================================================================================================
+class StackSAModuleMSGAttention(nn.Module):
+    """pointnet2_modules.py:31-158: per radius a grouper (no parameters) and a shared MLP of Conv2d 1x1 + BN + ReLU."""
+
+    def __init__(self, *, radii, nsamples, mlps, use_xyz=True, pool_method='max_pool', use_density=False):
+        super().__init__()
+        if pool_method != 'max_pool' or not use_xyz:
+            raise DetZeroHipError('StackSAModuleMSG: the HIP backend implements use_xyz + max_pool (the PDV configs)')
+        self.radii, self.nsamples, self.use_density = list(radii), list(nsamples), bool(use_density)
+        self.groupers = nn.ModuleList([nn.Module() for _ in radii])
+        self.mlps = nn.ModuleList()
+        for spec in mlps:
+            spec = list(spec)
+            spec[0] += 3 + (1 if use_density else 0)
+            layers = []
+            for k in range(len(spec) - 1):
+                layers += [nn.Conv2d(spec[k], spec[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(spec[k + 1]), nn.ReLU()]
+            self.mlps.append(nn.Sequential(*layers))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+
+class FeedForwardPositionalEncoding(nn.Module):
+    """attention_utils.py:112-133."""
+
+    def __init__(self, d_input, d_output):
+        super().__init__()
+        self.ffn = nn.Sequential(nn.Conv1d(d_input, d_output // 2, 1), nn.BatchNorm1d(d_output // 2), nn.ReLU(d_output // 2),
+                                 nn.Conv1d(d_output // 2, d_output, 1))
+
+
+class TransformerEncoder(nn.Module):
+    """attention_utils.py:7-52 (parameter holder: torch's own encoder modules give the reference's state-dict names)."""
+
+    def __init__(self, attention_cfg, pos_encoder=None):
+        super().__init__()
+        self.attention_cfg = attention_cfg
+        self.pos_encoder = pos_encoder
+        layer = nn.TransformerEncoderLayer(attention_cfg.NUM_FEATURES, attention_cfg.NUM_HEADS, attention_cfg.NUM_HIDDEN_FEATURES, attention_cfg.DROPOUT)
+        self.transformer_encoder = nn.TransformerEncoder(layer, attention_cfg.NUM_LAYERS, enable_nested_tensor=False)
+
+
+def get_positional_encoder(pool_cfg):
+    """attention_utils.py:136-154 (the feed-forward encoders; the frequency encoding has no parameters and is not used by any config)."""
+    att = pool_cfg.ATTENTION
+    d_in = {'grid_points': 3, 'density': 1, 'density_grid_points': 4}.get(att.POSITIONAL_ENCODER)
+    if d_in is None:
+        raise DetZeroHipError('PDV: POSITIONAL_ENCODER %r is not provided by the HIP backend' % att.POSITIONAL_ENCODER)
+    return FeedForwardPositionalEncoding(d_input=d_in, d_output=att.NUM_FEATURES)
+
+
+class ResidualCoder(object):
+    """box_coder_utils.py:5-80, decode only."""
+
+    def __init__(self, code_size=7, **kwargs):
+        self.code_size = code_size
+
+    @staticmethod
+    def decode_torch(box_encodings, anchors):
+        xa, ya, za, dxa, dya, dza, ra = torch.split(anchors[..., :7], 1, dim=-1)
+        xt, yt, zt, dxt, dyt, dzt, rt = torch.split(box_encodings[..., :7], 1, dim=-1)
+        diagonal = torch.sqrt(dxa ** 2 + dya ** 2)
+        return torch.cat([xt * diagonal + xa, yt * diagonal + ya, zt * dza + za, torch.exp(dxt) * dxa, torch.exp(dyt) * dya,
+                          torch.exp(dzt) * dza, rt + ra], dim=-1)
+
+
+def rotate_points_along_z(points, angle):
+    """common_utils.py:209-231 for (B, N, 3+) points and (B,) angles, written out instead of the batched matmul."""
+    cosa, sina = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    x, y = points[..., 0], points[..., 1]
+    out = points.clone()
+    out[..., 0] = x * cosa - y * sina
+    out[..., 1] = x * sina + y * cosa
+    return out
+
+
+# ================================================================================================
+# device wrappers
+# ================================================================================================
+def voxel_centroids(points_b, point_cloud_range, voxel_size, stride, batch_size, scaling=None):
+    """voxel_aggregation_utils.get_centroids_per_voxel_layer for one or two feature locations.
+    -> [(centroids (M, 1+C), coords (M, 4) int32 bzyx, counts (M,), grid dims (D, H, W)), ...] exact-sized (one host sync)."""
+    lib = L.load()
+    L.require_cuda(points_b)
+    n, cols = points_b.shape
+    c = cols - 1
+    vs = (torch.tensor(voxel_size).float() * stride).numpy()                               # float32, as the reference builds it
+    rng = np.asarray(point_cloud_range, dtype=np.float32)
+    grid = ((rng[3:6] - rng[0:3]) / vs).astype(np.int64)                                   # .long(): truncation
+    dev = points_b.device
+    cells = int(batch_size * grid[0] * grid[1] * grid[2])
+    cap1 = max(min(n, cells), 1)
+    two = scaling is not None
+    cen1 = torch.empty((cap1, cols), dtype=torch.float32, device=dev)
+    co1 = torch.empty((cap1, 4), dtype=torch.int32, device=dev)
+    cn1 = torch.empty((cap1,), dtype=torch.int32, device=dev)
+    dm = torch.zeros((2,), dtype=torch.int32, device=dev)
+    cen2 = torch.empty((cap1, cols), dtype=torch.float32, device=dev) if two else None
+    co2 = torch.empty((cap1, 4), dtype=torch.int32, device=dev) if two else None
+    cn2 = torch.empty((cap1,), dtype=torch.int32, device=dev) if two else None
+    sc = int(scaling) if two else 1
+    ws = torch.empty((lib.dz_pdv_centroids_workspace_bytes(n, batch_size, int(grid[0]), int(grid[1]), int(grid[2]), sc, cap1),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.dz_pdv_voxel_centroids(L.ptr(points_b), n, c, L.f6(rng), L.f3(vs), L.i3(grid), batch_size, sc, L.ptr(cen1), L.ptr(co1), L.ptr(cn1),
+                                        L.ptr(dm[0:1]), cap1, L.ptr(cen2), L.ptr(co2), L.ptr(cn2), L.ptr(dm[1:2]) if two else None, cap1 if two else 0,
+                                        L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, 'dz_pdv_voxel_centroids')
+    m1, m2 = (int(v) for v in dm.tolist())
+    out = [(cen1[:m1], co1[:m1], cn1[:m1], (int(grid[2]), int(grid[1]), int(grid[0])), vs)]
+    if two:
+        d2 = tuple((int(g) + sc - 1) // sc for g in (grid[2], grid[1], grid[0]))
+        out.append((cen2[:m2], co2[:m2], cn2[:m2], d2, vs * np.float32(sc)))
+    return out
+
+
+def index_lookup(coords_bzyx, level):
+    """Row of every cell in the sparse level, -1 where the level has no such cell (voxel_aggregation_utils.py:59-78)."""
+    n = coords_bzyx.shape[0]
+    out = torch.empty((max(n, 1),), dtype=torch.int32, device=coords_bzyx.device)
+    with torch.cuda.device(coords_bzyx.device):
+        rc = L.load().dz_index_lookup(L.ptr(coords_bzyx), None, n, L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, *level.shape, L.ptr(out), L.stream())
+    L.check(rc, 'dz_index_lookup')
+    return out[:n]
+
+
+def ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample):
+    """-> idx (M, nsample) int32 (within-batch indices, padded with the first hit, zeros for an empty ball), cnt (M,) int32."""
+    mq = new_xyz.shape[0]
+    dev = new_xyz.device
+    idx = torch.empty((max(mq, 1), nsample), dtype=torch.int32, device=dev)
+    cnt = torch.empty((max(mq, 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.load().dz_pdv_ball_query(L.ptr(new_xyz), mq, per_batch, L.ptr(xyz), L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, *level.shape,
+                                        L.f3(lo), L.f3(vs), float(radius), nsample, L.ptr(idx), L.ptr(cnt), L.stream())
+    L.check(rc, 'dz_pdv_ball_query')
+    return idx[:mq], cnt[:mq]
+
+
+def group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, row_stride):
+    mq, nsample = idx.shape
+    rows = torch.empty((max(mq * nsample, 1), row_stride), dtype=torch.float32, device=new_xyz.device)
+    cells = level.shape[0] * level.shape[1] * level.shape[2]
+    with torch.cuda.device(new_xyz.device):
+        rc = L.load().dz_pdv_group_features(L.ptr(new_xyz), mq, per_batch, L.ptr(xyz), L.ptr(feats), feats.shape[1], L.ptr(level.bitmap), L.ptr(level.prefix),
+                                            cells, L.ptr(idx), L.ptr(cnt), nsample, L.ptr(rows), row_stride, L.stream())
+    L.check(rc, 'dz_pdv_group_features')
+    return rows[:mq * nsample]
+
+
+def part_counts(points_b, rois, grid_size, max_num_boxes):
+    """density_utils.find_num_points_per_part_multi -> (B, O, G, G, G) int32."""
+    b, o = rois.shape[0], rois.shape[1]
+    counts = torch.empty((b, o, grid_size, grid_size, grid_size), dtype=torch.int32, device=rois.device)
+    r7 = rois[..., :7].float().contiguous()
+    with torch.cuda.device(rois.device):
+        rc = L.load().dz_pdv_part_counts(L.ptr(points_b), points_b.shape[0], points_b.shape[1], L.ptr(r7), b, o, grid_size, max_num_boxes, L.ptr(counts), L.stream())
+    L.check(rc, 'dz_pdv_part_counts')
+    return counts
+
+
+def attention_single_head(q, k, v, key_padding_mask, scale):
+    r, l, e = q.shape
+    out = torch.empty_like(q)
+    m8 = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(q.device):
+        rc = L.load().dz_attention_single_head(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(m8), r, l, e, float(scale), L.ptr(out), L.stream())
+    L.check(rc, 'dz_attention_single_head')
+    return out
+
+
+def _seq_plan(seq, cin_pad=None):
+    return _stack_plan(nn.Sequential(*[m for m in seq if not isinstance(m, nn.Dropout)]), cin_pad=cin_pad)
+
+
+# ================================================================================================
+# the head
+# ================================================================================================
+class PDVHead(_Cached):
+    def __init__(self, input_channels, model_cfg, point_cloud_range, voxel_size, num_class=1, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.pool_cfg = model_cfg.ROI_GRID_POOL
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.voxel_size = [float(v) for v in voxel_size]
+        if model_cfg.TARGET_CONFIG.BOX_CODER != 'ResidualCoder':
+            raise DetZeroHipError('PDVHead: BOX_CODER %s is not provided' % model_cfg.TARGET_CONFIG.BOX_CODER)
+        self.box_coder = ResidualCoder(**model_cfg.TARGET_CONFIG.get('BOX_CODER_CONFIG', {}))
+        if model_cfg.get('DENSITY_CONFIDENCE', {}).get('ENABLED') or model_cfg.VOXEL_AGGREGATION.get('USE_EMPTY_VOXELS'):
+            raise DetZeroHipError('PDVHead: DENSITY_CONFIDENCE / USE_EMPTY_VOXELS are not used by any DetZero config and not provided')
+        att = self.pool_cfg.get('ATTENTION', {})
+        if not att.get('ENABLED'):
+            raise DetZeroHipError('PDVHead: the HIP backend implements the attention variant of the DetZero configs')
+        layer_cfg = self.pool_cfg.POOL_LAYERS
+        c_out = 0
+        self.roi_grid_pool_layers = nn.ModuleList()
+        for i, src in enumerate(self.pool_cfg.FEATURE_LOCATIONS):
+            mlps = [[model_cfg.VOXEL_AGGREGATION.NUM_FEATURES[i]] + list(m) for m in layer_cfg[src].MLPS]
+            self.roi_grid_pool_layers.append(StackSAModuleMSGAttention(
+                radii=layer_cfg[src].POOL_RADIUS, nsamples=layer_cfg[src].NSAMPLE, mlps=mlps, use_xyz=True,
+                pool_method=layer_cfg[src].POOL_METHOD, use_density=layer_cfg[src].get('USE_DENSITY')))
+            c_out += sum(m[-1] for m in mlps)
+        assert att.NUM_FEATURES == c_out, 'ATTENTION.NUM_FEATURES must equal voxel aggregation output dimension of %d.' % c_out
+        if att.NUM_HEADS != 1 or att.NUM_LAYERS != 1:
+            raise DetZeroHipError('PDVHead: one encoder layer with one head (the DetZero configs)')
+        self.attention_head = TransformerEncoder(att, get_positional_encoder(self.pool_cfg))
+        for p in self.attention_head.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        g = self.pool_cfg.GRID_SIZE
+        pre = g * g * g * c_out
+        shared = []
+        for k in range(len(model_cfg.SHARED_FC)):
+            shared += [nn.Conv1d(pre, model_cfg.SHARED_FC[k], kernel_size=1, bias=False), nn.BatchNorm1d(model_cfg.SHARED_FC[k]), nn.ReLU()]
+            pre = model_cfg.SHARED_FC[k]
+            if k != len(model_cfg.SHARED_FC) - 1 and model_cfg.DP_RATIO > 0:
+                shared.append(nn.Dropout(model_cfg.DP_RATIO))
+        self.shared_fc_layer = nn.Sequential(*shared)
+        self.reg_layers = self.make_fc_layers(pre, self.box_coder.code_size * self.num_class, model_cfg.REG_FC)
+        self.cls_layers = self.make_fc_layers(pre, self.num_class, model_cfg.CLS_FC)
+        self.c_out = c_out
+        self.forward_ret_dict = None
+
+    def make_fc_layers(self, input_channels, output_channels, fc_list):
+        """pdv_head.py:35-49."""
+        layers, pre = [], input_channels
+        for k in range(len(fc_list)):
+            layers += [nn.Conv1d(pre, fc_list[k], kernel_size=1, bias=False), nn.BatchNorm1d(fc_list[k]), nn.ReLU()]
+            pre = fc_list[k]
+            if self.model_cfg.DP_RATIO >= 0 and k == 0:
+                layers.append(nn.Dropout(self.model_cfg.DP_RATIO))
+        layers.append(nn.Conv1d(pre, output_channels, kernel_size=1, bias=True))
+        return nn.Sequential(*layers)
+
+    # ---- kernel-layout parameters
+    def plan(self):
+        if self._plan is not None:
+            return self._plan
+        g3 = self.pool_cfg.GRID_SIZE ** 3
+        p = {'pool': []}
+        for layer in self.roi_grid_pool_layers:
+            cin = layer.mlps[0][0].weight.shape[1]
+            p['pool'].append([{'stack': _seq_plan(m, cin_pad=_pad16(cin)), 'stride': _pad16(cin)} for m in layer.mlps])
+        enc = self.attention_head.transformer_encoder.layers[0]
+        p['pos'] = _seq_plan(self.attention_head.pos_encoder.ffn, cin_pad=16)
+        p['mha'] = _mha_plan(enc.self_attn)
+        p['enc'] = {'w1': enc.linear1.weight.detach().float().t().contiguous(), 'b1': enc.linear1.bias.detach().float().contiguous(),
+                    'w2': enc.linear2.weight.detach().float().t().contiguous(), 'b2': enc.linear2.bias.detach().float().contiguous(),
+                    'one1': torch.ones(enc.linear1.out_features, device=enc.linear1.weight.device),
+                    'one2': torch.ones(enc.linear2.out_features, device=enc.linear1.weight.device),
+                    'ln': [(n.weight.detach().float().contiguous(), n.bias.detach().float().contiguous(), n.eps) for n in (enc.norm1, enc.norm2)]}
+        if getattr(enc, 'norm_first', False):
+            raise DetZeroHipError('PDVHead: post-norm encoder layers only')
+        # shared FC: the reference flattens (RoI, C, 216) channel-major; the pooled rows here are (RoI, 216, C) -> permute the columns once
+        shared = [m for m in self.shared_fc_layer if not isinstance(m, nn.Dropout)]
+        w0 = shared[0].weight.detach()
+        first = nn.Conv1d(w0.shape[1], w0.shape[0], 1, bias=False)
+        first.weight.data = w0.view(w0.shape[0], self.c_out, g3).permute(0, 2, 1).reshape(w0.shape[0], g3 * self.c_out, 1).contiguous()
+        p['shared'] = _stack_plan(nn.Sequential(first.to(w0.device), *shared[1:]))
+        p['reg'] = _seq_plan(self.reg_layers)
+        p['cls'] = _seq_plan(self.cls_layers)
+        self._plan = p
+        return p
+
+    # ---- proposals (pdv_head.py:51-107)
+    @torch.no_grad()
+    def proposal_layer(self, batch_dict, nms_config):
+        if batch_dict.get('rois', None) is not None:
+            return batch_dict
+        batch_size = batch_dict['batch_size']
+        box_preds_all, cls_preds_all = batch_dict['batch_box_preds'], batch_dict['batch_cls_preds']
+        rois = box_preds_all.new_zeros((batch_size, nms_config.NMS_POST_MAXSIZE, box_preds_all.shape[-1]))
+        roi_scores = box_preds_all.new_zeros((batch_size, nms_config.NMS_POST_MAXSIZE))
+        roi_labels = box_preds_all.new_zeros((batch_size, nms_config.NMS_POST_MAXSIZE), dtype=torch.long)
+        if nms_config.MULTI_CLASSES_NMS:
+            raise NotImplementedError
+        for index in range(batch_size):
+            mask = (batch_dict['batch_index'] == index) if batch_dict.get('batch_index', None) is not None else index
+            box_preds, cls_preds = box_preds_all[mask], cls_preds_all[mask]
+            cur_scores, cur_labels = torch.max(cls_preds, dim=1)
+            selected, _ = iou3d_nms_utils.nms_gpu(box_preds[:, 0:7], cur_scores, nms_config.NMS_THRESH, pre_maxsize=nms_config.NMS_PRE_MAXSIZE)
+            selected = selected[:nms_config.NMS_POST_MAXSIZE]
+            rois[index, :len(selected)] = box_preds[selected]
+            roi_scores[index, :len(selected)] = cur_scores[selected]
+            roi_labels[index, :len(selected)] = cur_labels[selected]
+        batch_dict['rois'], batch_dict['roi_scores'], batch_dict['roi_labels'] = rois, roi_scores, roi_labels + 1
+        batch_dict['has_class_labels'] = cls_preds_all.shape[-1] > 1
+        batch_dict.pop('batch_index', None)
+        return batch_dict
+
+    # ---- voxel centroids and the feature rows under them (pdv_head.py:598-637)
+    def get_point_voxel_features(self, batch_dict):
+        locs = list(self.model_cfg.VOXEL_AGGREGATION.FEATURE_LOCATIONS)
+        if len(locs) > 2:
+            raise DetZeroHipError('PDVHead: one or two VOXEL_AGGREGATION.FEATURE_LOCATIONS')
+        strides = batch_dict['multi_scale_3d_strides']
+        points = batch_dict['points'].float().contiguous()
+        scaling = int(strides[locs[1]] / strides[locs[0]]) if len(locs) == 2 else None
+        levels = voxel_centroids(points, self.point_cloud_range, self.voxel_size, strides[locs[0]], batch_dict['batch_size'], scaling)
+        point_features, point_coords, self._point_index = {}, {}, {}
+        for loc, (cen, coords, _, dims, vs) in zip(locs, levels):
+            x_conv = batch_dict['multi_scale_3d_features'][loc]
+            level = getattr(x_conv, '_level', None)
+            if level is None:                                   # a tensor of another backend: index its coordinates first
+                level = ops.SparseLevel(x_conv.batch_size, x_conv.spatial_shape, max(x_conv.indices.shape[0], 1), points.device)
+                level.build_from_coords(x_conv.indices.int().contiguous(), want_rank=False)
+            rows = index_lookup(coords, level)
+            sel = torch.nonzero(rows >= 0).flatten()
+            point_coords[loc] = cen[sel][:, :4].contiguous()
+            point_features[loc] = x_conv.features[rows[sel].long()].contiguous()
+            self._point_index[loc] = (coords[sel].contiguous(), dims, vs)
+        return point_features, point_coords
+
+    # ---- RoI grid pooling (pdv_head.py:375-473)
+    @staticmethod
+    def get_dense_grid_points(rois, batch_size_rcnn, grid_size):
+        dense_idx = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().repeat(batch_size_rcnn, 1, 1).float()
+        size = rois.view(batch_size_rcnn, -1)[:, 3:6]
+        return (dense_idx + 0.5) / grid_size * size.unsqueeze(dim=1) - (size.unsqueeze(dim=1) / 2)
+
+    def get_global_grid_points_of_roi(self, batch_dict, grid_size):
+        rois = batch_dict['rois'].view(-1, batch_dict['rois'].shape[-1])
+        local = self.get_dense_grid_points(rois, rois.shape[0], grid_size)
+        glob = rotate_points_along_z(local.clone(), rois[:, 6]) + rois[:, 0:3].unsqueeze(dim=1)
+        return glob, local
+
+    def roi_grid_pool(self, batch_dict):
+        p = self.plan()
+        batch_size = batch_dict['batch_size']
+        g = self.pool_cfg.GRID_SIZE
+        glob, local = self.get_global_grid_points_of_roi(batch_dict, g)
+        new_xyz = glob.reshape(-1, 3).float().contiguous()
+        per_batch = new_xyz.shape[0] // batch_size
+        lo = np.asarray(self.point_cloud_range[:3], dtype=np.float32)
+        pooled, balls = [], []
+        for k, loc in enumerate(self.pool_cfg.FEATURE_LOCATIONS):
+            coords, dims, vs = self._point_index[loc]
+            xyz = batch_dict['point_coords'][loc][:, 1:4].contiguous()
+            feats = batch_dict['point_features'][loc].float().contiguous()
+            level = ops.SparseLevel(batch_size, dims, max(coords.shape[0], 1), new_xyz.device)
+            level.build_from_coords(coords, want_rank=False)      # rank of a centroid's cell = its row (rows are in cell-key order)
+            layer = self.roi_grid_pool_layers[k]
+            for s, (radius, nsample) in enumerate(zip(layer.radii, layer.nsamples)):
+                idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
+                rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
+                out, _ = _run_stack(rows, p['pool'][k][s]['stack'])
+                pooled.append(ops.group_max(out, new_xyz.shape[0], nsample))
+                balls.append(idx)
+        all_pooled = torch.cat(pooled, dim=-1).view(-1, g ** 3, self.c_out)
+        all_balls = torch.cat(balls, dim=-1).view(-1, g ** 3, sum(b.shape[1] for b in balls))
+        return all_pooled, glob.view(batch_size, -1, 3), local, all_balls
+
+    def get_positional_input(self, points, rois, local_roi_grid_points):
+        att = self.pool_cfg.ATTENTION
+        ppp = part_counts(points.float().contiguous(), rois, self.pool_cfg.GRID_SIZE, att.MAX_NUM_BOXES)
+        ppp = ppp.view(ppp.shape[0] * ppp.shape[1], -1, 1).float()
+        ppp = torch.log10(ppp + 0.5) - (math.log10(0.5) if self.model_cfg.get('DENSITY_LOG_SHIFT') else 0)
+        if att.POSITIONAL_ENCODER == 'grid_points':
+            return local_roi_grid_points
+        if att.POSITIONAL_ENCODER == 'density':
+            return ppp
+        return torch.cat((local_roi_grid_points, ppp), dim=-1)
+
+    # ---- the encoder layer (attention_utils.py:17-52 around nn.TransformerEncoderLayer, post-norm, ReLU)
+    def attention(self, point_features, positional_input, key_padding_mask):
+        p = self.plan()
+        r, l, e = point_features.shape
+        feats = point_features.reshape(r * l, e).contiguous()
+        pos_in = positional_input.reshape(r * l, -1).float()
+        pos_rows = pos_in.new_zeros((r * l, 16))
+        pos_rows[:, :pos_in.shape[1]] = pos_in
+        pos, _ = _run_stack(pos_rows, p['pos'])
+        empty = key_padding_mask.all(-1)                                   # RoIs without any point: left untouched (:31-44)
+        add_pos = (~key_padding_mask) & (~empty)[:, None]
+        src = torch.where(add_pos.reshape(r * l, 1), feats + pos, feats)
+        m = p['mha']
+        q = ops.linear(src, m['wq'], m['one'], m['bq'], False, e)
+        k = ops.linear(src, m['wk'], m['one'], m['bk'], False, e)
+        v = ops.linear(src, m['wv'], m['one'], m['bv'], False, e)
+        mask = key_padding_mask & (~empty)[:, None]                        # (an all-masked row would divide 0 by 0; its result is discarded)
+        o = attention_single_head(q.view(r, l, e), k.view(r, l, e), v.view(r, l, e), mask, float(e) ** -0.5)
+        o = ops.linear(o.view(r * l, e), m['wo'], m['one'], m['bo'], False, e)
+        enc = p['enc']
+        x = ops.add_layernorm(src, o, *enc['ln'][0])
+        h = ops.linear(x, enc['w1'], enc['one1'], enc['b1'], True, enc['w1'].shape[1])
+        y = ops.linear(h, enc['w2'], enc['one2'], enc['b2'], False, enc['w2'].shape[1])
+        y = ops.add_layernorm(x, y, *enc['ln'][1])
+        return torch.where(empty[:, None, None], point_features, y.view(r, l, e))
+
+    def generate_predicted_boxes(self, batch_size, rois, cls_preds, box_preds):
+        """pdv_head.py:238-266."""
+        code_size = self.box_coder.code_size
+        batch_cls_preds = None if cls_preds is None else cls_preds.view(batch_size, -1, cls_preds.shape[-1])
+        roi_ry = rois[:, :, 6].reshape(-1)
+        roi_xyz = rois[:, :, 0:3].reshape(-1, 3)
+        local_rois = rois.clone().detach()
+        local_rois[:, :, 0:3] = 0
+        boxes = self.box_coder.decode_torch(box_preds.view(batch_size, -1, code_size), local_rois).view(-1, code_size)
+        boxes = rotate_points_along_z(boxes.unsqueeze(dim=1), roi_ry).squeeze(dim=1)
+        boxes[:, 0:3] += roi_xyz
+        return batch_cls_preds, boxes.view(batch_size, -1, code_size)
+
+    @torch.no_grad()
+    def forward(self, batch_dict):
+        if self.training:
+            raise DetZeroHipError('PDVHead: only the inference path is implemented on the HIP backend (call .eval())')
+        p = self.plan()
+        batch_dict['point_features'], batch_dict['point_coords'] = self.get_point_voxel_features(batch_dict)
+        self.proposal_layer(batch_dict, nms_config=self.model_cfg.NMS_CONFIG['TEST'])
+        pooled, _, local, ball_idxs = self.roi_grid_pool(batch_dict)
+        mask = (ball_idxs == 0).all(-1) if self.pool_cfg.ATTENTION.get('MASK_EMPTY_POINTS') else torch.zeros(pooled.shape[:2], dtype=torch.bool, device=pooled.device)
+        pos_in = self.get_positional_input(batch_dict['points'], batch_dict['rois'], local)
+        att = self.attention(pooled, pos_in, mask)
+        if self.pool_cfg.ATTENTION.get('COMBINE'):
+            att = pooled + att
+        rows = att.reshape(att.shape[0], -1).contiguous()                   # (RoI, 216 * C): the shared FC's columns were permuted to match
+        shared, _ = _run_stack(rows, p['shared'])
+        rcnn_reg, _ = _run_stack(shared, p['reg'])
+        rcnn_cls, _ = _run_stack(shared, p['cls'])
+        cls_preds, box_preds = self.generate_predicted_boxes(batch_dict['batch_size'], batch_dict['rois'], rcnn_cls.contiguous(), rcnn_reg.contiguous())
+        batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = cls_preds, box_preds
+        batch_dict['cls_preds_normalized'] = False
+        self.forward_ret_dict = {'pooled_features': pooled, 'ball_idxs': ball_idxs, 'positional_input': pos_in, 'key_padding_mask': mask,
+                                 'attention_output': att, 'rcnn_cls': rcnn_cls, 'rcnn_reg': rcnn_reg}
+        return batch_dict

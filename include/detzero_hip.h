@@ -387,6 +387,44 @@ size_t dz_merge_sweeps_workspace_bytes(int n_total);
 int dz_merge_sweeps(const float *raw, int n_total, const int *h_sweep_offsets, const double *h_transforms, const double *h_time_offsets,
                     int n_sweeps, float *out, int *d_count, void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PDV second stage (detection/detzero_det/models/centerpoint_modules/pdv_head.py:269-637)
+ * ------------------------------------------------------------------------------------------------ */
+/* voxel_aggregation_utils.get_centroids_per_voxel_layer (:96-157): centroids of the points per voxel of the first feature
+ * location's grid (voxel size already multiplied by its stride; grid = trunc((hi - lo) / vsize) as float32, :29-36) and, weighted
+ * by the point counts, per voxel of a second location `scaling` times coarser.  points_b (n, 1+c) [b, x, y, z, f...];
+ * cen (cap, 1+c) [b, mean x, y, z, f...], coords (cap, 4) int32 [b, z, y, x], counts (cap,), *d_m = number of voxels; rows come
+ * in ascending (b, z, y, x) order (the order of torch.unique(dim=0) in the reference).  cen2 .. d_m2 may all be NULL. */
+size_t dz_pdv_centroids_workspace_bytes(int n, int batch, int gx, int gy, int gz, int scaling, int cap1);
+int dz_pdv_voxel_centroids(const float *points_b, int n, int c, const float *h_range6, const float *h_vsize3, const int *h_grid3,
+                           int batch, int scaling, float *cen1, int *coords1, int *counts1, int *d_m1, int cap1, float *cen2,
+                           int *coords2, int *counts2, int *d_m2, int cap2, void *ws, size_t ws_bytes, void *stream);
+/* voxel_aggregation_utils.get_nonempty_voxel_feature_indices (:59-78) without the dense hash table: out[i] = row of cell
+ * coords[i] = [b, z, y, x] in the sparse level (bitmap, prefix of dz_index_*), or -1. */
+int dz_index_lookup(const int *coords, const int *d_n, int n, const uint32_t *bitmap, const uint32_t *prefix, int b, int d, int h,
+                    int w, int *out, void *stream);
+/* pointnet2_stack ball_query_count (src/ball_query_count_gpu.cu:16-62 + pointnet2_utils.py:78-83,186-189) for points that are
+ * voxel centroids: at most one per cell of the (b, d, h, w) bitmap, listed in cell-key order (xyz (np, 3)).  Queries new_xyz
+ * (mq, 3), `per_batch` consecutive queries per batch item.  idx (mq, nsample) int32: the first nsample points with d^2 < r^2 in
+ * index order (relative to the batch item's first point), padded with the first hit, all 0 for an empty ball; cnt (mq,) hits. */
+int dz_pdv_ball_query(const float *new_xyz, int mq, int per_batch, const float *xyz, const uint32_t *bitmap, const uint32_t *prefix,
+                      int b, int d, int h, int w, const float *h_lo3, const float *h_vs3, float radius, int nsample, int *idx,
+                      int *cnt, void *stream);
+/* QueryAndGroup with use_xyz and use_density (pointnet2_utils.py:192-211, kde_utils.py:17-64, bandwidth 0.25): rows
+ * (mq * nsample, row_stride) = [offset xyz, KDE density, the point's c features, zeros]. */
+int dz_pdv_group_features(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, int c,
+                          const uint32_t *bitmap, const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt,
+                          int nsample, float *rows, int row_stride, void *stream);
+/* density_utils.find_num_points_per_part_multi (:52-109) on points_in_multi_boxes (roiaware_pool3d_kernel.cu:377-404): counts
+ * (batch, o, grid, grid, grid) int32 of the points (n, stride) [b, x, y, z, ...] per cell of every RoI (batch, o, 7), a point
+ * counting for the first max_boxes RoIs (in RoI order) that contain it. */
+int dz_pdv_part_counts(const float *points_b, int n, int stride, const float *rois, int batch, int o, int grid, int max_boxes,
+                       int *counts, void *stream);
+/* softmax(q k^T * scale + key padding mask) v for r independent sequences of l <= 256 tokens, one head of e <= 256 channels
+ * (nn.MultiheadAttention core of attention_utils.TransformerEncoder; q, k, v, out (r, l, e) f32; mask (r, l) bytes or NULL). */
+int dz_attention_single_head(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask, int r, int l,
+                             int e, float scale, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

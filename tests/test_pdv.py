@@ -1,0 +1,184 @@
+"""PDV second stage (pdv_head.py:269-637 and its helpers) against tests/golden/pdv_golden.npz, which
+gen_pdv_golden.py produced by running the reference's OWN Python classes on the CPU over the numpy kernels of oracle/pdv.py.
+
+CPU: state-dict manifest, the oracle kernels on hand-made cases, config plumbing.  GPU: every stage of PDVHead.forward -
+centroids and the feature rows under them, ball query (exact indices), per-part counts, pooled features, the encoder layer,
+final boxes / confidences - and a CenterPoint model with SECOND_STAGE end to end.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from detzero_amd.synth import synth_state_dict
+from oracle import pdv as opdv
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import gen_pdv_golden as gen          # noqa: E402  (configuration + scene; importing it does not touch the reference)
+
+
+@pytest.fixture(scope='module')
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, 'pdv_golden.npz'))
+
+
+def _head():
+    from detzero_amd.pdv_modules import PDVHead
+    head = PDVHead(512, gen.roi_head_cfg(), gen.RANGE, gen.VOXEL, num_class=1).eval()
+    head.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in head.state_dict().items()}, seed=gen.WEIGHT_SEED), strict=True)
+    return head
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_state_dict_identical_to_reference_manifest(g):
+    head = _head()
+    ref = dict(zip(g['manifest_keys'].tolist(), g['manifest_shapes'].tolist()))
+    mine = {k: str(tuple(v.shape)) for k, v in head.state_dict().items()}
+    assert mine == ref and len(ref) == 109
+    assert 'attention_head.transformer_encoder.layers.0.self_attn.in_proj_weight' in ref and 'roi_grid_pool_layers.1.mlps.1.3.weight' in ref
+
+
+def test_oracle_kernels_on_small_cases():
+    xyz = np.array([[0, 0, 0], [0.5, 0, 0], [0.9, 0, 0], [5, 5, 5], [0.1, 0.1, 0], [0.2, 0, 0]], np.float32)
+    idx = opdv.ball_query_count(1.0, 3, xyz, np.array([4, 2]), np.array([[0, 0, 0], [9, 9, 9], [0, 0, 0]], np.float32), np.array([2, 1]))
+    assert idx.tolist() == [[0, 1, 2], [-1, -1, -1], [0, 1, -1]]             # first nsample in index order; per-batch indices; empty ball
+    feats = np.arange(12, dtype=np.float32).reshape(6, 2)
+    grp = opdv.group_points(feats, np.array([4, 2]), np.array([[0, 2], [1, 1], [1, 0]], np.int32), np.array([2, 1]))
+    assert grp.shape == (3, 2, 2) and grp[0, :, 1].tolist() == [4.0, 5.0] and grp[2, :, 0].tolist() == [10.0, 11.0]
+    boxes = np.array([[[0, 0, 0, 2, 2, 2, 0], [0.5, 0, 0, 2, 2, 2, 0.3], [0, 0, 0, 4, 4, 4, 0]]], np.float32)
+    pts = np.array([[[0.2, 0.1, 0.0], [1.8, 0, 0], [9, 9, 9]]], np.float32)
+    out = opdv.points_in_multi_boxes(pts, boxes, 2)
+    assert out[0].tolist() == [[0, 1], [2, -1], [-1, -1]]                      # the first max_num_boxes boxes in box order
+
+
+def test_second_stage_config_builds():
+    from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network
+    from detzero_amd.config import centerpoint_pdv_cfg
+    cfg = centerpoint_pdv_cfg()
+    model = build_network(cfg.MODEL, 3, SyntheticDatasetInfo(cfg, num_point_features=6))
+    assert type(model.roi_head).__name__ == 'PDVHead' and model.dense_head.predict_boxes_when_training
+    assert model.roi_head.shared_fc_layer[0].weight.shape == (256, 216 * 192, 1)
+    assert len([k for k in model.state_dict() if k.startswith('roi_head.')]) == 109
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+class _Sparse:
+    def __init__(self, indices, features, spatial_shape, batch_size):
+        self.indices, self.features, self.spatial_shape, self.batch_size = indices, features, list(spatial_shape), batch_size
+
+
+def _batch(g, device):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)        # noqa: E731
+    return {'batch_size': 2, 'points': t(g['points']), 'rois': t(g['rois']), 'roi_scores': t(g['roi_scores']), 'roi_labels': t(g['roi_labels']),
+            'has_class_labels': True, 'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8},
+            'multi_scale_3d_features': {'x_conv3': _Sparse(t(g['c3']), t(g['f3']), g['s3'], 2), 'x_conv4': _Sparse(t(g['c4']), t(g['f4']), g['s4'], 2)}}
+
+
+@pytest.mark.gpu
+def test_centroids_and_feature_rows(device, g):
+    """get_point_voxel_features: the centroid lists (order, count, coordinates) and the x_conv rows gathered under them.
+    Grid sizes follow the reference's float32 arithmetic (trunc((hi - lo) / (voxel * stride)))."""
+    head = _head().to(device)
+    bd = _batch(g, device)
+    pf, pc = head.get_point_voxel_features(bd)
+    for loc in ('x_conv3', 'x_conv4'):
+        ref = g['pc_' + loc]
+        assert tuple(pc[loc].shape) == ref.shape, (loc, pc[loc].shape, ref.shape)
+        np.testing.assert_array_equal(pc[loc][:, 0].cpu().numpy(), ref[:, 0])
+        np.testing.assert_allclose(pc[loc].cpu().numpy(), ref, rtol=0, atol=2e-5)           # float atomics: summation order differs
+        np.testing.assert_array_equal(pf[loc][:64].cpu().numpy(), g['pf_%s_head' % loc])    # gathered rows: exact
+    from detzero_amd.pdv_modules import voxel_centroids
+    lv = voxel_centroids(bd['points'], gen.RANGE, gen.VOXEL, 4, 2, 2)
+    assert lv[0][3] == (10, 120, 120) and lv[1][3] == (5, 60, 60)          # 6 / fl(0.15 * 4) rounds to 10.0 in float32
+    assert int(lv[0][2].sum()) == int(lv[1][2].sum()) <= g['points'].shape[0]             # counts carry over to the coarser level
+    k1 = lv[0][1].cpu().numpy().astype(np.int64)
+    key = ((k1[:, 0] * 10 + k1[:, 1]) * 120 + k1[:, 2]) * 120 + k1[:, 3]
+    assert np.all(np.diff(key) > 0)                                                        # ascending (b, z, y, x): torch.unique(dim=0) order
+
+
+@pytest.mark.gpu
+def test_ball_query_equals_the_full_scan(device, g):
+    """The cell walk returns exactly the indices of the reference's scan over all points (ball_query_count_gpu.cu:16-62 restated in
+    oracle/pdv.py) for both locations and all radii, and the golden ball_idxs of the reference run."""
+    head = _head().to(device)
+    bd = _batch(g, device)
+    bd['point_features'], bd['point_coords'] = head.get_point_voxel_features(bd)
+    pooled, glob, local, balls = head.roi_grid_pool(bd)
+    np.testing.assert_array_equal(balls.cpu().numpy(), g['ball_idxs'].astype(np.int32))
+    np.testing.assert_allclose(local.cpu().numpy(), g['grid_local'], rtol=0, atol=1e-6)
+    new_xyz = glob.reshape(-1, 3).cpu().numpy()
+    col = 0
+    for loc, layer in zip(('x_conv3', 'x_conv4'), head.roi_grid_pool_layers):
+        pc = bd['point_coords'][loc].cpu().numpy()
+        cnt = np.array([(pc[:, 0] == b).sum() for b in range(2)])
+        for radius, ns in zip(layer.radii, layer.nsamples):
+            raw = opdv.ball_query_count(radius, ns, pc[:, 1:4], cnt, new_xyz, np.array([new_xyz.shape[0] // 2] * 2))
+            empty = raw[:, 0] == -1
+            ref = raw.copy()
+            ref[empty] = 0
+            fill = np.repeat(ref[:, :1], ns, axis=1)
+            ref = np.where(ref == -1, fill, ref)
+            np.testing.assert_array_equal(balls.reshape(-1, balls.shape[-1])[:, col:col + ns].cpu().numpy(), ref)
+            col += ns
+            assert 0.02 < empty.mean() < 0.9
+
+
+@pytest.mark.gpu
+def test_pooled_features_positional_input_and_attention(device, g):
+    head = _head().to(device)
+    bd = _batch(g, device)
+    head(bd)
+    r = head.forward_ret_dict
+    sub = g['roi_subset']
+    torch.testing.assert_close(r['pooled_features'][sub].cpu(), torch.from_numpy(g['pooled']), rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(r['key_padding_mask'].cpu().numpy(), g['key_padding_mask'])
+    pos = r['positional_input'].cpu().numpy()
+    np.testing.assert_allclose(pos[..., :3], g['positional_input'][..., :3], rtol=0, atol=1e-6)
+    # per-part point counts (log10(n + 0.5)): cos / sin differ in the last bit between host and device, a point on a cell face may move
+    diff = np.abs(pos[..., 3] - g['positional_input'][..., 3]) > 1e-5
+    assert diff.mean() < 2e-3, diff.mean()
+    att = r['attention_output'][sub].cpu()                                        # COMBINE: pooled + encoder output
+    torch.testing.assert_close(att, torch.from_numpy(g['pooled'] + g['attention']), rtol=2e-3, atol=2e-3)
+    assert torch.equal(r['attention_output'][27], 2 * r['pooled_features'][27]) or bool(g['key_padding_mask'][27].all())
+
+
+@pytest.mark.gpu
+def test_final_boxes_and_confidences(device, g):
+    head = _head().to(device)
+    out = head(_batch(g, device))
+    assert out['cls_preds_normalized'] is False and tuple(out['batch_box_preds'].shape) == (2, 14, 7)
+    torch.testing.assert_close(out['batch_box_preds'].cpu(), torch.from_numpy(g['batch_box_preds']), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out['batch_cls_preds'].cpu(), torch.from_numpy(g['batch_cls_preds']), rtol=1e-3, atol=1e-3)
+    head.train()
+    from detzero_amd.lib import DetZeroHipError
+    with pytest.raises(DetZeroHipError):
+        head(_batch(g, device))
+
+
+@pytest.mark.gpu
+def test_centerpoint_with_second_stage_end_to_end(device):
+    """centerpoint_pdv_3sweeps-shaped model (DynamicMeanVFE, 6 point features, SECOND_STAGE): dense head -> RoIs -> PDVHead ->
+    post_processing's second-stage branch.  Checks the plumbing (keys, shapes, score rule) on a two-frame batch."""
+    from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network
+    from detzero_amd.config import centerpoint_pdv_cfg
+    from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
+    cfg = centerpoint_pdv_cfg((0.2, 0.2, 0.15))
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, 3, SyntheticDatasetInfo(cfg, num_point_features=6)).eval()
+    with torch.no_grad():
+        hl = model.dense_head.heads_list[0]
+        hl.hm[1].bias.fill_(-0.5); hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4])); hl.iou[1].bias.fill_(0.6)
+    model = model.to(device)
+    frames = [merge_two_sweeps(synth_waymo_frame(60 + i, 10000), synth_waymo_frame(70 + i, 10000)) for i in range(2)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), i, np.float32), f], 1) for i, f in enumerate(frames)])
+    bd = {'batch_size': 2, 'points': torch.from_numpy(pts).to(device)}
+    with torch.no_grad():
+        pred_dicts, recall = model(bd)
+    assert len(pred_dicts) == 2 and 'rois' in bd and bd['rois'].shape[0] == 2 and bd['batch_box_preds'].shape == bd['rois'].shape
+    for b, d in enumerate(pred_dicts):
+        n = int((bd['roi_labels'][b] != 0).sum())
+        assert d['pred_boxes'].shape == (n, 7) and n > 0 and torch.isfinite(d['pred_boxes']).all()
+        exp = torch.sqrt(torch.sigmoid(bd['batch_cls_preds'][b].reshape(-1)) * bd['roi_scores'][b])[bd['roi_labels'][b] != 0]
+        assert torch.equal(d['pred_scores'], exp) and set(d['pred_labels'].cpu().tolist()) <= {1, 2, 3}
