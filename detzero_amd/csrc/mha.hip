@@ -125,6 +125,160 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block variant for long query lists (PRM: 200 queries x 9600 keys per head).  k_mha_core lets every wave stream the whole K / V
+// of its (batch, head) from L2 - 13 waves re-read the same 2.4 MB, and V arrives through scalar 4-byte loads.  Here a workgroup
+// (up to 8 waves) owns up to 256 queries of one (batch, head): key blocks of 64 are staged ONCE per workgroup in LDS (double buffered, one
+// barrier per block; V transposed on the way in so that the A operand of the P.V product is one 16-byte LDS read), and every wave
+// carries TWO 16-query column tiles, so each K / V fragment read from LDS feeds two MFMAs.  Same register-resident online softmax.
+// ------------------------------------------------------------------------------------------------
+constexpr int MB_KEYS = 64;                 // keys per staged block
+constexpr int MB_KSTR = HD + 4;             // row stride of the K tile (floats): 16-byte aligned rows, staggered banks
+constexpr int MB_VSTR = MB_KEYS + 4;        // row stride of the transposed V tile
+
+template <bool MASK>
+__global__ __launch_bounds__(512) void k_mha_block(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                   const uint8_t *__restrict__ kpm, int lq, int lk, int heads, float scale,
+                                                   float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float ks[2][MB_KEYS * MB_KSTR];
+    __shared__ __attribute__((aligned(16))) float vt[2][HD * MB_VSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int e_dim = heads * HD;
+    const int qbase = (blockIdx.x * (blockDim.x >> 6) + wid) * 32;      // up to 8 waves x 32 queries per workgroup
+    const bool stager = tid < 256;                                      // 64 keys x 4 pieces of 8 channels per block
+    float qreg[2][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = qbase + t * 16 + r;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < lq) x = *reinterpret_cast<const float4 *>(q + ((size_t)b * lq + qi) * e_dim + h * HD + sl * 16 + g * 4);
+            // scores are kept in units of log2(e): the softmax below runs on v_exp_f32 (2^x) directly
+            const float sc2 = scale * 1.44269504088896340736f;
+            qreg[t][sl][0] = x.x * sc2; qreg[t][sl][1] = x.y * sc2; qreg[t][sl][2] = x.z * sc2; qreg[t][sl][3] = x.w * sc2;
+        }
+    }
+    f32x4 o[2][2];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *kb = k + (size_t)b * lk * e_dim + h * HD;
+    const float *vb = v + (size_t)b * lk * e_dim + h * HD;
+    const uint8_t *mb = kpm ? kpm + (size_t)b * lk : nullptr;
+    // staging: thread -> (key = tid / 4 [+0], 8 consecutive channels (tid % 4) * 8) of the block: two float4 of K and two of V
+    const int skey = tid >> 2, sch = (tid & 3) * 8;
+    float4 kst[2], vst[2];
+    auto fetch = [&](int key0) {
+        const int key = key0 + skey;
+        if (!stager) return;
+        if (key < lk) {
+            const float *kp = kb + (size_t)key * e_dim + sch, *vp = vb + (size_t)key * e_dim + sch;
+            kst[0] = *reinterpret_cast<const float4 *>(kp); kst[1] = *reinterpret_cast<const float4 *>(kp + 4);
+            vst[0] = *reinterpret_cast<const float4 *>(vp); vst[1] = *reinterpret_cast<const float4 *>(vp + 4);
+        } else {
+            kst[0] = kst[1] = vst[0] = vst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+        if (!stager) return;
+        float *kd = ks[buf] + skey * MB_KSTR + sch;
+        *reinterpret_cast<float4 *>(kd) = kst[0]; *reinterpret_cast<float4 *>(kd + 4) = kst[1];
+        float *vd = vt[buf] + sch * MB_VSTR + skey;                    // transposed: [channel][key]
+        vd[0] = vst[0].x; vd[MB_VSTR] = vst[0].y; vd[2 * MB_VSTR] = vst[0].z; vd[3 * MB_VSTR] = vst[0].w;
+        vd[4 * MB_VSTR] = vst[1].x; vd[5 * MB_VSTR] = vst[1].y; vd[6 * MB_VSTR] = vst[1].z; vd[7 * MB_VSTR] = vst[1].w;
+    };
+    const int nblocks = (lk + MB_KEYS - 1) / MB_KEYS;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int cur = blk & 1, key0 = blk * MB_KEYS;
+        if (blk + 1 < nblocks) fetch(key0 + MB_KEYS);                  // lands under this block's MFMAs
+#pragma unroll
+        for (int kt = 0; kt < MB_KEYS / 16; ++kt) {
+            // ---- S^T tiles: A = K rows (key r of this 16-key tile), shared by the wave's two query tiles
+            f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const float4 kv = *reinterpret_cast<const float4 *>(ks[cur] + (kt * 16 + r) * MB_KSTR + sl * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qreg[t][sl][0], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qreg[t][sl][1], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qreg[t][sl][2], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qreg[t][sl][3], s[t], 0, 0, 0);
+                }
+            }
+            bool dead[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = key0 + kt * 16 + g * 4 + e;
+                dead[e] = key >= lk;
+                if (MASK) dead[e] = dead[e] | (mb[min(key, lk - 1)] != 0);
+            }
+            float p[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float sv[4], tmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sv[e] = dead[e] ? -INFINITY : s[t][e]; tmax = fmaxf(tmax, sv[e]); }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[t], tmax);
+                float alpha = 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[t][e] = 0.f;
+                if (m_new != -INFINITY) {
+                    alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[t][e] = __builtin_amdgcn_exp2f(sv[e] - m_new);
+                }
+                l_run[t] = l_run[t] * alpha + (p[t][0] + p[t][1] + p[t][2] + p[t][3]);
+                m_run[t] = m_new;
+                if (!__all(alpha == 1.f)) {              // the running maxima settle after a few tiles: no rescale then
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[t][dt][e] *= alpha;
+                }
+            }
+            // ---- O^T += V^T . P^T: A = V^T[d = dt*16 + r][keys 4g .. 4g+3 of the tile] = one 16-byte read of the transposed tile
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float4 vv = *reinterpret_cast<const float4 *>(vt[cur] + (dt * 16 + r) * MB_VSTR + kt * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p[t][0], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p[t][1], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p[t][2], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p[t][3], o[t][dt], 0, 0, 0);
+                }
+            }
+        }
+        if (blk + 1 < nblocks) stash(cur ^ 1);         // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = qbase + t * 16 + r;
+        if (qi < lq) {
+            const float inv = 1.f / l;                 // fully masked row -> NaN, as torch.softmax gives
+            float *dst = out + ((size_t)b * lq + qi) * e_dim + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *reinterpret_cast<float4 *>(dst + dt * 16 + g * 4) = make_float4(o[t][dt][0] * inv, o[t][dt][1] * inv, o[t][dt][2] * inv, o[t][dt][3] * inv);
+        }
+    }
+}
+
 }  // namespace dz
 
 using namespace dz;
@@ -137,6 +291,19 @@ int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *k
     DZ_CHECK_ARG(batch >= 0 && lq >= 0 && lk >= 1 && heads >= 1, "dz_mha_core: bad sizes");
     if (batch == 0 || lq == 0) return DZ_OK;
     DZ_CHECK_ARG(q && k && v && out, "dz_mha_core: null pointer");
+    if (lq > 32 && batch <= 65535 && heads <= 65535) {           // long query lists: K / V staged once per 128 queries
+        // a workgroup = up to 8 waves of 32 queries (PRM: 200 queries -> 7 waves, K / V staged once per (batch, head))
+        const int qw = (lq + 31) / 32, blocks = (qw + 7) / 8;
+        int nw = (qw + blocks - 1) / blocks;
+        if (nw < 4) nw = 4;                                        // the first 256 threads stage the key blocks
+        const dim3 grid(blocks, heads, batch);
+        if (key_padding_mask)
+            hipLaunchKernelGGL(k_mha_block<true>, grid, dim3(64 * nw), 0, stream, q, k, v, key_padding_mask, lq, lk, heads, scale, out);
+        else
+            hipLaunchKernelGGL(k_mha_block<false>, grid, dim3(64 * nw), 0, stream, q, k, v, key_padding_mask, lq, lk, heads, scale, out);
+        DZ_LAUNCH_CHECK();
+        return DZ_OK;
+    }
     const long items = (long)batch * heads * ((lq + 15) / 16);
     if (key_padding_mask)
         hipLaunchKernelGGL(k_mha_core<true>, dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, key_padding_mask,

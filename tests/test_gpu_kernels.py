@@ -406,7 +406,8 @@ def test_mha_core_matches_reference_golden(device, golden_dir):
     torch.testing.assert_close(o.transpose(0, 1), torch.from_numpy(g['out']), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('b,lq,lk,heads,masked', [(3, 3, 4096, 8, False), (2, 200, 9600, 8, True), (2, 200, 200, 8, True), (1, 17, 50, 8, True)])
+@pytest.mark.parametrize('b,lq,lk,heads,masked', [(3, 3, 4096, 8, False), (2, 200, 9600, 8, True), (2, 200, 200, 8, True), (1, 17, 50, 8, True),
+                                                   (2, 130, 333, 8, False), (1, 33, 64, 2, True)])
 def test_mha_core_vs_torch(device, b, lq, lk, heads, masked):
     from detzero_amd import ops
     gen = torch.Generator().manual_seed(lq * 7 + lk)
