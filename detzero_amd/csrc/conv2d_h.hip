@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
     __shared__ int in_pix[T::BP];    // input pixel index of the (0,0) tap, -1 past the end
     __shared__ int out_pix[T::BP];   // output pixel index
+    __shared__ __attribute__((aligned(16))) float sc_s[T::BC], sh_s[T::BC];     // scale / shift of my channel tile (pair16 epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wp = wid / T::WC, wc = wid % T::WC;
@@ -47,6 +48,13 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
         }
         in_pix[r] = ip;
         out_pix[r] = op;
+    }
+    if constexpr (!OUT_F32) {
+        for (int c = tid; c < T::BC; c += 256) {
+            const bool in = n0 + c < p.g_cout[grp];
+            sc_s[c] = (in && p.scale) ? p.scale[grp * p.cout_pad + n0 + c] : 1.f;
+            sh_s[c] = (in && p.shift) ? p.shift[grp * p.cout_pad + n0 + c] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -107,6 +115,16 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const int h = lane >> 5;
     const int gcout = p.g_cout[grp];
     const int ooff = p.out_coff + p.g_ooff[grp];
+    if constexpr (!OUT_F32) {
+        if (!p.group_shift) {          // (the per-row-group addend of the PointNet concat keeps the direct path below)
+            store_tile_pair16<T, M>(acc, smem_raw, sc_s, sh_s, n0, gcout, p.relu != 0, nullptr, reinterpret_cast<unsigned char *>(p.out), wp, wc,
+                                    lane, wid, [&](int lr) {
+                                        const int op = out_pix[lr];
+                                        return op >= 0 ? ((size_t)op * p.out_cstride + ooff) * 4 : ~size_t(0);
+                                    });
+            return;
+        }
+    }
 #pragma unroll
     for (int pt = 0; pt < T::PT; ++pt) {
         const int lr = wp * T::PT * 32 + pt * 32 + (lane & 31);

@@ -14,6 +14,8 @@
 //   the next chunk's input tile is prefetched into registers during the taps and swapped in at the chunk boundary.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "hgemm.h"
 
 namespace dz {
@@ -23,31 +25,42 @@ constexpr int C3_ROW_U4 = C3_KC / 4 + 1;                          // 144-byte LD
 constexpr int C3_PXW = C3_TW + 2, C3_PXH = C3_TH + 2;
 constexpr int C3_PX_ROWS = C3_PXW * C3_PXH;                       // 340 input pixels per tile
 constexpr int C3_PX_PIECES = C3_PX_ROWS * (C3_KC / 4);            // 2720 16-byte pieces
-constexpr int C3_THREADS = 512;
-constexpr int C3_PXPT = (C3_PX_PIECES + C3_THREADS - 1) / C3_THREADS;   // 6 pieces per thread (last partly idle)
 constexpr int C3_NS = 3;                                          // weight stages in flight (9 taps % 3 == 0)
 
-template <int BC>
+// NT threads: 512 = 4 (pairs of image rows) x 2 (halves of BC) waves, one workgroup per CU; 256 = 4 x 1 waves, TWO workgroups
+// per CU whose barrier phases and epilogues interleave on the matrix pipe
+template <int BC, int NT>
 struct C3Cfg {
-    static constexpr int CT = BC / 64;                            // 32-channel fragments per wave
+    static constexpr int WC = NT / 256;                           // channel halves
+    static constexpr int CT = BC / (32 * WC);                     // 32-channel fragments per wave
+    static constexpr int PXPT = (C3_PX_PIECES + NT - 1) / NT;     // input pieces per thread (last partly idle)
     static constexpr int W_PIECES = BC * (C3_KC / 4);
-    static constexpr int WPT = W_PIECES / C3_THREADS;             // weight pieces per thread per tap (2 or 1)
+    static constexpr int WPT = W_PIECES / NT;                     // weight pieces per thread per tap (2 or 1)
     static constexpr int W_U4 = BC * C3_ROW_U4;                   // one weight buffer
-    static constexpr int LDS_BYTES = (C3_PX_ROWS * C3_ROW_U4 + 2 * W_U4) * 16;
+    static constexpr int LDS_MAIN_BYTES = (C3_PX_ROWS * C3_ROW_U4 + 2 * W_U4) * 16;
+    // epilogue staging window of a wave: 32 pixels x SG 8-channel groups (32 bytes each) + 16 bytes of padding
+    static constexpr int SG = NT == 512 ? 4 : 2;
+    static constexpr int STG_ROW = SG * 32 + 16, STG_BYTES = 32 * STG_ROW;
+    static constexpr int LDS_STG_END = LDS_MAIN_BYTES + (NT / 64) * STG_BYTES;
+    static constexpr int LDS_BYTES = LDS_STG_END + 2 * BC * 4;                 // + BatchNorm scale / shift of the channel tile
     static_assert(BC == 64 || BC == 128, "BC is 64 or 128");
+    static_assert(CT == 1 || CT == 2, "one or two channel fragments per wave");
+    static_assert(W_PIECES % NT == 0, "weight slice must split evenly over the threads");
 };
 
-template <int BC, class M, bool OUT_F32>
-__global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
-                                                          unsigned int w_bytes) {
-    using C = C3Cfg<BC>;
-    constexpr int CT = C::CT, WPT = C::WPT;
+// DIAG (-DDZ_C3_DIAG builds only, timing experiments, results are garbage): bit 0 = no per-tap barriers, 1 = no weight LDS
+// stores, 2 = no fragment LDS reads, 3 = no global loads, 4 = no MFMAs, 5 = no epilogue
+template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
+                                                          unsigned int w_bytes, int skew_ticks) {
+    using C = C3Cfg<BC, NT>;
+    constexpr int CT = C::CT, WPT = C::WPT, C3_THREADS = NT, C3_PXPT = C::PXPT, WC = C::WC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const px_s = reinterpret_cast<v4u *>(smem_raw);                     // [340][ROW_U4]
     v4u *const w_s = px_s + C3_PX_ROWS * C3_ROW_U4;                          // [2][BC][ROW_U4]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wp = wid >> 1, wc = wid & 1;                                   // image-row pair, channel half
+    const int wp = wid / WC, wc = wid % WC;                                  // image-row pair, channel half
     // Persistent workgroups, XCD-aware: the dispatcher places workgroup b on XCD b % 8 (own L2 each); XCD k walks the k-th
     // contiguous eighth of the pixel tiles, its workgroups side by side (neighbouring tiles share halo rows in that L2).
     // A workgroup keeps ONE channel tile (its weight stream simply wraps around from tile to tile) and the load pipeline
@@ -61,6 +74,10 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     const int tstep = nj / nty;                                   // workgroups of this XCD that share my channel tile
     int tile = band_lo + jloc / nty;
     if (tstep == 0 || tile >= band_hi) return;
+    if (NT == 256 && skew_ticks > 0 && jloc >= nj / 2) {          // second workgroup of a CU: start out of phase with the first
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)skew_ticks) __builtin_amdgcn_s_sleep(32);
+    }
 
     const srsrc_t prsrc = make_srsrc(p.in, in_bytes);
     const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
@@ -70,24 +87,22 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
         oy = ((t / tiles_x) % tiles_y) * C3_TH;
         ob = t / (tiles_x * tiles_y);
     };
-    // input pieces of a tile: pixel (y0 + in_off + ry, x0 + in_off + rx) of the padded image, rx < 34, ry < 10
-    auto tile_offsets = [&](int t, unsigned int (&off)[C3_PXPT]) {
+    // input pieces of a tile: pixel (y0 + in_off + ry, x0 + in_off + rx) of the padded image, rx < 34, ry < 10.  Piece i of a
+    // thread is the same (ry, rx, 16-byte piece) in every tile, so nothing per piece is kept in registers: the byte offset
+    // inside the tile is rebuilt from the thread index at every issue (a handful of VALU ops next to 32-cycle MFMAs) and the
+    // tile's origin rides in the scalar offset of the load; pieces past the image edge get an out-of-range voffset (zeros).
+    struct TileGeo { unsigned int base; int rows, cols; };       // byte offset of the tile's first input pixel; rows / columns left in the image
+    auto tile_geo = [&](int t) {
         int ox, oy, ob;
         tile_origin(t, ox, oy, ob);
-#pragma unroll
-        for (int i = 0; i < C3_PXPT; ++i) {
-            const int idx = tid + i * C3_THREADS;
-            off[i] = OOB_OFFSET;
-            if (idx < C3_PX_PIECES) {
-                const int r = idx / (C3_KC / 4), q = idx % (C3_KC / 4);
-                const int iy = oy + p.in_off + r / C3_PXW, ix = ox + p.in_off + r % C3_PXW;
-                if (iy < p.in_hp && ix < p.in_wp)
-                    off[i] = (unsigned int)((((long)(ob * p.in_hp + iy) * p.in_wp + ix) * p.in_cstride + p.in_coff + q * 4) * 4);
-            }
-        }
+        TileGeo g;
+        g.base = (unsigned int)((((long)(ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off) * p.in_cstride + p.in_coff) * 4);
+        g.rows = p.in_hp - (oy + p.in_off);
+        g.cols = p.in_wp - (ox + p.in_off);
+        return g;
     };
-    unsigned int pvoff[C3_PXPT], pvoff_next[C3_PXPT];
-    tile_offsets(tile, pvoff);
+    TileGeo geo = tile_geo(tile), geo_next = geo;
+    const int prow = tid / (C3_KC / 4), pq = tid % (C3_KC / 4);
     bool has_next = tile + tstep < band_hi;
     unsigned int cvoff[WPT];
 #pragma unroll
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
         // chunk = kc * 9 + tap of the current tile; past its end the stream wraps to the next tile's chunks (same
         // weights), or - after the last tile - to out-of-range offsets (zeros come back, nothing is fetched; the
         // per-wave load counts stay uniform)
+        if constexpr (DIAG & 8) return;
         if (chunk >= nchunks) chunk = has_next ? chunk - nchunks : -1;
         const int kc = chunk / 9, tap = chunk - kc * 9;
         const unsigned int add = chunk >= 0 ? (unsigned int)tap * tap_bytes + (unsigned int)(kc * C3_KC * 4) : OOB_OFFSET;
@@ -114,10 +130,20 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     };
     auto issue_px = [&](int kc) {
         // input tile of channel chunk kc; kc == nk: chunk 0 of the next tile
+        if constexpr (DIAG & 8) return;
+        const bool cur = kc < nk;
+        const TileGeo g = cur ? geo : geo_next;
+        const unsigned int sbase = g.base + (cur ? (unsigned int)(kc * C3_KC * 4) : 0u);
+        const bool any = cur || has_next;
+        int pr = prow;
+        asm volatile("" : "+v"(pr));             // keeps the per-piece offsets from being hoisted into registers for the whole loop
 #pragma unroll
         for (int i = 0; i < C3_PXPT; ++i) {
-            const unsigned int off = kc < nk ? pvoff[i] + (unsigned int)(kc * C3_KC * 4) : (has_next ? pvoff_next[i] : OOB_OFFSET);
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc));
+            const int r = pr + i * (C3_THREADS / (C3_KC / 4));
+            const int ry = r / C3_PXW, rx = r - ry * C3_PXW;
+            const bool ok = any && r < C3_PX_ROWS && ry < g.rows && rx < g.cols;
+            const unsigned int off = ok ? (unsigned int)(((ry * p.in_wp + rx) * p.in_cstride + pq * 4) * 4) : OOB_OFFSET;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc), "s"(sbase));
         }
     };
     auto own_w = [&](v4u (&st)[WPT]) {
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
         for (int i = 0; i < WPT; ++i) asm volatile("" : "+v"(st[i]));
     };
     auto store_w = [&](const v4u (&st)[WPT], int buf) {
+        if constexpr (DIAG & 2) return;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int idx = tid + i * C3_THREADS;
@@ -154,6 +181,13 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     const int wbase = (wc * CT * 32 + (lane & 31)) * C3_ROW_U4 + kg2;
     struct Frag { v4u p_hi[2], p_lo[2], c_hi[CT], c_lo[CT]; };
     auto load_frag = [&](Frag &f, int tap, int buf, int q) {
+        if constexpr (DIAG & 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(f.p_hi[i]), "+v"(f.p_lo[i]));
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("" : "+v"(f.c_hi[i]), "+v"(f.c_lo[i]));
+            return;
+        }
         const int ky = tap / 3, kx = tap - ky * 3;
         const v4u *pp = px_s + pbase + (ky * C3_PXW + kx) * C3_ROW_U4 + q * 4;
 #pragma unroll
@@ -169,6 +203,13 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
         }
     };
     auto mma = [&](const Frag &f) {
+        if constexpr (DIAG & 16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(f.p_hi[i]), "v"(f.p_lo[i]));
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("" ::"v"(f.c_hi[i]), "v"(f.c_lo[i]));
+            return;
+        }
         // term-major: consecutive MFMAs go to different accumulators (measured 1.7 % faster than three in a row into the same
         // one); each accumulator still receives lo.hi, hi.lo, hi.hi in that order, so the result does not depend on it
 #pragma unroll
@@ -180,6 +221,14 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
                     acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
     };
 
+    // BatchNorm scale / shift of my channel tile: read in every tile's epilogue (from global memory each (fragment, group) of
+    // the epilogue paid a full load latency: the stores in between may alias, so the compiler cannot hoist the loads)
+    float *const sc_s = reinterpret_cast<float *>(smem_raw + C::LDS_STG_END), *const sh_s = sc_s + BC;
+    if (tid < BC) {
+        const bool in = n0 + tid < p.g_cout[0];
+        sc_s[tid] = (in && p.scale) ? p.scale[n0 + tid] : 1.f;
+        sh_s[tid] = (in && p.shift) ? p.shift[n0 + tid] : 0.f;
+    }
     // ---- prologue: input tile of chunk 0 and weight slice of (chunk 0, tap 0) into LDS; taps 1..3 in flight
     issue_px(0);
     issue_w(wst[0], 0);
@@ -196,7 +245,7 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
 
     int kcg = 0;                                                 // channel chunks done so far, over all tiles (LDS buffer parity)
     for (;;) {
-    if (has_next) tile_offsets(tile + tstep, pvoff_next);
+    if (has_next) geo_next = tile_geo(tile + tstep);
     for (int kc = 0; kc < nk; ++kc, ++kcg) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -207,8 +256,10 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
             // ---- phase 1: k-step-1 fragments, weights of chunk c+1 to the other LDS buffer, MFMAs of k-step 0
             load_frag(f1, t, buf, 1);
             // loads younger than chunk c+1's: chunks c+2, c+3, plus this chunk's input prefetch while it is the youngest
-            if (t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2 + C3_PXPT));
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2));
+            if constexpr (!(DIAG & 8)) {
+                if (t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2 + C3_PXPT));
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2));
+            }
             own_w(wst[(t + 1) % 3]);
             store_w(wst[(t + 1) % 3], buf ^ 1);
             mma(f0);
@@ -216,7 +267,7 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
             // per tap), so memory instructions issued in a block of their own would leave the matrix pipe idle
             interleave_hint<0x100, 2 * (2 + CT), 1>();
             interleave_hint<0x200, WPT, 1>();
-            __syncthreads();
+            if constexpr (!(DIAG & 1)) __syncthreads();
             if (t == 8) {
                 // channel-chunk boundary: every wave has finished reading the old input tile (its last reads were the
                 // k-step-1 fragments above, complete before the barrier); swap in the prefetched tile
@@ -234,9 +285,78 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     tile_origin(tile, x0, y0, b);
 
     // ---- epilogue: 32x32 accumulator: pixel column = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
+    if constexpr (DIAG & 32) {                                   // no epilogue: the accumulators only have to stay alive
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+        if (sacc == 12345.f) p.out[0] = sacc;
+    } else {
     const int h = lane >> 5;
     const int gcout = p.g_cout[0];
     const int ooff = p.out_coff + p.g_ooff[0];
+    if constexpr (!OUT_F32) {
+        // pair16 result: the accumulator layout gives a lane 4 of the 8 channels of a group for ONE pixel (8 bytes of hi, 8 of
+        // lo, 512 bytes away from its neighbour lane's) - stored directly that is 64 separate 8-byte requests per instruction
+        // (measured: 19 % of the kernel).  Each 32-pixel x 32-channel fragment goes through a wave-private LDS window instead and
+        // leaves as 128 contiguous bytes per pixel, 8 full lines per store instruction.
+        constexpr int SG = C::SG, STG_ROW = C::STG_ROW;                        // 8-channel groups per staging round
+        constexpr int LPR = 2 * SG, RPI = 64 / LPR;                            // lanes per pixel row, rows per store instruction
+        unsigned char *const stg = smem_raw + C::LDS_MAIN_BYTES + wid * C::STG_BYTES;
+        const int srow = lane / LPR, spiece = lane % LPR;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int y = y0 + 2 * wp + pt;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int j0 = 0; j0 < 4; j0 += SG) {
+                    const int cbase = n0 + wc * CT * 32 + ct * 32 + j0 * 8;
+#pragma unroll
+                    for (int jj = 0; jj < SG; ++jj) {
+                        const int j = j0 + jj;
+                        const int lc = wc * CT * 32 + ct * 32 + 8 * j + 4 * h;
+                        const float4 sc = *reinterpret_cast<const float4 *>(sc_s + lc), sh = *reinterpret_cast<const float4 *>(sh_s + lc);
+                        float v[4] = {fmaf(acc[ct][pt][4 * j], sc.x, sh.x), fmaf(acc[ct][pt][4 * j + 1], sc.y, sh.y),
+                                      fmaf(acc[ct][pt][4 * j + 2], sc.z, sh.z), fmaf(acc[ct][pt][4 * j + 3], sc.w, sh.w)};
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        uint2 hi, lo;
+                        split4<M>(v, hi, lo);
+                        unsigned char *w = stg + (lane & 31) * STG_ROW + jj * 32 + h * 8;
+                        *reinterpret_cast<uint2 *>(w) = hi;
+                        *reinterpret_cast<uint2 *>(w + 16) = lo;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int gcol = cbase + (spiece >> 1) * 8;                // the 8-channel group of my 16-byte piece
+#pragma unroll
+                    for (int i = 0; i < 32 / RPI; ++i) {
+                        const int r = srow + RPI * i, x = x0 + r;
+                        const v4u d = *reinterpret_cast<const v4u *>(stg + r * STG_ROW + spiece * 16);
+                        if constexpr (DIAG & 64) {                        // no global stores
+                            asm volatile("" ::"v"(d));
+                            continue;
+                        }
+                        if (y < p.ho && x < p.wo && gcol < gcout) {
+                            const size_t op = ((size_t)b * p.out_hp + (size_t)y * p.out_sy + p.out_dy) * p.out_wp + (size_t)x * p.out_sx + p.out_dx;
+                            unsigned char *g = reinterpret_cast<unsigned char *>(p.out) + (op * p.out_cstride + ooff + gcol) * 4 + (spiece & 1) * 16;
+                            *reinterpret_cast<v4u *>(g) = d;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int y = y0 + 2 * wp + pt, x = x0 + (lane & 31);
@@ -248,34 +368,23 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wc * CT * 32 + ct * 32 + 8 * j + 4 * h;
                 if (col >= gcout) continue;
-                float v[4];
+                float *o = p.out + op * p.out_cstride + ooff + col;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float sc = p.scale ? p.scale[col + e] : 1.f;
-                    const float sh = p.shift ? p.shift[col + e] : 0.f;
-                    v[e] = fmaf(acc[ct][pt][4 * j + e], sc, sh);
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (OUT_F32) {
-                    float *o = p.out + op * p.out_cstride + ooff + col;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < gcout) o[e] = v[e];
-                } else {
-                    uint2 hi, lo;
-                    split4<M>(v, hi, lo);
-                    unsigned char *g = reinterpret_cast<unsigned char *>(p.out) + (op * p.out_cstride + ooff + (col & ~7)) * 4 + (col & 7) * 2;
-                    *reinterpret_cast<uint2 *>(g) = hi;
-                    *reinterpret_cast<uint2 *>(g + 16) = lo;
+                    const int lc = col - n0 + e;
+                    float v = fmaf(acc[ct][pt][4 * j + e], sc_s[lc], sh_s[lc]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (col + e < gcout) o[e] = v;
                 }
             }
         }
     }
+    }
+    }
     // ---- next tile: its first input chunk is already in LDS, its first weight slices are in flight
     if (!has_next) break;
     tile += tstep;
-#pragma unroll
-    for (int i = 0; i < C3_PXPT; ++i) pvoff[i] = pvoff_next[i];
+    geo = geo_next;
     has_next = tile + tstep < band_hi;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
@@ -287,9 +396,9 @@ __global__ __launch_bounds__(C3_THREADS) void k_conv3x3_h(dz_conv2d_desc p, int 
     asm volatile("s_waitcnt vmcnt(0)");      // nothing of this file's asm loads may stay in flight at exit
 }
 
-template <int BC, class M, bool OUT_F32>
-static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
-    using C = C3Cfg<BC>;
+template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0>
+static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
+    using C = C3Cfg<BC, NT>;
     const int tiles_x = ceil_div(p.wo, C3_TW), tiles_y = ceil_div(p.ho, C3_TH);
     const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
     if (in_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) {
@@ -298,23 +407,49 @@ static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
             set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", C::LDS_BYTES);
             return DZ_ERR_HIP;
         }
         attr_set = true;
     }
-    // persistent: one 512-thread workgroup per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
+    // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
     const int nty = p.cout_pad / BC;
-    int per_xcd = 32 / nty * nty;
+    int per_xcd = 32 * (512 / NT) / nty * nty;
     if (per_xcd < nty) per_xcd = nty;
     const long grid = 8L * per_xcd;
-    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32>), dim3((unsigned int)grid), dim3(C3_THREADS), C::LDS_BYTES, stream, p, tiles_x,
-                       tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes);
+    static const int skew = getenv("DZ_TUNE_C3_SKEW") ? atoi(getenv("DZ_TUNE_C3_SKEW")) : 0;     // 10 ns ticks
+    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
+                       tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
+}
+
+template <int BC, class M, bool OUT_F32>
+static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
+    static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
+#ifdef DZ_C3_DIAG
+    if constexpr (BC == 128 && !OUT_F32 && std::is_same<M, MathF16>::value) {
+        static const int diag = getenv("DZ_TUNE_C3_DIAG") ? atoi(getenv("DZ_TUNE_C3_DIAG")) : 0;
+        switch (diag) {
+            case 32: return launch_c3_nt<BC, M, OUT_F32, 512, 32>(p, w_bytes, stream);
+            case 47: return launch_c3_nt<BC, M, OUT_F32, 512, 47>(p, w_bytes, stream);
+            case 64: return launch_c3_nt<BC, M, OUT_F32, 512, 64>(p, w_bytes, stream);
+            default: break;
+        }
+    }
+    if constexpr (BC == 64 && !OUT_F32 && std::is_same<M, MathF16>::value) {
+        static const int diag = getenv("DZ_TUNE_C3_DIAG") ? atoi(getenv("DZ_TUNE_C3_DIAG")) : 0;
+        if (nt == 256 && diag == 32) return launch_c3_nt<BC, M, OUT_F32, 256, 32>(p, w_bytes, stream);
+        if (nt == 256 && diag == 64) return launch_c3_nt<BC, M, OUT_F32, 256, 64>(p, w_bytes, stream);
+    }
+#endif
+    if constexpr (BC == 64) {
+        if (nt == 256) return launch_c3_nt<BC, M, OUT_F32, 256>(p, w_bytes, stream);
+    }
+    return launch_c3_nt<BC, M, OUT_F32, 512>(p, w_bytes, stream);
 }
 
 // 0 = not eligible, 64 / 128 = channel tile of the resident-tile kernel
@@ -323,7 +458,8 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
     if (off) return 0;
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.groups != 1 || p.group_shift) return 0;
     if (p.cin % C3_KC != 0 || p.cout_pad % 64 != 0) return 0;
-    const int bc = p.cout_pad % 128 == 0 ? 128 : 64;
+    static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
+    const int bc = (p.cout_pad % 128 == 0 && nt != 256) ? 128 : 64;
     // one 512-thread workgroup per CU: below ~1.5 waves of tiles the 4-wave kernels of conv2d_h.hip fill the chip better
     const long tiles = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, C3_TH) * (p.cout_pad / bc);
     if (tiles < 384) return 0;

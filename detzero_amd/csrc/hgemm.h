@@ -208,6 +208,93 @@ __device__ __forceinline__ void store_hstage(const HStage<T> &st, v4u *__restric
     }
 }
 
+// ---- epilogue of a pair16 result, staged through LDS ---------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane 4 of the 8 channels of a pair16 group for ONE row (row = lane & 31, channel =
+// 8*(reg>>2) + 4*(lane>>5) + (reg&3)): stored from there, every store instruction is 64 separate 8-byte requests 256-512 bytes
+// apart, the residual is read the same way, and each (fragment, group) step waits for its own scale / shift load because the
+// stores in between may alias (measured on the resident-tile 3x3 kernel: 19 % of the kernel).  Instead each 32-row x 32-channel
+// fragment is written as raw fp32 into a wave-private LDS window (32 rows x 144 bytes, in the tile buffers the main loop has
+// finished with), and read back with a lane per (row, 8-channel group): 32 contiguous bytes of fp32 in, scale / shift from LDS,
+// 32 contiguous bytes of residual in, 32 contiguous bytes of hi | lo out - four lanes cover a 128-byte line.
+// Caller contract: every wave of the workgroup is past the main loop's last barrier (no LDS fragment reads outstanding), and a
+// workgroup barrier separates this call from the next write into the tile buffers.
+constexpr int STG_ROW_BYTES = 144, STG_WAVE_BYTES = 32 * STG_ROW_BYTES;
+
+// row_off(lr): byte offset of row lr of the tile in the output (and residual) image, channel 0 of this launch's block;
+// ~size_t(0) when the row does not exist.  sc_s / sh_s: scale and shift of the workgroup's BC channels (LDS).
+template <class T, class M, class RowOff>
+__device__ __forceinline__ void store_tile_pair16(const f32x16 (&acc)[T::CT][T::PT], unsigned char *smem_bytes, const float *sc_s,
+                                                  const float *sh_s, int n0, int cout, bool relu, const unsigned char *residual,
+                                                  unsigned char *out, int wp, int wc, int lane, int wid, RowOff &&row_off) {
+    static_assert((T::THREADS / 64) * STG_WAVE_BYTES <= T::LDS_BYTES, "staging windows must fit in the tile buffers");
+    unsigned char *const stg = smem_bytes + wid * STG_WAVE_BYTES;
+    const int h = lane >> 5, g = lane & 3;
+#pragma unroll
+    for (int pt = 0; pt < T::PT; ++pt) {
+#pragma unroll
+        for (int ct = 0; ct < T::CT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = make_float4(acc[ct][pt][4 * j], acc[ct][pt][4 * j + 1], acc[ct][pt][4 * j + 2], acc[ct][pt][4 * j + 3]);
+                *reinterpret_cast<float4 *>(stg + (lane & 31) * STG_ROW_BYTES + j * 32 + h * 16) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int lc = wc * T::CT * 32 + ct * 32 + g * 8;                 // my 8-channel group inside the BC tile
+            const int col = n0 + lc;
+            const float4 sc0 = *reinterpret_cast<const float4 *>(sc_s + lc), sc1 = *reinterpret_cast<const float4 *>(sc_s + lc + 4);
+            const float4 sh0 = *reinterpret_cast<const float4 *>(sh_s + lc), sh1 = *reinterpret_cast<const float4 *>(sh_s + lc + 4);
+            size_t off[2];
+            float4 va[2], vb[2];
+            uint4 rh[2], rl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                     // all loads of both items before the first store
+                const int r = (lane >> 2) + 16 * i;
+                off[i] = row_off(wp * T::PT * 32 + pt * 32 + r);
+                if (col >= cout) off[i] = ~size_t(0);
+                va[i] = *reinterpret_cast<const float4 *>(stg + r * STG_ROW_BYTES + g * 32);
+                vb[i] = *reinterpret_cast<const float4 *>(stg + r * STG_ROW_BYTES + g * 32 + 16);
+                rh[i] = rl[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (residual && off[i] != ~size_t(0)) {
+                    const unsigned char *rp = residual + off[i] + (size_t)col * 4;
+                    rh[i] = *reinterpret_cast<const uint4 *>(rp);
+                    rl[i] = *reinterpret_cast<const uint4 *>(rp + 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[8] = {fmaf(va[i].x, sc0.x, sh0.x), fmaf(va[i].y, sc0.y, sh0.y), fmaf(va[i].z, sc0.z, sh0.z), fmaf(va[i].w, sc0.w, sh0.w),
+                              fmaf(vb[i].x, sc1.x, sh1.x), fmaf(vb[i].y, sc1.y, sh1.y), fmaf(vb[i].z, sc1.z, sh1.z), fmaf(vb[i].w, sc1.w, sh1.w)};
+                if (residual) {
+                    const unsigned int hw[4] = {rh[i].x, rh[i].y, rh[i].z, rh[i].w}, lw[4] = {rl[i].x, rl[i].y, rl[i].z, rl[i].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] += M::join(hw[k] & 0xFFFFu, lw[k] & 0xFFFFu);
+                        v[2 * k + 1] += M::join(hw[k] >> 16, lw[k] >> 16);
+                    }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                uint2 h0, l0, h1, l1;
+                split4<M>(v0, h0, l0);
+                split4<M>(v1, h1, l1);
+                if (off[i] != ~size_t(0)) {
+                    unsigned char *gp = out + off[i] + (size_t)col * 4;
+                    *reinterpret_cast<uint4 *>(gp) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    *reinterpret_cast<uint4 *>(gp + 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // Schedule of gemm_pipeline (igemm.h) with a DEEPER global-load pipeline: at 16-bit MFMA rates a chunk lasts only
 // a few hundred cycles per wave, less than an L2 / HBM round trip, so the loads run NS chunks ahead in NS
 // register stages (the loop is unrolled NS times so that every stage index is static):

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
     v4u *const smem = reinterpret_cast<v4u *>(smem_raw);
     int *const nbr_s = reinterpret_cast<int *>(smem + T::LDS_U4);       // [kvol][BP]   (GN = false only)
     __shared__ unsigned int mask_s;
+    __shared__ __attribute__((aligned(16))) float sc_s[T::BC], sh_s[T::BC];     // BatchNorm scale / shift of my channel tile
     constexpr int P = T::P_PER_THREAD;
     constexpr int NST = T::P_PER_THREAD + T::C_PER_THREAD;
 
@@ -47,6 +48,12 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
     }
     const unsigned int tap_bytes = (unsigned int)(a.cout_pad * a.cin * 4);
     const unsigned int nbr_tap_bytes = (unsigned int)a.cap * 4u;
+    for (int c = tid; c < T::BC; c += T::THREADS) {
+        const bool in = n0 + c < a.cout;
+        sc_s[c] = (in && a.scale) ? a.scale[n0 + c] : 1.f;
+        sh_s[c] = (in && a.shift) ? a.shift[n0 + c] : 0.f;
+    }
+    __syncthreads();
 
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (private L2 each).  Tiles are dealt to the XCDs
     // in runs of XRUN consecutive (spatially sorted) row tiles: a run shares its gathered neighbour rows in one L2,
@@ -154,7 +161,6 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
                     if constexpr (DIAG != 7) fetch_nbr(nb[S]);
                 };
                 hgemm_pipeline<T, M, NS, DIAG == 7 ? 0 : P, DIAG, (T::THREADS == 512)>(nchunks, smem, issue, advance, acc, wp, wc, lane, tid);
-                __syncthreads();          // the next tile's first stage overwrites LDS buffer 0
             } else {
                 auto issue = [&](HStage<T> &st, auto) {
                     unsigned int pvoff[P];
@@ -175,47 +181,13 @@ __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(OCC)
             }
         }
 
-        // accumulator of a 32x32 fragment: row = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
-        const int h = lane >> 5;
-#pragma unroll
-        for (int pt = 0; pt < T::PT; ++pt) {
-            const int row = row0 + wp * T::PT * 32 + pt * 32 + (lane & 31);
-            if (row >= m) continue;
-#pragma unroll
-            for (int ct = 0; ct < T::CT; ++ct) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = n0 + wc * T::CT * 32 + ct * 32 + 8 * j + 4 * h;
-                    if (col >= a.cout) continue;
-                    const size_t goff = ((size_t)row * a.cout + (col & ~7)) * 4 + (col & 7) * 2;     // byte offset of the hi slot
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float sc = a.scale ? a.scale[col + e] : 1.f;
-                        const float sh = a.shift ? a.shift[col + e] : 0.f;
-                        v[e] = fmaf(acc[ct][pt][4 * j + e], sc, sh);
-                    }
-                    if (a.residual) {
-                        const unsigned char *rp = reinterpret_cast<const unsigned char *>(a.residual) + goff;
-                        const uint2 rh = *reinterpret_cast<const uint2 *>(rp), rl = *reinterpret_cast<const uint2 *>(rp + 16);
-                        v[0] += M::join(rh.x & 0xFFFFu, rl.x & 0xFFFFu);
-                        v[1] += M::join(rh.x >> 16, rl.x >> 16);
-                        v[2] += M::join(rh.y & 0xFFFFu, rl.y & 0xFFFFu);
-                        v[3] += M::join(rh.y >> 16, rl.y >> 16);
-                    }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    uint2 hi, lo;
-                    split4<M>(v, hi, lo);
-                    unsigned char *g = reinterpret_cast<unsigned char *>(a.out) + goff;
-                    *reinterpret_cast<uint2 *>(g) = hi;
-                    *reinterpret_cast<uint2 *>(g + 16) = lo;
-                }
-            }
-        }
-        if constexpr (!GN) __syncthreads();  // nbr_s / mask_s are rewritten by the next tile
+        // epilogue through the (now idle) tile buffers: see store_tile_pair16
+        store_tile_pair16<T, M>(acc, smem_raw, sc_s, sh_s, n0, a.cout, a.relu != 0, reinterpret_cast<const unsigned char *>(a.residual),
+                                reinterpret_cast<unsigned char *>(a.out), wp, wc, lane, wid, [&](int lr) {
+                                    const int row = row0 + lr;
+                                    return row < m ? (size_t)row * a.cout * 4 : ~size_t(0);
+                                });
+        __syncthreads();      // the next tile's first stage (and, without the ring, its table slice) overwrites the buffers
     }
 }
 
