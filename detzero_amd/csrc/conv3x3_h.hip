@@ -20,41 +20,47 @@
 
 namespace dz {
 
-constexpr int C3_TW = 32, C3_TH = 8, C3_KC = 32;
+constexpr int C3_TW = 32, C3_KC = 32;
 constexpr int C3_ROW_U4 = C3_KC / 4 + 1;                          // 144-byte LDS rows (conflict-free ds_read_b128)
-constexpr int C3_PXW = C3_TW + 2, C3_PXH = C3_TH + 2;
-constexpr int C3_PX_ROWS = C3_PXW * C3_PXH;                       // 340 input pixels per tile
-constexpr int C3_PX_PIECES = C3_PX_ROWS * (C3_KC / 4);            // 2720 16-byte pieces
+constexpr int C3_PXW = C3_TW + 2;
 constexpr int C3_NS = 3;                                          // weight stages in flight (9 taps % 3 == 0)
 
 // NT threads: 512 = 4 (pairs of image rows) x 2 (halves of BC) waves, one workgroup per CU; 256 = 4 x 1 waves, TWO workgroups
 // per CU whose barrier phases and epilogues interleave on the matrix pipe
-template <int BC, int NT>
+// PT = image rows per wave: 2 at two waves per SIMD; 3 (with NT = 256 and all BC channels in every wave: 3 x 4 fragments, 12
+// accumulators) at ONE wave per SIMD with the whole register file - fewer LDS fragment reads and staged bytes per MFMA
+template <int BC, int NT, int PT_>
 struct C3Cfg {
-    static constexpr int WC = NT / 256;                           // channel halves
+    static constexpr int PT = PT_;
+    static constexpr int WC = PT == 2 ? NT / 256 : 1;             // channel splits over waves
+    static constexpr int WP = NT / 64 / WC;                       // row groups
+    static constexpr int TH = WP * PT;                            // tile height
     static constexpr int CT = BC / (32 * WC);                     // 32-channel fragments per wave
-    static constexpr int PXPT = (C3_PX_PIECES + NT - 1) / NT;     // input pieces per thread (last partly idle)
+    static constexpr int PXH = TH + 2, PX_ROWS = C3_PXW * PXH, PX_PIECES = PX_ROWS * (C3_KC / 4);
+    static constexpr int PXPT = (PX_PIECES + NT - 1) / NT;        // input pieces per thread (last partly idle)
     static constexpr int W_PIECES = BC * (C3_KC / 4);
     static constexpr int WPT = W_PIECES / NT;                     // weight pieces per thread per tap (2 or 1)
     static constexpr int W_U4 = BC * C3_ROW_U4;                   // one weight buffer
-    static constexpr int LDS_MAIN_BYTES = (C3_PX_ROWS * C3_ROW_U4 + 2 * W_U4) * 16;
+    static constexpr int LDS_MAIN_BYTES = (PX_ROWS * C3_ROW_U4 + 2 * W_U4) * 16;
     // epilogue staging window of a wave: 32 pixels x SG 8-channel groups (32 bytes each) + 16 bytes of padding
-    static constexpr int SG = NT == 512 ? 4 : 2;
+    static constexpr int SG = (NT == 512 && PT == 2) ? 4 : 2;
     static constexpr int STG_ROW = SG * 32 + 16, STG_BYTES = 32 * STG_ROW;
     static constexpr int LDS_STG_END = LDS_MAIN_BYTES + (NT / 64) * STG_BYTES;
     static constexpr int LDS_BYTES = LDS_STG_END + 2 * BC * 4;                 // + BatchNorm scale / shift of the channel tile
     static_assert(BC == 64 || BC == 128, "BC is 64 or 128");
-    static_assert(CT == 1 || CT == 2, "one or two channel fragments per wave");
+    static_assert(CT == 1 || CT == 2 || CT == 4, "1, 2 or 4 channel fragments per wave");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS of a CU");
     static_assert(W_PIECES % NT == 0, "weight slice must split evenly over the threads");
 };
 
 // DIAG (-DDZ_C3_DIAG builds only, timing experiments, results are garbage): bit 0 = no per-tap barriers, 1 = no weight LDS
 // stores, 2 = no fragment LDS reads, 3 = no global loads, 4 = no MFMAs, 5 = no epilogue
-template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
+template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0, int PT = 2>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 : 1, PT == 2 ? 2 : 1))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
                                                           unsigned int w_bytes, int skew_ticks) {
-    using C = C3Cfg<BC, NT>;
-    constexpr int CT = C::CT, WPT = C::WPT, C3_THREADS = NT, C3_PXPT = C::PXPT, WC = C::WC;
+    using C = C3Cfg<BC, NT, PT>;
+    constexpr int CT = C::CT, WPT = C::WPT, C3_THREADS = NT, C3_PXPT = C::PXPT, WC = C::WC, C3_TH = C::TH, C3_PX_ROWS = C::PX_ROWS,
+                  C3_PX_PIECES = C::PX_PIECES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v4u *const px_s = reinterpret_cast<v4u *>(smem_raw);                     // [340][ROW_U4]
     v4u *const w_s = px_s + C3_PX_ROWS * C3_ROW_U4;                          // [2][BC][ROW_U4]
@@ -143,7 +149,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int ry = r / C3_PXW, rx = r - ry * C3_PXW;
             const bool ok = any && r < C3_PX_ROWS && ry < g.rows && rx < g.cols;
             const unsigned int off = ok ? (unsigned int)(((ry * p.in_wp + rx) * p.in_cstride + pq * 4) * 4) : OOB_OFFSET;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc), "s"(sbase));
+            // one wave per SIMD (PT == 3): the prefetched tile waits in the accumulation registers the 12 accumulators leave free
+            if constexpr (PT == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc), "s"(sbase));
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(pst[i]) : "v"(off), "s"(prsrc), "s"(sbase));
         }
     };
     auto own_w = [&](v4u (&st)[WPT]) {
@@ -161,29 +169,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto store_px = [&]() {
 #pragma unroll
         for (int i = 0; i < C3_PXPT; ++i) {
-            asm volatile("" : "+v"(pst[i]));
+            if constexpr (PT == 2) asm volatile("" : "+v"(pst[i]));
+            else asm volatile("" : "+a"(pst[i]));
             const int idx = tid + i * C3_THREADS;
             if (idx < C3_PX_PIECES) px_s[(idx / (C3_KC / 4)) * C3_ROW_U4 + idx % (C3_KC / 4)] = pst[i];
         }
     };
 
-    f32x16 acc[CT][2];
+    f32x16 acc[CT][PT];
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment base addresses (16-byte units): pixel fragment pt = image row 2*wp + pt, column lane & 31
     const int kg2 = (lane >> 5) * 2;
-    const int pbase = ((2 * wp) * C3_PXW + (lane & 31)) * C3_ROW_U4 + kg2;
+    const int pbase = ((PT * wp) * C3_PXW + (lane & 31)) * C3_ROW_U4 + kg2;
     const int wbase = (wc * CT * 32 + (lane & 31)) * C3_ROW_U4 + kg2;
-    struct Frag { v4u p_hi[2], p_lo[2], c_hi[CT], c_lo[CT]; };
+    struct Frag { v4u p_hi[PT], p_lo[PT], c_hi[CT], c_lo[CT]; };
     auto load_frag = [&](Frag &f, int tap, int buf, int q) {
         if constexpr (DIAG & 4) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(f.p_hi[i]), "+v"(f.p_lo[i]));
+            for (int i = 0; i < PT; ++i) asm volatile("" : "+v"(f.p_hi[i]), "+v"(f.p_lo[i]));
 #pragma unroll
             for (int i = 0; i < CT; ++i) asm volatile("" : "+v"(f.c_hi[i]), "+v"(f.c_lo[i]));
             return;
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int ky = tap / 3, kx = tap - ky * 3;
         const v4u *pp = px_s + pbase + (ky * C3_PXW + kx) * C3_ROW_U4 + q * 4;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
             f.p_hi[pt] = pp[pt * C3_PXW * C3_ROW_U4];
             f.p_lo[pt] = pp[pt * C3_PXW * C3_ROW_U4 + 1];
         }
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto mma = [&](const Frag &f) {
         if constexpr (DIAG & 16) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(f.p_hi[i]), "v"(f.p_lo[i]));
+            for (int i = 0; i < PT; ++i) asm volatile("" ::"v"(f.p_hi[i]), "v"(f.p_lo[i]));
 #pragma unroll
             for (int i = 0; i < CT; ++i) asm volatile("" ::"v"(f.c_hi[i]), "v"(f.c_lo[i]));
             return;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
+                for (int pt = 0; pt < PT; ++pt)
                     acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
     };
 
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             mma(f0);
             // one LDS read / write behind each of the first MFMAs: the two waves of a SIMD run in lock step (one barrier
             // per tap), so memory instructions issued in a block of their own would leave the matrix pipe idle
-            interleave_hint<0x100, 2 * (2 + CT), 1>();
+            interleave_hint<0x100, 2 * (PT + CT), 1>();
             interleave_hint<0x200, WPT, 1>();
             if constexpr (!(DIAG & 1)) __syncthreads();
             if (t == 8) {
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             issue_w(wst[(t + 1) % 3], c + 4);
             if (t == 0) issue_px(kc + 1);
             mma(f1);
-            interleave_hint<0x100, 2 * (2 + CT), 1>();
+            interleave_hint<0x100, 2 * (PT + CT), 1>();
         }
     }
     tile_origin(tile, x0, y0, b);
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < PT; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
         if (sacc == 12345.f) p.out[0] = sacc;
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         unsigned char *const stg = smem_raw + C::LDS_MAIN_BYTES + wid * C::STG_BYTES;
         const int srow = lane / LPR, spiece = lane % LPR;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int y = y0 + 2 * wp + pt;
+        for (int pt = 0; pt < PT; ++pt) {
+            const int y = y0 + PT * wp + pt;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     } else {
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int y = y0 + 2 * wp + pt, x = x0 + (lane & 31);
+    for (int pt = 0; pt < PT; ++pt) {
+        const int y = y0 + PT * wp + pt, x = x0 + (lane & 31);
         if (y >= p.ho || x >= p.wo) continue;
         const size_t op = ((size_t)b * p.out_hp + (size_t)y * p.out_sy + p.out_dy) * p.out_wp + (size_t)x * p.out_sx + p.out_dx;
 #pragma unroll
@@ -389,17 +398,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)");      // nothing of this file's asm loads may stay in flight at exit
 }
 
-template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0>
+template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0, int PT = 2>
 static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
-    using C = C3Cfg<BC, NT>;
-    const int tiles_x = ceil_div(p.wo, C3_TW), tiles_y = ceil_div(p.ho, C3_TH);
+    using C = C3Cfg<BC, NT, PT>;
+    const int tiles_x = ceil_div(p.wo, C3_TW), tiles_y = ceil_div(p.ho, C::TH);
     const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
     if (in_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) {
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
@@ -407,7 +416,7 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
             set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", C::LDS_BYTES);
             return DZ_ERR_HIP;
@@ -417,38 +426,45 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
     const int nty = p.cout_pad / BC;
-    int per_xcd = 32 * (512 / NT) / nty * nty;
+    int per_xcd = 32 * (PT == 2 ? 512 / NT : 1) / nty * nty;
     if (per_xcd < nty) per_xcd = nty;
     const long grid = 8L * per_xcd;
     static const int skew = getenv("DZ_TUNE_C3_SKEW") ? atoi(getenv("DZ_TUNE_C3_SKEW")) : 0;     // 10 ns ticks
-    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
+    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
                        tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
+// Shipped configuration: 512 threads (4 row pairs x 2 channel halves), one workgroup per CU.  Built and measured on the MI355X, all
+// slower, kept behind -DDZ_C3_DIAG for the record: two 256-thread workgroups per CU (DZ_TUNE_C3_NT=256: their phases
+// do not de-synchronise, and a start skew changes nothing - the CU is throughput-bound), one wave per SIMD with 3 x 4 fragments
+// (DZ_TUNE_C3_PT=3: fewer LDS reads per MFMA, but every barrier and wait is exposed: 543 vs 471 us), and the diag switches.
 template <int BC, class M, bool OUT_F32>
 static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
-    static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
 #ifdef DZ_C3_DIAG
+    static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
     if constexpr (BC == 128 && !OUT_F32 && std::is_same<M, MathF16>::value) {
         static const int diag = getenv("DZ_TUNE_C3_DIAG") ? atoi(getenv("DZ_TUNE_C3_DIAG")) : 0;
         switch (diag) {
+            case 1: return launch_c3_nt<BC, M, OUT_F32, 512, 1>(p, w_bytes, stream);
+            case 2: return launch_c3_nt<BC, M, OUT_F32, 512, 2>(p, w_bytes, stream);
+            case 4: return launch_c3_nt<BC, M, OUT_F32, 512, 4>(p, w_bytes, stream);
+            case 8: return launch_c3_nt<BC, M, OUT_F32, 512, 8>(p, w_bytes, stream);
+            case 15: return launch_c3_nt<BC, M, OUT_F32, 512, 15>(p, w_bytes, stream);
+            case 16: return launch_c3_nt<BC, M, OUT_F32, 512, 16>(p, w_bytes, stream);
             case 32: return launch_c3_nt<BC, M, OUT_F32, 512, 32>(p, w_bytes, stream);
             case 47: return launch_c3_nt<BC, M, OUT_F32, 512, 47>(p, w_bytes, stream);
             case 64: return launch_c3_nt<BC, M, OUT_F32, 512, 64>(p, w_bytes, stream);
             default: break;
         }
+        static const int pt = getenv("DZ_TUNE_C3_PT") ? atoi(getenv("DZ_TUNE_C3_PT")) : 2;
+        if (pt == 3) return launch_c3_nt<BC, M, OUT_F32, 256, 0, 3>(p, w_bytes, stream);
     }
-    if constexpr (BC == 64 && !OUT_F32 && std::is_same<M, MathF16>::value) {
-        static const int diag = getenv("DZ_TUNE_C3_DIAG") ? atoi(getenv("DZ_TUNE_C3_DIAG")) : 0;
-        if (nt == 256 && diag == 32) return launch_c3_nt<BC, M, OUT_F32, 256, 32>(p, w_bytes, stream);
-        if (nt == 256 && diag == 64) return launch_c3_nt<BC, M, OUT_F32, 256, 64>(p, w_bytes, stream);
-    }
-#endif
     if constexpr (BC == 64) {
         if (nt == 256) return launch_c3_nt<BC, M, OUT_F32, 256>(p, w_bytes, stream);
     }
+#endif
     return launch_c3_nt<BC, M, OUT_F32, 512>(p, w_bytes, stream);
 }
 
@@ -458,10 +474,14 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
     if (off) return 0;
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.groups != 1 || p.group_shift) return 0;
     if (p.cin % C3_KC != 0 || p.cout_pad % 64 != 0) return 0;
+#ifdef DZ_C3_DIAG
     static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
+#else
+    constexpr int nt = 512;
+#endif
     const int bc = (p.cout_pad % 128 == 0 && nt != 256) ? 128 : 64;
     // one 512-thread workgroup per CU: below ~1.5 waves of tiles the 4-wave kernels of conv2d_h.hip fill the chip better
-    const long tiles = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, C3_TH) * (p.cout_pad / bc);
+    const long tiles = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, 8) * (p.cout_pad / bc);
     if (tiles < 384) return 0;
     return bc;
 }
