@@ -42,6 +42,10 @@ rm -rf $O/trace_refine; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stat
 python tools/rocpd_summary.py $O/trace_refine/refine_results.db > $O/${TAG}_kernel_trace_refine.txt; head -14 $O/${TAG}_kernel_trace_refine.txt
 rm -rf $O/pmc_refine; ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --kernel-trace -d $O/pmc_refine -o refine -- python $GRAFT_REPO_ROOT/tools/bench_refine.py --objects 256 --steps 2 > $O/pmc_refine_stdout.txt 2>&1 )
 python tools/rocpd_summary.py $O/pmc_refine/refine_results.db | sed -n '/PMC/,$p' > $O/${TAG}_pmc_SQ_refine.txt; grep -E "k_mha|k_linear" $O/${TAG}_pmc_SQ_refine.txt | head -12
+echo "==== matrix-pipe micro-benchmarks (built by: hipcc --offload-arch=gfx950 -O3 tools/micro/<name>.hip -o tools/micro/<name>)"
+for b in mfma_peak mfma_lds; do [ -x tools/micro/$b ] && ./tools/micro/$b > $O/${TAG}_micro_$b.txt 2>&1 && cat $O/${TAG}_micro_$b.txt; done
+echo "==== conv3x3 alone: operand data vs time (power)"
+for d in randn relu zero; do timeout 120 python tools/bench_conv3x3.py --data $d 2>&1 | tail -1; done | tee $O/${TAG}_conv3x3_data.txt
 echo "==== tta"
 timeout 300 python tools/bench_tta.py 2>/dev/null | tail -1 > $O/${TAG}_bench_tta.json; cut -c1-300 $O/${TAG}_bench_tta.json
 find $O -name "*.db" -delete
