@@ -298,7 +298,7 @@ int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, co
 const char *dz_conv2d_variant_split(const dz_conv2d_desc *d) {
     if (!d) return "none";
     const int bc = conv3x3_h_variant(*d);
-    if (bc) return bc == 128 ? "k_conv3x3_h<8x32x128>" : "k_conv3x3_h<8x32x64>";
+    if (bc) return bc == 128 ? "k_conv3x3_h<8x32x128>" : bc == 64 ? "k_conv3x3_h<8x32x64>" : "k_conv3x3_h<16x32x32>";
     return kConvHVariantName[conv2d_h_select(*d)];
 }
 

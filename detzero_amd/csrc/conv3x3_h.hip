@@ -29,17 +29,19 @@ constexpr int C3_NS = 3;                                          // weight stag
 // per CU whose barrier phases and epilogues interleave on the matrix pipe
 // PT = image rows per wave: 2 at two waves per SIMD; 3 (with NT = 256 and all BC channels in every wave: 3 x 4 fragments, 12
 // accumulators) at ONE wave per SIMD with the whole register file - fewer LDS fragment reads and staged bytes per MFMA
+// BC = 32 (WC = 1, 8 row pairs: 16 x 32-pixel tiles): grouped convolutions with few output channels per group - the head's output
+// layer (6 groups of 64 -> 1..3 channels): memory-bound, every group reads its 64-channel slice of the input exactly once
 template <int BC, int NT, int PT_>
 struct C3Cfg {
     static constexpr int PT = PT_;
-    static constexpr int WC = PT == 2 ? NT / 256 : 1;             // channel splits over waves
+    static constexpr int WC = (PT == 2 && BC >= 64) ? NT / 256 : 1;             // channel splits over waves
     static constexpr int WP = NT / 64 / WC;                       // row groups
     static constexpr int TH = WP * PT;                            // tile height
     static constexpr int CT = BC / (32 * WC);                     // 32-channel fragments per wave
     static constexpr int PXH = TH + 2, PX_ROWS = C3_PXW * PXH, PX_PIECES = PX_ROWS * (C3_KC / 4);
     static constexpr int PXPT = (PX_PIECES + NT - 1) / NT;        // input pieces per thread (last partly idle)
     static constexpr int W_PIECES = BC * (C3_KC / 4);
-    static constexpr int WPT = W_PIECES / NT;                     // weight pieces per thread per tap (2 or 1)
+    static constexpr int WPT = (W_PIECES + NT - 1) / NT;          // weight pieces per thread per tap (2 or 1; BC = 32: 1, half the threads idle)
     static constexpr int W_U4 = BC * C3_ROW_U4;                   // one weight buffer
     static constexpr int LDS_MAIN_BYTES = (PX_ROWS * C3_ROW_U4 + 2 * W_U4) * 16;
     // epilogue staging window of a wave: 32 pixels x SG 8-channel groups (32 bytes each) + 16 bytes of padding
@@ -47,10 +49,10 @@ struct C3Cfg {
     static constexpr int STG_ROW = SG * 32 + 16, STG_BYTES = 32 * STG_ROW;
     static constexpr int LDS_STG_END = LDS_MAIN_BYTES + (NT / 64) * STG_BYTES;
     static constexpr int LDS_BYTES = LDS_STG_END + 2 * BC * 4;                 // + BatchNorm scale / shift of the channel tile
-    static_assert(BC == 64 || BC == 128, "BC is 64 or 128");
+    static_assert(BC == 32 || BC == 64 || BC == 128, "BC is 32, 64 or 128");
     static_assert(CT == 1 || CT == 2 || CT == 4, "1, 2 or 4 channel fragments per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS of a CU");
-    static_assert(W_PIECES % NT == 0, "weight slice must split evenly over the threads");
+    static_assert(W_PIECES % NT == 0 || W_PIECES < NT, "weight slice must split evenly over the threads");
 };
 
 // DIAG (-DDZ_C3_DIAG builds only, timing experiments, results are garbage): bit 0 = no per-tap barriers, 1 = no weight LDS
@@ -71,10 +73,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // contiguous eighth of the pixel tiles, its workgroups side by side (neighbouring tiles share halo rows in that L2).
     // A workgroup keeps ONE channel tile (its weight stream simply wraps around from tile to tile) and the load pipeline
     // never drains between tiles: the next tile's input is prefetched during the last channel chunk of the current one.
-    const int nty = p.cout_pad / BC;
+    const int ntn = p.cout_pad / BC, nty = ntn * p.groups;       // channel tiles per group, in all
     const int npx = p.batch * tiles_x * tiles_y;                 // pixel tiles
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, nj = gridDim.x >> 3;      // gridDim.x is a multiple of 8
-    const int n0 = (jloc % nty) * BC;
+    const int grp = (jloc % nty) / ntn;
+    const int n0 = ((jloc % nty) % ntn) * BC;
     const int per_xcd = (npx + 7) >> 3;
     const int band_lo = xcd * per_xcd, band_hi = min(npx, band_lo + per_xcd);
     const int tstep = nj / nty;                                   // workgroups of this XCD that share my channel tile
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         int ox, oy, ob;
         tile_origin(t, ox, oy, ob);
         TileGeo g;
-        g.base = (unsigned int)((((long)(ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off) * p.in_cstride + p.in_coff) * 4);
+        g.base = (unsigned int)((((long)(ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off) * p.in_cstride + p.in_coff + grp * p.cin) * 4);
         g.rows = p.in_hp - (oy + p.in_off);
         g.cols = p.in_wp - (ox + p.in_off);
         return g;
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int idx = tid + i * C3_THREADS;
-        cvoff[i] = (unsigned int)(((n0 + idx / (C3_KC / 4)) * p.cin + (idx % (C3_KC / 4)) * 4) * 4);
+        cvoff[i] = idx < C::W_PIECES ? (unsigned int)((((long)grp * 9 * p.cout_pad + n0 + idx / (C3_KC / 4)) * p.cin + (idx % (C3_KC / 4)) * 4) * 4)
+                                     : OOB_OFFSET;
     }
     const unsigned int tap_bytes = (unsigned int)((long)p.cout_pad * p.cin * 4);
     const int nk = p.cin / C3_KC;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         const unsigned int add = chunk >= 0 ? (unsigned int)tap * tap_bytes + (unsigned int)(kc * C3_KC * 4) : OOB_OFFSET;
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[i]) : "v"(cvoff[i] + add), "s"(crsrc));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[i]) : "v"(cvoff[i] == OOB_OFFSET ? OOB_OFFSET : cvoff[i] + add), "s"(crsrc));
     };
     auto issue_px = [&](int kc) {
         // input tile of channel chunk kc; kc == nk: chunk 0 of the next tile
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int idx = tid + i * C3_THREADS;
-            w_s[buf * C::W_U4 + (idx / (C3_KC / 4)) * C3_ROW_U4 + idx % (C3_KC / 4)] = st[i];
+            if (C::W_PIECES % NT == 0 || idx < C::W_PIECES) w_s[buf * C::W_U4 + (idx / (C3_KC / 4)) * C3_ROW_U4 + idx % (C3_KC / 4)] = st[i];
         }
     };
     auto store_px = [&]() {
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // the epilogue paid a full load latency: the stores in between may alias, so the compiler cannot hoist the loads)
     float *const sc_s = reinterpret_cast<float *>(smem_raw + C::LDS_STG_END), *const sh_s = sc_s + BC;
     if (tid < BC) {
-        const bool in = n0 + tid < p.g_cout[0];
-        sc_s[tid] = (in && p.scale) ? p.scale[n0 + tid] : 1.f;
-        sh_s[tid] = (in && p.shift) ? p.shift[n0 + tid] : 0.f;
+        const bool in = n0 + tid < p.g_cout[grp];
+        sc_s[tid] = (in && p.scale) ? p.scale[grp * p.cout_pad + n0 + tid] : 1.f;
+        sh_s[tid] = (in && p.shift) ? p.shift[grp * p.cout_pad + n0 + tid] : 0.f;
     }
     // ---- prologue: input tile of chunk 0 and weight slice of (chunk 0, tap 0) into LDS; taps 1..3 in flight
     issue_px(0);
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         if (sacc == 12345.f) p.out[0] = sacc;
     } else {
     const int h = lane >> 5;
-    const int gcout = p.g_cout[0];
-    const int ooff = p.out_coff + p.g_ooff[0];
+    const int gcout = p.g_cout[grp];
+    const int ooff = p.out_coff + p.g_ooff[grp];
     if constexpr (!OUT_F32) {
         // pair16 result: the accumulator layout gives a lane 4 of the 8 channels of a group for ONE pixel (8 bytes of hi, 8 of
         // lo, 512 bytes away from its neighbour lane's) - stored directly that is 64 separate 8-byte requests per instruction
@@ -425,7 +429,7 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     }
     // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
-    const int nty = p.cout_pad / BC;
+    const int nty = p.cout_pad / BC * p.groups;
     int per_xcd = 32 * (PT == 2 ? 512 / NT : 1) / nty * nty;
     if (per_xcd < nty) per_xcd = nty;
     const long grid = 8L * per_xcd;
@@ -472,8 +476,13 @@ static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream
 int conv3x3_h_variant(const dz_conv2d_desc &p) {
     static const int off = getenv("DZ_TUNE_NO_CONV3X3") ? atoi(getenv("DZ_TUNE_NO_CONV3X3")) : 0;
     if (off) return 0;
-    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.groups != 1 || p.group_shift) return 0;
-    if (p.cin % C3_KC != 0 || p.cout_pad % 64 != 0) return 0;
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.group_shift) return 0;
+    if (p.cin % C3_KC != 0) return 0;
+    if (p.cout_pad == 32) {               // few output channels (per group): the 16 x 32-pixel tiles of the BC = 32 configuration
+        const long t32 = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, 16) * p.groups;
+        return t32 >= 384 ? 32 : 0;
+    }
+    if (p.groups != 1 || p.cout_pad % 64 != 0) return 0;
 #ifdef DZ_C3_DIAG
     static const int nt = getenv("DZ_TUNE_C3_NT") ? atoi(getenv("DZ_TUNE_C3_NT")) : 512;
 #else
@@ -488,6 +497,10 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
 
 int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_bytes, hipStream_t stream) {
     const int bc = conv3x3_h_variant(p);
+    if (bc == 32) {
+        if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<32, MathF16, true>(p, w_bytes, stream) : launch_c3<32, MathF16, false>(p, w_bytes, stream);
+        return out_f32 ? launch_c3<32, MathBF16, true>(p, w_bytes, stream) : launch_c3<32, MathBF16, false>(p, w_bytes, stream);
+    }
     if (bc == 128) {
         if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<128, MathF16, true>(p, w_bytes, stream) : launch_c3<128, MathF16, false>(p, w_bytes, stream);
         return out_f32 ? launch_c3<128, MathBF16, true>(p, w_bytes, stream) : launch_c3<128, MathBF16, false>(p, w_bytes, stream);
