@@ -20,6 +20,7 @@ Besides the headline the default single-GPU run measures, into the same JSON lin
   ref_batch  the headline arithmetic at the reference's BATCH_SIZE_PER_GPU = 8 (centerpoint_1sweep.yaml:88)
   ragged     frames of 150k-180k points: padded to the slot capacity with out-of-range rows (the stacked route), and as a
              ragged list (per-frame voxelizers on parallel streams)
+  multisweep BASELINE configs[4] shape: two merged sweeps per frame (320k points, 6 features), DynamicMeanVFE, 3-sweep model
   with_h2d   frames start in pinned host memory; the H2D copy of step i+1 runs on a copy stream under step i
   stages     voxelize / index pyramid / sparse backbone / dense / post-processing: time per step (each stage replayed as its
              own hipGraph, serially), algorithmic bytes and HBM GB/s as a fraction of the 8 TB/s peak
@@ -104,7 +105,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
-    ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, with_h2d, stages)')
+    ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
     return ap.parse_args()
@@ -118,13 +119,15 @@ class Case:
     lengths = (lo, hi), mode 'padded': frames of lo..hi points padded with out-of-range rows to slots of hi rows (same route).
     lengths = (lo, hi), mode 'list': slot j holds a frame of its own length L_j in lo..hi (ragged list route)."""
 
-    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0):
+    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1):
         from detzero_amd.centerpoint import FramePipeline, synth_detector
-        from detzero_amd.synth import VOXEL_SIZE_01, synth_waymo_frame
+        from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
         self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
-        self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0)
+        # sweeps = 2: BASELINE configs[4] shape - two sweeps merged into one 6-feature frame (time-offset column), the
+        # centerpoint_3sweeps model with DynamicMeanVFE
+        self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0, sweeps=3 if sweeps > 1 else 1)
         self.model = self.model.to(dev)
-        self.pipe = FramePipeline(self.model, self.info, math=math)
+        self.pipe = FramePipeline(self.model, self.info, dynamic=sweeps > 1, math=math)
         B = self.B
         self.n_distinct = n_distinct = max(4, B + 1)
         rng = np.random.default_rng(77 + rank)
@@ -138,13 +141,16 @@ class Case:
         else:
             ns = [int(v) for v in rng.integers(lengths[0], lengths[1] + 1, size=n_distinct)]
         self.host_frames = [synth_waymo_frame(seed_base + 1000 * rank + i, n) for i, n in enumerate(ns)]
+        if sweeps > 1:
+            self.host_frames = [merge_two_sweeps(f, synth_waymo_frame(seed_base + 1000 * rank + 300 + i, f.shape[0]))
+                                for i, f in enumerate(self.host_frames)]
         self.mean_points = float(np.mean([f.shape[0] for f in self.host_frames]))
         if mode == 'list':
             self.frames = [torch.from_numpy(f).to(dev) for f in self.host_frames]
             self.static_in = [self.frames[j].clone() for j in range(B)]
             sample = self.frames[:n_distinct]
         else:
-            cap = args.points if lengths is None else lengths[1]
+            cap = (args.points if lengths is None else lengths[1]) * (2 if sweeps > 1 else 1)
             padded = np.zeros((n_distinct, cap, self.host_frames[0].shape[1]), np.float32)
             padded[:, :, 0] = 1e6                                        # rows outside POINT_CLOUD_RANGE: dropped by the xy mask
             for i, f in enumerate(self.host_frames):
@@ -472,8 +478,8 @@ def main():
         log('with_h2d %.1f frames/s' % fps)
         del hpool, stage
 
-        def leg(name, math, batch, lengths=None, mode='stacked', note=''):
-            c = Case(args, dev, rank, math, batch, lengths, mode, seed_base=500)
+        def leg(name, math, batch, lengths=None, mode='stacked', note='', sweeps=1):
+            c = Case(args, dev, rank, math, batch, lengths, mode, seed_base=500, sweeps=sweeps)
             fps, ms, k = c.aux_leg(sec)
             rec = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(ms, 4), 'steps': k, 'frames_per_step': c.B,
                    'math': math, 'dtype': dtype_names[math], 'launch': c.graph_note, 'mean_points_per_frame': round(c.mean_points), 'note': note}
@@ -495,6 +501,10 @@ def main():
                      note='slot j holds frames of its own length in 150k-180k: per-frame fused voxelizers on parallel streams')
         del c
         out['ragged'] = {'padded': padded, 'list': lst}
+        c, out['multisweep'] = leg('multisweep', args.math, REF_BATCH, sweeps=2,
+                                   note='BASELINE configs[4] shape: two merged sweeps per frame (2 x %d points, 6 features incl. the time '
+                                        'offset), DynamicMeanVFE + centerpoint_3sweeps backbone and head' % args.points)
+        del c
         torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample

@@ -51,6 +51,9 @@ def test_committed_bench_line_has_the_auxiliary_legs():
     for k in ('padded', 'list'):
         leg = d['ragged'][k]
         assert leg['value'] > 0 and 150000 <= leg['mean_points_per_frame'] <= 180000
+    if 'multisweep' in d:                                                   # BASELINE configs[4] shape (later lines of round 2)
+        ms = d['multisweep']
+        assert ms['value'] > 0 and ms['mean_points_per_frame'] == 320000 and ms['frames_per_step'] == 8
     h = d['with_h2d']
     assert h['value'] > 0 and h['h2d_bytes_per_step'] == h['frames_per_step'] * 160000 * 5 * 4
     assert h['value'] <= d['value'] * 1.05                                  # the H2D-inclusive rate is never the headline
