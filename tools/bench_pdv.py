@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Two-stage detector (centerpoint_pdv_3sweeps shape: DynamicMeanVFE, 6 point features, PDVHead second stage) on one MI355X:
+time per frame through the plugin modules, split into first stage and second stage (HIP events), RoIs per second.
+Development / evidence tool - the headline metric is single-stage (bench.py).
+
+    python tools/bench_pdv.py [--points 160000] [--reps 10] [--math f32]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--points', type=int, default=160000, help='points per sweep (two sweeps are merged per frame)')
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--math', default='f32')
+    args = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
+    from detzero_amd.config import centerpoint_pdv_cfg
+    from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
+    cfg = centerpoint_pdv_cfg((0.1, 0.1, 0.15))
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, 3, SyntheticDatasetInfo(cfg, num_point_features=6)).eval()
+    with torch.no_grad():       # random heads give no peaks: bias the heat map / sizes so that the first stage proposes boxes
+        hl = model.dense_head.heads_list[0]
+        hl.hm[1].bias.fill_(-0.5)
+        hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4]))
+        hl.iou[1].bias.fill_(0.6)
+    model = model.to(dev)
+    set_math(model, args.math)
+    frame = merge_two_sweeps(synth_waymo_frame(60, args.points), synth_waymo_frame(70, args.points))
+    pts = np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)
+    points = torch.from_numpy(pts).to(dev)
+    first = [model.vfe, model.backbone3d, model.map_to_bev, model.backbone2d, model.dense_head]
+
+    def run(timed):
+        bd = {'batch_size': 1, 'points': points}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        with torch.no_grad():
+            ev[0].record()
+            for m in first:
+                bd = m(bd)
+            ev[1].record()
+            bd = model.roi_head(bd)
+            ev[2].record()
+        torch.cuda.synchronize()
+        return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[1])) if timed else None
+    for _ in range(3):
+        run(False)
+    t1 = t2 = 0.0
+    for _ in range(args.reps):
+        a, b, n_roi = run(True)
+        t1 += a / args.reps
+        t2 += b / args.reps
+    print(json.dumps({'metric': 'two-stage detector, ms per frame (plugin modules, eager, one frame)', 'math': args.math,
+                      'points_per_frame': int(frame.shape[0]), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
+                      'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
+                      'frames_per_s': round(1000.0 / (t1 + t2), 2), 'data': 'synthetic'}))
+
+
+if __name__ == '__main__':
+    main()

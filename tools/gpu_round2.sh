@@ -46,6 +46,10 @@ echo "==== matrix-pipe micro-benchmarks (built by: hipcc --offload-arch=gfx950 -
 for b in mfma_peak mfma_lds; do [ -x tools/micro/$b ] && ./tools/micro/$b > $O/${TAG}_micro_$b.txt 2>&1 && cat $O/${TAG}_micro_$b.txt; done
 echo "==== conv3x3 alone: operand data vs time (power)"
 for d in randn relu zero; do timeout 120 python tools/bench_conv3x3.py --data $d 2>&1 | tail -1; done | tee $O/${TAG}_conv3x3_data.txt
+echo "==== two-stage detector (PDV second stage)"
+timeout 300 python tools/bench_pdv.py 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv.json; cat $O/${TAG}_bench_pdv.json
+rm -rf $O/trace_pdv; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_pdv -o pdv -- python $GRAFT_REPO_ROOT/tools/bench_pdv.py --reps 5 > $O/trace_pdv_stdout.txt 2>&1 )
+python tools/rocpd_summary.py $O/trace_pdv/pdv_results.db > $O/${TAG}_kernel_trace_pdv.txt; head -12 $O/${TAG}_kernel_trace_pdv.txt
 echo "==== tta"
 timeout 300 python tools/bench_tta.py 2>/dev/null | tail -1 > $O/${TAG}_bench_tta.json; cut -c1-300 $O/${TAG}_bench_tta.json
 find $O -name "*.db" -delete
