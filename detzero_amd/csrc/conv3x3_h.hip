@@ -495,8 +495,16 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
     return bc;
 }
 
+#ifdef DZ_C3_DIAG
+bool conv3x3_d_eligible(const dz_conv2d_desc &p);      // conv3x3_d.hip: direct-to-LDS 2 x 4-fragment variant (measured equal, not shipped)
+int conv3x3_d_launch(const dz_conv2d_desc &p, int math, size_t w_bytes, hipStream_t stream);
+#endif
+
 int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_bytes, hipStream_t stream) {
     const int bc = conv3x3_h_variant(p);
+#ifdef DZ_C3_DIAG
+    if (bc == 128 && !out_f32 && conv3x3_d_eligible(p)) return conv3x3_d_launch(p, math, w_bytes, stream);
+#endif
     if (bc == 32) {
         if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<32, MathF16, true>(p, w_bytes, stream) : launch_c3<32, MathF16, false>(p, w_bytes, stream);
         return out_f32 ? launch_c3<32, MathBF16, true>(p, w_bytes, stream) : launch_c3<32, MathBF16, false>(p, w_bytes, stream);
