@@ -53,15 +53,24 @@ __global__ void k_hard_keys(const float *__restrict__ pts, int n, int c, VoxGeom
     }
 }
 
-// round r: every point later than the voxel's (r-1)-th pick competes for the r-th pick
-__global__ void k_hard_round(const uint32_t *__restrict__ keys, int n, const uint32_t *__restrict__ bitmap,
-                             const uint32_t *__restrict__ prefix, const int *__restrict__ prev_min,
-                             int *__restrict__ cur_min) {
+// "the first max_points points of a voxel, in point order" = the max_points smallest point indices of the voxel.  One pass: every
+// point offers its index to the voxel's slot 0 with atomicMin and carries the LARGER of (what was there, what it offered) on to
+// slot 1, and so on - an insertion network whose result does not depend on the interleaving: an atomicMin conserves the multiset
+// {slot, carried value}, every index is offered to slot 0, so slot 0 ends as the minimum and everything else has been offered to
+// slot 1, and by induction slot q holds the (q+1)-th smallest.  An empty slot (0x7f7f7f7f) ends a point's walk: typically one or
+// two atomics per point instead of the max_points full passes (rank lookup + atomicMin each) of the round-by-round version.
+__global__ void k_hard_insert(const uint32_t *__restrict__ keys, int n, const uint32_t *__restrict__ bitmap,
+                              const uint32_t *__restrict__ prefix, int *__restrict__ mins, int cap, int max_points) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t key = keys[i];
         if (key == KEY_INVALID) continue;
         const int v = bitmap_rank(bitmap, prefix, key);
-        if (prev_min == nullptr || i > prev_min[v]) atomicMin(&cur_min[v], i);
+        int val = i;
+        for (int q = 0; q < max_points; ++q) {
+            const int old = atomicMin(&mins[(size_t)q * cap + v], val);
+            if (old == 0x7f7f7f7f) break;
+            val = max(old, val);
+        }
     }
 }
 
@@ -354,9 +363,7 @@ static int voxelize_hard_impl(const float *points, int n, int c, const float *h_
     rc = bitmap_scan(w.bitmap, nwords, w.prefix, w.d_m, 0, ScanDims{g.g[2], g.g[1], g.g[0]}, w.canon_coords, cap,
                          w.scan_ws, w.scan_ws_bytes, stream);
     if (rc) return rc;
-    for (int r = 0; r < max_points; ++r)
-        hipLaunchKernelGGL(k_hard_round, dim3(grid_n), dim3(256), 0, stream, w.keys, n, w.bitmap, w.prefix,
-                           r == 0 ? (const int *)nullptr : w.mins + (size_t)(r - 1) * cap, w.mins + (size_t)r * cap);
+    hipLaunchKernelGGL(k_hard_insert, dim3(grid_n), dim3(256), 0, stream, w.keys, n, w.bitmap, w.prefix, w.mins, cap, max_points);
     hipLaunchKernelGGL(k_hard_mark_first, dim3(grid_n), dim3(256), 0, stream, w.mins, w.d_m, cap, w.pt_bitmap);
     // scan over the point-index bitmap: rank of a voxel's first point = first-appearance voxel id.
     // d_num_voxels is used as a scratch total here and overwritten by k_hard_emit.
@@ -466,9 +473,7 @@ int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c,
     rc = bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw, sw_bytes,
                      stream);
     if (rc) return rc;
-    for (int r = 0; r < max_points; ++r)
-        hipLaunchKernelGGL(k_hard_round, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix,
-                           r == 0 ? (const int *)nullptr : mins + (size_t)(r - 1) * cap, mins + (size_t)r * cap);
+    hipLaunchKernelGGL(k_hard_insert, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix, mins, cap, max_points);
     const dim3 ge(stream_grid((long)cap * (c_dst / 8), 256));
     if (math == 0)
         hipLaunchKernelGGL(k_level_emit_mean<0>, ge, dim3(256), 0, stream, points, c, mins, cap, max_points, d_m, feats, c_dst);
