@@ -105,6 +105,6 @@ int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream);
 size_t bitmap_scan_workspace_bytes(size_t nwords);
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
-                hipStream_t stream);
+                hipStream_t stream, bool nonzero_only = false);     // nonzero_only (mode 0): prefix[] valid only at words with a bit set
 
 }  // namespace dz

@@ -97,7 +97,9 @@ __device__ __forceinline__ uint32_t fast_divmod(uint32_t n, const FastDiv f, uin
 }
 struct ScanDecode { FastDiv d0, d1, d2; };
 
-template <int MODE, int WPT>
+// NZ: prefix[] is written only for words that have a bit set - the rank queries (bitmap_find / bitmap_rank) test the bit before
+// they read the prefix, and a level-1 bitmap is > 97 % zero words (181 MB of prefix writes per 16 frames otherwise)
+template <int MODE, int WPT, bool NZ = false>
 __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ bitmap, size_t nwords,
                                                    const uint32_t *__restrict__ partial,
                                                    uint32_t *__restrict__ prefix, ScanDecode dec,
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ 
     for (int j = 0; j < WPT; ++j) { pv[j] = run; run += __popc(wv[j]); }
 #pragma unroll
     for (int j = 0; j < WPT; ++j)
-        if (base + j < nwords) prefix[base + j] = pv[j];
+        if (base + j < nwords && (!NZ || wv[j])) prefix[base + j] = pv[j];
     if (MODE < 0 || total == 0) return;
     // coordinate emission: words are re-distributed round-robin over the threads (dense clusters of
     // set bits are consecutive words; consecutive words per thread serialised them on one lane)
@@ -167,14 +169,17 @@ size_t bitmap_scan_workspace_bytes(size_t nwords) {
 
 template <int WPT>
 static void launch_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode, const ScanDecode &dec,
-                        int *coords_out, int cap_out, uint32_t *partial, hipStream_t stream) {
+                        int *coords_out, int cap_out, uint32_t *partial, hipStream_t stream, bool nonzero_only) {
     const int nblocks = (int)((nwords + 256 * WPT - 1) / (256 * WPT));
     hipLaunchKernelGGL(k_scan_reduce<WPT>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial);
     if (nblocks > 4096)
         hipLaunchKernelGGL(k_scan_partials<32>, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
     else
         hipLaunchKernelGGL(k_scan_partials<8>, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
-    if (mode == 0)
+    if (mode == 0 && nonzero_only)
+        hipLaunchKernelGGL((k_scan_down<0, WPT, true>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
+    else if (mode == 0)
         hipLaunchKernelGGL((k_scan_down<0, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
                            coords_out, cap_out);
     else if (mode == 1)
@@ -187,7 +192,7 @@ static void launch_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix,
 
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
-                hipStream_t stream) {
+                hipStream_t stream, bool nonzero_only) {
     if (ws_bytes < bitmap_scan_workspace_bytes(nwords)) {
         set_error("bitmap_scan: workspace %zu < %zu", ws_bytes, bitmap_scan_workspace_bytes(nwords));
         return DZ_ERR_WORKSPACE;
@@ -198,9 +203,9 @@ int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_
     dec.d1 = FastDiv{(uint32_t)(dims.d1 > 0 ? dims.d1 : 1), 1.0 / (double)(dims.d1 > 0 ? dims.d1 : 1)};
     dec.d2 = FastDiv{(uint32_t)(dims.d2 > 0 ? dims.d2 : 1), 1.0 / (double)(dims.d2 > 0 ? dims.d2 : 1)};
     if (nwords <= ((size_t)1 << 21))
-        launch_scan<1>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream);
+        launch_scan<1>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only);
     else
-        launch_scan<4>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream);
+        launch_scan<4>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -466,12 +466,12 @@ int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c,
     if (!rc) rc = fill_u32(mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
     if (rc) return rc;
     if (n == 0) return bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw,
-                                   sw_bytes, stream);
+                                   sw_bytes, stream, true);
     DZ_CHECK_ARG(points, "dz_voxelize_to_level: null points");
     const int grid_n = stream_grid(n, 256);
     hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, level_d, keys, bitmap);
     rc = bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw, sw_bytes,
-                     stream);
+                     stream, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_hard_insert, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix, mins, cap, max_points);
     const dim3 ge(stream_grid((long)cap * (c_dst / 8), 256));

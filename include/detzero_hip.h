@@ -100,7 +100,8 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
  * Sparse tensor index ("indice" machinery of spconv.pytorch.SparseConvTensor / SubMConv3d /
  * SparseConv3d — call sites detection/detzero_det/models/centerpoint_modules/backbone3d.py:
  * 243-280, 302-307).  A level is a bit per cell of the (B,D,H,W) grid plus an exclusive
- * popcount prefix per 32-bit word; active sites are numbered in ascending linear key
+ * popcount prefix per 32-bit word (dz_voxelize_to_level writes it only at words that hold at least one bit - the only ones
+ * the rank query of an ACTIVE cell reads; its level-1 bitmap is > 97 % empty words); active sites are numbered in ascending linear key
  * ((b*D+z)*H+y)*W+x, which is also their row in the feature matrix.
  * ------------------------------------------------------------------------------------------- */
 size_t dz_index_words(int b, int d, int h, int w);            /* uint32 words in bitmap / prefix */
