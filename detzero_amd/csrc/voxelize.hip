@@ -261,9 +261,14 @@ __global__ void k_dyn_keys(const float *__restrict__ pts, int n, int stride, Vox
     }
 }
 
+// Deterministic sums: every value is added as a 64-bit fixed-point number (2^-28 units: exact for |v| >= 2^-4 at fp32 precision,
+// 3.7e-9 absolute below; |v| * points per voxel up to 2^35), and integer addition commutes - the result does not depend on the
+// order the atomics land in (fp32 atomics, as torch_scatter uses them in the reference, give run-to-run differences).
+constexpr float DYN_FIX = 268435456.f;        // 2^28
+
 __global__ void k_dyn_accumulate(const float *__restrict__ pts, int n, int c, const uint32_t *__restrict__ keys,
                                  const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ prefix, int cap,
-                                 float *__restrict__ sums, int *__restrict__ counts) {
+                                 unsigned long long *__restrict__ acc, int *__restrict__ counts) {
     const long total = (long)n * c;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
@@ -272,19 +277,21 @@ __global__ void k_dyn_accumulate(const float *__restrict__ pts, int n, int c, co
         if (key == KEY_INVALID) continue;
         const int v = bitmap_rank(bitmap, prefix, key);
         if (v >= cap) continue;
-        atomicAdd(&sums[(size_t)v * c + ch], pts[(size_t)i * (c + 1) + 1 + ch]);
+        const long long q = __float2ll_rn(pts[(size_t)i * (c + 1) + 1 + ch] * DYN_FIX);
+        atomicAdd(&acc[(size_t)v * c + ch], (unsigned long long)q);          // two's complement: wrap-around addition is signed addition
         if (ch == 0) atomicAdd(&counts[v], 1);
     }
 }
 
-__global__ void k_dyn_divide(float *__restrict__ sums, const int *__restrict__ counts, const int *__restrict__ d_m,
-                             int cap, int c) {
+__global__ void k_dyn_divide(const unsigned long long *__restrict__ acc, float *__restrict__ feats, const int *__restrict__ counts,
+                             const int *__restrict__ d_m, int cap, int c) {
     const int m = min(*d_m, cap);
     const long total = (long)m * c;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int v = (int)(idx / c);
-        sums[idx] = __fdiv_rn(sums[idx], (float)counts[v]);
+        const double sum = (double)(long long)acc[idx] * (1.0 / (double)DYN_FIX);
+        feats[idx] = __fdiv_rn((float)sum, (float)counts[v]);
     }
 }
 
@@ -496,23 +503,23 @@ int dz_mean_vfe(const float *voxels, const int *num_points, const int *d_m, int 
     return DZ_OK;
 }
 
-static size_t dyn_layout(int n, size_t nwords, int cap, size_t *o_keys, size_t *o_bm, size_t *o_pf, size_t *o_cnt,
-                         size_t *o_sw, size_t *sw_bytes) {
+static size_t dyn_layout(int n, size_t nwords, int cap, int c, size_t *o_keys, size_t *o_bm, size_t *o_pf, size_t *o_cnt,
+                         size_t *o_acc, size_t *o_sw, size_t *sw_bytes) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     *o_keys = take((size_t)(n < 1 ? 1 : n) * 4);
     *o_bm = take(nwords * 4);
     *o_pf = take(nwords * 4);
     *o_cnt = take((size_t)(cap < 1 ? 1 : cap) * 4);
+    *o_acc = take((size_t)(cap < 1 ? 1 : cap) * (c < 1 ? 1 : c) * 8);        // fixed-point sums
     *sw_bytes = bitmap_scan_workspace_bytes(nwords);
     *o_sw = take(*sw_bytes);
     return off;
 }
 
 size_t dz_voxelize_dynamic_workspace_bytes(int n, int batch, int gx, int gy, int gz, int c, int cap) {
-    size_t a, b, d, e, f, g;
-    (void)c;
-    return dyn_layout(n, dz_index_words(batch, gx, gy, gz), cap, &a, &b, &d, &e, &f, &g);
+    size_t a, b, d, e, f, g, h;
+    return dyn_layout(n, dz_index_words(batch, gx, gy, gz), cap, c, &a, &b, &d, &e, &h, &f, &g);
 }
 
 int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h_range6, const float *h_vsize3,
@@ -528,15 +535,17 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
     // the reference's int32 merge key overflows for b >= 24 on the Waymo grid (vfe.py:128-131); we refuse instead
     if (cells >= 0x7FFFFFFFull) { set_error("dz_voxelize_dynamic_mean: batch*grid exceeds int32 merge keys"); return DZ_ERR_UNSUPPORTED; }
     const size_t nwords = dz_index_words(batch, g.g[0], g.g[1], g.g[2]);
-    size_t o_keys, o_bm, o_pf, o_cnt, o_sw, sw_bytes;
-    const size_t need = dyn_layout(n, nwords, cap, &o_keys, &o_bm, &o_pf, &o_cnt, &o_sw, &sw_bytes);
+    size_t o_keys, o_bm, o_pf, o_cnt, o_acc, o_sw, sw_bytes;
+    const size_t need = dyn_layout(n, nwords, cap, c, &o_keys, &o_bm, &o_pf, &o_cnt, &o_acc, &o_sw, &sw_bytes);
     if (ws_bytes < need) { set_error("dz_voxelize_dynamic_mean: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }
     char *base = (char *)ws;
     uint32_t *keys = (uint32_t *)(base + o_keys), *bitmap = (uint32_t *)(base + o_bm), *prefix = (uint32_t *)(base + o_pf);
     int *counts = (int *)(base + o_cnt);
+    unsigned long long *acc = (unsigned long long *)(base + o_acc);
 
     int rc = fill_u32(bitmap, 0u, nwords, stream);
     if (!rc && cap > 0) rc = fill_u32(feats, 0u, (size_t)cap * c, stream);
+    if (!rc && cap > 0) rc = fill_u32(acc, 0u, (size_t)cap * c * 2, stream);
     if (!rc && cap > 0) rc = fill_u32(counts, 0u, (size_t)cap, stream);
     if (rc) return rc;
     if (n > 0) {
@@ -549,8 +558,8 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
     if (rc) return rc;
     if (n > 0 && cap > 0) {
         hipLaunchKernelGGL(k_dyn_accumulate, dim3(stream_grid((long)n * c, 256)), dim3(256), 0, stream, points_b, n, c,
-                           keys, bitmap, prefix, cap, feats, counts);
-        hipLaunchKernelGGL(k_dyn_divide, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream, feats, counts,
+                           keys, bitmap, prefix, cap, acc, counts);
+        hipLaunchKernelGGL(k_dyn_divide, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream, acc, feats, counts,
                            d_num_voxels, cap, c);
     }
     DZ_LAUNCH_CHECK();

@@ -172,7 +172,7 @@ def multisweep(device):
 
 @pytest.mark.parametrize('math', MATHS)
 def test_multisweep_320k_dynamic_vfe(multisweep, device, math):
-    """6 point features, ~320k points, DynamicMeanVFE -> backbone -> head: voxel set bit-exact, voxel means 1e-5 (float atomics),
+    """6 point features, ~320k points, DynamicMeanVFE -> backbone -> head: voxel set bit-exact, voxel means 1e-5 (fixed-point sums vs the oracle's fp32 ones),
     every sparse stage, the final boxes within 1e-3 - through the plugin modules and through FramePipeline(dynamic=True)."""
     from detzero_amd.centerpoint import FramePipeline, set_math
     model, cfg, info, merged, ref = multisweep

@@ -93,6 +93,11 @@ def test_dynamic_vfe(device, golden_dir):
     f1, c1 = ops.voxelize_dynamic(_t(pb, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 1)
     assert np.array_equal(c1.cpu().numpy(), c0)
     np.testing.assert_allclose(f1.cpu().numpy(), f0, rtol=1e-5, atol=1e-5)
+    # deterministic: the sums are 64-bit fixed-point atomics, so the order the points land in does not matter - the same frame with
+    # its points shuffled gives the same bits (fp32 atomics would not)
+    perm = np.random.default_rng(0).permutation(pb.shape[0])
+    f2, c2 = ops.voxelize_dynamic(_t(pb[perm], device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 1)
+    assert torch.equal(c2, c1) and torch.equal(f2, f1)
 
 
 # ------------------------------------------------------------------------------------------------
