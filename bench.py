@@ -20,6 +20,7 @@ Besides the headline the default single-GPU run measures, into the same JSON lin
   ref_batch  the headline arithmetic at the reference's BATCH_SIZE_PER_GPU = 8 (centerpoint_1sweep.yaml:88)
   ragged     frames of 150k-180k points: padded to the slot capacity with out-of-range rows (the stacked route), and as a
              ragged list (per-frame voxelizers on parallel streams)
+  f16        opt-in fast mode: one fp16 MFMA per product on the same fp16-pair tensors (not fp32-class; its own tolerance), with roofline
   multisweep BASELINE configs[4] shape: two merged sweeps per frame (320k points, 6 features), DynamicMeanVFE, 3-sweep model
   with_h2d   frames start in pinned host memory; the H2D copy of step i+1 runs on a copy stream under step i
   stages     voxelize / index pyramid / sparse backbone / dense / post-processing: time per step (each stage replayed as its
@@ -71,7 +72,7 @@ def pmc_traffic(kernel, math):
     try:
         with open(files[-1]) as f:
             d = json.load(f)
-        tag = {'f16x2': '[F16]', 'bf16x2': '[BF16]'}.get(math, '')
+        tag = {'f16x2': '[F16]', 'bf16x2': '[BF16]', 'f16': '[F16H]'}.get(math, '')
         ent = d.get(kernel + tag) or d.get(kernel.replace('>', ' >'))
         if not ent or 'FETCH_SIZE' not in ent:
             return None
@@ -96,8 +97,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
     ap.add_argument('--batch', type=int, default=16, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
-    ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2'],
-                    help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores')
+    ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2', 'f16'],
+                    help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores; '
+                         'f16 = one fp16 MFMA per product on the same tensors (fast mode, not fp32-class)')
     ap.add_argument('--overlap', action='store_true',
                     help='two-stage streaming pipeline (StreamingDetector) instead of one graph per step; measured slower on MI355X')
     ap.add_argument('--no-calibrate', action='store_true', help='keep worst-case level capacities (limits the batch to ~4 frames)')
@@ -105,7 +107,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
-    ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, multisweep, with_h2d, stages)')
+    ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
     return ap.parse_args()
@@ -263,14 +265,15 @@ class Case:
             achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
             split = '_h<' in top['kernel']
             # split engine: three 16-bit MFMAs per algorithmic product -> algorithmic peak = f16 MFMA peak / 3
-            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+            terms = 1.0 if self.math == 'f16' else 3.0
+            peak = PEAK_F16_MFMA_TFLOPS / terms if split else PEAK_F32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
                     'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'traffic': pmc_traffic(top['kernel'], self.math),
                     'flop_per_launch': round(a['flops'] / a['launches'], 1),
                     'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
-                    'note': ('split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s '
-                             'algorithmic; ' if split else 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; ')
+                    'note': (('one v_mfma_f32_32x32x16_f16 per product (f16 mode), peak = 2516.6 TF/s; ' if self.math == 'f16' else
+                              'split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s algorithmic; ') if split else 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; ')
                             + 'algorithmic FLOP = 2*pixels*taps*Cin*Cout (dense) / 2*pairs*Cin*Cout (sparse); '
                               'fraction of the fp32-MFMA peak: %.3f' % (achieved / PEAK_F32_MFMA_TFLOPS)}
         return kern, roof, agg
@@ -408,7 +411,8 @@ def main():
 
     out = None
     dtype_names = {'f32': 'f32', 'f16x2': 'f32 as f16 pairs (hi+lo, 22-bit significand; 3 f16 MFMA per product, f32 accumulate)',
-                   'bf16x2': 'f32 as bf16 pairs (hi+lo, 16-bit significand; 3 bf16 MFMA per product, f32 accumulate)'}
+                   'bf16x2': 'f32 as bf16 pairs (hi+lo, 16-bit significand; 3 bf16 MFMA per product, f32 accumulate)',
+                   'f16': 'f16 products (hi halves of the f16 pairs: 11-bit inputs, 1 f16 MFMA per product), f32 accumulate, results stored as f16 pairs'}
     if rank == 0:
         value = world * K * B / dt
         out = {
@@ -501,6 +505,16 @@ def main():
                      note='slot j holds frames of its own length in 150k-180k: per-frame fused voxelizers on parallel streams')
         del c
         out['ragged'] = {'padded': padded, 'list': lst}
+        if args.math == 'f16x2':
+            c, rec = leg('f16', 'f16', B, note='opt-in fast mode on the same tensors: ONE fp16 MFMA per product (hi halves only) - plain-fp16 inputs, '
+                                             'fp32 accumulation; not fp32-class (boxes within 2.5e-3 of the oracle on this workload, '
+                                             'tests/test_gpu_f16.py) and never the headline value')
+            if args.profile_frames > 0:
+                kern, roof, _ = c.kernel_profile(args.profile_frames)
+                rec['roofline'] = roof
+                rec['kernels'] = kern[:6]
+            out['f16'] = rec
+            del c
         c, out['multisweep'] = leg('multisweep', args.math, REF_BATCH, sweeps=2,
                                    note='BASELINE configs[4] shape: two merged sweeps per frame (2 x %d points, 6 features incl. the time '
                                         'offset), DynamicMeanVFE + centerpoint_3sweeps backbone and head' % args.points)

@@ -239,7 +239,7 @@ extern "C" {
 int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward_split: null pointer");
-    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_conv2d_forward_split: math %d is not a split mode", math);
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_conv2d_forward_split: math %d is not a split mode", math);
     DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward_split: groups %d not in [1,8]", d->groups);
     DZ_CHECK_ARG(!d->group_shift || (d->group_rows >= 1 && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->batch == 1 && d->ho == 1 &&
                                      d->out_hp == 1 && d->out_sx == 1 && d->out_dx == 0),
@@ -264,6 +264,8 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
     if (conv3x3_h_variant(*d)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);
     if (math == DZ_MATH_F16X2)
         return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);
+    if (math == DZ_MATH_F16)
+        return out_f32 ? conv2d_h_dispatch<MathF16H, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16H, false>(*d, w_bytes, stream);
     return out_f32 ? conv2d_h_dispatch<MathBF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathBF16, false>(*d, w_bytes, stream);
 }
 

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         // term-major: consecutive MFMAs go to different accumulators (measured 1.7 % faster than three in a row into the same
         // one); each accumulator still receives lo.hi, hi.lo, hi.hi in that order, so the result does not depend on it
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = 3 - M::TERMS; term < 3; ++term)              // single-product mode: only hi.hi (term 2)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             mma(f0);
             // one LDS read / write behind each of the first MFMAs: the two waves of a SIMD run in lock step (one barrier
             // per tap), so memory instructions issued in a block of their own would leave the matrix pipe idle
-            interleave_hint<0x100, 2 * (PT + CT), 1>();
+            interleave_hint<0x100, M::TERMS == 1 ? (PT + CT) : 2 * (PT + CT), 1>();
             interleave_hint<0x200, WPT, 1>();
             if constexpr (!(DIAG & 1)) __syncthreads();
             if (t == 8) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             issue_w(wst[(t + 1) % 3], c + 4);
             if (t == 0) issue_px(kc + 1);
             mma(f1);
-            interleave_hint<0x100, 2 * (PT + CT), 1>();
+            interleave_hint<0x100, M::TERMS == 1 ? (PT + CT) : 2 * (PT + CT), 1>();
         }
     }
     tile_origin(tile, x0, y0, b);
@@ -505,16 +505,19 @@ int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_by
 #ifdef DZ_C3_DIAG
     if (bc == 128 && !out_f32 && conv3x3_d_eligible(p)) return conv3x3_d_launch(p, math, w_bytes, stream);
 #endif
-    if (bc == 32) {
-        if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<32, MathF16, true>(p, w_bytes, stream) : launch_c3<32, MathF16, false>(p, w_bytes, stream);
-        return out_f32 ? launch_c3<32, MathBF16, true>(p, w_bytes, stream) : launch_c3<32, MathBF16, false>(p, w_bytes, stream);
-    }
-    if (bc == 128) {
-        if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<128, MathF16, true>(p, w_bytes, stream) : launch_c3<128, MathF16, false>(p, w_bytes, stream);
-        return out_f32 ? launch_c3<128, MathBF16, true>(p, w_bytes, stream) : launch_c3<128, MathBF16, false>(p, w_bytes, stream);
-    }
-    if (math == DZ_MATH_F16X2) return out_f32 ? launch_c3<64, MathF16, true>(p, w_bytes, stream) : launch_c3<64, MathF16, false>(p, w_bytes, stream);
-    return out_f32 ? launch_c3<64, MathBF16, true>(p, w_bytes, stream) : launch_c3<64, MathBF16, false>(p, w_bytes, stream);
+    auto go = [&](auto bc_t, auto m_t) {
+        constexpr int BCV = decltype(bc_t)::value;
+        using MM = typename decltype(m_t)::type;
+        return out_f32 ? launch_c3<BCV, MM, true>(p, w_bytes, stream) : launch_c3<BCV, MM, false>(p, w_bytes, stream);
+    };
+    auto by_math = [&](auto bc_t) {
+        if (math == DZ_MATH_F16X2) return go(bc_t, TypeTag<MathF16>{});
+        if (math == DZ_MATH_F16) return go(bc_t, TypeTag<MathF16H>{});
+        return go(bc_t, TypeTag<MathBF16>{});
+    };
+    if (bc == 32) return by_math(std::integral_constant<int, 32>{});
+    if (bc == 128) return by_math(std::integral_constant<int, 128>{});
+    return by_math(std::integral_constant<int, 64>{});
 }
 
 }  // namespace dz

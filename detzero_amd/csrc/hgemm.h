@@ -32,6 +32,7 @@ typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
 
 struct MathF16 {
     static constexpr int ID = 1;
+    static constexpr int TERMS = 3;            // MFMAs per product: hi.hi + lo.hi + hi.lo
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
     }
@@ -54,6 +55,7 @@ struct MathF16 {
 
 struct MathBF16 {
     static constexpr int ID = 2;
+    static constexpr int TERMS = 3;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
     }
@@ -70,6 +72,15 @@ struct MathBF16 {
         return __uint_as_float(hi << 16) + __uint_as_float(lo << 16);
     }
 };
+
+// DZ_MATH_F16 ('f16'): the same pair16 tensors (results are still stored as hi + lo), but a product is the single fp16 MFMA hi.hi -
+// plain fp16 inputs with fp32 accumulation, a third of the matrix work.  NOT fp32-class: inputs carry 11 significant bits per layer
+// (opt-in; boxes move by up to ~1e-2 against the fp32 path - tests/test_gpu_f16.py states the measured tolerance).
+struct MathF16H : MathF16 {
+    static constexpr int TERMS = 1;
+};
+template <class T>
+struct TypeTag { using type = T; };        // carries a math type through generic lambdas
 
 // 4 consecutive channels -> the two 8-byte halves (hi, lo) of their slot in a pair16 group.  Two values at a time on the packed
 // conversions of gfx950 (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, v_pk_add_f32): ~4.5 VALU ops per value instead of ~10 for the
@@ -151,7 +162,12 @@ __device__ __forceinline__ void load_hfrag(HFrag<T> &f, const v4u *__restrict__ 
 // one (same bits: every accumulator still receives lo.hi, hi.lo, hi.hi in that order)
 template <class T, class M, bool TM = false>
 __device__ __forceinline__ void mma_hfrag(const HFrag<T> &f, f32x16 (&acc)[T::CT][T::PT]) {
-    if constexpr (TM) {
+    if constexpr (M::TERMS == 1) {              // single product on the hi halves (the lo fragment reads are dead code and disappear)
+#pragma unroll
+        for (int ct = 0; ct < T::CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < T::PT; ++pt) acc[ct][pt] = M::mma(f.c_hi[ct], f.p_hi[pt], acc[ct][pt]);
+    } else if constexpr (TM) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll

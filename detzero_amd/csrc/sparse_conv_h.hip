@@ -280,7 +280,7 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(in && nbr && d_m_out && w && out, "dz_spconv_forward_split: null pointer");
     DZ_CHECK_ARG(kvol >= 1 && kvol <= KVOL_MAX_H, "dz_spconv_forward_split: kvol %d not in [1,27]", kvol);
-    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_spconv_forward_split: math %d is not a split mode", math);
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_spconv_forward_split: math %d is not a split mode", math);
     DZ_CHECK_ARG(cout % 8 == 0 && cin % 8 == 0, "dz_spconv_forward_split: channels must be multiples of the 8-channel pair16 group");
     if (cap_out == 0) return DZ_OK;
     const int cout_pad = cout < 32 ? 32 : cout;
@@ -298,6 +298,7 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
 #ifdef DZ_SPCONV_DIAG
     a.diag = tune("DZ_TUNE_W_DIAG", 0);
 #endif
+    if (math == DZ_MATH_F16) return spconv_h_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? spconv_h_dispatch<MathF16>(a, stream) : spconv_h_dispatch<MathBF16>(a, stream);
 }
 

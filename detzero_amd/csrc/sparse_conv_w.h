@@ -240,14 +240,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
                     a1[cb] = wt[(cb * KG + ks * 2) * 32];
-                    a2[cb] = wt[(cb * KG + ks * 2) * 32 + 16];
+                    if constexpr (M::TERMS == 1) {               // single product: w_hi meets x_hi only (the k-slots of x_lo get zeros)
+                        if (kg & 1) a1[cb] = v4u{0u, 0u, 0u, 0u};
+                    } else {
+                        a2[cb] = wt[(cb * KG + ks * 2) * 32 + 16];
+                    }
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (!((pres >> (2 * s + h)) & 1u)) continue;  // wave-uniform
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) {
-                        acc[h][cb] = M::mma16(a2[cb], src[s][h][ks], acc[h][cb]);
+                        if constexpr (M::TERMS != 1) acc[h][cb] = M::mma16(a2[cb], src[s][h][ks], acc[h][cb]);
                         acc[h][cb] = M::mma16(a1[cb], src[s][h][ks], acc[h][cb]);
                     }
                 }

@@ -50,7 +50,7 @@ class _Cached(nn.Module):
     def __init__(self):
         super().__init__()
         self._plan = None
-        self.math = 0       # ops.MATH_MODES: 0 = fp32 MFMA, 1 = fp16-pair split, 2 = bf16-pair split (csrc/hgemm.h)
+        self.math = 0       # ops.MATH_MODES: 0 = fp32 MFMA, 1 = fp16-pair split, 2 = bf16-pair split, 3 = fp16 pairs with one product (csrc/hgemm.h)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     def invalidate(self):
@@ -64,9 +64,9 @@ class _Cached(nn.Module):
         """Weights of a plan entry in the layout of the active math mode (split layouts packed once, cached)."""
         if not self.math:
             return entry[key]
-        ck = '%s_split%d' % (key, self.math)
+        ck = '%s_split%d' % (key, ops.storage_math(self.math))
         if ck not in entry:
-            entry[ck] = ops.pack_weight_split(entry[key], self.math)
+            entry[ck] = ops.pack_weight_split(entry[key], ops.storage_math(self.math))
         return entry[ck]
 
     def _apply(self, fn, *a, **kw):
@@ -500,7 +500,7 @@ def nchw_to_padded_nhwc(x, pad=1):
 
 def _recode(img, enc, math):
     """Channel-last image from encoding `enc` (0 = fp32, else pair16 of that mode) to the encoding of `math`."""
-    if enc == math:
+    if ops.storage_math(enc) == ops.storage_math(math):
         return img
     plain = ops.pair16_to_f32(img, enc) if enc else img
     return ops.pair16_from_f32(plain, math=math) if math else plain

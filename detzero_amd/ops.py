@@ -105,7 +105,7 @@ def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxel
     ws = _ws(lib.dz_voxelize_to_level_workspace_bytes(n_per, batch, max_points, cap, *lvl.shape))
     rc = lib.dz_voxelize_to_level(L.ptr(points), n_per, batch, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid),
                                   1 if xy_range_mask else 0, max_points, int(max_voxels), lvl.shape[0], L.ptr(lvl.bitmap),
-                                  L.ptr(lvl.prefix), L.ptr(lvl.coords), L.ptr(lvl.d_m), cap, L.ptr(feats), c_dst, int(math),
+                                  L.ptr(lvl.prefix), L.ptr(lvl.coords), L.ptr(lvl.d_m), cap, L.ptr(feats), c_dst, storage_math(math),
                                   L.ptr(ws), ws.numel(), L.stream())
     L.check(rc, 'dz_voxelize_to_level')
     return lvl, feats
@@ -231,7 +231,7 @@ def scatter_rows(src, rank, c_dst, cap, d_n=None, math=0):
     n, c_src = src.shape
     dst = torch.zeros((max(cap, 1), c_dst), dtype=torch.float32, device=src.device)
     if math:
-        rc = lib.dz_scatter_rows_split(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, int(math), L.stream())
+        rc = lib.dz_scatter_rows_split(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, storage_math(math), L.stream())
     else:
         rc = lib.dz_scatter_rows(L.ptr(src), L.ptr(rank), L.ptr(d_n), n, c_src, L.ptr(dst), c_dst, L.stream())
     L.check(rc, 'dz_scatter_rows')
@@ -303,7 +303,14 @@ def sparse_to_bev(feats, level, c, pad=1, out=None, math=0):
 # ------------------------------------------------------------------------------------------------
 # split precision (pair16): csrc/hgemm.h
 # ------------------------------------------------------------------------------------------------
-MATH_MODES = {'f32': 0, 'f16x2': 1, 'bf16x2': 2}
+# 'f16' (3): the tensors of 'f16x2' (fp16 pairs), but every convolution product is ONE fp16 MFMA on the hi halves - plain-fp16
+# inputs with fp32 accumulation, a third of the matrix work.  Opt-in fast mode, NOT fp32-class.
+MATH_MODES = {'f32': 0, 'f16x2': 1, 'bf16x2': 2, 'f16': 3}
+
+
+def storage_math(math):
+    """The pair16 encoding a math mode keeps its tensors in (3 = 'f16' computes on the tensors of 1 = 'f16x2')."""
+    return 1 if int(math) == 3 else int(math)
 
 
 def math_id(mode):
@@ -317,6 +324,7 @@ def math_id(mode):
 def pair16_pack(x, math):
     """Host/torch packer (any device): x (..., C) fp32, C % 8 == 0 -> same-shape float32-typed pair16 bits.
     Used for weights at plan time; the device kernels (dz_pair16_from_f32, conv epilogues) do the same split."""
+    math = storage_math(math)
     dt = torch.float16 if math == 1 else torch.bfloat16
     x = x.float()
     if math == 1:
@@ -330,6 +338,7 @@ def pair16_pack(x, math):
 
 
 def pair16_unpack(x, math):
+    math = storage_math(math)
     dt = torch.float16 if math == 1 else torch.bfloat16
     shp = x.shape
     g = shp[-1] // 8
@@ -356,7 +365,7 @@ def pair16_from_f32(x, c_dst=None, math=1):
     c_dst = c if c_dst is None else c_dst
     rows = x.numel() // c
     out = torch.empty((*x.shape[:-1], c_dst), dtype=torch.float32, device=x.device)
-    L.check(lib.dz_pair16_from_f32(L.ptr(x), rows, c, c_dst, int(math), L.ptr(out), L.stream()), 'dz_pair16_from_f32')
+    L.check(lib.dz_pair16_from_f32(L.ptr(x), rows, c, c_dst, storage_math(math), L.ptr(out), L.stream()), 'dz_pair16_from_f32')
     return out
 
 
@@ -366,7 +375,7 @@ def pair16_to_f32(x, math=1):
     x = x.contiguous()
     c = x.shape[-1]
     out = torch.empty_like(x)
-    L.check(lib.dz_pair16_to_f32(L.ptr(x), x.numel() // c, c, int(math), L.ptr(out), L.stream()), 'dz_pair16_to_f32')
+    L.check(lib.dz_pair16_to_f32(L.ptr(x), x.numel() // c, c, storage_math(math), L.ptr(out), L.stream()), 'dz_pair16_to_f32')
     return out
 
 

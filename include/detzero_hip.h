@@ -193,6 +193,7 @@ const char *dz_spconv_variant(int cin, int cout);
 #define DZ_MATH_F32 0
 #define DZ_MATH_F16X2 1
 #define DZ_MATH_BF16X2 2
+#define DZ_MATH_F16 3      /* convolution entry points only: fp16-pair tensors (DZ_MATH_F16X2 storage), ONE fp16 MFMA per product (hi halves): plain-fp16 inputs, fp32 accumulation - a third of the matrix work, NOT fp32-class (opt-in fast mode) */
 /* dst (rows, c_dst) pair16 <- src (rows, c_src) f32, channels c_src..c_dst-1 zero; c_dst % 8 == 0 */
 int dz_pair16_from_f32(const float *src, long rows, int c_src, int c_dst, int math, float *dst, void *stream);
 /* dst (rows, c) f32 <- src (rows, c) pair16 (hi + lo) */

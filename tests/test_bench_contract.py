@@ -51,6 +51,8 @@ def test_committed_bench_line_has_the_auxiliary_legs():
     for k in ('padded', 'list'):
         leg = d['ragged'][k]
         assert leg['value'] > 0 and 150000 <= leg['mean_points_per_frame'] <= 180000
+    if 'f16' in d:                                                          # opt-in single-product mode: never the headline
+        assert d['f16']['math'] == 'f16' and d['f16']['value'] > 0 and d['dtype'] != d['f16']['dtype']
     if 'multisweep' in d:                                                   # BASELINE configs[4] shape (later lines of round 2)
         ms = d['multisweep']
         assert ms['value'] > 0 and ms['mean_points_per_frame'] == 320000 and ms['frames_per_step'] == 8
