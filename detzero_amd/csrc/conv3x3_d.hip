@@ -140,7 +140,7 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     };
     auto mma = [&](const Frag &f) {
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = 3 - M::TERMS; term < 3; ++term)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     load_frag(fb, tn, bufn, (u + 1) % D_NW);
                     mma(fa);
                 }
-                interleave_hint<0x100, 12, 2>();
+                interleave_hint<0x100, M::TERMS == 1 ? 6 : 12, M::TERMS == 1 ? 1 : 2>();
             }
         }
         tile_origin(tile, x0, y0, b);
@@ -295,6 +295,7 @@ bool conv3x3_d_eligible(const dz_conv2d_desc &p) {
 }
 
 int conv3x3_d_launch(const dz_conv2d_desc &p, int math, size_t w_bytes, hipStream_t stream) {
+    if (math == DZ_MATH_F16) return launch_c3d<MathF16H>(p, w_bytes, stream);
     return math == DZ_MATH_F16X2 ? launch_c3d<MathF16>(p, w_bytes, stream) : launch_c3d<MathBF16>(p, w_bytes, stream);
 }
 

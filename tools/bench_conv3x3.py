@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--cin', type=int, default=128)
     ap.add_argument('--cout', type=int, default=128)
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--math', type=int, default=1, help='1 = f16x2, 2 = bf16x2, 3 = f16 (single product)')
     ap.add_argument('--data', default='randn', choices=['randn', 'relu', 'zero', 'const'])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -40,7 +41,7 @@ def main():
 
     def run():
         conv_layer(xp, (h + 2, w + 2), wt, scale, shift, True, y, (h + 2, w + 2), cin=a.cin, in_cstride=a.cin, ksize=3,
-                   stride=1, in_off=0, out_cstride=a.cout, out_d=(1, 1), ho=h, wo=w, batch=a.batch, math=1)
+                   stride=1, in_off=0, out_cstride=a.cout, out_d=(1, 1), ho=h, wo=w, batch=a.batch, math=a.math)
     for _ in range(5):
         run()
     torch.cuda.synchronize()
