@@ -374,6 +374,16 @@ class FramePipeline:
         self.level_caps = [int(margin * b) + 4096 for b in best]
         return self.level_caps
 
+    def check_overflow(self):
+        """Host-side check (one sync) of the device flag the last pass left: with calibrated capacities (`calibrate`) a frame much
+        denser than the samples would silently lose the sites past a level's capacity - call this after a pass (or every N
+        passes: the flag is sticky per pass, the outputs of an overflowed pass are the ones to discard) and re-calibrate with a
+        larger margin, or run with worst-case capacities (no `calibrate`), when it raises."""
+        if self.last_overflow is not None and bool(self.last_overflow.item()):
+            raise DetZeroHipError('FramePipeline: a sparse level overflowed its calibrated row capacity (%s per frame): '
+                                  're-run calibrate() on denser samples / with a larger margin, or drop the calibration'
+                                  % (self.level_caps,))
+
     @torch.no_grad()
     def backbone_stage(self, prep):
         """The 21 sparse convolutions -> {name: (rows, SparseLevel)}."""

@@ -152,8 +152,19 @@ def test_calibrated_capacities_do_not_change_results(full, device, math):
     pipe.calibrate([inp[0], inp[1]])
     out, cnt = pipe(inp)
     assert not bool(pipe.last_overflow.item())
+    pipe.check_overflow()                                  # clear flag: no exception
     for i in range(2):
         _check_boxes(refs[i]['final'], out[i], int(cnt[i].item()), 'calibrated/%s/frame%d' % (math, i))
+    if math == 'f16x2':
+        # capacities calibrated on a sparse 20k-point frame: the 160k frames overflow them - the flag is raised and check_overflow() says so
+        from detzero_amd.lib import DetZeroHipError
+        small = torch.from_numpy(masked_frame(3, 20000)).to(device)
+        pipe2 = FramePipeline(model, info, math=math)
+        pipe2.calibrate([small], margin=1.0)
+        pipe2(inp)
+        assert bool(pipe2.last_overflow.item())
+        with pytest.raises(DetZeroHipError):
+            pipe2.check_overflow()
     set_math(model, 'f32')
 
 
