@@ -59,7 +59,7 @@ struct C3Cfg {
 // stores, 2 = no fragment LDS reads, 3 = no global loads, 4 = no MFMAs, 5 = no epilogue
 template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0, int PT = 2>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 : 1, PT == 2 ? 2 : 1))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
-                                                          unsigned int w_bytes, int skew_ticks) {
+                                                          unsigned int w_bytes, int skew_ticks, int q_sa, int q_sb, float q_act) {
     using C = C3Cfg<BC, NT, PT>;
     constexpr int CT = C::CT, WPT = C::WPT, C3_THREADS = NT, C3_PXPT = C::PXPT, WC = C::WC, C3_TH = C::TH, C3_PX_ROWS = C::PX_ROWS,
                   C3_PX_PIECES = C::PX_PIECES;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     const int kg2 = (lane >> 5) * 2;
     const int pbase = ((PT * wp) * C3_PXW + (lane & 31)) * C3_ROW_U4 + kg2;
     const int wbase = (wc * CT * 32 + (lane & 31)) * C3_ROW_U4 + kg2;
-    struct Frag { v4u p_hi[PT], p_lo[PT], c_hi[CT], c_lo[CT]; };
+    struct Frag { v4u p_hi[PT], p_lo[PT], c_hi[CT], c_lo[CT], p_x[PT], c_x[CT]; };        // (p_x, c_x: second fp8 piece, q16 prototype)
     auto load_frag = [&](Frag &f, int tap, int buf, int q) {
         if constexpr (DIAG & 4) {
 #pragma unroll
@@ -202,6 +202,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             return;
         }
         const int ky = tap / 3, kx = tap - ky * 3;
+        if constexpr (M::Q16) {
+            // q16 chunk row (128 bytes = 8 pieces): fp16 hi of channels 8i..8i+7 in piece i (0..3), hi8 in pieces 4-5, lo8 in 6-7.
+            // k-step q of the fp16 MFMA: piece 2q + kg.  The fp8 MFMA (issued with k-step 1) covers the 32 channels twice: its
+            // k-block 0 (lanes 0-31) multiplies lo8(x) by hi8(w), block 1 (lanes 32-63) hi8(x) by lo8(w).
+            const int kb = lane >> 5;
+            const v4u *pp = px_s + (pbase - kg2) + (ky * C3_PXW + kx) * C3_ROW_U4;
+            const v4u *cp = w_s + buf * C::W_U4 + (wbase - kg2);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                f.p_hi[pt] = pp[pt * C3_PXW * C3_ROW_U4 + 2 * q + kb];
+                if (q == 1) {
+                    f.p_lo[pt] = pp[pt * C3_PXW * C3_ROW_U4 + (kb ? 4 : 6)];
+                    f.p_x[pt] = pp[pt * C3_PXW * C3_ROW_U4 + (kb ? 5 : 7)];
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f.c_hi[ct] = cp[ct * 32 * C3_ROW_U4 + 2 * q + kb];
+                if (q == 1) {
+                    f.c_lo[ct] = cp[ct * 32 * C3_ROW_U4 + (kb ? 6 : 4)];
+                    f.c_x[ct] = cp[ct * 32 * C3_ROW_U4 + (kb ? 7 : 5)];
+                }
+            }
+            return;
+        }
         const v4u *pp = px_s + pbase + (ky * C3_PXW + kx) * C3_ROW_U4 + q * 4;
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -215,7 +240,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             f.c_lo[ct] = cp[ct * 32 * C3_ROW_U4 + 1];
         }
     };
-    auto mma = [&](const Frag &f) {
+    auto mma = [&](const Frag &f, int q = 0) {
+        if constexpr (M::Q16) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = M::mma(f.c_hi[ct], f.p_hi[pt], acc[ct][pt]);
+            if (q == 1) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = mma_f8(f.c_lo[ct], f.c_x[ct], f.p_lo[pt], f.p_x[pt], acc[ct][pt], q_sa, q_sb);
+            }
+            return;
+        }
         if constexpr (DIAG & 16) {
 #pragma unroll
             for (int i = 0; i < PT; ++i) asm volatile("" ::"v"(f.p_hi[i]), "v"(f.p_lo[i]));
@@ -291,7 +329,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             load_frag(f0, (t + 1) % 9, buf ^ 1, 0);
             issue_w(wst[(t + 1) % 3], c + 4);
             if (t == 0) issue_px(kc + 1);
-            mma(f1);
+            mma(f1, 1);
             interleave_hint<0x100, M::TERMS == 1 ? (PT + CT) : 2 * (PT + CT), 1>();
         }
     }
@@ -339,11 +377,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
+                        if constexpr (M::Q16) {
+                            // q16 out (SG == 4: the staged row is the whole 128-byte chunk of the fragment's 32 channels): fp16 hi of
+                            // channel c at byte 2c, hi8 at 64 + c, lo8 at 96 + c; c = 8j + 4h + e
+                            const int c0 = 8 * j + 4 * h;
+                            unsigned int hh[2], h8 = 0u, l8 = 0u;
+                            float r[4];
+#pragma unroll
+                            for (int e2 = 0; e2 < 2; ++e2) {
+                                const float a0 = v[2 * e2], a1 = v[2 * e2 + 1];
+                                const h2_t hp = __builtin_convertvector(f32x2v{__builtin_amdgcn_fmed3f(a0, -65504.f, 65504.f),
+                                                                               __builtin_amdgcn_fmed3f(a1, -65504.f, 65504.f)}, h2_t);
+                                hh[e2] = __builtin_bit_cast(unsigned int, hp);
+                                const f32x2v hb = __builtin_convertvector(hp, f32x2v);
+                                r[2 * e2] = a0 - hb.x; r[2 * e2 + 1] = a1 - hb.y;
+                                v[2 * e2] = hb.x; v[2 * e2 + 1] = hb.y;
+                            }
+                            const float s8 = q_act, sl = q_act * 2048.f;
+                            auto clamp8 = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); };
+                            h8 = (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[0] * s8), clamp8(v[1] * s8), (int)h8, false);
+                            h8 = (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(v[2] * s8), clamp8(v[3] * s8), (int)h8, true);
+                            l8 = (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(r[0] * sl), clamp8(r[1] * sl), (int)l8, false);
+                            l8 = (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(clamp8(r[2] * sl), clamp8(r[3] * sl), (int)l8, true);
+                            unsigned char *w = stg + (lane & 31) * STG_ROW;
+                            *reinterpret_cast<uint2 *>(w + 2 * c0) = make_uint2(hh[0], hh[1]);
+                            *reinterpret_cast<unsigned int *>(w + 64 + c0) = h8;
+                            *reinterpret_cast<unsigned int *>(w + 96 + c0) = l8;
+                        } else {
                         uint2 hi, lo;
                         split4<M>(v, hi, lo);
                         unsigned char *w = stg + (lane & 31) * STG_ROW + jj * 32 + h * 8;
                         *reinterpret_cast<uint2 *>(w) = hi;
                         *reinterpret_cast<uint2 *>(w + 16) = lo;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -409,6 +475,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     asm volatile("s_waitcnt vmcnt(0)");      // nothing of this file's asm loads may stay in flight at exit
 }
 
+// q16 prototype (diag builds): tensor exponents from the environment: activations scaled by 2^-DZ_TUNE_Q16_EA, weights by 2^-DZ_TUNE_Q16_EW
+static int q16_env(const char *n, int d) { const char *v = getenv(n); return v ? atoi(v) : d; }
+static int q16_sa() { return 127 + q16_env("DZ_TUNE_Q16_EW", -4); }                       // weights are the A operand
+static int q16_sb() { return 127 + q16_env("DZ_TUNE_Q16_EA", 2) - 11; }                   // activations the B operand; both correction terms carry 2^-11
+static float q16_act() { return ldexpf(1.f, -q16_env("DZ_TUNE_Q16_EA", 2)); }
+
 template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0, int PT = 2>
 static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
     using C = C3Cfg<BC, NT, PT>;
@@ -435,7 +507,7 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     const long grid = 8L * per_xcd;
     static const int skew = getenv("DZ_TUNE_C3_SKEW") ? atoi(getenv("DZ_TUNE_C3_SKEW")) : 0;     // 10 ns ticks
     hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
-                       tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew);
+                       tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew, q16_sa(), q16_sb(), q16_act());
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -464,6 +536,8 @@ static int launch_c3(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream
         }
         static const int pt = getenv("DZ_TUNE_C3_PT") ? atoi(getenv("DZ_TUNE_C3_PT")) : 2;
         if (pt == 3) return launch_c3_nt<BC, M, OUT_F32, 256, 0, 3>(p, w_bytes, stream);
+        static const int q16 = getenv("DZ_TUNE_C3_Q16") ? atoi(getenv("DZ_TUNE_C3_Q16")) : 0;
+        if (q16) return launch_c3_nt<BC, MathF16Q, OUT_F32, 512>(p, w_bytes, stream);
     }
     if constexpr (BC == 64) {
         if (nt == 256) return launch_c3_nt<BC, M, OUT_F32, 256>(p, w_bytes, stream);

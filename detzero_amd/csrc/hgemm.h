@@ -33,6 +33,7 @@ typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
 struct MathF16 {
     static constexpr int ID = 1;
     static constexpr int TERMS = 3;            // MFMAs per product: hi.hi + lo.hi + hi.lo
+    static constexpr bool Q16 = false;         // (MathF16Q: the q16 tensor format of the fp16 + fp8 prototype)
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
     }
@@ -56,6 +57,7 @@ struct MathF16 {
 struct MathBF16 {
     static constexpr int ID = 2;
     static constexpr int TERMS = 3;
+    static constexpr bool Q16 = false;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
     }
@@ -81,6 +83,20 @@ struct MathF16H : MathF16 {
 };
 template <class T>
 struct TypeTag { using type = T; };        // carries a math type through generic lambdas
+
+// PROTOTYPE (diag builds of conv3x3_h.hip only): hi.hi on the fp16 pipe + both correction terms in ONE block-scaled fp8
+// MFMA.  Tensor format "q16": a 32-channel block is 128 bytes = [hi: 32 x fp16][hi8: 32 x fp8 e4m3 of hi * 2^-E][lo8: 32 x fp8 of
+// (x - hi) * 2^(11-E)] - the footprint of pair16, 15 significant bits, one power-of-two scale E per tensor.
+struct MathF16Q : MathF16 {
+    static constexpr bool Q16 = true;
+};
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+// D += 2^(sa + sb - 254) * sum over k of A[k] B[k], 64 fp8 values per row: lanes 0-31 hold k 0..31, lanes 32-63 k 32..63
+__device__ __forceinline__ f32x16 mma_f8(v4u a0, v4u a1, v4u b0, v4u b1, f32x16 c, int sa, int sb) {
+    const v8i_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const v8i_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
 
 // 4 consecutive channels -> the two 8-byte halves (hi, lo) of their slot in a pair16 group.  Two values at a time on the packed
 // conversions of gfx950 (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, v_pk_add_f32): ~4.5 VALU ops per value instead of ~10 for the

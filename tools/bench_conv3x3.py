@@ -11,6 +11,26 @@ from detzero_amd import ops                      # noqa: E402
 from detzero_amd.det_modules import conv_layer   # noqa: E402
 
 
+def q16_pack(x, e):
+    """(..., C) fp32 -> same-shape float32-typed q16 bits: per 32 channels [hi fp16 x32 | fp8(hi * 2^-e) x32 | fp8((x - hi) * 2^(11-e)) x32]."""
+    shp = x.shape
+    xb = x.reshape(-1, shp[-1] // 32, 32).float()
+    hi = xb.half()
+    hf = hi.float()
+    hi8 = (hf * 2.0 ** (-e)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    lo8 = ((xb - hf) * 2.0 ** (11 - e)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    by = torch.cat([hi.view(torch.uint8).reshape(*xb.shape[:2], 64), hi8.view(torch.uint8), lo8.view(torch.uint8)], dim=-1)
+    return by.reshape(-1, shp[-1] * 4).view(torch.float32).reshape(shp)
+
+
+def q16_unpack(q, e):
+    shp = q.shape
+    by = q.contiguous().view(torch.uint8).reshape(-1, shp[-1] // 32, 128)
+    hi = by[..., :64].contiguous().view(torch.float16).float()
+    lo = by[..., 96:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** (e - 11)
+    return (hi + lo).reshape(shp)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
@@ -19,6 +39,7 @@ def main():
     ap.add_argument('--cout', type=int, default=128)
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--math', type=int, default=1, help='1 = f16x2, 2 = bf16x2, 3 = f16 (single product)')
+    ap.add_argument('--q16', action='store_true', help='fp16 + fp8 prototype (diag build, DZ_TUNE_C3_Q16=1): q16 tensors, checked against fp32 torch')
     ap.add_argument('--data', default='randn', choices=['randn', 'relu', 'zero', 'const'])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -33,8 +54,13 @@ def main():
         x, wr = x * 0, wr * 0
     elif a.data == 'const':
         x, wr = (x != 0).float(), wr * 0 + 0.5
-    xp = ops.pair16_from_f32(x.to(dev), math=1)
-    wt = ops.pack_weight_split(wr.to(dev), 1)
+    ea, ew = int(os.environ.get('DZ_TUNE_Q16_EA', '2')), int(os.environ.get('DZ_TUNE_Q16_EW', '-4'))
+    if a.q16:
+        xp = q16_pack(x, ea).to(dev)
+        wt = q16_pack(wr.transpose(-1, -2).contiguous(), ew).to(dev)
+    else:
+        xp = ops.pair16_from_f32(x.to(dev), math=1)
+        wt = ops.pack_weight_split(wr.to(dev), 1)
     scale = torch.ones(wt.shape[-2], device=dev)
     shift = torch.zeros(wt.shape[-2], device=dev)
     y = torch.zeros(a.batch, h + 2, w + 2, a.cout, device=dev)
@@ -45,6 +71,11 @@ def main():
     for _ in range(5):
         run()
     torch.cuda.synchronize()
+    if a.q16 or os.environ.get('DZ_CHECK'):
+        ref = torch.nn.functional.conv2d(x[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double(), wr.reshape(3, 3, a.cin, a.cout).permute(3, 2, 0, 1).double(),
+                                         padding=1).permute(0, 2, 3, 1).clamp_min(0)
+        got = (q16_unpack(y.cpu(), ea) if a.q16 else ops.pair16_to_f32(y, 1).cpu())[:, 1:-1, 1:-1].double()
+        print('max |err| / max |ref| = %.3e   mean %.3e' % (float((got - ref).abs().max() / ref.abs().max()), float((got - ref).abs().mean() / ref.abs().mean())))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
