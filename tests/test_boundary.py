@@ -159,3 +159,17 @@ def test_collate_batch_matches_reference_layout():
     assert out['batch_size'] == 2 and out['voxels'].shape == (5, 5, 5) and out['voxel_coords'].shape == (5, 4)
     assert out['voxel_coords'][:, 0].tolist() == [0, 0, 0, 1, 1] and out['points'].shape == (11, 6)
     assert out['gt_boxes'].shape == (2, 5, 8) and out['gt_boxes'][0, 2:].sum() == 0 and out['frame_id'].tolist() == [4, 5]
+
+
+def test_math_modes_and_their_tensor_encoding():
+    """'f16' computes on the tensors of 'f16x2' (same packers, same conversion entry points); the header names the same ids."""
+    from detzero_amd import ops
+    assert ops.MATH_MODES == {'f32': 0, 'f16x2': 1, 'bf16x2': 2, 'f16': 3}
+    assert [ops.storage_math(m) for m in (0, 1, 2, 3)] == [0, 1, 2, 1]
+    hdr = open(os.path.join(ROOT, 'include', 'detzero_hip.h')).read()
+    for name, val in (('DZ_MATH_F32', 0), ('DZ_MATH_F16X2', 1), ('DZ_MATH_BF16X2', 2), ('DZ_MATH_F16', 3)):
+        assert ('#define %s %d' % (name, val)) in hdr
+    x = torch.randn(4, 16)
+    assert torch.equal(ops.pair16_pack(x, 3), ops.pair16_pack(x, 1))
+    with pytest.raises(Exception):
+        ops.math_id('fp8')
