@@ -475,11 +475,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     asm volatile("s_waitcnt vmcnt(0)");      // nothing of this file's asm loads may stay in flight at exit
 }
 
-// q16 prototype (diag builds): tensor exponents from the environment: activations scaled by 2^-DZ_TUNE_Q16_EA, weights by 2^-DZ_TUNE_Q16_EW
+// q16 prototype (diag builds): tensor exponents from the environment (read once): activations scaled by 2^-DZ_TUNE_Q16_EA, weights by
+// 2^-DZ_TUNE_Q16_EW; the kernels of every other math type ignore the three arguments
 static int q16_env(const char *n, int d) { const char *v = getenv(n); return v ? atoi(v) : d; }
-static int q16_sa() { return 127 + q16_env("DZ_TUNE_Q16_EW", -4); }                       // weights are the A operand
-static int q16_sb() { return 127 + q16_env("DZ_TUNE_Q16_EA", 2) - 11; }                   // activations the B operand; both correction terms carry 2^-11
-static float q16_act() { return ldexpf(1.f, -q16_env("DZ_TUNE_Q16_EA", 2)); }
+static int q16_sa() { static const int v = 127 + q16_env("DZ_TUNE_Q16_EW", -4); return v; }               // weights are the A operand
+static int q16_sb() { static const int v = 127 + q16_env("DZ_TUNE_Q16_EA", 2) - 11; return v; }           // activations the B operand; both correction terms carry 2^-11
+static float q16_act() { static const float v = ldexpf(1.f, -q16_env("DZ_TUNE_Q16_EA", 2)); return v; }
 
 template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0, int PT = 2>
 static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
