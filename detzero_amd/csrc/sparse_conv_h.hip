@@ -262,7 +262,10 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
         }
 #endif
         if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));   // 4 waves (r01d)
-        return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);                   // 8 waves of 32 x 64
+        if (t128 == 2) return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);    // three register stages (r01e-r02f)
+        // 8 waves of 32 x 64, four register stages with the ring (202 registers at two waves per SIMD): +0.3 % of a pass over three,
+        // A/B inside the detector on one box (tools/gpu_ab_env.sh) - gather latency is not what limits this kernel
+        return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 4, 2, 2>(a, stream);
     }
     set_error("dz_spconv_forward_split: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return DZ_ERR_UNSUPPORTED;
