@@ -338,7 +338,7 @@ class FramePipeline:
             pts = frames.tensor.reshape(-1, c) if isinstance(frames, _StackedFrames) else torch.cat(list(frames), dim=0)
             lvl1, x = ops.voxelize_to_level(pts, nb, self.info.point_cloud_range, self.info.voxel_size,
                                             self.info.max_points_per_voxel, self.info.max_voxels[self.mode], bb.sparse_shape,
-                                            bb.CIN_PAD, math=bb.math, xy_range_mask=True)
+                                            bb.CIN_PAD, math=bb.math, xy_range_mask=True, layout=bb.layout)
             return ('level', lvl1, x)
         return ('voxels',) + tuple(self._voxelize(frames))
 

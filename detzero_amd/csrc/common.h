@@ -69,6 +69,38 @@ __device__ __forceinline__ int bitmap_find(const uint32_t *__restrict__ bitmap,
     return (int)(prefix[w] + __popc(word & ((1u << bit) - 1u)));
 }
 
+// ---- cell keys of a sparse level -------------------------------------------------------------------------------
+// layout 0 (DZ_LAYOUT_LINEAR): key = ((b*D + z)*H + y)*W + x - rows in ascending (b, z, y, x) order.
+// layout 1 (DZ_LAYOUT_BRICK):  the (y, x) plane is cut into 8 x 8 columns that run through all of z; a column ("brick") is
+//   D * 64 consecutive keys = 2 * D bitmap words:  key = ((((b*NBY + y/8)*NBX + x/8)*D + z) << 6) | (y%8 << 3) | x%8.
+//   Feature rows (= ranks of the set bits) of a spatial neighbourhood are then close together in memory: the rows a
+//   128-row tile of a 3x3x3 convolution reads are 1.3-1.8x its own rows (4.3x in the linear order), which is what lets
+//   the tile convolution (sparse_conv_t.hip) stage a tile's inputs in LDS once.
+struct LevelGeom {
+    int b, d, h, w, layout, nby, nbx;
+    __host__ __device__ __forceinline__ uint32_t key(int bi, int z, int y, int x) const {
+        if (layout == 0) return (uint32_t)(((bi * d + z) * h + y) * w + x);
+        const uint32_t brick = (uint32_t)((bi * nby + (y >> 3)) * nbx + (x >> 3));
+        return ((brick * (uint32_t)d + (uint32_t)z) << 6) | (uint32_t)(((y & 7) << 3) | (x & 7));
+    }
+    __host__ __device__ __forceinline__ bool inside(int bi, int z, int y, int x) const {
+        return (unsigned)bi < (unsigned)b && (unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+    }
+    __host__ __device__ __forceinline__ size_t cells() const {
+        return layout == 0 ? (size_t)b * d * h * w : (size_t)b * nby * nbx * d * 64;
+    }
+    // first key of batch item bi (its keys are one contiguous range in both layouts)
+    __host__ __device__ __forceinline__ uint32_t batch_key(int bi) const {
+        return layout == 0 ? (uint32_t)bi * (uint32_t)(d * h * w) : (uint32_t)bi * (uint32_t)(nby * nbx * d * 64);
+    }
+};
+static inline LevelGeom make_level(int b, int d, int h, int w, int layout) {
+    LevelGeom g;
+    g.b = b; g.d = d; g.h = h; g.w = w; g.layout = layout ? 1 : 0;
+    g.nby = (h + 7) / 8; g.nbx = (w + 7) / 8;
+    return g;
+}
+
 // Exclusive scan of one value per thread across a 256-thread block (4 waves of 64).
 // lds: >= 4 uint32.  Returns the exclusive prefix of `v`; `total` = block sum.
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *lds, uint32_t &total) {
@@ -96,6 +128,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *ld
 // Bitmap scan (3 launches): prefix[w] = #set bits in words < w ; *d_total = popcount of all.
 // Optionally emits the coordinates of every set bit at its rank:
 //   mode 0: key = ((b*D+z)*H+y)*W+x  -> coords [b,z,y,x]   (dims = D,H,W)
+//   mode 2: brick keys of a LevelGeom (layout 1; dims = D, NBY, NBX) -> coords [b,z,y,x]
 //   mode 1: key = ((b*GX+x)*GY+y)*GZ+z -> coords [b,z,y,x] (dims = GX,GY,GZ)   (DynamicMeanVFE order)
 //   mode -1: no coordinates
 struct ScanDims { int d0, d1, d2; };
@@ -105,6 +138,9 @@ int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream);
 size_t bitmap_scan_workspace_bytes(size_t nwords);
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
-                hipStream_t stream, bool nonzero_only = false);     // nonzero_only (mode 0): prefix[] valid only at words with a bit set
+                hipStream_t stream, bool nonzero_only = false);     // nonzero_only (modes 0, 2): prefix[] valid only at words with a bit set
+// scan of a level's bitmap, coordinates [b,z,y,x] emitted at their rank in the level's key layout
+int level_scan(const uint32_t *bitmap, const LevelGeom &lg, uint32_t *prefix, int *d_total, int *coords_out, int cap_out, void *ws,
+               size_t ws_bytes, hipStream_t stream, bool nonzero_only);
 
 }  // namespace dz

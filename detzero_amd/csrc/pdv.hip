@@ -97,14 +97,13 @@ __global__ void k_cen_divide(float *__restrict__ sums, const int *__restrict__ c
 
 // ------------------------------------------------------------------------------------------------ lookup in a sparse level
 __global__ void k_index_lookup(const int *__restrict__ coords, const int *__restrict__ d_n, int n, const uint32_t *__restrict__ bitmap,
-                               const uint32_t *__restrict__ prefix, int B, int D, int H, int W, int *__restrict__ out) {
+                               const uint32_t *__restrict__ prefix, LevelGeom lg, int *__restrict__ out) {
     const int nn = d_n ? min(*d_n, n) : n;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int v = -1;
         if (i < nn) {
             const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-            if ((unsigned)c.x < (unsigned)B && (unsigned)c.y < (unsigned)D && (unsigned)c.z < (unsigned)H && (unsigned)c.w < (unsigned)W)
-                v = bitmap_find(bitmap, prefix, (uint32_t)(((c.x * D + c.y) * H + c.z) * W + c.w));
+            if (lg.inside(c.x, c.y, c.z, c.w)) v = bitmap_find(bitmap, prefix, lg.key(c.x, c.y, c.z, c.w));
         }
         out[i] = v;
     }
@@ -344,9 +343,9 @@ extern "C" {
 
 static size_t cen_layout(int n, int batch, int gx, int gy, int gz, int scaling, int cap1, size_t *o_bm1, size_t *o_pf1, size_t *o_bm2, size_t *o_pf2,
                          size_t *o_keys2, size_t *o_sw, size_t *sw_bytes, size_t *words1, size_t *words2) {
-    *words1 = dz_index_words(batch, gz, gy, gx);
+    *words1 = dz_index_words(batch, gz, gy, gx, DZ_LAYOUT_LINEAR);
     const int d2 = (gz + scaling - 1) / scaling, h2 = (gy + scaling - 1) / scaling, w2 = (gx + scaling - 1) / scaling;
-    *words2 = dz_index_words(batch, d2, h2, w2);
+    *words2 = dz_index_words(batch, d2, h2, w2, DZ_LAYOUT_LINEAR);
     size_t off = align_up((size_t)(n < 1 ? 1 : n) * 4, 256);                 // keys of the points
     *o_bm1 = off; off += align_up(*words1 * 4, 256);
     *o_pf1 = off; off += align_up(*words1 * 4, 256);
@@ -422,13 +421,13 @@ int dz_pdv_voxel_centroids(const float *points_b, int n, int c, const float *h_r
     return DZ_OK;
 }
 
-int dz_index_lookup(const int *coords, const int *d_n, int n, const uint32_t *bitmap, const uint32_t *prefix, int b, int d, int h, int w, int *out,
-                    void *stream_) {
+int dz_index_lookup(const int *coords, const int *d_n, int n, const uint32_t *bitmap, const uint32_t *prefix, int b, int d, int h, int w, int layout,
+                    int *out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(n >= 0 && b >= 1 && d >= 1 && h >= 1 && w >= 1, "dz_index_lookup: bad sizes");
+    DZ_CHECK_ARG(n >= 0 && b >= 1 && d >= 1 && h >= 1 && w >= 1 && (layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK), "dz_index_lookup: bad sizes");
     if (n == 0) return DZ_OK;
     DZ_CHECK_ARG(coords && bitmap && prefix && out, "dz_index_lookup: null pointer");
-    hipLaunchKernelGGL(k_index_lookup, dim3(stream_grid(n, 256)), dim3(256), 0, stream, coords, d_n, n, bitmap, prefix, b, d, h, w, out);
+    hipLaunchKernelGGL(k_index_lookup, dim3(stream_grid(n, 256)), dim3(256), 0, stream, coords, d_n, n, bitmap, prefix, make_level(b, d, h, w, layout), out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -135,8 +135,23 @@ __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ 
         uint32_t word = w_s[idx];
         if (!word) continue;
         uint32_t r = p_s[idx];
-        // decode the word's first cell once (3 divisions), then walk the bits with carries only
         const uint32_t key0 = (uint32_t)(((size_t)blockIdx.x * CHUNK + idx) << 5);
+        if (MODE == 2) {
+            // brick keys (LevelGeom layout 1; dec = D, NBY, NBX): the 32 cells of a word share (b, y/8, x/8, z) and y%8 / 4
+            uint32_t z, by, bx;
+            const uint32_t brick = fast_divmod(key0 >> 6, dec.d0, z);
+            const uint32_t t = fast_divmod(brick, dec.d2, bx);
+            const uint32_t bb = fast_divmod(t, dec.d1, by);
+            const int y0 = (int)(by * 8u + ((key0 >> 3) & 7u)), x0 = (int)(bx * 8u);
+            while (word) {
+                const int bit = __ffs((int)word) - 1;
+                word &= word - 1;
+                if ((int)r < cap_out) reinterpret_cast<int4 *>(coords_out)[r] = make_int4((int)bb, (int)z, y0 + (bit >> 3), x0 + (bit & 7));
+                ++r;
+            }
+            continue;
+        }
+        // decode the word's first cell once (3 divisions), then walk the bits with carries only
         uint32_t c2, c1, c0;
         const uint32_t t1 = fast_divmod(key0, dec.d2, c2);
         const uint32_t t0 = fast_divmod(t1, dec.d1, c1);
@@ -185,6 +200,12 @@ static void launch_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix,
     else if (mode == 1)
         hipLaunchKernelGGL((k_scan_down<1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
                            coords_out, cap_out);
+    else if (mode == 2 && nonzero_only)
+        hipLaunchKernelGGL((k_scan_down<2, WPT, true>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
+    else if (mode == 2)
+        hipLaunchKernelGGL((k_scan_down<2, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
+                           coords_out, cap_out);
     else
         hipLaunchKernelGGL((k_scan_down<-1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
                            coords_out, cap_out);
@@ -214,31 +235,24 @@ int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_
 // level construction
 // ------------------------------------------------------------------------------------------
 __global__ void k_set_bits_from_coords(const int *__restrict__ coords, const int *__restrict__ d_n, int n_cap,
-                                       int B, int D, int H, int W, uint32_t *__restrict__ bitmap) {
+                                       LevelGeom lg, uint32_t *__restrict__ bitmap) {
     const int n = d_n ? min(*d_n, n_cap) : n_cap;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-        if ((unsigned)c.x >= (unsigned)B || (unsigned)c.y >= (unsigned)D || (unsigned)c.z >= (unsigned)H ||
-            (unsigned)c.w >= (unsigned)W)
-            continue;
-        const uint32_t key = (uint32_t)(((c.x * D + c.y) * H + c.z) * W + c.w);
+        if (!lg.inside(c.x, c.y, c.z, c.w)) continue;
+        const uint32_t key = lg.key(c.x, c.y, c.z, c.w);
         atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
     }
 }
 
-__global__ void k_rank_of_coords(const int *__restrict__ coords, const int *__restrict__ d_n, int n_cap, int B,
-                                 int D, int H, int W, const uint32_t *__restrict__ bitmap,
-                                 const uint32_t *__restrict__ prefix, int *__restrict__ rank) {
+__global__ void k_rank_of_coords(const int *__restrict__ coords, const int *__restrict__ d_n, int n_cap, LevelGeom lg,
+                                 const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ prefix, int *__restrict__ rank) {
     const int n = d_n ? min(*d_n, n_cap) : n_cap;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
         int r = -1;
         if (i < n) {
             const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-            if ((unsigned)c.x < (unsigned)B && (unsigned)c.y < (unsigned)D && (unsigned)c.z < (unsigned)H &&
-                (unsigned)c.w < (unsigned)W) {
-                const uint32_t key = (uint32_t)(((c.x * D + c.y) * H + c.z) * W + c.w);
-                r = bitmap_rank(bitmap, prefix, key);
-            }
+            if (lg.inside(c.x, c.y, c.z, c.w)) r = bitmap_rank(bitmap, prefix, lg.key(c.x, c.y, c.z, c.w));
         }
         rank[i] = r;
     }
@@ -263,7 +277,7 @@ __device__ __forceinline__ int outs_of(int c, int k, int s, int p, int od, int (
 }
 
 __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__restrict__ d_m_in, int cap_in,
-                               ConvGeom g, uint32_t *__restrict__ bitmap_out) {
+                               ConvGeom g, LevelGeom lo, uint32_t *__restrict__ bitmap_out) {
     const int m = min(*d_m_in, cap_in);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
@@ -273,11 +287,10 @@ __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__r
         const int nx = outs_of(c.w, g.k[2], g.s[2], g.p[2], g.ow, wx);
         for (int a = 0; a < nz; ++a)
             for (int b = 0; b < ny; ++b) {
-                const uint32_t rowkey = (uint32_t)(((c.x * g.od + wz[a]) * g.oh + wy[b]) * g.ow);
-                // the x candidates of one row are adjacent cells: usually one bitmap word
+                // the x candidates of one row are adjacent cells: usually one bitmap word (in both layouts)
                 uint32_t word_idx = 0xFFFFFFFFu, bits = 0u;
                 for (int e = 0; e < nx; ++e) {
-                    const uint32_t key = rowkey + (uint32_t)wx[e];
+                    const uint32_t key = lo.key(c.x, wz[a], wy[b], wx[e]);
                     if ((key >> 5) != word_idx) {
                         // ~8 inputs feed every output: test before the atomic (a stale read only costs a redundant atomicOr)
                         if (bits && (__builtin_nontemporal_load(&bitmap_out[word_idx]) & bits) != bits) atomicOr(&bitmap_out[word_idx], bits);
@@ -296,8 +309,8 @@ __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__r
 __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__ coords_out,
                                                          const int *__restrict__ d_m_out, int cap_out,
                                                          const uint32_t *__restrict__ bitmap_in,
-                                                         const uint32_t *__restrict__ prefix_in, int B, int D,
-                                                         int H, int W, ConvGeom g, int *__restrict__ nbr,
+                                                         const uint32_t *__restrict__ prefix_in, LevelGeom li,
+                                                         ConvGeom g, int *__restrict__ nbr,
                                                          uint32_t *__restrict__ tile_masks) {
     // tile_masks (optional): word o/32 collects, for 32 consecutive output rows (the pixel side of one 32x32 MFMA fragment),
     // the kernel taps that have at least one neighbour - what the conv kernels need to skip empty taps without scanning the
@@ -317,13 +330,12 @@ __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__
             const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
             const int uz = c.y * g.s[0] - g.p[0] + tz;
             const int uy = c.z * g.s[1] - g.p[1] + ty;
-            const bool row_ok = (unsigned)uz < (unsigned)D && (unsigned)uy < (unsigned)H;
+            const bool row_ok = (unsigned)uz < (unsigned)li.d && (unsigned)uy < (unsigned)li.h;
             const int base_x = c.w * g.s[2] - g.p[2];
-            const uint32_t row_key = (uint32_t)(((c.x * D + uz) * H + uy) * W);
             for (int tx = 0; tx < g.k[2]; ++tx) {
                 const int ux = base_x + tx;
                 int v = -1;
-                if (row_ok && (unsigned)ux < (unsigned)W) v = bitmap_find(bitmap_in, prefix_in, row_key + (uint32_t)ux);
+                if (row_ok && (unsigned)ux < (unsigned)li.w) v = bitmap_find(bitmap_in, prefix_in, li.key(c.x, uz, uy, ux));
                 const int tap = (tz * g.k[1] + ty) * g.k[2] + tx;
                 nbr[(size_t)tap * cap_out + o] = v;
                 if (v >= 0) bits |= 1u << tap;
@@ -373,6 +385,15 @@ static bool geom_from(const int *k3, const int *s3, const int *p3, int d, int h,
     return g.od > 0 && g.oh > 0 && g.ow > 0;
 }
 
+// scan of a level's bitmap with coordinate emission in the level's key layout
+int level_scan(const uint32_t *bitmap, const LevelGeom &lg, uint32_t *prefix, int *d_total, int *coords_out, int cap_out, void *ws,
+               size_t ws_bytes, hipStream_t stream, bool nonzero_only) {
+    const size_t nwords = align_up((lg.cells() + 31) / 32, 8);        // = dz_index_words
+    if (lg.layout == 0)
+        return bitmap_scan(bitmap, nwords, prefix, d_total, 0, ScanDims{lg.d, lg.h, lg.w}, coords_out, cap_out, ws, ws_bytes, stream, nonzero_only);
+    return bitmap_scan(bitmap, nwords, prefix, d_total, 2, ScanDims{lg.d, lg.nby, lg.nbx}, coords_out, cap_out, ws, ws_bytes, stream, nonzero_only);
+}
+
 }  // namespace dz
 
 using namespace dz;
@@ -389,49 +410,51 @@ int dz_device_cu_count(void) {
     return n;
 }
 
-size_t dz_index_words(int b, int d, int h, int w) {
-    const size_t cells = (size_t)b * d * h * w;
+size_t dz_index_words(int b, int d, int h, int w, int layout) {
+    const size_t cells = make_level(b, d, h, w, layout).cells();
     // padded to a multiple of 8 words so the scan can use 32-byte vector loads
     return align_up((cells + 31) / 32, 8);
 }
 
-size_t dz_index_workspace_bytes(int b, int d, int h, int w) {
-    return bitmap_scan_workspace_bytes(dz_index_words(b, d, h, w));
+size_t dz_index_workspace_bytes(int b, int d, int h, int w, int layout) {
+    return bitmap_scan_workspace_bytes(dz_index_words(b, d, h, w, layout));
 }
 
-static int check_cells(int b, int d, int h, int w) {
-    const size_t cells = (size_t)b * d * h * w;
-    if (b < 1 || d < 1 || h < 1 || w < 1 || cells >= 0xFFFFFFFFull) {
-        set_error("grid %d x %d x %d x %d does not fit 32-bit cell keys", b, d, h, w);
+static int check_cells(int b, int d, int h, int w, int layout) {
+    if (b < 1 || d < 1 || h < 1 || w < 1 || (layout != DZ_LAYOUT_LINEAR && layout != DZ_LAYOUT_BRICK) ||
+        make_level(b, d, h, w, layout).cells() >= 0xFFFFFFFFull) {
+        set_error("grid %d x %d x %d x %d (layout %d) does not fit 32-bit cell keys", b, d, h, w, layout);
         return DZ_ERR_UNSUPPORTED;
     }
     return DZ_OK;
 }
 
-int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, int d, int h, int w,
+
+int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, int d, int h, int w, int layout,
                          uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap_out,
                          int *rank_of_input, void *ws, size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG((coords || n_cap == 0) && bitmap && prefix && coords_out && d_m && n_cap >= 0 && cap_out >= 0,
                  "dz_index_from_coords: null/negative argument");
-    int rc = check_cells(b, d, h, w);
+    int rc = check_cells(b, d, h, w, layout);
     if (rc) return rc;
-    const size_t nwords = dz_index_words(b, d, h, w);
+    const LevelGeom lg = make_level(b, d, h, w, layout);
+    const size_t nwords = dz_index_words(b, d, h, w, layout);
     rc = fill_u32(bitmap, 0u, nwords, stream);
     if (rc) return rc;
     if (n_cap > 0)
         hipLaunchKernelGGL(k_set_bits_from_coords, dim3(stream_grid(n_cap, 256)), dim3(256), 0, stream, coords,
-                           d_n, n_cap, b, d, h, w, bitmap);
-    rc = bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{d, h, w}, coords_out, cap_out, ws, ws_bytes, stream);
+                           d_n, n_cap, lg, bitmap);
+    rc = level_scan(bitmap, lg, prefix, d_m, coords_out, cap_out, ws, ws_bytes, stream, false);
     if (rc) return rc;
     if (rank_of_input && n_cap > 0)
         hipLaunchKernelGGL(k_rank_of_coords, dim3(stream_grid(n_cap, 256)), dim3(256), 0, stream, coords, d_n,
-                           n_cap, b, d, h, w, bitmap, prefix, rank_of_input);
+                           n_cap, lg, bitmap, prefix, rank_of_input);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
-int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int b, int d, int h, int w,
+int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int b, int d, int h, int w, int layout,
                         const int *h_k3, const int *h_s3, const int *h_p3, uint32_t *bitmap_out,
                         uint32_t *prefix_out, int *coords_out, int *d_m_out, int cap_out, void *ws,
                         size_t ws_bytes, void *stream_) {
@@ -440,16 +463,16 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
                  "dz_index_downsample: null argument");
     ConvGeom g;
     DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_index_downsample: bad kernel/stride/padding");
-    int rc = check_cells(b, g.od, g.oh, g.ow);
+    int rc = check_cells(b, g.od, g.oh, g.ow, layout);
     if (rc) return rc;
-    const size_t nwords = dz_index_words(b, g.od, g.oh, g.ow);
+    const LevelGeom lo = make_level(b, g.od, g.oh, g.ow, layout);
+    const size_t nwords = dz_index_words(b, g.od, g.oh, g.ow, layout);
     rc = fill_u32(bitmap_out, 0u, nwords, stream);
     if (rc) return rc;
     if (cap_in > 0)
         hipLaunchKernelGGL(k_mark_outputs, dim3(stream_grid(cap_in, 256)), dim3(256), 0, stream, coords_in, d_m_in,
-                           cap_in, g, bitmap_out);
-    rc = bitmap_scan(bitmap_out, nwords, prefix_out, d_m_out, 0, ScanDims{g.od, g.oh, g.ow}, coords_out, cap_out,
-                     ws, ws_bytes, stream);
+                           cap_in, g, lo, bitmap_out);
+    rc = level_scan(bitmap_out, lo, prefix_out, d_m_out, coords_out, cap_out, ws, ws_bytes, stream, false);
     if (rc) return rc;
     DZ_LAUNCH_CHECK();
     return DZ_OK;
@@ -458,12 +481,13 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
 int dz_tile_masks_words(int cap_out) { return cap_out < 0 ? 0 : tile_masks_words(cap_out); }
 
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
-                       const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3, const int *h_s3,
+                       const uint32_t *prefix_in, int b, int d, int h, int w, int layout, const int *h_k3, const int *h_s3,
                        const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(coords_out && d_m_out && bitmap_in && prefix_in && nbr, "dz_build_neighbors: null argument");
     ConvGeom g;
     DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_build_neighbors: bad kernel/stride/padding");
+    DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_build_neighbors: bad layout %d", layout);
     if (cap_out == 0) return DZ_OK;
     if (tile_masks) {
         const int rc = fill_u32(tile_masks, 0u, (size_t)tile_masks_words(cap_out), stream);
@@ -471,7 +495,7 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
     }
     const long work = (long)cap_out * g.k[0] * g.k[1];
     hipLaunchKernelGGL(k_build_neighbors, dim3(stream_grid(work, 256)), dim3(256), 0, stream, coords_out, d_m_out,
-                       cap_out, bitmap_in, prefix_in, b, d, h, w, g, nbr, tile_masks);
+                       cap_out, bitmap_in, prefix_in, make_level(b, d, h, w, layout), g, nbr, tile_masks);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

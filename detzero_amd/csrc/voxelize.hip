@@ -168,7 +168,7 @@ __global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int
 // ((b*D + z)*H + y)*W + x, the scan writes the level's prefix / canonical coordinates / count, and the voxel means go
 // to the voxel's canonical row directly (zero-padded to the backbone's input width, optionally as pair16).  The
 // first-appearance ordering, the voxel list, dz_index_from_coords and dz_scatter_rows all disappear.
-__global__ void k_level_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, int n_per, int level_d,
+__global__ void k_level_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, int n_per, LevelGeom lg,
                              uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *p = pts + (size_t)i * c;
@@ -176,7 +176,7 @@ __global__ void k_level_keys(const float *__restrict__ pts, int n, int c, VoxGeo
         int cx, cy, cz;
         uint32_t key = KEY_INVALID;
         if (voxel_coord(xyz, g, cx, cy, cz)) {
-            key = (uint32_t)((((i / n_per) * level_d + cz) * g.g[1] + cy) * g.g[0] + cx);
+            key = lg.key(i / n_per, cz, cy, cx);
             atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
         }
         keys[i] = key;
@@ -339,7 +339,7 @@ extern "C" {
 
 size_t dz_voxelize_hard_workspace_bytes(int n, int gx, int gy, int gz, int max_points) {
     if (n < 1) n = 1;
-    return carve_hard(nullptr, n, dz_index_words(1, gz, gy, gx), max_points).total;
+    return carve_hard(nullptr, n, dz_index_words(1, gz, gy, gx, DZ_LAYOUT_LINEAR), max_points).total;
 }
 
 // shared driver of the two emit flavours: feats != nullptr selects the fused emit + mean
@@ -355,7 +355,7 @@ static int voxelize_hard_impl(const float *points, int n, int c, const float *h_
     if (n == 0) return fill_u32(d_num_voxels, 0u, (size_t)batch, stream);
     DZ_CHECK_ARG(points, "dz_voxelize_hard: null points");
     const int n_per = n / batch;
-    const size_t nwords = dz_index_words(batch, g.g[2], g.g[1], g.g[0]);
+    const size_t nwords = dz_index_words(batch, g.g[2], g.g[1], g.g[0], DZ_LAYOUT_LINEAR);
     HardWs w = carve_hard(ws, n, nwords, max_points);
     if (ws_bytes < w.total) { set_error("dz_voxelize_hard: workspace %zu < %zu", ws_bytes, w.total); return DZ_ERR_WORKSPACE; }
     const size_t pt_words = align_up(((size_t)n + 31) / 32, 8);
@@ -409,7 +409,7 @@ int dz_voxelize_hard_mean(const float *points, int n, int c, const float *h_rang
 
 size_t dz_voxelize_hard_batched_workspace_bytes(int n_per_frame, int batch, int gx, int gy, int gz, int max_points) {
     const long n = (long)(n_per_frame < 1 ? 1 : n_per_frame) * (batch < 1 ? 1 : batch);
-    return carve_hard(nullptr, (int)n, dz_index_words(batch < 1 ? 1 : batch, gz, gy, gx), max_points).total;
+    return carve_hard(nullptr, (int)n, dz_index_words(batch < 1 ? 1 : batch, gz, gy, gx, DZ_LAYOUT_LINEAR), max_points).total;
 }
 
 int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batch, int c, const float *h_range6,
@@ -437,13 +437,13 @@ static size_t level_ws_layout(long n, int max_points, int cap, size_t nwords, si
     return off;
 }
 
-size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w) {
+size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w, int layout) {
     size_t a, b, c;
-    return level_ws_layout((long)n_per_frame * batch, max_points, cap, dz_index_words(batch, d, h, w), &a, &b, &c);
+    return level_ws_layout((long)n_per_frame * batch, max_points, cap, dz_index_words(batch, d, h, w, layout), &a, &b, &c);
 }
 
 int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c, const float *h_range6, const float *h_vsize3,
-                         const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int level_d, uint32_t *bitmap,
+                         const int *h_grid3, int xy_range_mask, int max_points, int max_voxels, int level_d, int layout, uint32_t *bitmap,
                          uint32_t *prefix, int *coords_out, int *d_m, int cap, float *feats, int c_dst, int math, void *ws,
                          size_t ws_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -461,9 +461,10 @@ int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c,
     }
     const long n = (long)n_per_frame * batch;
     DZ_CHECK_ARG(n < 0x7FFFFFFFl && cap >= (n < 1 ? 1 : 0), "dz_voxelize_to_level: too many points");
-    const size_t cells = (size_t)batch * level_d * g.g[1] * g.g[0];
-    if (cells >= 0xFFFFFFFFull) { set_error("dz_voxelize_to_level: grid x batch too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
-    const size_t nwords = dz_index_words(batch, level_d, g.g[1], g.g[0]);
+    DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_voxelize_to_level: bad layout %d", layout);
+    const LevelGeom lg = make_level(batch, level_d, g.g[1], g.g[0], layout);
+    if (lg.cells() >= 0xFFFFFFFFull) { set_error("dz_voxelize_to_level: grid x batch too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
+    const size_t nwords = dz_index_words(batch, level_d, g.g[1], g.g[0], layout);
     size_t o_min, o_sw, sw_bytes;
     const size_t need = level_ws_layout(n, max_points, cap, nwords, &o_min, &o_sw, &sw_bytes);
     if (ws_bytes < need) { set_error("dz_voxelize_to_level: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }
@@ -472,13 +473,11 @@ int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c,
     int rc = fill_u32(bitmap, 0u, nwords, stream);
     if (!rc) rc = fill_u32(mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
     if (rc) return rc;
-    if (n == 0) return bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw,
-                                   sw_bytes, stream, true);
+    if (n == 0) return level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true);
     DZ_CHECK_ARG(points, "dz_voxelize_to_level: null points");
     const int grid_n = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, level_d, keys, bitmap);
-    rc = bitmap_scan(bitmap, nwords, prefix, d_m, 0, ScanDims{level_d, g.g[1], g.g[0]}, coords_out, cap, (char *)ws + o_sw, sw_bytes,
-                     stream, true);
+    hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, lg, keys, bitmap);
+    rc = level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_hard_insert, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix, mins, cap, max_points);
     const dim3 ge(stream_grid((long)cap * (c_dst / 8), 256));
@@ -519,7 +518,7 @@ static size_t dyn_layout(int n, size_t nwords, int cap, int c, size_t *o_keys, s
 
 size_t dz_voxelize_dynamic_workspace_bytes(int n, int batch, int gx, int gy, int gz, int c, int cap) {
     size_t a, b, d, e, f, g, h;
-    return dyn_layout(n, dz_index_words(batch, gx, gy, gz), cap, c, &a, &b, &d, &e, &h, &f, &g);
+    return dyn_layout(n, dz_index_words(batch, gx, gy, gz, DZ_LAYOUT_LINEAR), cap, c, &a, &b, &d, &e, &h, &f, &g);
 }
 
 int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h_range6, const float *h_vsize3,
@@ -534,7 +533,7 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
     const size_t cells = (size_t)batch * g.g[0] * g.g[1] * g.g[2];
     // the reference's int32 merge key overflows for b >= 24 on the Waymo grid (vfe.py:128-131); we refuse instead
     if (cells >= 0x7FFFFFFFull) { set_error("dz_voxelize_dynamic_mean: batch*grid exceeds int32 merge keys"); return DZ_ERR_UNSUPPORTED; }
-    const size_t nwords = dz_index_words(batch, g.g[0], g.g[1], g.g[2]);
+    const size_t nwords = dz_index_words(batch, g.g[0], g.g[1], g.g[2], DZ_LAYOUT_LINEAR);
     size_t o_keys, o_bm, o_pf, o_cnt, o_acc, o_sw, sw_bytes;
     const size_t need = dyn_layout(n, nwords, cap, c, &o_keys, &o_bm, &o_pf, &o_cnt, &o_acc, &o_sw, &sw_bytes);
     if (ws_bytes < need) { set_error("dz_voxelize_dynamic_mean: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }

@@ -257,6 +257,10 @@ class VoxelResBackBone8x(_Cached):
                          indice_key='spconv_down2'),
             norm_fn(channels[3]), nn.ReLU())
         self.num_point_features = channels[3]
+        # row order of the sparse levels (ops.LAYOUT_*) and convolution engine of the split math modes: 'tiles' = tile-resident
+        # inputs (csrc/sparse_conv_t.hip), 'gather' = one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h)
+        self.layout = ops.LAYOUT_BRICK
+        self.engine = 'tiles'
         self.backbone_channels = {'x_conv1': channels[0], 'x_conv2': channels[1], 'x_conv3': channels[2],
                                   'x_conv4': channels[3]}
         self.channels = channels
@@ -306,7 +310,7 @@ class VoxelResBackBone8x(_Cached):
         dev = voxel_features.device
         if level1 is None:
             n = voxel_features.shape[0]
-            lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev)
+            lvl1 = ops.SparseLevel(batch_size, self.sparse_shape, max(n, 1), dev, layout=self.layout)
             rank = lvl1.build_from_coords(voxel_coords, d_n)
         else:
             # ops.voxelize_to_level already produced the level-1 index and its feature rows (voxel_features = those rows)
@@ -316,16 +320,21 @@ class VoxelResBackBone8x(_Cached):
         if overlap:
             side.wait_stream(main)
         steps = []          # (down neighbour table or None, same-level table or None, level, ready event or None)
+        tiled = self.engine == 'tiles' and self.math != 0
+
+        def table(src, dst, k, s, p):
+            nbr = src.neighbors_to(dst, k, s, p)
+            return ops.build_tiles(nbr, dst) if tiled and k[0] * k[1] * k[2] >= 3 else nbr
         with torch.cuda.stream(side):
-            nbr1 = lvl1.neighbors_to(lvl1, K3, S1, P1)
+            nbr1 = table(lvl1, lvl1, K3, S1, P1)
             steps.append((None, nbr1, lvl1, side.record_event() if overlap else None))
             level = lvl1
             overflow = None
             for li, name in enumerate(('conv2', 'conv3', 'conv4', 'conv_out')):
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
                 nxt = level.downsample(dp['k'], dp['s'], dp['p'], cap=None if caps is None else int(caps[li]))
-                nbr_d = level.neighbors_to(nxt, dp['k'], dp['s'], dp['p'])
-                nbr_s = nxt.neighbors_to(nxt, K3, S1, P1) if name != 'conv_out' else None
+                nbr_d = table(level, nxt, dp['k'], dp['s'], dp['p'])
+                nbr_s = table(nxt, nxt, K3, S1, P1) if name != 'conv_out' else None
                 if name == 'conv_out' and caps is not None:
                     # overflow flag of the calibrated capacities (same stream as the index build: it is covered by
                     # the last stage's event, so the main stream does not wait for the whole pyramid up front)
@@ -344,6 +353,8 @@ class VoxelResBackBone8x(_Cached):
                         t.record_stream(main)
                         if getattr(t, 'tile_masks', None) is not None:
                             t.tile_masks.record_stream(main)
+                        for tt in getattr(t, 'tiles', None) or ():
+                            tt.record_stream(main)
             if overflow is not None:
                 overflow.record_stream(main)
         x = voxel_features if level1 is not None else ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)

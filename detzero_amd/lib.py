@@ -53,18 +53,18 @@ _SIGS = {
     'dz_voxelize_hard_batched_workspace_bytes': (c_size_t, [c_int] * 6),
     'dz_voxelize_hard_mean_batched': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                               c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'dz_voxelize_to_level_workspace_bytes': (c_size_t, [c_int] * 7),
-    'dz_voxelize_to_level': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+    'dz_voxelize_to_level_workspace_bytes': (c_size_t, [c_int] * 8),
+    'dz_voxelize_to_level': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'dz_mean_vfe': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_voxelize_dynamic_workspace_bytes': (c_size_t, [c_int] * 7),
     'dz_voxelize_dynamic_mean': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'dz_index_words': (c_size_t, [c_int] * 4),
-    'dz_index_workspace_bytes': (c_size_t, [c_int] * 4),
-    'dz_index_from_coords': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+    'dz_index_words': (c_size_t, [c_int] * 5),
+    'dz_index_workspace_bytes': (c_size_t, [c_int] * 5),
+    'dz_index_from_coords': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'dz_index_downsample': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+    'dz_index_downsample': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                     c_void_p]),
     'dz_draw_subsets': (c_int, [c_void_p, c_int, c_int, ctypes.c_ulonglong, c_int, c_void_p, c_void_p]),
@@ -85,7 +85,7 @@ _SIGS = {
     'dz_linear_forward_split': (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                         c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dz_tile_masks_words': (c_int, [c_int]),
-    'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_spconv_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -100,6 +100,12 @@ _SIGS = {
     'dz_scatter_rows_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_forward_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'dz_spconv_tile_rows': (c_int, []),
+    'dz_build_tiles_halo_stride': (c_size_t, [c_int]),
+    'dz_build_tiles': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dz_spconv_tiles_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'dz_spconv_tiles_variant': (ctypes.c_char_p, [c_int, c_int]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
     'dz_conv2d_forward_split': (c_int, [ctypes.POINTER(Conv2dDesc), c_int, c_int, c_void_p]),
@@ -121,7 +127,7 @@ _SIGS = {
     'dz_pdv_centroids_workspace_bytes': (c_size_t, [c_int] * 7),
     'dz_pdv_voxel_centroids': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'dz_index_lookup': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_index_lookup': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_pdv_ball_query': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                   c_int, c_void_p, c_void_p, c_void_p]),
     'dz_pdv_group_features': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

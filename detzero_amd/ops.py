@@ -89,7 +89,8 @@ def voxelize_hard_mean_batched(points, batch, pc_range, voxel_size, max_points, 
     return feats, coords, d_num
 
 
-def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxels, level_shape, c_dst, math=0, xy_range_mask=False):
+def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxels, level_shape, c_dst, math=0, xy_range_mask=False,
+                      layout=0):
     """points (batch*n, C), equally long frames back to back, n <= max_voxels -> (SparseLevel of the frames' voxels, level-1
     feature rows (cap, c_dst) fp32 or pair16): hard voxelizer + MeanVFE + sparse-tensor construction in one launch chain."""
     lib = L.load()
@@ -100,11 +101,11 @@ def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxel
     grid = grid_size_of(pc_range, voxel_size)
     assert [int(level_shape[1]), int(level_shape[2])] == [int(grid[1]), int(grid[0])], (level_shape, grid)
     cap = batch * max(min(int(max_voxels), n_per), 1)
-    lvl = SparseLevel(batch, level_shape, cap, points.device)
+    lvl = SparseLevel(batch, level_shape, cap, points.device, layout=layout)
     feats = torch.empty((cap, c_dst), dtype=torch.float32, device=points.device)
-    ws = _ws(lib.dz_voxelize_to_level_workspace_bytes(n_per, batch, max_points, cap, *lvl.shape))
+    ws = _ws(lib.dz_voxelize_to_level_workspace_bytes(n_per, batch, max_points, cap, *lvl.shape, lvl.layout))
     rc = lib.dz_voxelize_to_level(L.ptr(points), n_per, batch, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid),
-                                  1 if xy_range_mask else 0, max_points, int(max_voxels), lvl.shape[0], L.ptr(lvl.bitmap),
+                                  1 if xy_range_mask else 0, max_points, int(max_voxels), lvl.shape[0], lvl.layout, L.ptr(lvl.bitmap),
                                   L.ptr(lvl.prefix), L.ptr(lvl.coords), L.ptr(lvl.d_m), cap, L.ptr(feats), c_dst, storage_math(math),
                                   L.ptr(ws), ws.numel(), L.stream())
     L.check(rc, 'dz_voxelize_to_level')
@@ -156,21 +157,27 @@ def voxelize_dynamic(points_b, pc_range, voxel_size, batch_size):
 # ------------------------------------------------------------------------------------------------
 # sparse index
 # ------------------------------------------------------------------------------------------------
-class SparseLevel:
-    """One resolution level of the sparse tensor: bitmap + popcount prefix + canonical coordinates.
-    Plays the role of spconv's SparseConvTensor.indices / indice_dict (backbone3d.py:302-307)."""
+LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1
 
-    def __init__(self, batch, shape, cap, device):
+
+class SparseLevel:
+    """One resolution level of the sparse tensor: bitmap + popcount prefix + coordinates of the rows.
+    Plays the role of spconv's SparseConvTensor.indices / indice_dict (backbone3d.py:302-307).
+    layout: the cell key that orders the rows (include/detzero_hip.h: DZ_LAYOUT_LINEAR = ascending (b, z, y, x), the canonical
+    order of the parity statements; DZ_LAYOUT_BRICK = 8 x 8 columns of the (y, x) plane, the order the backbone computes in)."""
+
+    def __init__(self, batch, shape, cap, device, layout=LAYOUT_LINEAR):
         lib = L.load()
         self.batch = int(batch)
         self.shape = [int(s) for s in shape]           # (D, H, W)
         self.cap = int(cap)
-        nwords = lib.dz_index_words(self.batch, *self.shape)
+        self.layout = int(layout)
+        nwords = lib.dz_index_words(self.batch, *self.shape, self.layout)
         self.bitmap = torch.empty((nwords,), dtype=torch.int32, device=device)
         self.prefix = torch.empty((nwords,), dtype=torch.int32, device=device)
         self.coords = torch.empty((max(self.cap, 1), 4), dtype=torch.int32, device=device)
         self.d_m = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.ws = _ws(lib.dz_index_workspace_bytes(self.batch, *self.shape))
+        self.ws = _ws(lib.dz_index_workspace_bytes(self.batch, *self.shape, self.layout))
         self._m_host = None
 
     def num_active(self):
@@ -185,7 +192,7 @@ class SparseLevel:
         L.require_cuda(coords)
         n = coords.shape[0]
         rank = torch.empty((max(n, 1),), dtype=torch.int32, device=coords.device) if want_rank else None
-        rc = lib.dz_index_from_coords(L.ptr(coords), L.ptr(d_n), n, self.batch, *self.shape, L.ptr(self.bitmap),
+        rc = lib.dz_index_from_coords(L.ptr(coords), L.ptr(d_n), n, self.batch, *self.shape, self.layout, L.ptr(self.bitmap),
                                       L.ptr(self.prefix), L.ptr(self.coords), L.ptr(self.d_m), self.cap,
                                       L.ptr(rank), L.ptr(self.ws), self.ws.numel(), L.stream())
         L.check(rc, 'dz_index_from_coords')
@@ -202,8 +209,8 @@ class SparseLevel:
             for i in range(3):
                 per_in *= (k[i] + s[i] - 1) // s[i]
             cap = min(cells, self.cap * per_in)
-        out = SparseLevel(self.batch, oshape, cap, self.coords.device)
-        rc = lib.dz_index_downsample(L.ptr(self.coords), L.ptr(self.d_m), self.cap, self.batch, *self.shape,
+        out = SparseLevel(self.batch, oshape, cap, self.coords.device, layout=self.layout)
+        rc = lib.dz_index_downsample(L.ptr(self.coords), L.ptr(self.d_m), self.cap, self.batch, *self.shape, self.layout,
                                      L.i3(k), L.i3(s), L.i3(p), L.ptr(out.bitmap), L.ptr(out.prefix),
                                      L.ptr(out.coords), L.ptr(out.d_m), out.cap, L.ptr(out.ws), out.ws.numel(),
                                      L.stream())
@@ -217,11 +224,29 @@ class SparseLevel:
         nbr = torch.empty((kvol, max(out_level.cap, 1)), dtype=torch.int32, device=self.coords.device)
         masks = torch.empty((lib.dz_tile_masks_words(max(out_level.cap, 1)),), dtype=torch.int32, device=self.coords.device)
         rc = lib.dz_build_neighbors(L.ptr(out_level.coords), L.ptr(out_level.d_m), out_level.cap,
-                                    L.ptr(self.bitmap), L.ptr(self.prefix), self.batch, *self.shape, L.i3(k),
+                                    L.ptr(self.bitmap), L.ptr(self.prefix), self.batch, *self.shape, self.layout, L.i3(k),
                                     L.i3(s), L.i3(p), L.ptr(nbr), L.ptr(masks), L.stream())
         L.check(rc, 'dz_build_neighbors')
-        nbr.tile_masks = masks        # per-64-row tap masks ride along with the table (consumed by spconv_forward)
+        nbr.tile_masks = masks        # per-32-row tap masks ride along with the table (consumed by spconv_forward)
         return nbr
+
+
+def build_tiles(nbr, out_level):
+    """Tile form of a neighbour table for the tile-resident convolution (dz_spconv_tiles_forward): per tile of
+    dz_spconv_tile_rows() output rows the list of distinct input rows and the local (uint16) table.  Attached to the table as
+    ``nbr.tiles`` - spconv_forward picks the tile kernel whenever it is there (split math modes)."""
+    lib = L.load()
+    kvol, cap = nbr.shape
+    tr = lib.dz_spconv_tile_rows()
+    ntiles = (cap + tr - 1) // tr
+    dev = nbr.device
+    halo = torch.empty((ntiles, lib.dz_build_tiles_halo_stride(kvol)), dtype=torch.int32, device=dev)
+    nhalo = torch.zeros((ntiles,), dtype=torch.int32, device=dev)
+    ltab = torch.empty((ntiles, kvol, tr), dtype=torch.int16, device=dev)
+    rc = lib.dz_build_tiles(L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(halo), L.ptr(nhalo), L.ptr(ltab), L.stream())
+    L.check(rc, 'dz_build_tiles')
+    nbr.tiles = (halo, nhalo, ltab)
+    return nbr
 
 
 def scatter_rows(src, rank, c_dst, cap, d_n=None, math=0):
@@ -247,7 +272,7 @@ def gather_rows(src, idx, d_n, n_cap):
     return out
 
 
-def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, relu=True, out=None, in_level=None, math=0):
+def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, relu=True, out=None, in_level=None, math=0, cout=None):
     """feats (m_in,cin); nbr (kvol,cap); returns (cap,cout).
     math == 0: fp32 rows, w_taps (kvol,cin,cout) fp32.
     math != 0: pair16 rows (in, residual, out), w_taps (kvol,cout_pad,cin) pair16 from pack_weight_split."""
@@ -255,15 +280,22 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     L.require_cuda(feats, nbr, w_taps, scale, shift, residual)
     kvol, cap = nbr.shape
     if math:
-        cin, cout = w_taps.shape[2], scale.shape[0]
+        # (split weights are padded to 32 output channels: the true count comes from the BatchNorm vector, or `cout=`)
+        cin, cout = w_taps.shape[2], (int(cout) if cout is not None else scale.shape[0] if scale is not None else w_taps.shape[1])
     else:
         cin, cout = w_taps.shape[1], w_taps.shape[2]
     assert feats.shape[1] == cin, (feats.shape, w_taps.shape)
     if out is None:
         out = torch.empty((cap, cout), dtype=torch.float32, device=feats.device)
 
+    tiles = getattr(nbr, 'tiles', None) if (math and kvol >= 3) else None
+
     def launch():
-        if math:
+        if tiles is not None:
+            rc = lib.dz_spconv_tiles_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(tiles[0]), L.ptr(tiles[1]), L.ptr(tiles[2]),
+                                             L.ptr(nbr.tile_masks), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale),
+                                             L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
+        elif math:
             rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(getattr(nbr, 'tile_masks', None)),
                                              kvol, cap, L.ptr(out_level.d_m),
                                              L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual), 1 if relu else 0,
@@ -282,7 +314,8 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
         flops = 2.0 * pairs * cin * cout
         n_in = in_level.num_active() if in_level is not None else m
         nbytes = 4.0 * (n_in * cin + m * cout + kvol * cin * cout + (m * cout if residual is not None else 0)) + 8.0 * pairs
-        name = lib.dz_spconv_variant_split(cin, cout) if math else lib.dz_spconv_variant(cin, cout)
+        name = (lib.dz_spconv_tiles_variant(cin, cout) if tiles is not None else
+                lib.dz_spconv_variant_split(cin, cout) if math else lib.dz_spconv_variant(cin, cout))
         PROFILER.wrap(name.decode(), flops, nbytes, launch)
     return out
 

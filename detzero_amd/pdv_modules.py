@@ -155,7 +155,8 @@ def index_lookup(coords_bzyx, level):
     n = coords_bzyx.shape[0]
     out = torch.empty((max(n, 1),), dtype=torch.int32, device=coords_bzyx.device)
     with torch.cuda.device(coords_bzyx.device):
-        rc = L.load().dz_index_lookup(L.ptr(coords_bzyx), None, n, L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, *level.shape, L.ptr(out), L.stream())
+        rc = L.load().dz_index_lookup(L.ptr(coords_bzyx), None, n, L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, *level.shape, level.layout,
+                                      L.ptr(out), L.stream())
     L.check(rc, 'dz_index_lookup')
     return out[:n]
 

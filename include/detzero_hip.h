@@ -75,11 +75,11 @@ int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batc
  * (level_d, gy, gx)) and writes every voxel's mean to its canonical row of `feats` (cap, c_dst), channels >= c zero,
  * fp32 (math 0) or pair16.  Valid only when a frame cannot exceed max_voxels (n_per_frame <= max_voxels; otherwise
  * DZ_ERR_UNSUPPORTED: the first-appearance cut of the reference needs dz_voxelize_hard_mean_batched). */
-size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w);
+size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w, int layout);
 int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c, const float *h_range6,
                          const float *h_vsize3, const int *h_grid3, int xy_range_mask, int max_points, int max_voxels,
-                         int level_d, uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap, float *feats,
-                         int c_dst, int math, void *ws, size_t ws_bytes, void *stream);
+                         int level_d, int layout, uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap,
+                         float *feats, int c_dst, int math, void *ws, size_t ws_bytes, void *stream);
 
 /* MeanVFE.forward — detection/detzero_det/models/centerpoint_modules/vfe.py:66-83.
  * out (m, c_out_stride) f32: columns [0,c) = sum over slots / max(num_points,1); columns
@@ -101,23 +101,32 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
  * SparseConv3d — call sites detection/detzero_det/models/centerpoint_modules/backbone3d.py:
  * 243-280, 302-307).  A level is a bit per cell of the (B,D,H,W) grid plus an exclusive
  * popcount prefix per 32-bit word (dz_voxelize_to_level writes it only at words that hold at least one bit - the only ones
- * the rank query of an ACTIVE cell reads; its level-1 bitmap is > 97 % empty words); active sites are numbered in ascending linear key
- * ((b*D+z)*H+y)*W+x, which is also their row in the feature matrix.
+ * the rank query of an ACTIVE cell reads; its level-1 bitmap is > 97 % empty words); active sites are numbered in ascending cell
+ * key, which is also their row in the feature matrix.  `layout` selects the key of cell (b, z, y, x):
+ *   DZ_LAYOUT_LINEAR  ((b*D+z)*H+y)*W+x: rows in ascending (b, z, y, x) order - the canonical order of SURVEY App. C;
+ *   DZ_LAYOUT_BRICK   the (y, x) plane cut into 8 x 8 columns through all of z, column-major:
+ *                     ((((b*ceil(H/8) + y/8)*ceil(W/8) + x/8)*D + z) << 6) | (y%8 << 3) | x%8.  Rows of a spatial neighbourhood are
+ *                     then neighbours in memory (the order the backbone keeps its levels in: dz_spconv_tiles_forward stages the
+ *                     1.3-1.8x halo of a 128..512-row tile in LDS instead of gathering every (row, tap) pair from L2).  spconv's own
+ *                     row order is a hash-table detail: parity is stated on rows sorted by the linear key.
+ * Every function below that takes (b, d, h, w) takes the layout next to it; bitmap / prefix sizes depend on it.
  * ------------------------------------------------------------------------------------------- */
-size_t dz_index_words(int b, int d, int h, int w);            /* uint32 words in bitmap / prefix */
-size_t dz_index_workspace_bytes(int b, int d, int h, int w);
+#define DZ_LAYOUT_LINEAR 0
+#define DZ_LAYOUT_BRICK 1
+size_t dz_index_words(int b, int d, int h, int w, int layout);            /* uint32 words in bitmap / prefix */
+size_t dz_index_workspace_bytes(int b, int d, int h, int w, int layout);
 
 /* Build a level from (n,4) i32 [b,z,y,x] coordinates in any order (duplicates allowed).
  * d_n may be NULL (then n_cap rows are all valid).  Writes bitmap, prefix, canonical coords and
  * *d_m; rank_of_input (n_cap) receives the canonical row of each input row (may be NULL). */
-int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, int d, int h, int w,
+int dz_index_from_coords(const int *coords, const int *d_n, int n_cap, int b, int d, int h, int w, int layout,
                          uint32_t *bitmap, uint32_t *prefix, int *coords_out, int *d_m, int cap_out,
                          int *rank_of_input, void *ws, size_t ws_bytes, void *stream);
 
 /* Output level of a regular sparse convolution (SparseConv3d, backbone3d.py:256-277):
  * out dims = floor((in + 2p - k)/s) + 1; a site is active iff >=1 active input in its window. */
 int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int b, int d, int h,
-                        int w, const int *h_k3, const int *h_s3, const int *h_p3, uint32_t *bitmap_out,
+                        int w, int layout, const int *h_k3, const int *h_s3, const int *h_p3, uint32_t *bitmap_out,
                         uint32_t *prefix_out, int *coords_out, int *d_m_out, int cap_out, void *ws,
                         size_t ws_bytes, void *stream);
 
@@ -125,7 +134,7 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
  * through kernel tap t = (tz*kH+ty)*kW+tx (input coordinate = o*s - p + t), or -1.
  * SubMConv3d = (k=3,s=1,p=1) with the output level equal to the input level. */
 int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
-                       const uint32_t *prefix_in, int b, int d, int h, int w, const int *h_k3,
+                       const uint32_t *prefix_in, int b, int d, int h, int w, int layout, const int *h_k3,
                        const int *h_s3, const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream);
 /* tile_masks (dz_tile_masks_words(cap_out) words, 16-byte aligned, or NULL): bit t of word o/32 = some row of the 32-row
  * group o/32 has a neighbour at tap t (what the conv kernels need to skip empty taps without scanning the table). */
@@ -207,6 +216,24 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
                             int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
                             const float *residual, int relu, float *out, int cout, int math, void *stream);
 /* tile_masks: the buffer dz_build_neighbors filled for this table (NULL: the kernel scans the table itself, slower). */
+/* Tile-resident sparse convolution (csrc/sparse_conv_t.hip; the same SubMConv3d / SparseConv3d call sites as dz_spconv_forward:
+ * backbone3d.py:64-121, :243-280).  dz_build_tiles turns a neighbour table of dz_build_neighbors (kvol x cap_out, once per
+ * indice_key) into, per tile of dz_spconv_tile_rows() consecutive output rows: the list of DISTINCT input rows the tile reads
+ * (halo: ntiles x dz_build_tiles_halo_stride(kvol) int32, nhalo: ntiles counts) and a local table ltab (ntiles x kvol x
+ * tile_rows uint16: position of the neighbour in the tile's list, 0xFFFF = none; rows permuted as the kernel's lanes read them).
+ * dz_spconv_tiles_forward stages a tile's halo rows in LDS once per 16-channel chunk and runs every kernel tap from there -
+ * same operands, same result convention (pair16 in / out, BatchNorm scale / shift, residual, ReLU) as dz_spconv_forward_split,
+ * tile_masks = the per-32-row tap masks dz_build_neighbors wrote for the table.  kvol in [3, 27], cin % 16 == 0,
+ * cout in {16, 32, 64, 128}.  Any row order is correct; the brick layout (DZ_LAYOUT_BRICK) is what keeps a tile's halo small. */
+int dz_spconv_tile_rows(void);
+size_t dz_build_tiles_halo_stride(int kvol);
+int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, int *halo, int *nhalo, unsigned short *ltab,
+                   void *stream);
+int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *halo, const int *nhalo, const unsigned short *ltab,
+                            const uint32_t *tile_masks, int kvol, int cap_out, const int *d_m_out, const float *w,
+                            const float *scale, const float *shift, const float *residual, int relu, float *out, int cout,
+                            int math, void *stream);
+const char *dz_spconv_tiles_variant(int cin, int cout);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);
@@ -404,7 +431,7 @@ int dz_pdv_voxel_centroids(const float *points_b, int n, int c, const float *h_r
 /* voxel_aggregation_utils.get_nonempty_voxel_feature_indices (:59-78) without the dense hash table: out[i] = row of cell
  * coords[i] = [b, z, y, x] in the sparse level (bitmap, prefix of dz_index_*), or -1. */
 int dz_index_lookup(const int *coords, const int *d_n, int n, const uint32_t *bitmap, const uint32_t *prefix, int b, int d, int h,
-                    int w, int *out, void *stream);
+                    int w, int layout, int *out, void *stream);
 /* pointnet2_stack ball_query_count (src/ball_query_count_gpu.cu:16-62 + pointnet2_utils.py:78-83,186-189) for points that are
  * voxel centroids: at most one per cell of the (b, d, h, w) bitmap, listed in cell-key order (xyz (np, 3)).  Queries new_xyz
  * (mq, 3), `per_batch` consecutive queries per batch item.  idx (mq, nsample) int32: the first nsample points with d^2 < r^2 in

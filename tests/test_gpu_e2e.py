@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_01, VOXEL_SIZE_02
-from tests.util import POST, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
+from tests.util import POST, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect, canon_order, canon_tensor
 
 pytestmark = pytest.mark.gpu
 
@@ -42,12 +42,14 @@ def test_modules_match_oracle_stage_by_stage(small, device):
         t = bd['multi_scale_3d_features'][name]
         rf, rc, rs = ref['backbone'][name]
         assert t.spatial_shape == list(rs)
-        assert np.array_equal(t.indices.cpu().numpy(), rc), name                        # active sets: bit-exact
-        torch.testing.assert_close(t.features.cpu(), rf, rtol=1e-3, atol=1e-3)
+        ti, tf = canon_tensor(t)                                                        # rows sorted by the linear key
+        assert np.array_equal(ti, rc), name                                             # active sets: bit-exact
+        torch.testing.assert_close(tf, rf, rtol=1e-3, atol=1e-3)
     t = bd['encoded_spconv_tensor']
     rf, rc, rs = ref['backbone']['encoded']
-    assert np.array_equal(t.indices.cpu().numpy(), rc)
-    torch.testing.assert_close(t.features.cpu(), rf, rtol=1e-3, atol=1e-3)
+    ti, tf = canon_tensor(t)
+    assert np.array_equal(ti, rc)
+    torch.testing.assert_close(tf, rf, rtol=1e-3, atol=1e-3)
     dense = t.dense()
     assert tuple(dense.shape) == (1, 128, rs[0], rs[1], rs[2])
     bd = model.map_to_bev(bd)
@@ -161,7 +163,8 @@ def test_full_size_frame_properties(device):
                                [((3, 3, 3), (2, 2, 2), (1, 1, 1))] * 2 + [((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]):
         cur, shape = osp.conv_out_coords(cur, shape, k, s, p)
         lvl = r1[name][1]
-        assert lvl.num_active() == cur.shape[0] and np.array_equal(lvl.coords[:cur.shape[0]].cpu().numpy(), cur)
+        got = lvl.coords[:cur.shape[0]].cpu().numpy()
+        assert lvl.num_active() == cur.shape[0] and np.array_equal(got[canon_order(got, shape)], cur)
 
 
 def test_hip_graph_capture_of_frame_pipeline(device):

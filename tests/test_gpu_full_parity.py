@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
-from tests.util import cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
+from tests.util import canon_order, canon_tensor, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
 
 pytestmark = pytest.mark.gpu
 MATHS = ['f32', 'f16x2', 'bf16x2']
@@ -56,8 +56,9 @@ def _check_sparse(res, ref, math, model, names=('x_conv1', 'x_conv2', 'x_conv3',
         rf, rc, rs = ref['backbone'][name]
         sel = np.nonzero(coords[:, 0] == frame)[0]
         assert lvl.shape == list(rs) and sel.size == rc.shape[0], (name, sel.size, rc.shape[0])
+        sel = sel[canon_order(coords[sel], lvl.shape)]                             # the frame's rows in canonical (linear-key) order
         got_c = coords[sel].copy(); got_c[:, 0] = 0
-        assert np.array_equal(got_c, rc), name                                     # active set + canonical order: bit-exact
+        assert np.array_equal(got_c, rc), name                                     # active set: bit-exact
         plain = ops.pair16_to_f32(feats[:m], mid) if mid else feats[:m]
         torch.testing.assert_close(plain[torch.from_numpy(sel).to(plain.device)].cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math],
                                    msg=lambda s: '%s [%s]: %s' % (name, math, s))
@@ -82,12 +83,14 @@ def test_modules_stage_by_stage_160k(full, device, math):
     for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
         t = bd['multi_scale_3d_features'][name]
         rf, rc, rs = ref['backbone'][name]
-        assert t.spatial_shape == list(rs) and np.array_equal(t.indices.cpu().numpy(), rc), name
-        torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+        ti, tf = canon_tensor(t)
+        assert t.spatial_shape == list(rs) and np.array_equal(ti, rc), name
+        torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
     t = bd['encoded_spconv_tensor']
     rf, rc, rs = ref['backbone']['encoded']
-    assert np.array_equal(t.indices.cpu().numpy(), rc)
-    torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    ti, tf = canon_tensor(t)
+    assert np.array_equal(ti, rc)
+    torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
     bd = model.map_to_bev(bd)
     torch.testing.assert_close(bd['spatial_features'].cpu(), ref['bev'], rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
     bd = model.backbone2d(bd)
@@ -199,8 +202,9 @@ def test_multisweep_320k_dynamic_vfe(multisweep, device, math):
     for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
         t = bd['multi_scale_3d_features'][name]
         rf, rc, rs = ref['backbone'][name]
-        assert np.array_equal(t.indices.cpu().numpy(), rc), name
-        torch.testing.assert_close(t.features.cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+        ti, tf = canon_tensor(t)
+        assert np.array_equal(ti, rc), name
+        torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
     for mod in (model.map_to_bev, model.backbone2d, model.dense_head):
         bd = mod(bd)
     torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=MAP_TOL[math], atol=MAP_TOL[math])

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_01, VOXEL_SIZE_02, synth_boxes, synth_waymo_frame
-from tests.util import masked_frame
+from tests.util import canon_order, canon_table, masked_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -113,38 +113,193 @@ def _voxel_coords(seed, n, vs, batch=1):
     return np.concatenate(cs, 0)
 
 
+@pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('seed,n,vs,batch', [(0, 20000, VOXEL_SIZE_02, 2), (1, 160000, VOXEL_SIZE_01, 1)])
-def test_index_and_rulebooks_bit_exact(device, seed, n, vs, batch):
+def test_index_and_rulebooks_bit_exact(device, seed, n, vs, batch, layout):
+    """Active sets and all rulebooks of the backbone's index pyramid against the oracle, in both row orders: layout 0 keeps the
+    rows in the canonical (linear-key) order itself; layout 1 (brick order, what the backbone runs in) is compared after sorting
+    rows by the linear key - the statement of SURVEY App. C: equality of the sorted coordinate list and of the (in, out, tap) triples."""
     from detzero_amd import ops
     from oracle import sparse as osp
     from oracle import voxelize as ov
     coords = _voxel_coords(seed, n, vs, batch)
     grid = ov.grid_size_of(POINT_CLOUD_RANGE, vs)
     shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
-    lvl = ops.SparseLevel(batch, shape, coords.shape[0], device)
+    lvl = ops.SparseLevel(batch, shape, coords.shape[0], device, layout=layout)
     rank = lvl.build_from_coords(_t(coords, device))
     order = osp.canonical_order(coords, shape)
     m = lvl.num_active()
     assert m == coords.shape[0]
-    assert np.array_equal(lvl.coords[:m].cpu().numpy(), coords[order])               # canonical (sorted) order
-    inv = np.empty_like(order); inv[order] = np.arange(order.size)
-    assert np.array_equal(rank.cpu().numpy(), inv.astype(np.int32))
+    got = lvl.coords[:m].cpu().numpy()
+    if layout == 0:
+        assert np.array_equal(got, coords[order])                                    # canonical (sorted) order
+        inv = np.empty_like(order); inv[order] = np.arange(order.size)
+        assert np.array_equal(rank.cpu().numpy(), inv.astype(np.int32))
+    else:
+        # brick order: ascending (b, y/8, x/8, z, y%8, x%8)
+        c = got.astype(np.int64)
+        bk = ((((c[:, 0] * ((shape[1] + 7) // 8) + c[:, 2] // 8) * ((shape[2] + 7) // 8) + c[:, 3] // 8) * shape[0] + c[:, 1]) * 64
+              + (c[:, 2] % 8) * 8 + c[:, 3] % 8)
+        assert np.all(np.diff(bk) > 0)
+    assert np.array_equal(got[rank.cpu().numpy()], coords)                           # rank_of_input points at the input's own cell
+    cur_order = canon_order(got, shape)
+    assert np.array_equal(got[cur_order], coords[order])
     cur, cur_shape, cur_lvl = coords[order], shape, lvl
     K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     for k, s, p in [(K3, (2, 2, 2), (1, 1, 1)), (K3, (2, 2, 2), (1, 1, 1)), (K3, (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]:
         # submanifold rulebook of the current level
         nbr = cur_lvl.neighbors_to(cur_lvl, K3, S1, P1)
         ref = osp.neighbor_table(cur, cur_shape, cur, K3, S1, P1)
-        assert np.array_equal(nbr[:, :cur.shape[0]].cpu().numpy(), ref)
+        assert np.array_equal(canon_table(nbr[:, :cur.shape[0]].cpu().numpy(), cur_order, cur_order), ref)
         # strided conv: output set + rulebook
         nxt = cur_lvl.downsample(k, s, p)
         oc, oshape = osp.conv_out_coords(cur, cur_shape, k, s, p)
-        assert nxt.shape == list(oshape) and nxt.num_active() == oc.shape[0]
-        assert np.array_equal(nxt.coords[:oc.shape[0]].cpu().numpy(), oc)
+        assert nxt.shape == list(oshape) and nxt.num_active() == oc.shape[0] and nxt.layout == layout
+        got_o = nxt.coords[:oc.shape[0]].cpu().numpy()
+        nxt_order = canon_order(got_o, oshape)
+        assert np.array_equal(got_o[nxt_order], oc)
+        if layout == 0:
+            assert np.array_equal(nxt_order, np.arange(oc.shape[0]))
         nbr = cur_lvl.neighbors_to(nxt, k, s, p)
         ref = osp.neighbor_table(cur, cur_shape, oc, k, s, p)
-        assert np.array_equal(nbr[:, :oc.shape[0]].cpu().numpy(), ref)
-        cur, cur_shape, cur_lvl = oc, oshape, nxt
+        assert np.array_equal(canon_table(nbr[:, :oc.shape[0]].cpu().numpy(), nxt_order, cur_order), ref)
+        cur, cur_shape, cur_lvl, cur_order = oc, oshape, nxt, nxt_order
+
+
+def _random_level(rng, shape, n, batch, device, layout, dense_block=False):
+    """A level of n random cells (plus, optionally, a fully occupied 12 x 32 x 32 block: tiles whose halo exceeds the LDS capacity)."""
+    from detzero_amd import ops
+    cells = shape[0] * shape[1] * shape[2]
+    lin = rng.choice(batch * cells, size=n, replace=False)
+    coords = np.stack([lin // cells, (lin % cells) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    if dense_block:
+        z, y, x = np.meshgrid(np.arange(min(16, shape[0])), np.arange(8, 40), np.arange(8, 40), indexing='ij')
+        blk = np.stack([np.zeros(z.size, np.int64), z.ravel(), y.ravel(), x.ravel()], 1).astype(np.int32)
+        coords = np.unique(np.concatenate([coords, blk], 0), axis=0)
+    lvl = ops.SparseLevel(batch, shape, coords.shape[0] + 7, device, layout=layout)
+    lvl.build_from_coords(_t(coords, device), want_rank=False)
+    return lvl
+
+
+@pytest.mark.parametrize('layout', [0, 1])
+@pytest.mark.parametrize('kvol', [27, 3])
+def test_build_tiles_is_the_table(device, layout, kvol):
+    """dz_build_tiles: per tile the halo list holds exactly the distinct neighbour rows of the tile, and the local table points
+    every (tap, row) at its neighbour's position in that list (0xFFFF where the table has -1) - i.e. halo[ltab] == nbr."""
+    from detzero_amd import lib as L
+    from detzero_amd import ops
+    rng = np.random.default_rng(11 + layout + kvol)
+    lvl = _random_level(rng, [12, 48, 40], 2500, 2, device, layout, dense_block=True)
+    if kvol == 27:
+        k, s, p, out = (3, 3, 3), (1, 1, 1), (1, 1, 1), lvl
+    else:
+        k, s, p = (3, 1, 1), (2, 1, 1), (0, 0, 0)
+        out = lvl.downsample(k, s, p)
+    nbr = ops.build_tiles(lvl.neighbors_to(out, k, s, p), out)
+    halo, nhalo, ltab = (t.cpu().numpy() for t in nbr.tiles)
+    tr = L.load().dz_spconv_tile_rows()
+    m = out.num_active()
+    tab = nbr.cpu().numpy()
+    ltab = ltab.view(np.uint16)
+    assert m > tr and ltab.shape == ((out.cap + tr - 1) // tr, kvol, tr)
+    r = np.arange(tr)
+    perm = (r >> 6) * 64 + (r & 31) * 2 + ((r >> 5) & 1)
+    worst = 0
+    for t in range((m + tr - 1) // tr):
+        rows = np.arange(t * tr, min((t + 1) * tr, m))
+        want = tab[:, rows]                                                           # (kvol, rows)
+        uniq = np.unique(want[want >= 0])
+        nh = int(nhalo[t])
+        assert nh == uniq.size and np.array_equal(np.sort(halo[t, :nh]), uniq), t   # distinct rows, each once
+        loc = ltab[t][:, perm[:rows.size]].astype(np.int64)                           # (kvol, rows) positions
+        assert np.array_equal(loc == 0xFFFF, want < 0)
+        assert np.array_equal(np.where(loc != 0xFFFF, halo[t][np.minimum(loc, nh - 1)], -1), want), t
+        if rows.size < tr:
+            assert np.all(ltab[t][:, perm[rows.size:]] == 0xFFFF)                    # rows past the end: no neighbours
+        worst = max(worst, nh)
+    assert worst > 895                                                               # the dense block needs more than one LDS pass
+
+
+@pytest.mark.parametrize('layout', [0, 1])
+@pytest.mark.parametrize('math', ['f16x2', 'bf16x2', 'f16'])
+@pytest.mark.parametrize('cin,cout,kvol', [(16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 27),
+                                           (128, 128, 27), (128, 128, 3)])
+def test_spconv_tiles_vs_oracle_and_gather(device, cin, cout, kvol, math, layout):
+    """The tile-resident convolution against the oracle (rulebook + fp32 torch) and against the gather kernels on the same
+    pair16 operands, in both row orders; the level holds a fully occupied block, so some tiles run in two LDS passes, the last
+    tile is ragged, and the epilogue (BatchNorm scale / shift, residual, ReLU) is exercised with and without its parts."""
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    if math != 'f16x2' and (layout == 0 or (cin, cout) not in [(16, 16), (64, 64), (128, 128)]):
+        pytest.skip('the other math modes run a subset')
+    mid = ops.math_id(math)
+    rng = np.random.default_rng(cin * 1000 + cout + kvol)
+    shape = [12, 48, 40]
+    lvl = _random_level(rng, shape, 2500, 2, device, layout, dense_block=True)
+    n = lvl.num_active()
+    coords = lvl.coords[:n].cpu().numpy()
+    if kvol == 27:
+        k, s, p, out_lvl = (3, 3, 3), (1, 1, 1), (1, 1, 1), lvl
+    else:
+        k, s, p = (3, 1, 1), (2, 1, 1), (0, 0, 0)
+        out_lvl = lvl.downsample(k, s, p)
+    mo = out_lvl.num_active()
+    oc = out_lvl.coords[:mo].cpu().numpy()
+    feats = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((kvol, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32) * 0.1
+    res = rng.standard_normal((mo, cout)).astype(np.float32)
+    rb = osp.build_rulebook(coords, shape, oc, k, s, p)                               # the oracle works on any row order
+    ref2 = osp.sparse_conv(torch.from_numpy(feats), rb, torch.from_numpy(w), mo)
+    ref = torch.relu(ref2 * torch.from_numpy(scale) + torch.from_numpy(shift) + torch.from_numpy(res))
+
+    x = ops.pair16_from_f32(_t(np.concatenate([feats, np.zeros((lvl.cap - n, cin), np.float32)]), device), math=mid)
+    wp = ops.pack_weight_split(_t(w, device), mid)
+    res_pad = np.zeros((out_lvl.cap, cout), np.float32); res_pad[:mo] = res
+    rp = ops.pair16_from_f32(_t(res_pad, device), math=mid)
+    nbr = lvl.neighbors_to(out_lvl, k, s, p)
+    g1 = ops.spconv_forward(x, nbr, out_lvl, wp, _t(scale, device), _t(shift, device), rp, relu=True, math=mid)
+    g2 = ops.spconv_forward(x, nbr, out_lvl, wp, None, None, None, relu=False, math=mid, cout=cout)
+    ops.build_tiles(nbr, out_lvl)
+    assert nbr.tiles is not None
+    t1 = ops.spconv_forward(x, nbr, out_lvl, wp, _t(scale, device), _t(shift, device), rp, relu=True, math=mid)
+    t2 = ops.spconv_forward(x, nbr, out_lvl, wp, None, None, None, relu=False, math=mid, cout=cout)
+    tol = {'f16x2': 2e-4, 'bf16x2': 2e-3, 'f16': 2e-2}[math]
+    for got, gat, want in ((t1, g1, ref), (t2, g2, ref2)):
+        a = ops.pair16_to_f32(got[:mo], mid).cpu()
+        b = ops.pair16_to_f32(gat[:mo], mid).cpu()
+        print('tiles %s %d->%d kvol %d layout %d: |tiles - oracle| %.2e, |tiles - gather| %.2e' % (
+            math, cin, cout, kvol, layout, float((a - want).abs().max()), float((a - b).abs().max())))
+        torch.testing.assert_close(a, want, rtol=tol, atol=tol)
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol)                          # same products, another summation order
+
+
+def test_spconv_tiles_small_and_empty(device):
+    """Fewer rows than a tile, a level with a single site (one tap: the step list is padded with empty taps), and no rows at all."""
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    rng = np.random.default_rng(5)
+    for n in (1, 37, 0):
+        shape = [5, 16, 16]
+        lvl = ops.SparseLevel(1, shape, max(n, 1), device, layout=1)
+        lin = rng.choice(5 * 256, size=n, replace=False)
+        coords = np.stack([np.zeros(n, np.int64), lin // 256, (lin // 16) % 16, lin % 16], 1).astype(np.int32)
+        lvl.build_from_coords(_t(coords.reshape(-1, 4), device), want_rank=False)
+        assert lvl.num_active() == n
+        cs = lvl.coords[:n].cpu().numpy()
+        feats = rng.standard_normal((max(n, 1), 32)).astype(np.float32)
+        w = (rng.standard_normal((27, 32, 32)) / 16).astype(np.float32)
+        nbr = ops.build_tiles(lvl.neighbors_to(lvl, (3, 3, 3), (1, 1, 1), (1, 1, 1)), lvl)
+        out = torch.full((lvl.cap, 32), 7.0, dtype=torch.float32, device=device)
+        ops.spconv_forward(ops.pair16_from_f32(_t(feats, device), math=1), nbr, lvl, ops.pack_weight_split(_t(w, device), 1), None, None,
+                           None, relu=False, out=out, math=1, cout=32)
+        if n:
+            rb = osp.build_rulebook(cs, shape, cs, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+            ref = osp.sparse_conv(torch.from_numpy(feats[:n]), rb, torch.from_numpy(w), n)
+            torch.testing.assert_close(ops.pair16_to_f32(out[:n], 1).cpu(), ref, rtol=2e-4, atol=2e-4)
+        else:
+            assert float((out - 7.0).abs().max()) == 0                                # nothing written
 
 
 def test_index_duplicates_and_empty(device):
@@ -459,8 +614,9 @@ def test_voxelize_hard_mean_batched_equals_per_frame(device, max_voxels):
         assert int(dn.item()) == m and torch.equal(mean[:m], fi[:m]) and torch.equal(zyx[:m], ci[:m, 1:])
 
 
+@pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('math', [0, 1])
-def test_voxelize_to_level_equals_voxelize_index_scatter(device, math):
+def test_voxelize_to_level_equals_voxelize_index_scatter(device, math, layout):
     """The fused batch voxelizer -> level-1 index equals hard voxelizer + MeanVFE + dz_index_from_coords + dz_scatter_rows
     bit for bit: same bitmap, prefix, canonical coordinates, count and feature rows (fp32 and pair16)."""
     from detzero_amd import ops
@@ -468,10 +624,10 @@ def test_voxelize_to_level_equals_voxelize_index_scatter(device, math):
     frames = [_t(synth_waymo_frame(50 + i, n), device) for i in range(b)]
     shape = [41, 752, 752]                           # VOXEL_SIZE_02 grid (752,752,40) + 1 in z
     lvl, x = ops.voxelize_to_level(torch.cat(frames, 0), b, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000, shape, 16, math=math,
-                                   xy_range_mask=True)
+                                   xy_range_mask=True, layout=layout)
     feats, coords, d_num = ops.voxelize_hard_mean_batched(torch.cat(frames, 0), b, POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000, n,
                                                           xy_range_mask=True)
-    ref = ops.SparseLevel(b, shape, b * n, device)
+    ref = ops.SparseLevel(b, shape, b * n, device, layout=layout)
     rank = ref.build_from_coords(coords)
     xr = ops.scatter_rows(feats, rank, 16, ref.cap, None, math=math)
     m = ref.num_active()

@@ -71,3 +71,27 @@ def match_boxes(a_boxes, a_scores, b_boxes, b_scores, tol=1e-3):
                 n += 1
                 worst = max(worst, float(diff.max()), sd)
     return n, worst
+
+
+def canon_order(coords, shape):
+    """Permutation that puts rows given by coords (m,4) [b,z,y,x] (any storage order, e.g. the brick order of the backbone's levels)
+    into the canonical order of the parity statements: ascending linear key ((b*D+z)*H+y)*W+x."""
+    c = np.asarray(coords).astype(np.int64)
+    d, h, w = (int(x) for x in shape)
+    return np.argsort(((c[:, 0] * d + c[:, 1]) * h + c[:, 2]) * w + c[:, 3], kind='stable')
+
+
+def canon_table(nbr, out_order, in_order):
+    """Neighbour table (kvol, m_out) in STORAGE rows -> the same table in canonical rows on both sides."""
+    nbr = np.asarray(nbr)
+    inv_in = np.empty(in_order.size, np.int64)
+    inv_in[in_order] = np.arange(in_order.size)
+    t = nbr[:, out_order]
+    return np.where(t >= 0, inv_in[np.maximum(t, 0)], -1).astype(np.int32)
+
+
+def canon_tensor(t):
+    """(indices, features) of a SparseConvTensor sorted into the canonical row order."""
+    idx = t.indices.cpu().numpy()
+    o = canon_order(idx, t.spatial_shape)
+    return idx[o], t.features.cpu()[torch.from_numpy(o)]
