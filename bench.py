@@ -25,6 +25,16 @@ Besides the headline the default single-GPU run measures, into the same JSON lin
   with_h2d   frames start in pinned host memory; the H2D copy of step i+1 runs on a copy stream under step i
   stages     voxelize / index pyramid / sparse backbone / dense / post-processing: time per step (each stage replayed as its
              own hipGraph, serially), algorithmic bytes and HBM GB/s as a fraction of the 8 TB/s peak
+  tiles      the opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip, rows in brick order) on the headline workload
+  refine     BASELINE configs[3], the secondary kernel set: GRM objects/s and PRM tracks/s (fp32 and f16x2 stacks) and the
+             attention core (k_mha_block) with its roofline against the fp32-MFMA peak
+  pdv        the two-stage detector (PDVHead second stage) on a merged 2-sweep frame: ms per stage, RoIs/s
+The exact-fp32 leg is also promoted to the top-level keys value_fp32 / roofline_fp32 (the precision-equivalent number next to
+`value`, whose arithmetic carries 22 significant bits).
+
+N > 1: `python bench.py --gpus N` starts the N ranks itself (re-executes under torch.distributed.run on 127.0.0.1) when it is not
+already running under a launcher, and fails if the node has fewer than N GPUs; the line carries ranks_seen (all-reduced) and the
+time of the box gather.
 """
 import argparse
 import json
@@ -110,7 +120,30 @@ def parse():
     ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
+    ap.add_argument('--sparse-engine', default='gather', choices=['gather', 'tiles'], help='sparse-backbone engine of the headline run')
+    ap.add_argument('--no-refine', action='store_true', help='skip the refiner leg (BASELINE configs[3])')
+    ap.add_argument('--no-pdv', action='store_true', help='skip the two-stage (PDV) leg')
+    ap.add_argument('--stub', action='store_true',
+                    help='launch-structure test without a GPU: gloo ranks on CPU, a no-op step; exercises the self-spawn, the barrier / '
+                         'gather / max-over-ranks timed region and the JSON line (tests/test_bench_contract.py), measures nothing')
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+    by re-executing under torch.distributed.run - the same command line the driver uses.  Fails loudly when the node has fewer GPUs."""
+    import socket
+    if not args.stub:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit('bench.py: --gpus %d but this node exposes %d GPU(s)' % (args.gpus, have))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('starting %d ranks: %s' % (args.gpus, ' '.join(cmd[1:9])))
+    os.execvp(cmd[0], cmd)
 
 
 class Case:
@@ -121,14 +154,16 @@ class Case:
     lengths = (lo, hi), mode 'padded': frames of lo..hi points padded with out-of-range rows to slots of hi rows (same route).
     lengths = (lo, hi), mode 'list': slot j holds a frame of its own length L_j in lo..hi (ragged list route)."""
 
-    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1):
-        from detzero_amd.centerpoint import FramePipeline, synth_detector
+    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1, engine='gather'):
+        from detzero_amd.centerpoint import FramePipeline, set_sparse_engine, synth_detector
         from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
         self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
         # sweeps = 2: BASELINE configs[4] shape - two sweeps merged into one 6-feature frame (time-offset column), the
         # centerpoint_3sweeps model with DynamicMeanVFE
         self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0, sweeps=3 if sweeps > 1 else 1)
         self.model = self.model.to(dev)
+        set_sparse_engine(self.model, engine)
+        self.engine = engine
         self.pipe = FramePipeline(self.model, self.info, dynamic=sweeps > 1, math=math)
         B = self.B
         self.n_distinct = n_distinct = max(4, B + 1)
@@ -163,7 +198,16 @@ class Case:
             sample = [self.pool[i] for i in range(n_distinct)]
         self.caps = None
         if not args.no_calibrate:
-            self.caps = self.pipe.calibrate(sample)       # row capacities of the deep sparse levels from the sample frames (x1.5)
+            # row capacities of the deep sparse levels (x1.5 of the largest count seen) from frames DISJOINT from the timed ones
+            # (other seeds, same generator and lengths): the overflow flag checked after the timed region is then a real guard
+            cal = []
+            for i, f in enumerate(self.host_frames[:4]):
+                g = synth_waymo_frame(seed_base + 1000 * rank + 7000 + i, f.shape[0] // (2 if sweeps > 1 else 1))
+                if sweeps > 1:
+                    g = merge_two_sweeps(g, synth_waymo_frame(seed_base + 1000 * rank + 7300 + i, g.shape[0]))
+                cal.append(torch.from_numpy(g).to(dev))
+            self.caps = self.pipe.calibrate(cal)
+            del cal
         self.graph = None
         self.g_out = self.g_n = None
         self.graph_note = 'eager launches'
@@ -357,18 +401,48 @@ class Case:
         return out
 
 
+def stub_main(args, world, rank):
+    """--stub: the launch structure only (gloo ranks on CPU, a no-op step, the shared timed region, the JSON line)."""
+    from detzero_amd import frame_parallel as fp
+    B, K = 2, args.steps
+    results = torch.zeros((K, B, 4, 9), dtype=torch.float32)
+    counts = torch.zeros((K, B), dtype=torch.int32)
+
+    def step(i):
+        counts[i % K] = rank + 1
+    info = {}
+    dt, all_b, all_c = fp.timed_steps(step, K, args.warmup, results, counts, sync=lambda: None, info=info)
+    if rank == 0:
+        print(json.dumps({'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(world * K * B / max(dt, 1e-9), 3), 'unit': 'frames/s',
+                          'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * dt / K, 4), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub (launch-structure test: no GPU work, measures nothing)',
+                          'ranks_seen': info['ranks_seen'], 'gather_ms': info['gather_ms'],
+                          'config': {'workload': 'stub', 'frames_per_step_per_gpu': B, 'parallelism': 'frame-parallel x%d' % world,
+                                     'gathered_counts': None if all_c is None else [int(v) for v in all_c[:, 0].tolist()]}}), flush=True)
+
+
 def main():
     args = parse()
+    launched = 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args)                        # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if args.stub else 'nccl', rank=rank, world_size=world)
     if args.gpus != world:
-        if rank == 0:
-            print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    if args.stub:
+        stub_main(args, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py: rank %d has no GPU (local rank %d, %d visible)' % (rank, local_rank, torch.cuda.device_count()))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -376,7 +450,7 @@ def main():
 
     torch.set_num_threads(min(usable_cores(), 32))
     log('rank', rank, 'of', world, 'usable host cores', usable_cores())
-    case = Case(args, dev, rank, args.math, args.batch)
+    case = Case(args, dev, rank, args.math, args.batch, engine=args.sparse_engine)
     if case.caps is not None:
         log('calibrated level capacities per frame:', case.caps)
     B = case.B
@@ -404,7 +478,8 @@ def main():
     log('launch mode:', graph_note)
     # W + 1 untimed steps (streaming mode: the first feed has no stage B), then exactly K timed steps, barrier + synchronize on
     # both sides, box gather inside the timed region, MAX over ranks
-    dt, all_b, all_c = fp.timed_steps(step, K, W + 1, case.results, case.counts, sync=torch.cuda.synchronize)
+    tinfo = {}
+    dt, all_b, all_c = fp.timed_steps(step, K, W + 1, case.results, case.counts, sync=torch.cuda.synchronize, info=tinfo)
     case.check_overflow()
     n_boxes = case.counts.float().mean().item()
     log('timed region: %d steps x %d frames in %.3f s' % (K, B, dt))
@@ -419,11 +494,14 @@ def main():
             'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(value, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_names[args.math], 'data': 'synthetic',
+            'ranks_seen': tinfo.get('ranks_seen', 1), 'gather_ms': tinfo.get('gather_ms', 0.0),
             'config': {'workload': 'BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
                                    '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
                                    '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'parallelism': 'frame-parallel x%d' % world,
-                       'launch': graph_note, 'math': args.math, 'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded random init (no checkpoints offline)',
+                       'launch': graph_note, 'math': args.math, 'sparse_engine': args.sparse_engine,
+                       'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',
+                       'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded random init (no checkpoints offline)',
                        'mean_boxes_per_frame': round(n_boxes, 1)},
         }
 
@@ -495,6 +573,9 @@ def main():
             rec['roofline'] = roof
             rec['kernels'] = kern[:6]
         out['fp32'] = rec
+        # the precision-equivalent figure next to `value` (whose arithmetic carries 22 significant bits): promoted to top-level keys
+        out['value_fp32'] = rec['value']
+        out['roofline_fp32'] = rec.get('roofline')
         del c
         c, out['ref_batch'] = leg('ref_batch', args.math, REF_BATCH, note='BATCH_SIZE_PER_GPU of centerpoint_1sweep.yaml:88')
         del c
@@ -520,6 +601,55 @@ def main():
                                         'offset), DynamicMeanVFE + centerpoint_3sweeps backbone and head' % args.points)
         del c
         torch.cuda.empty_cache()
+        if args.math != 'f32':
+            try:
+                c = Case(args, dev, rank, args.math, B, seed_base=500, engine='tiles')
+                fps, ms, k = c.aux_leg(sec)
+                rec = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(ms, 4), 'steps': k, 'frames_per_step': B, 'math': args.math,
+                       'note': 'opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip: 512-row tiles, halo staged in LDS once per 16-channel '
+                               'chunk, rows of every level in brick order) - parity-tested, slower than the gather engine inside the detector'}
+                if args.profile_frames > 0:
+                    kern, _, _ = c.kernel_profile(args.profile_frames)
+                    rec['kernels'] = [r for r in kern if 'spconv' in r['kernel']]
+                out['tiles'] = rec
+                log('tiles %.1f frames/s' % fps)
+                del c
+            except Exception as e:
+                out['tiles'] = {'error': str(e).split('\n')[0][:200]}
+            torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        if not args.no_refine:
+            # BASELINE configs[3]: the refiner's GRM / PRM at the reference's shapes, 1024 objects in chunks of 128 / 96
+            try:
+                import bench_refine
+                r32 = bench_refine.measure(dev, 1024, 128, 2, 'f32', with_crop=True)
+                r16 = bench_refine.measure(dev, 1024, 128, 2, 'f16x2', with_crop=False)
+                out['refine'] = {
+                    'workload': 'BASELINE configs[3]: 1024 objects; GRM 3 x 256 query + 4096 memory points, PRM 200 x 256 query + 200 x 48 memory points '
+                                '(reference dataset defaults), random weights and inputs resident in HBM',
+                    'grm_objects_per_s': {'f32': r32['grm_objects_per_s'], 'f16x2': r16['grm_objects_per_s']},
+                    'prm_tracks_per_s': {'f32': r32['prm_objects_per_s'], 'f16x2': r16['prm_objects_per_s']},
+                    'grm_tflops': {'f32': r32['grm_tflops'], 'f16x2': r16['grm_tflops']},
+                    'prm_tflops': {'f32': r32['prm_tflops'], 'f16x2': r16['prm_tflops']},
+                    'points_in_boxes_us': r32.get('points_in_boxes_us'),
+                    'roofline': {'bound': 'mfma', 'kernel': 'k_mha_block', 'achieved': r32['mha_core_prm_tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': round(r32['mha_core_prm_tflops'] / PEAK_F32_MFMA_TFLOPS, 4),
+                                 'avg_launch_us': r32['mha_core_prm_us'],
+                                 'note': 'PRM cross-attention core: 96 tracks x 8 heads, 200 queries x 9600 keys x 32, exact fp32 on v_mfma_f32_16x16x4_f32; '
+                                         'algorithmic FLOP = 4 * Lq * Lk * d per track'}}
+                log('refine GRM %.0f / %.0f objects/s, PRM %.0f / %.0f tracks/s (f32 / f16x2)' % (
+                    r32['grm_objects_per_s'], r16['grm_objects_per_s'], r32['prm_objects_per_s'], r16['prm_objects_per_s']))
+            except Exception as e:
+                out['refine'] = {'error': str(e).split('\n')[0][:200]}
+            torch.cuda.empty_cache()
+        if not args.no_pdv:
+            try:
+                import bench_pdv
+                out['pdv'] = bench_pdv.measure(dev, args.points, 8, 'f32')
+                log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs)' % (out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois']))
+            except Exception as e:
+                out['pdv'] = {'error': str(e).split('\n')[0][:200]}
+            torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (reference-semantics restatement) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -529,18 +659,36 @@ def main():
         sd = cpu_state_dict(case.model)
         pts = case.host_frames
         from oracle.voxelize import mask_points_by_range
-        done, t_cpu = 0, 0.0
-        while t_cpu < args.cpu_baseline_seconds and done < 8:
-            p = pts[done % case.n_distinct]
-            p = p[mask_points_by_range(p, case.info.point_cloud_range)]
-            t1 = time.perf_counter()
-            oracle_detect(sd, p, case.info)
-            t_cpu += time.perf_counter() - t1
-            done += 1
-        out['cpu_baseline'] = {'value': round(done / t_cpu, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-                               'sample': '%d frames of the same 160k-pt workload through oracle/ (numpy + CPU torch '
-                                         'restatement of the spconv/PyTorch path; spconv itself is not installable), '
-                                         '%.1f s' % (done, t_cpu)}
+
+        def run_oracle(budget, max_frames, warm):
+            """-> (per-frame seconds list, per-stage seconds summed) within `budget` seconds of CPU time"""
+            times, stage, spent, i = [], {}, 0.0, 0
+            for _ in range(warm):                                   # untimed warm-up frames (allocator, thread pool)
+                p = pts[0]
+                oracle_detect(sd, p[mask_points_by_range(p, case.info.point_cloud_range)], case.info)
+            while spent < budget and i < max_frames:
+                p = pts[i % case.n_distinct]
+                p = p[mask_points_by_range(p, case.info.point_cloud_range)]
+                t1 = time.perf_counter()
+                oracle_detect(sd, p, case.info, times=stage)
+                times.append(time.perf_counter() - t1)
+                spent += times[-1]
+                i += 1
+            return times, stage
+        # SURVEY 8(d): all host cores and one thread, warm-up, median over the frames that fit the time budget, per-stage split
+        times, stage = run_oracle(args.cpu_baseline_seconds, 12, 1)
+        med = float(np.median(times))
+        torch.set_num_threads(1)
+        t1x, stage1 = run_oracle(args.cpu_baseline_seconds * 0.6, 3, 0)
+        torch.set_num_threads(cores)
+        n = len(times)
+        out['cpu_baseline'] = {'value': round(1.0 / med, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+                               'sample': 'median of %d frames (after 1 warm-up frame) of the same 160k-pt workload through oracle/ (numpy + CPU torch '
+                                         'restatement of the spconv/PyTorch path; spconv itself is not installable), %.1f s of CPU time' % (n, sum(times)),
+                               'frames': n, 'mean_value': round(n / sum(times), 4),
+                               'stages_ms_per_frame': {k: round(1000.0 * v / n, 1) for k, v in stage.items()},
+                               'one_thread': {'value': round(len(t1x) / sum(t1x), 4), 'cores': 1, 'frames': len(t1x),
+                                              'stages_ms_per_frame': {k: round(1000.0 * v / len(t1x), 1) for k, v in stage1.items()}}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -217,6 +217,13 @@ def set_math(model, mode):
     return model
 
 
+def set_sparse_engine(model, engine):
+    """Convolution engine of the sparse backbone in the split math modes: 'gather' (default: sparse_conv_h.hip / sparse_conv_w.h on
+    rows in the canonical linear-key order) or 'tiles' (sparse_conv_t.hip: tile-resident inputs on rows in the brick order)."""
+    model.backbone3d.set_engine(engine)
+    return model
+
+
 F16_PAIR_SAFE_MAX = 3.0e4      # |activation| up to which fp16 pairs are used (fp16 saturates at 65504; interior layers get 2x headroom)
 
 

@@ -1,23 +1,28 @@
 // Sparse 3-D convolution on pair16 operands, third generation: TILE-RESIDENT inputs.
 //
 // k_spconv_h / k_spconv_w (sparse_conv_h.hip, sparse_conv_w.h) gather every (output row, kernel tap) pair from L2: a neighbour row
-// is fetched 8-15 times per convolution and their time follows that gather volume (r02: ~5 TB/s of gathered rows whatever the
-// channel count; one fp16 MFMA instead of three changes them by 13 %).  Here a workgroup owns TR consecutive output rows and
-// stages the rows those outputs read - the tile's HALO, 1.2-1.8x TR rows when the level is kept in the brick key order of
-// common.h (LevelGeom layout 1) - in LDS ONCE per 16-channel chunk; all kernel taps then take their operands from LDS:
+// is fetched 8-15 times per convolution.  Here a workgroup owns TR = 512 consecutive output rows and stages the rows those outputs
+// read - the tile's HALO, 1.2-1.4x TR rows when the level is kept in the brick key order of common.h (LevelGeom layout 1) - in LDS
+// ONCE per 16-channel chunk; all kernel taps then take their operands from LDS:
 //   * dz_build_tiles (once per rulebook, shared by the convolutions of an indice_key like the table itself) turns the
-//     output-stationary neighbour table into, per tile: the list of distinct input rows (halo) and a LOCAL table
-//     ltab[tap][row] = position in that list (uint16, 0xFFFF = no neighbour) - half the bytes of the global table;
+//     output-stationary neighbour table into, per tile: the list of distinct input rows (halo); the tile's SLOT list (its non-empty
+//     kernel taps, ascending); a LOCAL table ltab[slot][row] = position in the halo list (uint16, 0xFFFF = no neighbour) - half
+//     the bytes of the global table; and an order of the tile's rows: rows are SORTED BY THEIR TAP SET inside the tile, so that
+//     the 32-row MFMA fragments hold rows with similar neighbourhoods and a fragment can skip the slots none of its rows has
+//     (26 -> ~20 of 27 taps issued per fragment on the 160k-point frames; spconv sorts whole tensors by mask for the same reason
+//     - with a gather kernel that costs more in locality than it saves, with the inputs resident in LDS it is free);
 //   * the convolution is the resident-tile dense 3x3 kernel's design (conv3x3_d.hip) with the image tile replaced by the halo:
 //     nothing is staged in registers (buffer_load_dwordx4 ... lds), 64-byte rows per 16-channel chunk with the XOR swizzle
-//     slot = piece ^ ((row >> 2) & 3), the halo double-buffered (the next chunk arrives during the first taps of the current
-//     one), weight slices of a (tap, chunk) step through a ring of three, the step's local-table slice through a ring of four,
-//     one workgroup barrier per step, static vmcnt counts (every step issues the same number of loads; the ones that are not
-//     needed are pointed at a zero region of LDS with an out-of-range offset: zeros arrive, nothing is fetched);
+//     slot = piece ^ ((row >> 2) & 3), the halo double-buffered (the next chunk arrives during the first steps of the current
+//     one), weights and local-table slices through rings, static vmcnt counts (every step issues the same number of loads; the
+//     ones that are not needed go to a zero region of LDS with an out-of-range offset: zeros arrive, nothing is fetched);
+//   * a STEP = G slots x 16 channels between two workgroup barriers (G = 4 / 2 / 1 for 32 / 64 / 128 output channels): the
+//     bookkeeping of a step (~130 scalar / address instructions per wave: a wave issues one instruction at a time, so they
+//     cost as much as 4 MFMAs) is paid once per G taps, and the inline-asm loads - scheduling barriers for the compiler - are
+//     dealt out between the MFMA groups by hand;
 //   * a fragment's B operand is read from the LDS row ltab says (missing neighbour = the zero region): a tap costs no global
 //     gather, no index load from HBM, no LDS write;
-//   * 8 waves x (PT x 32 rows) x all output channels: the weights of a step are read from L2 once per TR = 512 rows (128 in
-//     k_spconv_h), and a wave skips the MFMAs of a 32-row fragment that has no neighbour at the step's tap;
+//   * 8 waves x 64 rows x all output channels: the weights of a step are read from L2 once per 512 rows (128 in k_spconv_h);
 //   * a tile whose halo exceeds the LDS capacity (HL - 1 rows) is processed in passes over slices of its halo list, the
 //     accumulators staying in registers - any input works, dense tiles cost extra passes.
 // Same arithmetic as k_spconv_h: the three fp16 / bf16 MFMAs per product, taps ascending inside a channel chunk, chunks ascending.
@@ -29,21 +34,21 @@
 
 namespace dz {
 
-constexpr int T_THREADS = 512, T_WAVES = 8;
+constexpr int T_THREADS = 512, T_WAVES = 8, T_TR = 512;
 constexpr int T_HL = 896;                         // LDS rows of a halo buffer (the last one is never loaded: HL - 1 usable; 512-row tiles of the
-                                                  // brick order read <= 840 rows on the 160k-point frames; two buffers + rings = 150 KB)
+                                                  // brick order read <= 840 rows on the 160k-point frames; two buffers + rings = 155-160 KB)
 constexpr int T_XBUF = T_HL * 64;                 // bytes
 constexpr int T_PXL = T_HL * 4 / T_THREADS;       // direct loads per thread per halo chunk (7)
 constexpr int T_ZERO = 1024;                      // zero region: target of the dummy loads, source of missing neighbours
-constexpr int T_NW = 3, T_NL = 4;                 // weight ring, local-table ring
 constexpr int T_KVOL_MAX = 27;
+constexpr int T_SLOTS = 32;                       // slot capacity of a tile (>= kvol, a multiple of 4)
+constexpr int T_INFO = 64;                        // int32 words of a tile's info record
+constexpr int TI_NSLOTS = 0, TI_NHALO = 1, TI_TAP = 4, TI_FSLOT = 36;     // info record: [4 .. 35] tap of slot s (-1: padding), [36 .. 51] slot bits of sorted fragment f
+constexpr int T_LTAB = T_SLOTS * T_TR;            // uint16 entries of a tile's local table (32 KB)
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// tile prepass
-// ---------------------------------------------------------------------------------------------------------------------------
-// layout of the local table: entry of (tile, tap k, row r of the tile) at ((tile * kvol + k) * TR + perm(r)) with
-// perm(r) = (r >> 6) * 64 + (r & 31) * 2 + ((r >> 5) & 1): the two rows (l, l + 32) a lane of the convolution serves are one dword
-__device__ __forceinline__ int ltab_perm(int r) { return (r >> 6) * 64 + (r & 31) * 2 + ((r >> 5) & 1); }
+// uint16 index of the local-table entry of (slot s, sorted position q): [slot group s / 4][wave q / 64][lane q % 32][s % 4][q / 32 % 2] -
+// the 16 bytes a lane needs for one group of four slots (its two rows l and l + 32) are contiguous, a wave's slice is 512 bytes
+__device__ __forceinline__ int ltab_index(int s, int q) { return ((((s >> 2) * T_WAVES + (q >> 6)) * 32 + (q & 31)) * 4 + (s & 3)) * 2 + ((q >> 5) & 1); }
 
 // exclusive scan of one value per thread over a block of NT threads (NT / 64 <= 16 waves); lds: >= 16 words
 template <int NT>
@@ -69,26 +74,40 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, u
     return woff + incl - v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// tile prepass
+// ---------------------------------------------------------------------------------------------------------------------------
 // One workgroup per tile.  The distinct neighbour rows of the tile are collected in an LDS hash set (open addressing, identity
-// hash: runs of consecutive rows keep their order), ranked by a scan over the slots, written as the halo list; the second sweep
-// over the table looks every neighbour up again and writes its position.
-template <int TR, int NT>
+// hash: runs of consecutive rows keep their order), ranked by a scan over the slots and written as the halo list; the rows are
+// sorted by (touches the z - 1 plane, touches the z + 1 plane, tap set) with a bitonic sort; the second sweep over the table
+// looks every neighbour up again and writes its position at (slot of the tap, sorted position of the row).
+template <int NT>
 __global__ __launch_bounds__(NT) void k_build_tiles(const int *__restrict__ nbr, const int *__restrict__ d_m_out, int cap, int kvol,
-                                                    int hstride, int *__restrict__ halo, int *__restrict__ nhalo,
-                                                    unsigned short *__restrict__ ltab) {
+                                                    int hstride, int *__restrict__ halo, int *__restrict__ tinfo,
+                                                    unsigned short *__restrict__ ltab, unsigned short *__restrict__ rowmap) {
+    constexpr int TR = T_TR;
     constexpr int HS = TR * 64;                   // slots (>= 2 x the 27 * TR candidates), a power of two
     constexpr int GROUPS = HS / 32;
-    static_assert(GROUPS % NT == 0 || NT % GROUPS == 0, "groups per thread");
+    static_assert(GROUPS == NT, "one occupancy group per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *const hs = reinterpret_cast<uint32_t *>(smem_raw);                 // [HS] row + 1, 0 = empty
     uint32_t *const occ = hs + HS;                                                // [GROUPS] occupancy of 32 slots
     uint32_t *const base = occ + GROUPS;                                          // [GROUPS] occupied slots before the group
-    uint32_t *const scan_s = base + GROUPS;                                       // [16]
+    uint32_t *const rmask = base + GROUPS;                                        // [TR] tap set of a row
+    unsigned long long *const keys = reinterpret_cast<unsigned long long *>(rmask + TR);     // [TR] sort keys
+    unsigned short *const inv = reinterpret_cast<unsigned short *>(keys + TR);    // [TR] sorted position of a row
+    uint32_t *const scan_s = reinterpret_cast<uint32_t *>(inv + TR);              // [16], [16] = tile tap mask
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int m = min(*d_m_out, cap);
     const int tile = blockIdx.x, row0 = tile * TR;
     if (row0 >= m) return;
     for (int s = tid; s < HS; s += NT) hs[s] = 0u;
+    if (tid < TR) rmask[tid] = 0u;
+    if (tid == 0) scan_s[16] = 0u;
+    {   // the whole local table of the tile = "no neighbour"
+        uint4 *lt4 = reinterpret_cast<uint4 *>(ltab + (size_t)tile * T_LTAB);
+        for (int i = tid; i < T_LTAB * 2 / 16; i += NT) lt4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
     __syncthreads();
     const int ncand = kvol * TR;
     for (int idx = tid; idx < ncand; idx += NT) {
@@ -96,6 +115,7 @@ __global__ __launch_bounds__(NT) void k_build_tiles(const int *__restrict__ nbr,
         const int row = row0 + r;
         const int v = row < m ? nbr[(size_t)k * cap + row] : -1;
         if (v < 0) continue;
+        atomicOr(&rmask[r], 1u << k);
         const uint32_t key = (uint32_t)v + 1u;
         uint32_t h = (uint32_t)v & (HS - 1);
         for (;;) {
@@ -109,44 +129,76 @@ __global__ __launch_bounds__(NT) void k_build_tiles(const int *__restrict__ nbr,
         const unsigned long long bal = __ballot(hs[g2 * 64 + lane] != 0u);
         if (lane == 0) { occ[2 * g2] = (uint32_t)bal; occ[2 * g2 + 1] = (uint32_t)(bal >> 32); }
     }
+    if (tid < TR) {
+        const uint32_t mk = rmask[tid];
+        if (mk) atomicOr(&scan_s[16], mk);
+        // sort key: rows of the tile by (reaches below, reaches above, tap set); rows past the end last
+        const uint32_t zk = (kvol == 27) ? ((((mk & 0x1FFu) != 0u) ? 2u : 0u) | (((mk >> 18) != 0u) ? 1u : 0u)) : 0u;
+        keys[tid] = (row0 + tid < m) ? (((unsigned long long)zk << 36) | ((unsigned long long)mk << 9) | (unsigned long long)tid)
+                                     : (~0ull << 9) | (unsigned long long)tid;
+    }
     __syncthreads();
-    // exclusive scan of the group counts (GROUPS = 2 * TR entries; NT threads take GROUPS / NT consecutive groups each)
-    constexpr int GPT = GROUPS / NT > 0 ? GROUPS / NT : 1;
-    uint32_t cnt[GPT], sum = 0;
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-        const int g = tid * GPT + j;
-        cnt[j] = g < GROUPS ? (uint32_t)__popc(occ[g]) : 0u;
-        sum += cnt[j];
-    }
+    const uint32_t cnt = (uint32_t)__popc(occ[tid]);
     uint32_t total;
-    uint32_t run = block_excl_scan<NT>(sum, scan_s, total);
+    base[tid] = block_excl_scan<NT>(cnt, scan_s, total);
+    // bitonic sort of the TR keys (threads 0 .. TR - 1, one element each)
+    for (int k = 2; k <= TR; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            if (tid < TR) {
+                const int o = tid ^ j;
+                if (o > tid) {
+                    const unsigned long long a = keys[tid], b = keys[o];
+                    if ((a > b) == ((tid & k) == 0)) { keys[tid] = b; keys[o] = a; }
+                }
+            }
+        }
+    __syncthreads();
+    const uint32_t tmask = scan_s[16];
+    int *const ti = tinfo + (size_t)tile * T_INFO;
+    if (tid < TR) {
+        const int r = (int)(keys[tid] & 511ull);
+        inv[r] = (unsigned short)tid;
+        rowmap[(size_t)tile * TR + tid] = (unsigned short)r;
+        // slot bits of this sorted position's row, OR-ed over the 32 rows of its fragment
+        uint32_t mk = rmask[r], sb = 0u;
+        while (mk) {
+            const int t = __ffs((int)mk) - 1;
+            mk &= mk - 1;
+            sb |= 1u << __popc(tmask & ((1u << t) - 1u));
+        }
 #pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-        const int g = tid * GPT + j;
-        if (g < GROUPS) base[g] = run;
-        run += cnt[j];
+        for (int d = 16; d >= 1; d >>= 1) sb |= (uint32_t)__shfl_xor((int)sb, d, 64);
+        if ((tid & 31) == 0) ti[TI_FSLOT + (tid >> 5)] = (int)sb;
     }
-    if (tid == 0) nhalo[tile] = (int)total;
+    if (tid < T_SLOTS) {                          // slot s = the s-th set bit of the tile's tap mask
+        uint32_t rem = tmask;
+        int tap = -1;
+        for (int i = 0; i <= tid; ++i) {
+            if (!rem) { tap = -1; break; }
+            tap = __ffs((int)rem) - 1;
+            rem &= rem - 1;
+        }
+        ti[TI_TAP + tid] = tap;
+    }
+    if (tid == 0) { ti[TI_NSLOTS] = __popc(tmask); ti[TI_NHALO] = (int)total; ti[2] = 0; ti[3] = 0; }
     __syncthreads();
     int *const hl = halo + (size_t)tile * hstride;
     for (int s = tid; s < HS; s += NT) {
         const uint32_t key = hs[s];
         if (key) hl[base[s >> 5] + __popc(occ[s >> 5] & ((1u << (s & 31)) - 1u))] = (int)(key - 1u);
     }
-    unsigned short *const lt = ltab + (size_t)tile * kvol * TR;
+    unsigned short *const lt = ltab + (size_t)tile * T_LTAB;
     for (int idx = tid; idx < ncand; idx += NT) {
         const int k = idx / TR, r = idx - k * TR;
         const int row = row0 + r;
         const int v = row < m ? nbr[(size_t)k * cap + row] : -1;
-        unsigned short pos = 0xFFFFu;
-        if (v >= 0) {
-            const uint32_t key = (uint32_t)v + 1u;
-            uint32_t h = (uint32_t)v & (HS - 1);
-            while (hs[h] != key) h = (h + 1) & (HS - 1);
-            pos = (unsigned short)(base[h >> 5] + __popc(occ[h >> 5] & ((1u << (h & 31)) - 1u)));
-        }
-        lt[k * TR + ltab_perm(r)] = pos;
+        if (v < 0) continue;
+        const uint32_t key = (uint32_t)v + 1u;
+        uint32_t h = (uint32_t)v & (HS - 1);
+        while (hs[h] != key) h = (h + 1) & (HS - 1);
+        const int pos = (int)(base[h >> 5] + __popc(occ[h >> 5] & ((1u << (h & 31)) - 1u)));
+        lt[ltab_index(__popc(tmask & ((1u << k) - 1u)), inv[r])] = (unsigned short)pos;
     }
 }
 
@@ -156,9 +208,9 @@ __global__ __launch_bounds__(NT) void k_build_tiles(const int *__restrict__ nbr,
 struct SpConvTArgs {
     const float *in;              // pair16 rows (in_rows, cin)
     const int *halo;              // (ntiles, hstride)
-    const int *nhalo;             // (ntiles)
-    const unsigned short *ltab;   // (ntiles, kvol, TR) permuted (ltab_perm)
-    const uint32_t *tile_masks;   // per 32 output rows: taps with a neighbour (dz_build_neighbors)
+    const int *tinfo;             // (ntiles, T_INFO)
+    const unsigned short *ltab;   // (ntiles, T_LTAB)
+    const unsigned short *rowmap; // (ntiles, TR): row (relative to the tile) at a sorted position
     const int *d_m_out;
     const float *w;               // (kvol, cout_pad, cin) pair16
     const float *scale, *shift;
@@ -184,27 +236,43 @@ __device__ __forceinline__ void t_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// CT: 32-channel output fragments (cout_pad = 32 * CT); PT: 32-row fragments per wave (TR = 8 * PT * 32);
-// PXS: halo loads per thread and step while the next chunk is being fetched (XSTEPS = ceil(PXL / PXS) steps; a chunk has at least
-// XSTEPS + 1 steps - the tap list is padded with empty taps when the tile has fewer)
-template <class M, int CT, int PT, int PXS>
+template <int CT, int G, int D>
+struct TCfg {
+    static constexpr int BC = CT * 32;
+    static constexpr int WBUF = BC * 64;                          // bytes of one slot's weight slice (16 channels)
+    static constexpr int WSLOT = G * WBUF;                        // bytes of a step's weights
+    static constexpr int WL = (G * BC * 4 + T_THREADS - 1) / T_THREADS;   // weight loads per thread and step
+    static constexpr int LSLOT = G == 4 ? 4096 : G * 1024;        // bytes of a step's local table
+    static constexpr int LL = G == 4 ? 1 : G;                     // local-table loads per thread and step (waves 0-3 real)
+    // rings: a slot is rewritten right after the barrier that follows its last read.  G = 1: a step's weights are read during the
+    // step before it (fragments are loaded one step ahead), its table two steps before; G > 1: the weights of slots 1 .. G - 1 are
+    // read during the step itself, the table one step before
+    static constexpr int NW = G == 1 ? D + 2 : D + 3, NL = G == 1 ? D + 3 : D + 2;
+    static constexpr bool HREG = CT == 1;                         // halo-load offsets of a pass in registers instead of LDS (32 output channels: LDS is short, registers are not)
+    static constexpr int OFF_X = 0, OFF_ZERO = 2 * T_XBUF, OFF_W = OFF_ZERO + T_ZERO, OFF_L = OFF_W + NW * WSLOT;
+    static constexpr int OFF_HAL = OFF_L + NL * LSLOT, OFF_SS = OFF_HAL + (HREG ? T_TR * 2 : T_HL * 4), OFF_END = OFF_SS + 2 * BC * 4;
+    static constexpr int LDS = OFF_END;
+};
+
+// CT: 32-channel output fragments (cout_pad = 32 * CT).  G: slots per step.  D: prefetch distance in steps - the loads a step
+// issues (weights and local table of step u + D + 2 / u + D + 3, a share of the next halo chunk) have to land only by the wait of
+// step u + D + 1.  PXS: halo loads per thread and step while the next chunk is fetched (XSTEPS = ceil(PXL / PXS) steps; a chunk
+// has at least XSTEPS + D + 1 steps - the slot list is padded with empty slots when the tile has fewer taps).
+template <class M, int CT, int G, int PXS, int D>
 __global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_spconv_t(SpConvTArgs a) {
-    constexpr int TR = T_WAVES * PT * 32;
-    constexpr int BC = CT * 32;
-    constexpr int WBUF = BC * 64;                               // bytes of a weight slice (16 channels)
-    constexpr int WL = (BC * 4 + T_THREADS - 1) / T_THREADS;    // weight loads per thread and step (1)
+    using C = TCfg<CT, G, D>;
+    constexpr int PT = 2, TR = T_TR, BC = C::BC, WBUF = C::WBUF, WL = C::WL, LL = C::LL;
     constexpr int XSTEPS = (T_PXL + PXS - 1) / PXS;
-    constexpr int MINSTEPS = XSTEPS + 1;
-    constexpr int OFF_X = 0, OFF_ZERO = 2 * T_XBUF, OFF_W = OFF_ZERO + T_ZERO, OFF_L = OFF_W + T_NW * WBUF;
-    constexpr int LBUF = T_WAVES * 256;                         // a step's local-table slice: one dword per lane and wave
-    constexpr int OFF_HAL = OFF_L + T_NL * LBUF, OFF_SS = OFF_HAL + T_HL * 4, OFF_TAP = OFF_SS + 2 * BC * 4;
-    static_assert(WL == 1, "one weight piece per thread and step at most");
+    constexpr int MINSTEPS = XSTEPS + D + 1;
+    constexpr int LPS = PXS + WL + LL;                          // loads per thread and step
+    static_assert(D * LPS <= 63, "vmcnt is a 6-bit counter");
+    static_assert(G == 1 || G == 2 || G == 4, "slots per step");
+    static_assert(G * BC * 4 >= T_THREADS, "every thread loads a weight piece");
     using ET = HTile<TR, BC, 16, T_WAVES, 1>;                   // epilogue traits (store_tile_pair16)
     static_assert(ET::PT == PT && ET::CT == CT, "epilogue traits");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int *const hal_s = reinterpret_cast<int *>(smem_raw + OFF_HAL);
-    float *const sc_s = reinterpret_cast<float *>(smem_raw + OFF_SS), *const sh_s = sc_s + BC;
-    int *const tap_s = reinterpret_cast<int *>(smem_raw + OFF_TAP);          // [0] = number of steps per chunk, [1 + i] = tap of step i
+    int *const hal_s = reinterpret_cast<int *>(smem_raw + C::OFF_HAL);
+    float *const sc_s = reinterpret_cast<float *>(smem_raw + C::OFF_SS), *const sh_s = sc_s + BC;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg = lane >> 5;
@@ -221,39 +289,26 @@ __global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int nk = a.cin / 16;
     const unsigned int row_bytes = (unsigned int)a.cin * 4u;
     const unsigned int tap_bytes = (unsigned int)(BC * a.cin * 4);
-    const int nh = a.nhalo[tile];
+    const int *const ti = a.tinfo + (size_t)tile * T_INFO;
+    const int nh = __builtin_amdgcn_readfirstlane(ti[TI_NHALO]);
+    const int nsl_real = __builtin_amdgcn_readfirstlane(ti[TI_NSLOTS]);
     const int *const hl_g = a.halo + (size_t)tile * a.hstride;
     const int npass = nh > 0 ? (nh + (T_HL - 2)) / (T_HL - 1) : 1;
-
-    // tap masks of my two fragments and of the tile; the tile's step list
-    unsigned int fm[PT];
+    // steps of a chunk: the tile's slots in groups of G, padded (empty slots: no weights, no neighbours, no MFMAs) to MINSTEPS
+    int nst = (nsl_real + G - 1) / G;
+    if (nst < MINSTEPS) nst = MINSTEPS;
+    // tap of every slot in a register (lane s = slot s; -1 = padding): read with v_readlane, no memory access in the loop
+    const int tapvec = ti[TI_TAP + (lane & 31)];
+    auto tap_at = [&](int s) { return __builtin_amdgcn_readlane(tapvec, s); };
+    // slots my two fragments (sorted rows wid * 64 .. + 31, + 32 .. + 63) take part in
+    unsigned int fs[PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int r32 = (row0 >> 5) + wid * PT + pt;
-        fm[pt] = (r32 << 5) < m ? a.tile_masks[r32] : 0u;
-        fm[pt] = __builtin_amdgcn_readfirstlane(fm[pt]);
-    }
+    for (int pt = 0; pt < PT; ++pt) fs[pt] = __builtin_amdgcn_readfirstlane((unsigned int)ti[TI_FSLOT + wid * PT + pt]);
     if (tid < BC) {
         const bool in = tid < a.cout;
         sc_s[tid] = (in && a.scale) ? a.scale[tid] : 1.f;
         sh_s[tid] = (in && a.shift) ? a.shift[tid] : 0.f;
     }
-    if (tid == 0) {
-        unsigned int tm = 0u;
-        for (int i = 0; i < TR / 32; ++i) {
-            const int r32 = (row0 >> 5) + i;
-            if ((r32 << 5) < m) tm |= a.tile_masks[r32];
-        }
-        int n = 0;
-        for (int k = 0; k < a.kvol; ++k)
-            if ((tm >> k) & 1u) tap_s[1 + n++] = k;
-        for (int k = 0; k < a.kvol && n < MINSTEPS; ++k)         // pad with empty taps (their local-table rows are all 0xFFFF)
-            if (!((tm >> k) & 1u)) tap_s[1 + n++] = k;
-        tap_s[0] = n;
-    }
-    __syncthreads();
-    const int ntap = __builtin_amdgcn_readfirstlane(tap_s[0]);
-    if (ntap < MINSTEPS) return;                                  // (kvol < MINSTEPS: refused by the launcher)
 
     f32x16 acc[CT][PT];
 #pragma unroll
@@ -263,173 +318,253 @@ __global__ __launch_bounds__(T_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // weight piece of this thread: row wr = tid >> 2 of the slice, LDS slot tid & 3 holds piece (tid & 3) ^ ((wr >> 2) & 3)
-    const int wr = tid >> 2;
-    const unsigned int wvoff = wr < BC ? (unsigned int)(wr * a.cin * 4 + (((tid & 3) ^ ((wr >> 2) & 3)) * 16)) : OOB_OFFSET;
-    const unsigned int w_lds = (unsigned int)(wid * 1024);
-    const bool w_real = wid * 16 < BC;                                         // wave-uniform: waves beyond the slice write zeros into the zero region
-    // local-table dword of this lane for tap k: byte ((tile * kvol + k) * TR + wid * 64 + l31 * 2) * 2
-    const unsigned int lvoff = (unsigned int)((wid * 64 + l31 * 2) * 2);
-    const unsigned int ltile = (unsigned int)((size_t)tile * a.kvol * TR * 2);
-
-    struct It { int ti, kc; };                                   // position in the (chunk, tap) step sequence of a pass
-    auto next = [&](It &it) { if (++it.ti == ntap) { it.ti = 0; ++it.kc; } };
-    auto issue_w = [&](const It &it, int slot) {
-        const bool ok = it.kc < nk;
-        const int tap = __builtin_amdgcn_readfirstlane(tap_s[1 + it.ti]);
-        t_load16_lds((unsigned int)(w_real ? OFF_W + slot * WBUF + w_lds : OFF_ZERO), ok ? wvoff : OOB_OFFSET, crsrc,
-                     ok ? (unsigned int)tap * tap_bytes + (unsigned int)(it.kc * 64) : 0u);
+    // weight piece j of this thread in a step's G slices: piece index pw = j * 512 + tid -> slot g = pw / (BC * 4) (wave-uniform: a
+    // wave covers 64 consecutive pieces, a slice has BC * 4 >= 128), row wr, LDS piece-slot pw & 3 holds global piece (pw & 3) ^ ((wr >> 2) & 3)
+    auto wpiece_g = [&](int j) { return (j * T_THREADS + wid * 64) / (BC * 4); };
+    auto wpiece_voff = [&](int j) {
+        const int pw = j * T_THREADS + tid;
+        const int wr = (pw % (BC * 4)) >> 2;
+        return (unsigned int)(wr * a.cin * 4 + (((pw & 3) ^ ((wr >> 2) & 3)) * 16));
     };
-    auto issue_l = [&](const It &it, int slot) {
-        const bool ok = it.kc < nk;
-        const int tap = __builtin_amdgcn_readfirstlane(tap_s[1 + it.ti]);
-        t_load4_lds((unsigned int)(OFF_L + slot * LBUF + wid * 256), ok ? lvoff : OOB_OFFSET, lrsrc, ok ? ltile + (unsigned int)(tap * TR * 2) : 0u);
+    // local-table bytes of this lane in a step's slice: waves 0-3 load it for the whole tile ((w', l31') pair p = wid * 64 + lane)
+    const unsigned int ltile = (unsigned int)((size_t)tile * T_LTAB * 2);
+    const bool l_real = wid < 4;
+
+    struct It { int st, kc; };                                   // position in the (chunk, step) sequence of a pass
+    auto next = [&](It &it) { if (++it.st == nst) { it.st = 0; ++it.kc; } };
+    // weights / local table of the step at `it` (past the last step, empty slots: out-of-range offsets, zeros arrive)
+    auto issue_w = [&](const It &it, int ring) {
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int s = it.st * G + (G == 1 ? 0 : wpiece_g(j));
+            const int tap = (it.kc < nk && s < T_SLOTS) ? tap_at(s) : -1;
+            t_load16_lds((unsigned int)(C::OFF_W + ring * C::WSLOT + (j * T_THREADS + wid * 64) * 16), tap >= 0 ? wpiece_voff(j) : OOB_OFFSET, crsrc,
+                         tap >= 0 ? (unsigned int)tap * tap_bytes + (unsigned int)(it.kc * 64) : 0u);
+        }
+    };
+    auto issue_l = [&](const It &it, int ring) {
+        if constexpr (G == 4) {
+            // one dwordx4 per lane: the 4 slots x 2 rows of pair p; slot group = step
+            const bool ok = it.kc < nk && l_real && it.st * 4 < T_SLOTS;
+            t_load16_lds((unsigned int)(l_real ? C::OFF_L + ring * C::LSLOT + wid * 1024 : C::OFF_ZERO), ok ? (unsigned int)((wid * 64 + lane) * 16) : OOB_OFFSET,
+                         lrsrc, ok ? ltile + (unsigned int)(it.st * 4096) : 0u);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int s = it.st * G + g;
+                const bool ok = it.kc < nk && l_real && s < T_SLOTS;
+                t_load4_lds((unsigned int)(l_real ? C::OFF_L + ring * C::LSLOT + g * 1024 + wid * 256 : C::OFF_ZERO),
+                            ok ? (unsigned int)((wid * 64 + lane) * 16 + (s & 3) * 4) : OOB_OFFSET, lrsrc, ok ? ltile + (unsigned int)((s >> 2) * 4096) : 0u);
+            }
+        }
     };
     // halo chunk kc into X buffer `buf`: load i of wave w fills pieces (i * 8 + w) * 64 + lane
-    auto issue_x = [&](int i, int kc, int buf, bool real) {
-        int pc = (i * T_WAVES + wid) * 64 + lane;
-        asm volatile("" : "+v"(pc));
-        const int r = pc >> 2;
-        const int g = hal_s[r];
-        const unsigned int voff = (real && g >= 0) ? (unsigned int)g * row_bytes + (unsigned int)(((pc & 3) ^ ((r >> 2) & 3)) * 16) : OOB_OFFSET;
-        t_load16_lds((unsigned int)(real ? OFF_X + buf * T_XBUF + (i * T_WAVES + wid) * 1024 : OFF_ZERO), voff, prsrc, (unsigned int)(kc * 64));
+    unsigned int xv[C::HREG ? T_PXL : 1];                         // (HREG) byte offset of this thread's piece of load i in the input
+    auto x_voff = [&](int i, int g) {
+        const int pc = (i * T_WAVES + wid) * 64 + lane, r = pc >> 2;
+        return g >= 0 ? (unsigned int)g * row_bytes + (unsigned int)(((pc & 3) ^ ((r >> 2) & 3)) * 16) : OOB_OFFSET;
+    };
+    auto issue_x = [&](int i, int kc, int buf) {
+        unsigned int voff;
+        if constexpr (C::HREG) {
+            voff = xv[0];
+#pragma unroll
+            for (int q = 1; q < T_PXL; ++q) voff = i == q ? xv[q] : voff;          // (i is a constant after unrolling, or wave-uniform)
+        } else {
+            int pc = (i * T_WAVES + wid) * 64 + lane;
+            asm volatile("" : "+v"(pc));
+            voff = x_voff(i, hal_s[pc >> 2]);
+        }
+        t_load16_lds((unsigned int)(C::OFF_X + buf * T_XBUF + (i * T_WAVES + wid) * 1024), voff, prsrc, (unsigned int)(kc * 64));
+    };
+    auto issue_dummy = [&]() { t_load16_lds((unsigned int)C::OFF_ZERO, OOB_OFFSET, prsrc, 0u); };
+
+    // local-table entries of this lane for the G slots of a step (slot g: low half = row l31, high half = row l31 + 32)
+    struct LT { unsigned int e[G]; };
+    auto table_of = [&](int step) {
+        LT t;
+        const int ring = step % C::NL;
+        if constexpr (G == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(smem_raw + C::OFF_L + ring * C::LSLOT + (wid * 32 + l31) * 16);
+            t.e[0] = v.x; t.e[1] = v.y; t.e[2] = v.z; t.e[3] = v.w;
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) t.e[g] = *reinterpret_cast<const unsigned int *>(smem_raw + C::OFF_L + ring * C::LSLOT + g * 1024 + (wid * 32 + l31) * 4);
+        }
+        return t;
     };
 
     struct Frag { v4u p_hi[PT], p_lo[PT], c_hi[CT], c_lo[CT]; };
-    const unsigned int c_lds = (unsigned int)(OFF_W + l31 * 64 + (((2 * kg) ^ ((l31 >> 2) & 3)) * 16));
-    // lt: the lane's local-table dword of the step (rows l31 and l31 + 32 of the wave: low / high half)
-    auto load_frag = [&](Frag &f, unsigned int lt, int pass_base, int xbuf, int wslot) {
+    const unsigned int c_lds = (unsigned int)(C::OFF_W + l31 * 64 + (((2 * kg) ^ ((l31 >> 2) & 3)) * 16));
+    auto load_frag = [&](Frag &f, unsigned int lt, int pass_base, int xbuf, int wring, int g) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const unsigned int e = (pt & 1) ? (lt >> 16) : (lt & 0xFFFFu);
             const unsigned int lr = e - (unsigned int)pass_base;
-            const unsigned int ax = (unsigned int)(OFF_X + xbuf * T_XBUF) + lr * 64u + (((2u * kg) ^ ((lr >> 2) & 3u)) * 16u);
-            const unsigned int adr = lr < (unsigned int)(T_HL - 1) ? ax : (unsigned int)(OFF_ZERO + kg * 32);
+            const unsigned int ax = (unsigned int)(C::OFF_X + xbuf * T_XBUF) + lr * 64u + (((2u * kg) ^ ((lr >> 2) & 3u)) * 16u);
+            const unsigned int adr = lr < (unsigned int)(T_HL - 1) ? ax : (unsigned int)(C::OFF_ZERO + kg * 32);
             f.p_hi[pt] = *reinterpret_cast<const v4u *>(smem_raw + adr);
             f.p_lo[pt] = *reinterpret_cast<const v4u *>(smem_raw + (adr ^ 16u));
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const unsigned int adr = c_lds + (unsigned int)(wslot * WBUF + ct * 2048);
+            const unsigned int adr = c_lds + (unsigned int)(wring * C::WSLOT + g * WBUF + ct * 2048);
             f.c_hi[ct] = *reinterpret_cast<const v4u *>(smem_raw + adr);
             f.c_lo[ct] = *reinterpret_cast<const v4u *>(smem_raw + (adr ^ 16u));
         }
     };
-    static_assert(PT <= 2, "a local-table dword carries two rows");
-    auto mma = [&](const Frag &f, int tap) {
+    // MFMAs of one slot for fragment pt, term-major (every accumulator receives lo.hi, hi.lo, hi.hi in that order)
+    auto mma_pt = [&](const Frag &f, auto pt_t) {
+        constexpr int P = decltype(pt_t)::value;
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            if (!((fm[pt] >> tap) & 1u)) continue;               // wave-uniform: this 32-row fragment has no neighbour at the tap
+        for (int term = 3 - M::TERMS; term < 3; ++term)
 #pragma unroll
-            for (int term = 3 - M::TERMS; term < 3; ++term)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
-        }
+            for (int ct = 0; ct < CT; ++ct)
+                acc[ct][P] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[P] : f.p_hi[P], acc[ct][P]);
+    };
+    auto mma_slot = [&](const Frag &f, int s) {                  // wave-uniform skips: fragments none of whose rows has the slot's tap
+        if ((fs[0] >> s) & 1u) mma_pt(f, std::integral_constant<int, 0>{});
+        if ((fs[1] >> s) & 1u) mma_pt(f, std::integral_constant<int, 1>{});
     };
 
     for (int pass = 0; pass < npass; ++pass) {
         const int pass_base = pass * (T_HL - 1);
-        // halo slice of the pass -> LDS (row HL - 1 is never loaded: the slice has at most HL - 1 entries)
-        for (int r = tid; r < T_HL; r += T_THREADS) hal_s[r] = (r < T_HL - 1 && pass_base + r < nh) ? hl_g[pass_base + r] : -1;
-        __syncthreads();
-        // ---- prologue: halo chunk 0, weights of steps 0 and 1, local tables of steps 0, 1, 2, the zero region
-        t_load16_lds((unsigned int)OFF_ZERO, OOB_OFFSET, prsrc, 0u);
+        // halo slice of the pass -> LDS / registers (row HL - 1 is never loaded: the slice has at most HL - 1 entries)
+        if constexpr (C::HREG) {
 #pragma unroll
-        for (int i = 0; i < T_PXL; ++i) issue_x(i, 0, 0, true);
+            for (int i = 0; i < T_PXL; ++i) {
+                const int r = ((i * T_WAVES + wid) * 64 + lane) >> 2;
+                xv[i] = x_voff(i, (r < T_HL - 1 && pass_base + r < nh) ? hl_g[pass_base + r] : -1);
+            }
+        } else {
+            for (int r = tid; r < T_HL; r += T_THREADS) hal_s[r] = (r < T_HL - 1 && pass_base + r < nh) ? hl_g[pass_base + r] : -1;
+        }
+        __syncthreads();
+        // ---- prologue: halo chunk 0, weights of steps 0 .. D + 1, local tables of steps 0 .. D + 2, the zero region
+        issue_dummy();
+#pragma unroll
+        for (int i = 0; i < T_PXL; ++i) issue_x(i, 0, 0);
+        // (look-ahead of the table: D + 3 steps with G = 1 - it is read one step before its fragments are -, D + 2 otherwise)
+        constexpr int DL = G == 1 ? D + 3 : D + 2;
         It iw{0, 0}, il{0, 0}, ic{0, 0};
-        issue_w(iw, 0); next(iw);
-        issue_w(iw, 1); next(iw);
-        issue_l(il, 0); next(il);
-        issue_l(il, 1); next(il);
-        issue_l(il, 2); next(il);
+#pragma unroll
+        for (int j = 0; j < D + 2; ++j) { issue_w(iw, j % C::NW); next(iw); }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) { issue_l(il, j % C::NL); next(il); }
         t_wait_vm<0>();
         __syncthreads();
-        const unsigned int lt_0 = *reinterpret_cast<const unsigned int *>(smem_raw + OFF_L + 0 * LBUF + wid * 256 + (lane & 31) * 4);
-        unsigned int lt_nxt = *reinterpret_cast<const unsigned int *>(smem_raw + OFF_L + 1 * LBUF + wid * 256 + (lane & 31) * 4);
+        LT lt_cur = table_of(0), lt_nxt = table_of(1);
         Frag fa, fb;
-        load_frag(fa, lt_0, pass_base, 0, 0);
-        const int nsteps = nk * ntap;
-        // step u: (ic.kc, ic.ti).  iw is at step u + 2, il at step u + 3.
-        auto step = [&](int u, Frag &fcur, Frag &fnxt) {
-            const int tap = __builtin_amdgcn_readfirstlane(tap_s[1 + ic.ti]);
-            const int kc = ic.kc;
-            // halo of the next chunk during the first XSTEPS steps of this one (dummies otherwise: static load counts)
-            {
-                const bool real = ic.ti < XSTEPS && kc + 1 < nk;
-#pragma unroll
-                for (int j = 0; j < PXS; ++j) {
-                    const int i = (ic.ti < XSTEPS ? ic.ti : 0) * PXS + j;
-                    issue_x(i < T_PXL ? i : 0, kc + 1, (kc + 1) & 1, real && i < T_PXL);
-                }
-            }
-            issue_w(iw, (u + 2) % T_NW); next(iw);
-            issue_l(il, (u + 3) % T_NL); next(il);
-            // everything issued before this step has landed: weights + local table of step u + 1 (and u + 2's table), and -
-            // at a chunk's last step - the next chunk's halo (its last loads were issued at step XSTEPS - 1 < ntap - 1)
-            t_wait_vm<PXS + WL + 1>();
+        load_frag(fa, lt_cur.e[0], pass_base, 0, 0, 0);
+        const int nsteps = nk * nst;
+        // Step u = (ic.kc, ic.st); iw is at step u + D + 2, il at step u + DL.  Everything a step needs was put in flight D + 2
+        // steps earlier, and nothing between the barrier and the MFMAs waits on memory.  Inside a step the fragments of slot g + 1
+        // are read while the MFMAs of slot g run (f0 / f1 alternate; G is 1 - steps come in pairs - or even).
+        auto step = [&](int u, Frag &f0, Frag &f1) {
+            const int kc = ic.kc, st = ic.st;
+            // all loads issued D + 1 or more steps ago have landed: weights of steps <= u + 1, local tables of steps <= u + 2, and -
+            // at a chunk's last step - the next chunk's halo (its last loads were issued at step XSTEPS - 1 <= nst - 2 - D)
+            t_wait_vm<D * LPS>();
             __syncthreads();
             It in = ic;
             next(in);
-            const unsigned int lt_nn = *reinterpret_cast<const unsigned int *>(smem_raw + OFF_L + ((u + 2) % T_NL) * LBUF + wid * 256 + (lane & 31) * 4);
-            if (u + 1 < nsteps) load_frag(fnxt, lt_nxt, pass_base, in.kc & 1, (u + 1) % T_NW);
-            mma(fcur, tap);
-            lt_nxt = lt_nn;
+            LT lt_nn;
+            if constexpr (G == 1) lt_nn = table_of(u + 2); else lt_nxt = table_of(u + 1);
+            const bool xreal = st < XSTEPS && kc + 1 < nk;
+            // slot 0: fragments of slot 1 (or of the next step's slot 0), MFMAs of slot 0
+            if constexpr (G == 1) load_frag(f1, lt_nxt.e[0], pass_base, in.kc & 1, (u + 1) % C::NW, 0);
+            else load_frag(f1, lt_cur.e[1], pass_base, kc & 1, u % C::NW, 1);
+            if constexpr (G == 1) {                              // one slot per step: its two fragments' MFMAs on either side of the loads
+                if ((fs[0] >> st) & 1u) mma_pt(f0, std::integral_constant<int, 0>{});
+            } else {
+                mma_slot(f0, st * G);
+            }
+            // this step's share of the look-ahead loads (static count: the ones with nothing to fetch go to the zero region), dealt
+            // out between the MFMA groups of the slots: the inline-asm loads are scheduling barriers for the compiler
+#pragma unroll
+            for (int j = 0; j < PXS; ++j) {
+                const int i = (st < XSTEPS ? st : 0) * PXS + j;
+                if (xreal && i < T_PXL) issue_x(i, kc + 1, (kc + 1) & 1); else issue_dummy();
+                if (G >= 2 && j == PXS / 2 - 1) {               // slot 1 in the middle of the halo loads
+                    if constexpr (G == 2) load_frag(f0, lt_nxt.e[0], pass_base, in.kc & 1, (u + 1) % C::NW, 0);
+                    else if constexpr (G == 4) load_frag(f0, lt_cur.e[2], pass_base, kc & 1, u % C::NW, 2);
+                    if constexpr (G >= 2) mma_slot(f1, st * G + 1);
+                }
+            }
+            if constexpr (G == 4) {
+                load_frag(f1, lt_cur.e[3], pass_base, kc & 1, u % C::NW, 3);
+                mma_slot(f0, st * G + 2);
+            }
+            issue_w(iw, (u + D + 2) % C::NW);
+            next(iw);
+            if constexpr (G == 4) {
+                load_frag(f0, lt_nxt.e[0], pass_base, in.kc & 1, (u + 1) % C::NW, 0);
+                mma_slot(f1, st * G + 3);
+            }
+            issue_l(il, (u + DL) % C::NL);
+            next(il);
+            if constexpr (G == 1) {
+                if ((fs[1] >> st) & 1u) mma_pt(f0, std::integral_constant<int, 1>{});
+            }
+            lt_cur = lt_nxt;
+            if constexpr (G == 1) lt_nxt = lt_nn;
             ic = in;
         };
-        for (int u = 0; u < nsteps; u += 2) {
-            step(u, fa, fb);
-            if (u + 1 < nsteps) step(u + 1, fb, fa);
+        if constexpr (G == 1) {
+            for (int u = 0; u < nsteps; u += 2) {
+                step(u, fa, fb);
+                if (u + 1 < nsteps) step(u + 1, fb, fa);
+            }
+        } else {
+            for (int u = 0; u < nsteps; ++u) step(u, fa, fb);
         }
         t_wait_vm<0>();                                          // the look-ahead loads of the last steps (dummies) before LDS is reused
         __syncthreads();
     }
 
-    // ---- epilogue through the idle halo buffers (hgemm.h)
+    // ---- epilogue through the idle halo buffers (hgemm.h); sorted position -> row of the tile
+    unsigned short *const rm_s = reinterpret_cast<unsigned short *>(smem_raw + C::OFF_HAL);          // (the halo list is done with)
+    for (int q = tid; q < TR; q += T_THREADS) rm_s[q] = a.rowmap[(size_t)tile * TR + q];
+    __syncthreads();
     store_tile_pair16<ET, M>(acc, smem_raw, sc_s, sh_s, 0, a.cout, a.relu != 0, reinterpret_cast<const unsigned char *>(a.residual),
-                             reinterpret_cast<unsigned char *>(a.out), wid, 0, lane, wid, [&](int lr) {
-                                 const int row = row0 + lr;
+                             reinterpret_cast<unsigned char *>(a.out), wid, 0, lane, wid, [&](int lq) {
+                                 const int row = row0 + (int)rm_s[lq];
                                  return row < m ? (size_t)row * a.cout * 4 : ~size_t(0);
                              });
 }
 
-template <int CT>
-constexpr int t_lds_bytes() {
-    return 2 * T_XBUF + T_ZERO + T_NW * CT * 32 * 64 + T_NL * T_WAVES * 256 + T_HL * 4 + 2 * CT * 32 * 4 + 32 * 4;
-}
-
-template <class M, int CT, int PT, int PXS>
+template <class M, int CT, int G, int PXS, int D>
 static int launch_spconv_t(const SpConvTArgs &a, hipStream_t stream) {
-    constexpr int LDS = t_lds_bytes<CT>();
-    constexpr int TR = T_WAVES * PT * 32;
+    constexpr int LDS = TCfg<CT, G, D>::LDS;
+    static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
     static bool attr_set[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return DZ_ERR_HIP;
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_t<M, CT, PT, PXS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_t<M, CT, G, PXS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             set_error("dz_spconv_tiles_forward: cannot reserve %d bytes of LDS", LDS);
             return DZ_ERR_HIP;
         }
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    int grid = ceil_div(a.cap, TR);
+    int grid = ceil_div(a.cap, T_TR);
     grid = (grid + 31) & ~31;            // whole runs of XRUN tiles on every XCD
-    hipLaunchKernelGGL((k_spconv_t<M, CT, PT, PXS>), dim3(grid), dim3(T_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((k_spconv_t<M, CT, G, PXS, D>), dim3(grid), dim3(T_THREADS), LDS, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
 template <class M>
 static int spconv_t_dispatch(const SpConvTArgs &a, int cout_pad, hipStream_t stream) {
-    // kvol 27: the next halo chunk arrives over 4 steps (a chunk has >= 5); small kernels (3 x 1 x 1): over 2 steps (>= 3)
-    if (a.kvol >= 5) {
-        if (cout_pad == 32) return launch_spconv_t<M, 1, 2, 2>(a, stream);
-        if (cout_pad == 64) return launch_spconv_t<M, 2, 2, 2>(a, stream);
-        if (cout_pad == 128) return launch_spconv_t<M, 4, 2, 2>(a, stream);
-    } else if (a.kvol >= 3) {
-        if (cout_pad == 32) return launch_spconv_t<M, 1, 2, 4>(a, stream);
-        if (cout_pad == 64) return launch_spconv_t<M, 2, 2, 4>(a, stream);
-        if (cout_pad == 128) return launch_spconv_t<M, 4, 2, 4>(a, stream);
+    // 3 x 3 x 3 kernels: 4 / 2 / 1 slots per step for 32 / 64 / 128 output channels (a step's weights are 8 KB in all three), the
+    // next halo chunk arrives over 2 / 2 / 4 steps, prefetch distance 1 / 1 / 2 steps (what LDS leaves room for);
+    // small kernels (3 x 1 x 1): one slot per step, the whole chunk in the first of its 3 steps, distance 1
+    if (a.kvol >= 11) {
+        if (cout_pad == 32) return launch_spconv_t<M, 1, 4, 4, 1>(a, stream);
+        if (cout_pad == 64) return launch_spconv_t<M, 2, 2, 4, 1>(a, stream);
+        if (cout_pad == 128) return launch_spconv_t<M, 4, 1, 2, 2>(a, stream);
+    } else if (a.kvol >= 3 && cout_pad == 128) {
+        return launch_spconv_t<M, 4, 1, 7, 1>(a, stream);
     }
     set_error("dz_spconv_tiles_forward: unsupported shape cout=%d kvol=%d", a.cout, a.kvol);
     return DZ_ERR_UNSUPPORTED;
@@ -441,39 +576,41 @@ using namespace dz;
 
 extern "C" {
 
-int dz_spconv_tile_rows(void) { return T_WAVES * 2 * 32; }
+int dz_spconv_tile_rows(void) { return T_TR; }
+int dz_spconv_tile_info_words(void) { return T_INFO; }
+int dz_spconv_tile_table_entries(void) { return T_LTAB; }
 
-size_t dz_build_tiles_halo_stride(int kvol) { return (size_t)(kvol < 1 ? 1 : kvol) * (T_WAVES * 2 * 32); }
+size_t dz_build_tiles_halo_stride(int kvol) { return (size_t)(kvol < 1 ? 1 : kvol) * T_TR; }
 
-int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, int *halo, int *nhalo, unsigned short *ltab, void *stream_) {
+int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, int *halo, int *tinfo, unsigned short *ltab,
+                   unsigned short *rowmap, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    constexpr int TR = T_WAVES * 2 * 32, NT = 1024;
-    DZ_CHECK_ARG(nbr && d_m_out && halo && nhalo && ltab, "dz_build_tiles: null pointer");
+    constexpr int NT = 1024;
+    DZ_CHECK_ARG(nbr && d_m_out && halo && tinfo && ltab && rowmap, "dz_build_tiles: null pointer");
     DZ_CHECK_ARG(kvol >= 1 && kvol <= T_KVOL_MAX && cap_out >= 0, "dz_build_tiles: kvol %d not in [1,27]", kvol);
     if (cap_out == 0) return DZ_OK;
-    constexpr int LDS = TR * 64 * 4 + 2 * (TR * 64 / 32) * 4 + 64;
+    constexpr int LDS = T_TR * 64 * 4 + 2 * (T_TR * 64 / 32) * 4 + T_TR * 4 + T_TR * 8 + T_TR * 2 + 17 * 4 + 60;
     static bool attr_set[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return DZ_ERR_HIP;
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_tiles<TR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_tiles<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             set_error("dz_build_tiles: cannot reserve %d bytes of LDS", LDS);
             return DZ_ERR_HIP;
         }
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_build_tiles<TR, NT>), dim3(ceil_div(cap_out, TR)), dim3(NT), LDS, stream, nbr, d_m_out, cap_out, kvol,
-                       (int)dz_build_tiles_halo_stride(kvol), halo, nhalo, ltab);
+    hipLaunchKernelGGL((k_build_tiles<NT>), dim3(ceil_div(cap_out, T_TR)), dim3(NT), LDS, stream, nbr, d_m_out, cap_out, kvol,
+                       (int)dz_build_tiles_halo_stride(kvol), halo, tinfo, ltab, rowmap);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
-int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *halo, const int *nhalo, const unsigned short *ltab,
-                            const uint32_t *tile_masks, int kvol, int cap_out, const int *d_m_out, const float *w, const float *scale,
+int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *halo, const int *tinfo, const unsigned short *ltab,
+                            const unsigned short *rowmap, int kvol, int cap_out, const int *d_m_out, const float *w, const float *scale,
                             const float *shift, const float *residual, int relu, float *out, int cout, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    constexpr int TR = T_WAVES * 2 * 32;
-    DZ_CHECK_ARG(in && halo && nhalo && ltab && tile_masks && d_m_out && w && out, "dz_spconv_tiles_forward: null pointer");
+    DZ_CHECK_ARG(in && halo && tinfo && ltab && rowmap && d_m_out && w && out, "dz_spconv_tiles_forward: null pointer");
     DZ_CHECK_ARG(kvol >= 3 && kvol <= T_KVOL_MAX, "dz_spconv_tiles_forward: kvol %d not in [3,27]", kvol);
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_spconv_tiles_forward: math %d is not a split mode", math);
     DZ_CHECK_ARG(cout % 8 == 0 && cin % 16 == 0, "dz_spconv_tiles_forward: cin must be a multiple of 16, cout of 8");
@@ -481,12 +618,12 @@ int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *ha
     const int cout_pad = cout < 32 ? 32 : cout;
     const size_t in_bytes = (size_t)in_rows * cin * sizeof(float);
     const size_t w_bytes = (size_t)kvol * cout_pad * cin * sizeof(float);
-    const size_t ltab_bytes = (size_t)ceil_div(cap_out, TR) * kvol * TR * 2;
+    const size_t ltab_bytes = (size_t)ceil_div(cap_out, T_TR) * T_LTAB * 2;
     if (in_rows < 0 || in_bytes >= 0x80000000ull || ltab_bytes >= 0x80000000ull) {
         set_error("dz_spconv_tiles_forward: input of %zu bytes / local table of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, ltab_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
-    SpConvTArgs a{in, halo, nhalo, ltab, tile_masks, d_m_out, w, scale, shift, residual, out, cin, cout, kvol, cap_out, relu,
+    SpConvTArgs a{in, halo, tinfo, ltab, rowmap, d_m_out, w, scale, shift, residual, out, cin, cout, kvol, cap_out, relu,
                   (int)dz_build_tiles_halo_stride(kvol), (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)ltab_bytes};
     if (math == DZ_MATH_F16) return spconv_t_dispatch<MathF16H>(a, cout_pad, stream);
     return math == DZ_MATH_F16X2 ? spconv_t_dispatch<MathF16>(a, cout_pad, stream) : spconv_t_dispatch<MathBF16>(a, cout_pad, stream);
@@ -494,7 +631,7 @@ int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *ha
 
 const char *dz_spconv_tiles_variant(int cin, int cout) {
     const int cout_pad = cout < 32 ? 32 : cout;
-    if (cout_pad == 32) return "k_spconv_t<512x32>";
+    if (cout_pad == 32) return cin <= 16 ? "k_spconv_t<512x32,c16>" : "k_spconv_t<512x32>";
     if (cout_pad == 64) return "k_spconv_t<512x64>";
     if (cout_pad == 128) return "k_spconv_t<512x128>";
     return "none";

@@ -13,6 +13,7 @@ Internal data layout (differs from the reference on purpose):
     batch_dict; the NCHW tensors the reference's keys promise are zero-copy permuted views.
 """
 import contextlib
+import os
 from functools import partial
 
 import numpy as np
@@ -257,13 +258,24 @@ class VoxelResBackBone8x(_Cached):
                          indice_key='spconv_down2'),
             norm_fn(channels[3]), nn.ReLU())
         self.num_point_features = channels[3]
-        # row order of the sparse levels (ops.LAYOUT_*) and convolution engine of the split math modes: 'tiles' = tile-resident
-        # inputs (csrc/sparse_conv_t.hip), 'gather' = one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h)
-        self.layout = ops.LAYOUT_BRICK
-        self.engine = 'tiles'
+        # Row order of the sparse levels (ops.LAYOUT_*) and convolution engine of the split math modes.
+        #   engine 'gather' + LAYOUT_LINEAR (default): one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h);
+        #   engine 'tiles'  + LAYOUT_BRICK: tile-resident inputs (sparse_conv_t.hip) - built and parity-tested in round 3, measured
+        #   SLOWER inside the detector on MI355X (743 vs 865 frames/s), so it is opt-in: set_sparse_engine(model, 'tiles').
+        self.layout = int(os.environ.get('DZ_TUNE_LAYOUT', ops.LAYOUT_LINEAR))          # (environment: A/B runs on one box)
+        self.engine = os.environ.get('DZ_TUNE_SPCONV_ENGINE', 'gather')
+        # output widths whose convolutions run on the tile engine when it is selected (the others keep the gather kernels)
+        self.tile_couts = tuple(int(c) for c in os.environ.get('DZ_TUNE_SPCONV_TILE_COUTS', '16,32,64,128').split(',') if c)
         self.backbone_channels = {'x_conv1': channels[0], 'x_conv2': channels[1], 'x_conv3': channels[2],
                                   'x_conv4': channels[3]}
         self.channels = channels
+
+    def set_engine(self, engine):
+        """'gather' (default; rows in the canonical linear-key order) or 'tiles' (tile-resident convolution; rows in brick order)."""
+        if engine not in ('gather', 'tiles'):
+            raise DetZeroHipError('unknown sparse engine %r (gather | tiles)' % (engine,))
+        self.engine = engine
+        self.layout = ops.LAYOUT_BRICK if engine == 'tiles' else ops.LAYOUT_LINEAR
 
     # ---- kernel-layout parameters -------------------------------------------------------------
     def plan(self):
@@ -322,19 +334,21 @@ class VoxelResBackBone8x(_Cached):
         steps = []          # (down neighbour table or None, same-level table or None, level, ready event or None)
         tiled = self.engine == 'tiles' and self.math != 0
 
-        def table(src, dst, k, s, p):
+        def table(src, dst, k, s, p, cout):
             nbr = src.neighbors_to(dst, k, s, p)
-            return ops.build_tiles(nbr, dst) if tiled and k[0] * k[1] * k[2] >= 3 else nbr
+            return ops.build_tiles(nbr, dst) if tiled and cout in self.tile_couts and k[0] * k[1] * k[2] >= 3 else nbr
+        ch = self.channels
         with torch.cuda.stream(side):
-            nbr1 = table(lvl1, lvl1, K3, S1, P1)
+            nbr1 = table(lvl1, lvl1, K3, S1, P1, ch[0])
             steps.append((None, nbr1, lvl1, side.record_event() if overlap else None))
             level = lvl1
             overflow = None
             for li, name in enumerate(('conv2', 'conv3', 'conv4', 'conv_out')):
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
                 nxt = level.downsample(dp['k'], dp['s'], dp['p'], cap=None if caps is None else int(caps[li]))
-                nbr_d = table(level, nxt, dp['k'], dp['s'], dp['p'])
-                nbr_s = table(nxt, nxt, K3, S1, P1) if name != 'conv_out' else None
+                co = ch[min(li + 1, 3)]
+                nbr_d = table(level, nxt, dp['k'], dp['s'], dp['p'], co)
+                nbr_s = table(nxt, nxt, K3, S1, P1, co) if name != 'conv_out' else None
                 if name == 'conv_out' and caps is not None:
                     # overflow flag of the calibrated capacities (same stream as the index build: it is covered by
                     # the last stage's event, so the main stream does not wait for the whole pyramid up front)

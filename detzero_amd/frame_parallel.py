@@ -107,12 +107,14 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
     return [boxes_to_annos(b, c, class_names, metas[i] if metas else None) for i, (b, c) in enumerate(ordered)]
 
 
-def timed_steps(step, steps, warmup, results, counts, sync, group=None):
+def timed_steps(step, steps, warmup, results, counts, sync, group=None, info=None):
     """The timed region of bench.py, shared with the CPU (gloo) test of the multi-GPU plumbing: ``warmup`` untimed calls of
     ``step(i)``, then exactly ``steps`` timed calls bracketed by barrier + ``sync()`` on both sides; with more than one rank
     the per-frame boxes in ``results`` (steps, B, K, 9) / ``counts`` (steps, B) are gathered inside the timed region
     (the tracker needs them on rank 0) and the elapsed time is the MAX over ranks.
-    Returns (seconds, gathered boxes (world, steps*B, K, 9) or None, gathered counts or None) - gathered tensors on rank 0 only."""
+    Returns (seconds, gathered boxes (world, steps*B, K, 9) or None, gathered counts or None) - gathered tensors on rank 0 only.
+    info (optional dict) receives ``ranks_seen`` (an all-reduced count of the ranks that ran the region) and ``gather_ms``
+    (this rank's time from the end of its last step to the end of the box gather, inside the timed region)."""
     import time
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     for i in range(warmup):
@@ -125,16 +127,28 @@ def timed_steps(step, steps, warmup, results, counts, sync, group=None):
     for i in range(warmup, warmup + steps):
         step(i)
     all_b = all_c = None
+    t_g = 0.0
     if world > 1:
+        sync()
+        tg0 = time.perf_counter()
         k, b = results.shape[0], results.shape[1]
         all_b, all_c = gather_frame_boxes(results.view(k * b, results.shape[2], results.shape[3]), counts.view(k * b), group)
+        sync()
+        t_g = time.perf_counter() - tg0
     sync()
     if world > 1:
         dist.barrier(group)
     sync()
     dt = time.perf_counter() - t0
+    seen = 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=results.device)
+        t = torch.tensor([dt, t_g], dtype=torch.float64, device=results.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        dt = float(t.item())
+        dt, t_g = float(t[0].item()), float(t[1].item())
+        one = torch.ones((1,), dtype=torch.int32, device=results.device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+        seen = int(one.item())
+    if info is not None:
+        info['ranks_seen'] = seen
+        info['gather_ms'] = round(1000.0 * t_g, 3)
     return dt, all_b, all_c

@@ -101,8 +101,10 @@ _SIGS = {
     'dz_spconv_forward_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_tile_rows': (c_int, []),
+    'dz_spconv_tile_info_words': (c_int, []),
+    'dz_spconv_tile_table_entries': (c_int, []),
     'dz_build_tiles_halo_stride': (c_size_t, [c_int]),
-    'dz_build_tiles': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dz_build_tiles': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_spconv_tiles_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_tiles_variant': (ctypes.c_char_p, [c_int, c_int]),

@@ -233,19 +233,22 @@ class SparseLevel:
 
 def build_tiles(nbr, out_level):
     """Tile form of a neighbour table for the tile-resident convolution (dz_spconv_tiles_forward): per tile of
-    dz_spconv_tile_rows() output rows the list of distinct input rows and the local (uint16) table.  Attached to the table as
-    ``nbr.tiles`` - spconv_forward picks the tile kernel whenever it is there (split math modes)."""
+    dz_spconv_tile_rows() output rows the list of distinct input rows (halo), the tile record (slots = non-empty taps, halo
+    size, fragment slot masks), the local uint16 table and the tap-set order of the tile's rows (include/detzero_hip.h).
+    Attached to the table as ``nbr.tiles`` = (halo, tinfo, ltab, rowmap) - spconv_forward picks the tile kernel whenever it is
+    there (split math modes)."""
     lib = L.load()
     kvol, cap = nbr.shape
     tr = lib.dz_spconv_tile_rows()
     ntiles = (cap + tr - 1) // tr
     dev = nbr.device
     halo = torch.empty((ntiles, lib.dz_build_tiles_halo_stride(kvol)), dtype=torch.int32, device=dev)
-    nhalo = torch.zeros((ntiles,), dtype=torch.int32, device=dev)
-    ltab = torch.empty((ntiles, kvol, tr), dtype=torch.int16, device=dev)
-    rc = lib.dz_build_tiles(L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(halo), L.ptr(nhalo), L.ptr(ltab), L.stream())
+    tinfo = torch.zeros((ntiles, lib.dz_spconv_tile_info_words()), dtype=torch.int32, device=dev)
+    ltab = torch.empty((ntiles, lib.dz_spconv_tile_table_entries()), dtype=torch.int16, device=dev)
+    rowmap = torch.empty((ntiles, tr), dtype=torch.int16, device=dev)
+    rc = lib.dz_build_tiles(L.ptr(nbr), kvol, cap, L.ptr(out_level.d_m), L.ptr(halo), L.ptr(tinfo), L.ptr(ltab), L.ptr(rowmap), L.stream())
     L.check(rc, 'dz_build_tiles')
-    nbr.tiles = (halo, nhalo, ltab)
+    nbr.tiles = (halo, tinfo, ltab, rowmap)
     return nbr
 
 
@@ -293,7 +296,7 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     def launch():
         if tiles is not None:
             rc = lib.dz_spconv_tiles_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(tiles[0]), L.ptr(tiles[1]), L.ptr(tiles[2]),
-                                             L.ptr(nbr.tile_masks), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale),
+                                             L.ptr(tiles[3]), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale),
                                              L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
         elif math:
             rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(getattr(nbr, 'tile_masks', None)),

@@ -218,19 +218,25 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
 /* tile_masks: the buffer dz_build_neighbors filled for this table (NULL: the kernel scans the table itself, slower). */
 /* Tile-resident sparse convolution (csrc/sparse_conv_t.hip; the same SubMConv3d / SparseConv3d call sites as dz_spconv_forward:
  * backbone3d.py:64-121, :243-280).  dz_build_tiles turns a neighbour table of dz_build_neighbors (kvol x cap_out, once per
- * indice_key) into, per tile of dz_spconv_tile_rows() consecutive output rows: the list of DISTINCT input rows the tile reads
- * (halo: ntiles x dz_build_tiles_halo_stride(kvol) int32, nhalo: ntiles counts) and a local table ltab (ntiles x kvol x
- * tile_rows uint16: position of the neighbour in the tile's list, 0xFFFF = none; rows permuted as the kernel's lanes read them).
+ * indice_key) into, per tile of dz_spconv_tile_rows() = 512 consecutive output rows:
+ *   halo   (ntiles x dz_build_tiles_halo_stride(kvol) int32)  the DISTINCT input rows the tile reads;
+ *   tinfo  (ntiles x dz_spconv_tile_info_words() = 64 int32)  [0] slots = non-empty kernel taps of the tile, [1] halo rows,
+ *          [4..35] tap of slot s (ascending; -1 beyond), [36..51] bit s of word f: sorted fragment f (32 rows) has a row with slot s;
+ *   rowmap (ntiles x 512 uint16)  the tile's rows sorted by their tap set: row (relative to the tile) at sorted position q;
+ *   ltab   (ntiles x dz_spconv_tile_table_entries() = 16384 uint16)  position in the halo list of the neighbour of (slot s, sorted
+ *          position q), 0xFFFF = none, at [s / 4][q / 64][q % 32][s % 4][q / 32 % 2].
  * dz_spconv_tiles_forward stages a tile's halo rows in LDS once per 16-channel chunk and runs every kernel tap from there -
- * same operands, same result convention (pair16 in / out, BatchNorm scale / shift, residual, ReLU) as dz_spconv_forward_split,
- * tile_masks = the per-32-row tap masks dz_build_neighbors wrote for the table.  kvol in [3, 27], cin % 16 == 0,
- * cout in {16, 32, 64, 128}.  Any row order is correct; the brick layout (DZ_LAYOUT_BRICK) is what keeps a tile's halo small. */
+ * same operands, same result convention (pair16 in / out, BatchNorm scale / shift, residual, ReLU) as dz_spconv_forward_split.
+ * kvol 27 with cout in {16, 32, 64, 128}, kvol in [3, 10] with cout 128; cin % 16 == 0.  Any row order of the level is correct;
+ * the brick layout (DZ_LAYOUT_BRICK) is what keeps a tile's halo small. */
 int dz_spconv_tile_rows(void);
+int dz_spconv_tile_info_words(void);
+int dz_spconv_tile_table_entries(void);
 size_t dz_build_tiles_halo_stride(int kvol);
-int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, int *halo, int *nhalo, unsigned short *ltab,
-                   void *stream);
-int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *halo, const int *nhalo, const unsigned short *ltab,
-                            const uint32_t *tile_masks, int kvol, int cap_out, const int *d_m_out, const float *w,
+int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, int *halo, int *tinfo, unsigned short *ltab,
+                   unsigned short *rowmap, void *stream);
+int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *halo, const int *tinfo, const unsigned short *ltab,
+                            const unsigned short *rowmap, int kvol, int cap_out, const int *d_m_out, const float *w,
                             const float *scale, const float *shift, const float *residual, int relu, float *out, int cout,
                             int math, void *stream);
 const char *dz_spconv_tiles_variant(int cin, int cout);

@@ -72,3 +72,32 @@ def test_bench_arguments():
     assert out.returncode == 0
     for flag in ('--gpus', '--steps', '--warmup'):
         assert flag in out.stdout
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` outside a launcher re-executes under torch.distributed.run and really runs two ranks: the --stub
+    switch replaces the GPU work by a no-op step (gloo on CPU) but keeps the spawn, the barrier + gather + max-over-ranks timed
+    region and the JSON line - n_gpus and the all-reduced ranks_seen are 2, and rank 0 holds both ranks' gathered counts."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout                                   # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['steps'] == 3 and d['warmup'] == 1
+    assert d['config']['gathered_counts'] == [1, 2]                      # rank r wrote r + 1: the gather reached rank 0
+    assert d['data'].startswith('stub')
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """No silent single-rank fallback: without GPUs (this container) --gpus 2 must fail, not print a 1-GPU line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('node has the GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and 'GPU' in (out.stderr + out.stdout)
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

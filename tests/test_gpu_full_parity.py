@@ -105,6 +105,32 @@ def test_modules_stage_by_stage_160k(full, device, math):
     set_math(model, 'f32')
 
 
+@pytest.mark.parametrize('math', ['f16x2', 'bf16x2'])
+def test_tile_engine_brick_order_160k(full, device, math):
+    """The opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip; rows of every level in the brick order) through the batched
+    FramePipeline at the headline configuration: active sets bit-exact and x_conv1..4 / encoded features against the oracle after
+    sorting rows by the linear key, final boxes within 1e-3 - the same statements as for the default engine."""
+    from detzero_amd.centerpoint import FramePipeline, set_math, set_sparse_engine
+    model, cfg, info, frames, refs = full
+    set_sparse_engine(model, 'tiles')
+    try:
+        pipe = FramePipeline(model, info, math=math)
+        from detzero_amd.centerpoint import _StackedFrames
+        pts = _equalised(frames, device)
+        prep = pipe.prepare(_StackedFrames(pts))
+        assert prep['steps'][0][2].layout == 1 and getattr(prep['steps'][0][1], 'tiles', None) is not None
+        res = pipe.backbone_stage(prep)
+        for i, ref in enumerate(refs):
+            _check_sparse(res, ref, math, model, frame=i, nb=len(frames))
+        boxes9, counts = pipe(pts)
+        for i, ref in enumerate(refs):
+            worst = _check_boxes(ref['final'], boxes9[i], int(counts[i].item()), 'tiles/%s/frame%d' % (math, i))
+            print('tile engine %s frame %d: worst matched box error %.2e' % (math, i, worst))
+    finally:
+        set_sparse_engine(model, 'gather')
+        set_math(model, 'f32')
+
+
 def _equalised(frames, device):
     """Frames padded to one length with rows outside the point-cloud range (x = 1e6): the xy range mask of
     data_processor.py:24-37 removes them inside the kernels, so the stacked route sees the same points."""

@@ -184,8 +184,10 @@ def _random_level(rng, shape, n, batch, device, layout, dense_block=False):
 @pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('kvol', [27, 3])
 def test_build_tiles_is_the_table(device, layout, kvol):
-    """dz_build_tiles: per tile the halo list holds exactly the distinct neighbour rows of the tile, and the local table points
-    every (tap, row) at its neighbour's position in that list (0xFFFF where the table has -1) - i.e. halo[ltab] == nbr."""
+    """dz_build_tiles: per tile the halo list holds exactly the distinct neighbour rows of the tile; the slot list is the tile's
+    non-empty taps in ascending order; rowmap is a permutation of the tile's rows; the local table points every (slot, sorted row)
+    at its neighbour's position in the halo list (0xFFFF where the table has -1) - i.e. halo[ltab] == nbr; and the fragment slot
+    masks say exactly which 32-row fragments have a neighbour at a slot."""
     from detzero_amd import lib as L
     from detzero_amd import ops
     rng = np.random.default_rng(11 + layout + kvol)
@@ -196,26 +198,39 @@ def test_build_tiles_is_the_table(device, layout, kvol):
         k, s, p = (3, 1, 1), (2, 1, 1), (0, 0, 0)
         out = lvl.downsample(k, s, p)
     nbr = ops.build_tiles(lvl.neighbors_to(out, k, s, p), out)
-    halo, nhalo, ltab = (t.cpu().numpy() for t in nbr.tiles)
+    halo, tinfo, ltab, rowmap = (t.cpu().numpy() for t in nbr.tiles)
     tr = L.load().dz_spconv_tile_rows()
     m = out.num_active()
     tab = nbr.cpu().numpy()
     ltab = ltab.view(np.uint16)
-    assert m > tr and ltab.shape == ((out.cap + tr - 1) // tr, kvol, tr)
-    r = np.arange(tr)
-    perm = (r >> 6) * 64 + (r & 31) * 2 + ((r >> 5) & 1)
+    rowmap = rowmap.view(np.uint16).astype(np.int64)
+    assert tr == 512 and m > tr and ltab.shape == ((out.cap + tr - 1) // tr, 32 * tr)
+    q = np.arange(tr)
     worst = 0
     for t in range((m + tr - 1) // tr):
-        rows = np.arange(t * tr, min((t + 1) * tr, m))
-        want = tab[:, rows]                                                           # (kvol, rows)
+        n_rows = min(tr, m - t * tr)
+        want = np.full((kvol, tr), -1, np.int64)
+        want[:, :n_rows] = tab[:, t * tr:t * tr + n_rows]                             # (kvol, row of the tile)
         uniq = np.unique(want[want >= 0])
-        nh = int(nhalo[t])
+        nsl, nh = int(tinfo[t, 0]), int(tinfo[t, 1])
         assert nh == uniq.size and np.array_equal(np.sort(halo[t, :nh]), uniq), t   # distinct rows, each once
-        loc = ltab[t][:, perm[:rows.size]].astype(np.int64)                           # (kvol, rows) positions
-        assert np.array_equal(loc == 0xFFFF, want < 0)
-        assert np.array_equal(np.where(loc != 0xFFFF, halo[t][np.minimum(loc, nh - 1)], -1), want), t
-        if rows.size < tr:
-            assert np.all(ltab[t][:, perm[rows.size:]] == 0xFFFF)                    # rows past the end: no neighbours
+        taps = np.nonzero((want >= 0).any(axis=1))[0]
+        assert nsl == taps.size and np.array_equal(tinfo[t, 4:4 + nsl], taps) and np.all(tinfo[t, 4 + nsl:36] == -1)
+        rm = rowmap[t]
+        assert np.array_equal(np.sort(rm), q)                                         # a permutation of the tile's rows
+        assert np.all(rm[:n_rows] < n_rows)                                           # rows past the end sort last
+        for sl in range(32):
+            idx = ((((sl >> 2) * 8 + (q >> 6)) * 32 + (q & 31)) * 4 + (sl & 3)) * 2 + ((q >> 5) & 1)
+            loc = ltab[t][idx].astype(np.int64)                                       # entry of (slot, sorted position q)
+            if sl >= nsl:
+                assert np.all(loc == 0xFFFF)
+                continue
+            w = want[taps[sl]][rm]                                                    # neighbour of the row at sorted position q
+            assert np.array_equal(loc == 0xFFFF, w < 0)
+            assert np.array_equal(np.where(loc != 0xFFFF, halo[t][np.minimum(loc, nh - 1)], -1), w), (t, sl)
+            frag = (loc != 0xFFFF).reshape(16, 32).any(axis=1)
+            got = (tinfo[t, 36:52].astype(np.int64) >> sl) & 1
+            assert np.array_equal(got.astype(bool), frag), (t, sl)
         worst = max(worst, nh)
     assert worst > 895                                                               # the dense block needs more than one LDS pass
 

@@ -28,10 +28,13 @@ def masked_frame(seed, n):
     return pts[m]
 
 
-def oracle_detect(sd, points, info, post=POST, dynamic=False):
+def oracle_detect(sd, points, info, post=POST, dynamic=False, times=None):
     """Whole per-frame path on the CPU oracle: returns dict of intermediates + final boxes.
-    dynamic: DynamicMeanVFE (multi-sweep configs, vfe.py:109-147) instead of the hard voxelizer + MeanVFE."""
+    dynamic: DynamicMeanVFE (multi-sweep configs, vfe.py:109-147) instead of the hard voxelizer + MeanVFE.
+    times (optional dict): seconds per stage are ADDED to its keys voxelize / sparse_backbone / dense / post (bench.py's cpu_baseline)."""
+    import time
     from oracle import dense, sparse as osp, voxelize as ov
+    t0 = time.perf_counter()
     if dynamic:
         pb = np.concatenate([np.zeros((points.shape[0], 1), np.float32), points], 1)
         feats, coords = ov.dynamic_mean_vfe(pb, info.point_cloud_range, info.voxel_size)
@@ -40,14 +43,21 @@ def oracle_detect(sd, points, info, post=POST, dynamic=False):
         vox, czyx, nump = ov.hard_voxelize(points, info.point_cloud_range, info.voxel_size, 5, info.max_voxels['test'])
         feats = ov.mean_vfe(vox, nump)
         coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    t1 = time.perf_counter()
     grid = info.grid_size
     sparse_shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
     res = osp.backbone_forward(sd, feats, coords, sparse_shape)
+    t2 = time.perf_counter()
     x, oc, shape = res['encoded']
     bev = osp.to_bev(x, oc, shape, 1)
     f2d = dense.bev_backbone_forward(sd, bev)
     pred = dense.center_head_forward(sd, f2d)
+    t3 = time.perf_counter()
     final = dense.generate_predicted_boxes(pred, info.point_cloud_range, info.voxel_size, 8, post)
+    t4 = time.perf_counter()
+    if times is not None:
+        for k, v in (('voxelize', t1 - t0), ('sparse_backbone', t2 - t1), ('dense', t3 - t2), ('post', t4 - t3)):
+            times[k] = times.get(k, 0.0) + v
     return {'voxels': vox, 'coords': coords, 'num_points': nump, 'feats': feats, 'backbone': res, 'bev': bev,
             'f2d': f2d, 'pred': pred, 'final': final}
 

@@ -16,13 +16,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--points', type=int, default=160000, help='points per sweep (two sweeps are merged per frame)')
-    ap.add_argument('--reps', type=int, default=10)
-    ap.add_argument('--math', default='f32')
-    args = ap.parse_args()
-    dev = torch.device('cuda', 0)
+def measure(dev, points=160000, reps=10, math='f32'):
+    """Two-stage detector on one merged 2-sweep frame -> dict (also the `pdv` leg of bench.py)."""
     from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
     from detzero_amd.config import centerpoint_pdv_cfg
     from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
@@ -35,14 +30,14 @@ def main():
         hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4]))
         hl.iou[1].bias.fill_(0.6)
     model = model.to(dev)
-    set_math(model, args.math)
-    frame = merge_two_sweeps(synth_waymo_frame(60, args.points), synth_waymo_frame(70, args.points))
+    set_math(model, math)
+    frame = merge_two_sweeps(synth_waymo_frame(60, points), synth_waymo_frame(70, points))
     pts = np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)
-    points = torch.from_numpy(pts).to(dev)
+    points_t = torch.from_numpy(pts).to(dev)
     first = [model.vfe, model.backbone3d, model.map_to_bev, model.backbone2d, model.dense_head]
 
     def run(timed):
-        bd = {'batch_size': 1, 'points': points}
+        bd = {'batch_size': 1, 'points': points_t}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         with torch.no_grad():
             ev[0].record()
@@ -56,14 +51,24 @@ def main():
     for _ in range(3):
         run(False)
     t1 = t2 = 0.0
-    for _ in range(args.reps):
+    n_roi = 0
+    for _ in range(reps):
         a, b, n_roi = run(True)
-        t1 += a / args.reps
-        t2 += b / args.reps
-    print(json.dumps({'metric': 'two-stage detector, ms per frame (plugin modules, eager, one frame)', 'math': args.math,
-                      'points_per_frame': int(frame.shape[0]), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
-                      'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
-                      'frames_per_s': round(1000.0 / (t1 + t2), 2), 'data': 'synthetic'}))
+        t1 += a / reps
+        t2 += b / reps
+    return {'metric': 'two-stage detector, ms per frame (plugin modules, eager, one frame)', 'math': math,
+            'points_per_frame': int(frame.shape[0]), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
+            'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
+            'frames_per_s': round(1000.0 / (t1 + t2), 2), 'data': 'synthetic'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--points', type=int, default=160000, help='points per sweep (two sweeps are merged per frame)')
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--math', default='f32')
+    args = ap.parse_args()
+    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math)))
 
 
 if __name__ == '__main__':

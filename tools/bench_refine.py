@@ -29,6 +29,66 @@ def timed(fn, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def measure(dev, objects=1024, chunk=128, steps=3, math='f32', with_crop=True):
+    """Refiner throughput on `dev` -> dict (also the `refine` leg of bench.py: BASELINE configs[3])."""
+    from detzero_amd import ops
+    from detzero_amd.refine_modules import GeometryTransformer, PositionTransformer
+    from detzero_amd.synth import synth_boxes, synth_state_dict, synth_waymo_frame
+    if os.path.join(ROOT, 'tests') not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_refine import GCFG, PCFG
+    out = {'metric': 'refiner objects/sec (GRM 3x256+4096 pts, PRM 200x256+200x48 pts)', 'dtype': math, 'data': 'synthetic',
+           'objects': objects, 'chunk': chunk}
+    gen = torch.Generator().manual_seed(0)
+    b = chunk
+    nchunks = max(objects // b, 1)
+
+    grm = GeometryTransformer(GCFG, 11, 4).eval()
+    grm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in grm.state_dict().items()}, 1))
+    grm = grm.to(dev).set_math(math)
+    gd = {'geo_memory_points': torch.randn((b, 4096, 11), generator=gen).to(dev),
+          'geo_query_points': torch.randn((b, 3, 256, 4), generator=gen).to(dev),
+          'geo_query_boxes': torch.randn((b, 3, 7), generator=gen).to(dev), 'geo_query_num': torch.full((b,), 3)}
+    t = timed(lambda: [grm(dict(gd)) for _ in range(nchunks)], steps)
+    out['grm_objects_per_s'] = round(nchunks * b / t, 1)
+    # algorithmic FLOP per object (SURVEY 8d): encoders 4.4 G + K/V projections 1.1 G
+    out['grm_tflops'] = round(nchunks * b * 5.5e9 / t / 1e12, 2)
+    del grm, gd
+
+    prm = PositionTransformer(PCFG, 32, 32).eval()
+    prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, 2))
+    prm = prm.to(dev).set_math(math)
+    bp = min(b, 96)
+    pchunks = max(objects // bp, 1)
+    lens = torch.randint(5, 201, (bp,), generator=gen)
+    pad = (torch.arange(200)[None, :] >= lens[:, None]).float()
+    pd = {'pos_query_points': torch.randn((bp, 200, 256, 32), generator=gen).to(dev),
+          'pos_memory_points': torch.randn((bp, 200, 48, 32), generator=gen).to(dev),
+          'pos_trajectory': torch.randn((bp, 200, 7), generator=gen).to(dev), 'padding_mask': pad.to(dev)}
+    t = timed(lambda: [prm(dict(pd)) for _ in range(pchunks)], steps)
+    out['prm_objects_per_s'] = round(pchunks * bp / t, 1)
+    out['prm_tflops'] = round(pchunks * bp * (12.8e9 + 2.5e9 + 2 * 0.98e9) / t / 1e12, 2)
+    del prm, pd
+
+    # attention core alone, PRM cross-attention shape (200 queries x 9600 keys, 8 heads x 32): exact fp32 on the fp32 matrix cores
+    q = torch.randn((bp, 200, 256), generator=gen).to(dev)
+    k = torch.randn((bp, 9600, 256), generator=gen).to(dev)
+    v = torch.randn((bp, 9600, 256), generator=gen).to(dev)
+    t = timed(lambda: ops.mha_core(q, k, v, None, 8, 32 ** -0.5), 5)
+    out['mha_core_prm_tflops'] = round(bp * 4.0 * 200 * 9600 * 256 / t / 1e12, 2)
+    out['mha_core_prm_us'] = round(t * 1e6, 1)
+    del q, k, v
+
+    if with_crop:       # object crop mask
+        from detzero_amd import roiaware_pool3d_utils
+        pts = torch.from_numpy(synth_waymo_frame(0, 180000)[:, :3]).to(dev)[None].contiguous()
+        boxes = torch.from_numpy(synth_boxes(0, 128, 60.0)).to(dev)[None].contiguous()
+        t = timed(lambda: roiaware_pool3d_utils.points_in_boxes_gpu_v2(pts, boxes), 10)
+        out['points_in_boxes_us'] = round(t * 1e6, 1)
+        out['points_in_boxes_write_gbs'] = round(128 * 180000 * 4 / t / 1e9, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--objects', type=int, default=1024)
@@ -36,59 +96,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--math', default='f32', choices=['f32', 'f16x2', 'bf16x2'], help="arithmetic of the big MLP stacks (set_math)")
     args = ap.parse_args()
-    dev = torch.device('cuda', 0)
-    from detzero_amd import ops
-    from detzero_amd.refine_modules import GeometryTransformer, PositionTransformer
-    from detzero_amd.synth import synth_boxes, synth_state_dict, synth_waymo_frame
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    from test_refine import GCFG, PCFG
-    out = {'metric': 'refiner objects/sec (GRM 3x256+4096 pts, PRM 200x256+200x48 pts)', 'dtype': args.math, 'data': 'synthetic',
-           'objects': args.objects, 'chunk': args.chunk}
-    gen = torch.Generator().manual_seed(0)
-    b = args.chunk
-    nchunks = max(args.objects // b, 1)
-
-    grm = GeometryTransformer(GCFG, 11, 4).eval()
-    grm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in grm.state_dict().items()}, 1))
-    grm = grm.to(dev).set_math(args.math)
-    gd = {'geo_memory_points': torch.randn((b, 4096, 11), generator=gen).to(dev),
-          'geo_query_points': torch.randn((b, 3, 256, 4), generator=gen).to(dev),
-          'geo_query_boxes': torch.randn((b, 3, 7), generator=gen).to(dev), 'geo_query_num': torch.full((b,), 3)}
-    t = timed(lambda: [grm(dict(gd)) for _ in range(nchunks)], args.steps)
-    out['grm_objects_per_s'] = round(nchunks * b / t, 1)
-    # algorithmic FLOP per object: encoders 4.4 G + K/V projections 1.1 G
-    out['grm_tflops'] = round(nchunks * b * 5.5e9 / t / 1e12, 2)
-
-    prm = PositionTransformer(PCFG, 32, 32).eval()
-    prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, 2))
-    prm = prm.to(dev).set_math(args.math)
-    bp = min(b, 96)
-    pchunks = max(args.objects // bp, 1)
-    lens = torch.randint(5, 201, (bp,), generator=gen)
-    pad = (torch.arange(200)[None, :] >= lens[:, None]).float()
-    pd = {'pos_query_points': torch.randn((bp, 200, 256, 32), generator=gen).to(dev),
-          'pos_memory_points': torch.randn((bp, 200, 48, 32), generator=gen).to(dev),
-          'pos_trajectory': torch.randn((bp, 200, 7), generator=gen).to(dev), 'padding_mask': pad.to(dev)}
-    t = timed(lambda: [prm(dict(pd)) for _ in range(pchunks)], args.steps)
-    out['prm_objects_per_s'] = round(pchunks * bp / t, 1)
-    out['prm_tflops'] = round(pchunks * bp * (12.8e9 + 2.5e9 + 2 * 0.98e9) / t / 1e12, 2)
-
-    # attention core alone, PRM cross-attention shape
-    q = torch.randn((bp, 200, 256), generator=gen).to(dev)
-    k = torch.randn((bp, 9600, 256), generator=gen).to(dev)
-    v = torch.randn((bp, 9600, 256), generator=gen).to(dev)
-    t = timed(lambda: ops.mha_core(q, k, v, None, 8, 32 ** -0.5), 5)
-    out['mha_core_prm_tflops'] = round(bp * 4.0 * 200 * 9600 * 256 / t / 1e12, 2)
-    out['mha_core_prm_us'] = round(t * 1e6, 1)
-
-    # object crop mask
-    from detzero_amd import roiaware_pool3d_utils
-    pts = torch.from_numpy(synth_waymo_frame(0, 180000)[:, :3]).to(dev)[None].contiguous()
-    boxes = torch.from_numpy(synth_boxes(0, 128, 60.0)).to(dev)[None].contiguous()
-    t = timed(lambda: roiaware_pool3d_utils.points_in_boxes_gpu_v2(pts, boxes), 10)
-    out['points_in_boxes_us'] = round(t * 1e6, 1)
-    out['points_in_boxes_write_gbs'] = round(128 * 180000 * 4 / t / 1e9, 1)
-    print(json.dumps(out))
+    print(json.dumps(measure(torch.device('cuda', 0), args.objects, args.chunk, args.steps, args.math)))
 
 
 if __name__ == '__main__':

@@ -39,9 +39,9 @@ def main():
     calls = []
     real = ops.spconv_forward
 
-    def spy(f, nbr, out_level, w, scale, shift, residual=None, relu=True, out=None, in_level=None, math=0):
+    def spy(f, nbr, out_level, w, scale, shift, residual=None, relu=True, out=None, in_level=None, math=0, cout=None):
         calls.append((f, nbr, out_level, w, scale, shift, residual, relu, in_level))
-        return real(f, nbr, out_level, w, scale, shift, residual, relu, out, in_level, math)
+        return real(f, nbr, out_level, w, scale, shift, residual, relu, out, in_level, math, cout)
     ops.spconv_forward = spy
     import detzero_amd.det_modules as dm
     dm.ops.spconv_forward = spy
@@ -78,11 +78,15 @@ def main():
             us = 1000.0 * e0.elapsed_time(e1) / args.reps
             seen[key] = (us, stats)
         us, (pairs, t16, t32, t64, t128) = seen[key]
+        halo = ''
+        if getattr(nbr, 'tiles', None) is not None:
+            nh = nbr.tiles[1][:(m + 511) // 512].float()
+            halo = '  tiles: halo/rows %.2f max %d' % (float(nh.sum().item()) / max(m, 1), int(nh.max().item()))
         total += us
         flop = 2.0 * pairs * cin * cout
         print('k%-2d %3d->%-3d rows %8d pairs/row %5.2f taps/tile[16|32|64|128] %5.2f %5.2f %5.2f %5.2f  %8.1f us  alg %6.2f TF/s  '
               'dense64 %6.2f TF/s%s' % (kvol, cin, cout, m, pairs / max(m, 1), t16, t32, t64, t128, us, flop / us / 1e6,
-                                        2.0 * m * t64 * cin * cout / us / 1e6, '  +res' if residual is not None else ''))
+                                        2.0 * m * t64 * cin * cout / us / 1e6, ('  +res' if residual is not None else '') + halo))
     print('sum over the %d sparse convs: %.1f us per step (%.1f us per frame)' % (len(calls), total, total / args.batch))
 
 
