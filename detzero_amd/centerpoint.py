@@ -147,6 +147,7 @@ class CenterPoint(nn.Module):
         """centerpoint.py:310-352."""
         if 'gt_boxes' not in data_dict:
             return recall_dict
+        rois = data_dict['rois'][batch_index] if 'rois' in data_dict else None          # second-stage runs: recall of the proposals too
         gt_boxes = data_dict['gt_boxes'][batch_index]
         if len(recall_dict) == 0:
             recall_dict = {'gt': 0}
@@ -163,9 +164,14 @@ class CenterPoint(nn.Module):
                 iou3d = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7].contiguous(), cur_gt[:, 0:7].contiguous())
             else:
                 iou3d = torch.zeros((0, cur_gt.shape[0]))
+            iou3d_roi = None
+            if rois is not None and rois.shape[0] > 0:
+                iou3d_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7].contiguous(), cur_gt[:, 0:7].contiguous())
             for t in thresh_list:
                 if iou3d.shape[0] > 0:
                     recall_dict['rcnn_%s' % str(t)] += (iou3d.max(dim=0)[0] > t).sum().item()
+                if iou3d_roi is not None:
+                    recall_dict['roi_%s' % str(t)] += (iou3d_roi.max(dim=0)[0] > t).sum().item()
             recall_dict['gt'] += cur_gt.shape[0]
         return recall_dict
 

@@ -16,8 +16,17 @@ from tests.util import canon_order, canon_tensor, cpu_state_dict, make_model, ma
 
 pytestmark = pytest.mark.gpu
 MATHS = ['f32', 'f16x2', 'bf16x2']
-FEAT_TOL = {'f32': 2e-3, 'f16x2': 2e-3, 'bf16x2': 2e-3}
-MAP_TOL = {'f32': 2e-3, 'f16x2': 2e-3, 'bf16x2': 5e-3}
+# Tolerances = ~10x the largest error OBSERVED on the MI355X (r03, printed by _close for every stage and math mode; the achieved
+# values are in profiles/r03*_gputests.txt), not one flat bound: f32 / f16x2 sit at fp32 summation-order noise (x_conv1 carries the
+# largest activations, |x| ~ 30), bf16x2 at its 16-bit pairs.
+TOL = {             # stage: (f32, f16x2, bf16x2)
+    'x_conv1': (1.5e-4, 1.5e-4, 3.5e-3), 'x_conv2': (5e-5, 1e-4, 2e-3), 'x_conv3': (2e-5, 5e-5, 3e-4), 'x_conv4': (1e-5, 2e-5, 2e-4),
+    'encoded': (6e-6, 1e-5, 1e-4), 'spatial_features': (6e-6, 1e-5, 1e-4), 'spatial_features_2d': (2e-6, 4e-6, 6e-5), 'head': (6e-6, 8e-6, 6e-5)}
+_MI = {'f32': 0, 'f16x2': 1, 'bf16x2': 2}
+
+
+def _tol(name, math):
+    return TOL['head' if name.startswith('head/') else name][_MI[math]]
 N_FULL = 160000
 
 
@@ -31,14 +40,49 @@ def full(device):
     return model.to(device), cfg, info, frames, refs
 
 
+SEEN = {}            # (stage, math) -> largest max-abs error observed in this run (printed at the end of the module)
+
+
+def _close(name, math, got, ref, tol=None):
+    """max |got - ref| <= tol, with the achieved error printed and collected (a regression by two decimal digits would otherwise
+    hide under a flat tolerance)."""
+    tol = _tol(name, math) if tol is None else tol
+    err = float((got.float() - ref.float()).abs().max()) if got.numel() else 0.0
+    SEEN[(name, math)] = max(SEEN.get((name, math), 0.0), err)
+    print('  parity %-22s [%-6s] max abs err %.3e (tolerance %.1e)' % (name, math, err, tol))
+    assert err <= tol, '%s [%s]: max abs error %.3e above %.1e' % (name, math, err, tol)
+    return err
+
+
+def _flip_is_on_a_threshold(box, score, others, others_scores, post_thresh=0.03, nms_thresh=0.7):
+    """A box that one side reports and the other does not is acceptable only when it sits ON a decision threshold: its score
+    within 1e-4 of SCORE_THRESH, or its BEV IoU with a higher-scored box within 1e-3 of the NMS threshold."""
+    from oracle import cref
+    if abs(float(score) - post_thresh) <= 1e-4:
+        return True
+    hi = others[others_scores > score]
+    if hi.shape[0] == 0:
+        return False
+    iou = cref.boxes_iou_bev(box[None, :7].astype(np.float32), hi[:, :7].astype(np.float32))[0]
+    return bool(np.any(np.abs(iou - nms_thresh) <= 1e-3))
+
+
 def _check_boxes(ref_final, boxes9, n, tag):
     rb = ref_final[0]
     n_ref = rb['pred_boxes'].shape[0]
     assert n_ref > 50, (tag, n_ref)
     got = boxes9[:n].cpu().numpy()
     nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), got[:, :7], got[:, 7], tol=1e-3)
-    # a candidate sitting exactly on SCORE_THRESH / the NMS threshold may flip; everything else matches within 1e-3
+    # a candidate sitting exactly on SCORE_THRESH / the NMS threshold may flip; everything else matches within 1e-3 - and every
+    # box that did flip is shown to sit on one of the two thresholds
     assert abs(n - n_ref) <= 2 and nm >= n_ref - 2, (tag, n, n_ref, nm, worst)
+    if nm < n_ref or nm < n:
+        rbx, rsc = rb['pred_boxes'].numpy(), rb['pred_scores'].numpy()
+        d = np.abs(rbx[:, None, :3] - got[None, :, :3]).max(-1)
+        for i in np.nonzero(d.min(axis=1) > 1e-3)[0]:                    # reference boxes without a partner
+            assert _flip_is_on_a_threshold(rbx[i], rsc[i], rbx, rsc), (tag, 'reference box without partner', rbx[i], rsc[i])
+        for j in np.nonzero(d.min(axis=0) > 1e-3)[0]:                    # our boxes without a partner
+            assert _flip_is_on_a_threshold(got[j, :7], got[j, 7], got[:, :7], got[:, 7]), (tag, 'box without partner', got[j])
     lab = {tuple(np.round(b[:3], 2)): int(l) for b, l in zip(rb['pred_boxes'].numpy(), rb['pred_labels'].numpy())}
     hits = sum(1 for g in got if lab.get(tuple(np.round(g[:3], 2)), int(g[8])) == int(g[8]))
     assert hits >= n - 2, (tag, hits, n)
@@ -60,8 +104,7 @@ def _check_sparse(res, ref, math, model, names=('x_conv1', 'x_conv2', 'x_conv3',
         got_c = coords[sel].copy(); got_c[:, 0] = 0
         assert np.array_equal(got_c, rc), name                                     # active set: bit-exact
         plain = ops.pair16_to_f32(feats[:m], mid) if mid else feats[:m]
-        torch.testing.assert_close(plain[torch.from_numpy(sel).to(plain.device)].cpu(), rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math],
-                                   msg=lambda s: '%s [%s]: %s' % (name, math, s))
+        _close(name, math, plain[torch.from_numpy(sel).to(plain.device)].cpu(), rf)
 
 
 @pytest.mark.parametrize('math', MATHS)
@@ -85,20 +128,20 @@ def test_modules_stage_by_stage_160k(full, device, math):
         rf, rc, rs = ref['backbone'][name]
         ti, tf = canon_tensor(t)
         assert t.spatial_shape == list(rs) and np.array_equal(ti, rc), name
-        torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+        _close(name, math, tf, rf)
     t = bd['encoded_spconv_tensor']
     rf, rc, rs = ref['backbone']['encoded']
     ti, tf = canon_tensor(t)
     assert np.array_equal(ti, rc)
-    torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    _close('encoded', math, tf, rf)
     bd = model.map_to_bev(bd)
-    torch.testing.assert_close(bd['spatial_features'].cpu(), ref['bev'], rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+    _close('spatial_features', math, bd['spatial_features'].cpu(), ref['bev'])
     bd = model.backbone2d(bd)
-    torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=MAP_TOL[math], atol=MAP_TOL[math])
+    _close('spatial_features_2d', math, bd['spatial_features_2d'].cpu(), ref['f2d'])
     bd = model.dense_head(bd)
     pred = model.dense_head.forward_ret_dict['pred_dicts'][0]
     for k, v in ref['pred'].items():
-        torch.testing.assert_close(pred[k].cpu(), v, rtol=MAP_TOL[math], atol=MAP_TOL[math])
+        _close('head/' + k, math, pred[k].cpu(), v)
     got = bd['final_box_dicts'][0]
     b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
     _check_boxes(ref['final'], b9, b9.shape[0], 'modules/' + math)
@@ -230,10 +273,10 @@ def test_multisweep_320k_dynamic_vfe(multisweep, device, math):
         rf, rc, rs = ref['backbone'][name]
         ti, tf = canon_tensor(t)
         assert np.array_equal(ti, rc), name
-        torch.testing.assert_close(tf, rf, rtol=FEAT_TOL[math], atol=FEAT_TOL[math])
+        _close('ms/' + name, math, tf, rf, 5.0 * _tol(name, math))      # (another model and input: 5x the single-sweep table, achieved value printed)
     for mod in (model.map_to_bev, model.backbone2d, model.dense_head):
         bd = mod(bd)
-    torch.testing.assert_close(bd['spatial_features_2d'].cpu(), ref['f2d'], rtol=MAP_TOL[math], atol=MAP_TOL[math])
+    _close('ms/spatial_features_2d', math, bd['spatial_features_2d'].cpu(), ref['f2d'], 5.0 * _tol('spatial_features_2d', math))
     got = bd['final_box_dicts'][0]
     b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
     _check_boxes(ref['final'], b9, b9.shape[0], 'multisweep-modules/' + math)

@@ -287,23 +287,23 @@ def test_eval_one_epoch_drives_the_hip_detector(device, tmp_path):
 
 
 @pytest.mark.gpu
-def test_generate_recall_record_on_planted_boxes(device):
-    """C5 in isolation: predictions that ARE ground-truth boxes (shifted by known amounts) give the recall counts the reference's
-    rule implies (centerpoint.py:325-352: trailing all-zero gt rows are padding; max IoU over predictions per gt)."""
+def test_generate_recall_record_matches_reference_golden(device, golden_dir):
+    """C5 against the reference's OWN generate_recall_record (centerpoint.py:310-352) and boxes_iou3d_gpu, executed on CPU by
+    tests/golden/gen_recall_golden.py (only the CUDA overlap call is replaced, by the routine pinned on iou3d_cpu.cpp): the
+    accumulated record after each of four frames - padded ground truth, a frame without detections, a second-stage frame with rois."""
     from detzero_amd.centerpoint import CenterPoint
-    from detzero_amd.synth import synth_boxes
-    gt = torch.from_numpy(synth_boxes(1, 10, near_duplicates=0.0)).to(device)
-    gt[:, 6] = 0
-    pred = gt.clone()
-    pred[:5, 0] += 0.1 * gt[:5, 3]          # IoU = 0.9/1.1 = 0.818
-    pred[5:8, 0] += 0.4 * gt[5:8, 3]        # IoU = 0.6/1.4 = 0.429
-    pred[8:, 0] += 2.0 * gt[8:, 3]          # disjoint
-    gt_pad = torch.cat([torch.cat([gt, torch.ones((10, 1), device=device)], 1), torch.zeros((3, 8), device=device)], 0)
-    rec = CenterPoint.generate_recall_record(pred, {}, 0, {'gt_boxes': gt_pad[None]}, [0.3, 0.5, 0.7])
-    assert rec['gt'] == 10 and rec['rcnn_0.3'] == 8 and rec['rcnn_0.5'] == 5 and rec['rcnn_0.7'] == 5
-    rec = CenterPoint.generate_recall_record(pred[:0], rec, 0, {'gt_boxes': gt_pad[None]}, [0.3, 0.5, 0.7])
-    assert rec['gt'] == 20 and rec['rcnn_0.3'] == 8
-    assert CenterPoint.generate_recall_record(pred, {}, 0, {}, [0.3]) == {}
+    g = np.load(os.path.join(golden_dir, 'recall_golden.npz'))
+    thresh = [float('%g' % t) for t in g['thresh']]
+    rec = {}
+    for ci in range(int(g['n_cases'])):
+        data = {'gt_boxes': torch.from_numpy(g['gt%d' % ci]).to(device)[None]}
+        if 'rois%d' % ci in g.files:
+            data['rois'] = torch.from_numpy(g['rois%d' % ci]).to(device)[None]
+        rec = CenterPoint.generate_recall_record(torch.from_numpy(g['pred%d' % ci]).to(device), rec, 0, data, thresh)
+        got = [rec['gt']] + [rec['roi_%s' % t] for t in thresh] + [rec['rcnn_%s' % t] for t in thresh]
+        assert got == g['recall_after%d' % ci].tolist(), (ci, rec)
+    assert rec['roi_0.3'] > 0 and rec['rcnn_0.7'] > 0
+    assert CenterPoint.generate_recall_record(torch.from_numpy(g['pred0']).to(device), {}, 0, {}, [0.3]) == {}
 
 
 @pytest.mark.gpu
