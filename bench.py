@@ -262,7 +262,7 @@ class Case:
         self.counts[i % K].copy_(self.g_n, non_blocking=True)
 
     def check_overflow(self):
-        if self.pipe.last_overflow is not None and bool(self.pipe.last_overflow.item()):
+        if self.pipe.overflow_seen():         # sticky over every pass (graph replay included) since the last check
             raise SystemExit('bench: a sparse level overflowed its calibrated capacity - rerun with --no-calibrate')
 
     def time_steps(self, steps, warmup, step=None):

@@ -293,6 +293,7 @@ class FramePipeline:
         self.level_caps = None        # per-frame row capacities of the strided stages (None = worst case)
         self._ws = {}                 # zero-bordered activation images of the dense stage, reused across steps
         self.last_overflow = None
+        self._overflow_acc = None
 
     def _voxelize(self, frames, cid=0):
         """-> (features (M,C), coords (M,4) [b,z,y,x], d_n or None).  Rows of a frame beyond its device-side
@@ -387,12 +388,22 @@ class FramePipeline:
         self.level_caps = [int(margin * b) + 4096 for b in best]
         return self.level_caps
 
+    def overflow_seen(self, clear=True):
+        """Host-side read (one sync) of the STICKY overflow counter: True when any pass since the last read (eager or replayed from
+        a graph - the OR into the counter is a kernel of the pass) lost sparse sites to a calibrated capacity."""
+        if self._overflow_acc is None:
+            return False
+        seen = bool(self._overflow_acc.item())
+        if clear:
+            self._overflow_acc.zero_()
+        return seen
+
     def check_overflow(self):
-        """Host-side check (one sync) of the device flag the last pass left: with calibrated capacities (`calibrate`) a frame much
-        denser than the samples would silently lose the sites past a level's capacity - call this after a pass (or every N
-        passes: the flag is sticky per pass, the outputs of an overflowed pass are the ones to discard) and re-calibrate with a
-        larger margin, or run with worst-case capacities (no `calibrate`), when it raises."""
-        if self.last_overflow is not None and bool(self.last_overflow.item()):
+        """Raises when a pass since the last check overflowed a calibrated level capacity (`calibrate`): a frame much denser than
+        the samples silently loses the sites past a capacity, so the outputs since the last check are the ones to discard - re-run
+        calibrate() on denser samples / with a larger margin, or use worst-case capacities (no `calibrate`).  One host sync: call it
+        after a pass or once per chunk of passes (frame_parallel.run_frame_parallel does)."""
+        if self.overflow_seen():
             raise DetZeroHipError('FramePipeline: a sparse level overflowed its calibrated row capacity (%s per frame): '
                                   're-run calibrate() on denser samples / with a larger margin, or drop the calibration'
                                   % (self.level_caps,))
@@ -400,7 +411,11 @@ class FramePipeline:
     @torch.no_grad()
     def backbone_stage(self, prep):
         """The 21 sparse convolutions -> {name: (rows, SparseLevel)}."""
-        self.last_overflow = prep.get('overflow', None)
+        self.last_overflow = prep.get('overflow', None)          # flag of THIS pass (device bool); the counter below is sticky
+        if self.last_overflow is not None:
+            if self._overflow_acc is None:                       # (first pass is an eager warm-up: never allocated inside a capture)
+                self._overflow_acc = torch.zeros((), dtype=torch.int32, device=self.last_overflow.device)
+            self._overflow_acc |= self.last_overflow.to(torch.int32)
         return self.model.backbone3d.run_pyramid(prep)
 
     @torch.no_grad()

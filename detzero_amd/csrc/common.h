@@ -50,10 +50,41 @@ static inline int stream_grid(long work_items, int block) {
     return (int)g;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may drive several GPUs
+// (ops._guarded), so the "already raised" flag of a kernel is kept per device.  `done` = a function-local static array.
+constexpr int DZ_MAX_DEVICES = 32;
+struct PerDeviceFlags { bool v[DZ_MAX_DEVICES] = {}; };
+static inline int reserve_lds(const void *kernel, int bytes, PerDeviceFlags &done, const char *who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("%s: hipGetDevice failed", who); return DZ_ERR_HIP; }
+    if (dev >= 0 && dev < DZ_MAX_DEVICES && done.v[dev]) return DZ_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS on device %d", who, bytes, dev);
+        return DZ_ERR_HIP;
+    }
+    if (dev >= 0 && dev < DZ_MAX_DEVICES) done.v[dev] = true;
+    return DZ_OK;
+}
+// compute units of the CURRENT device (cached per device)
+static inline int device_cus() {
+    static int cus[DZ_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < DZ_MAX_DEVICES && cus[dev]) return cus[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < DZ_MAX_DEVICES) cus[dev] = n;
+    return n;
+}
+
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
 // ---- bitmap index lookups -------------------------------------------------------------------
-// rank of an ACTIVE cell `key` = number of active cells with a smaller key
+// rank of an ACTIVE cell `key` = number of active cells with a smaller key.
+// CONTRACT: levels built by dz_voxelize_to_level carry a PARTIAL prefix (written only at words that hold a bit: their level-1
+// bitmap is > 97 % empty words) - bitmap_rank on a key whose WORD is empty reads an unwritten prefix entry.  Rank only ACTIVE keys
+// on such a level (bitmap_find tests the bit first and is always safe); ops.SparseLevel.prefix_partial records the property and
+// the wrappers that rank arbitrary keys (PDV ball query / grouping: batch starts) refuse a partial level.
 __device__ __forceinline__ int bitmap_rank(const uint32_t *__restrict__ bitmap,
                                            const uint32_t *__restrict__ prefix, uint32_t key) {
     const uint32_t w = key >> 5, bit = key & 31u;

@@ -175,15 +175,8 @@ static int launch_conv_h(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t st
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_h<T, M, OUT_F32, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                T::LDS_BYTES) != hipSuccess) {
-            set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", T::LDS_BYTES);
-            return DZ_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_conv2d_h<T, M, OUT_F32, NS>), T::LDS_BYTES, lds_done, "dz_conv2d_forward_split")) return rc_;
     hipLaunchKernelGGL((k_conv2d_h<T, M, OUT_F32, NS>), grid, dim3(256), T::LDS_BYTES, stream, p, m_total, (unsigned int)in_bytes,
                        (unsigned int)w_bytes);
     DZ_LAUNCH_CHECK();

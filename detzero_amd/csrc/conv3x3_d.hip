@@ -271,14 +271,8 @@ static int launch_c3d(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t strea
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_d<M>), hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) != hipSuccess) {
-            set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", D_LDS_BYTES);
-            return DZ_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_conv3x3_d<M>), D_LDS_BYTES, lds_done, "dz_conv2d_forward_split")) return rc_;
     const int nty = p.cout_pad / D_BC;
     int per_xcd = 32 / nty * nty;
     if (per_xcd < nty) per_xcd = nty;

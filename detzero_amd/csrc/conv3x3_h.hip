@@ -491,15 +491,8 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess) {
-            set_error("dz_conv2d_forward_split: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-            return DZ_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), C::LDS_BYTES, lds_done, "dz_conv2d_forward_split")) return rc_;
     // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
     const int nty = p.cout_pad / BC * p.groups;

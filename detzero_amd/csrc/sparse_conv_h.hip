@@ -200,15 +200,8 @@ static int tune(const char *name, int dflt) {
 template <class T, class M, int NS, bool GN, int OCC, int DIAG = 0>
 static int launch_spconv_h_impl(const SpConvHArgs &a, hipStream_t stream) {
     constexpr int LDS = T::LDS_BYTES + (GN ? 0 : KVOL_MAX_H * T::BP * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS, GN, OCC, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess) {
-            set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", LDS);
-            return DZ_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_spconv_h<T, M, NS, GN, OCC, DIAG>), LDS, lds_done, "dz_spconv_forward_split")) return rc_;
     int grid = ceil_div(a.cap, T::BP);
     if (grid > 2048) grid = 2048;
     grid = (grid + 7) & ~7;            // a multiple of 8: see the XCD schedule in the kernel

@@ -537,16 +537,8 @@ template <class M, int CT, int G, int PXS, int D>
 static int launch_spconv_t(const SpConvTArgs &a, hipStream_t stream) {
     constexpr int LDS = TCfg<CT, G, D>::LDS;
     static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-    static bool attr_set[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return DZ_ERR_HIP;
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_t<M, CT, G, PXS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            set_error("dz_spconv_tiles_forward: cannot reserve %d bytes of LDS", LDS);
-            return DZ_ERR_HIP;
-        }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_spconv_t<M, CT, G, PXS, D>), LDS, lds_done, "dz_spconv_tiles_forward")) return rc_;
     int grid = ceil_div(a.cap, T_TR);
     grid = (grid + 31) & ~31;            // whole runs of XRUN tiles on every XCD
     hipLaunchKernelGGL((k_spconv_t<M, CT, G, PXS, D>), dim3(grid), dim3(T_THREADS), LDS, stream, a);
@@ -590,16 +582,8 @@ int dz_build_tiles(const int *nbr, int kvol, int cap_out, const int *d_m_out, in
     DZ_CHECK_ARG(kvol >= 1 && kvol <= T_KVOL_MAX && cap_out >= 0, "dz_build_tiles: kvol %d not in [1,27]", kvol);
     if (cap_out == 0) return DZ_OK;
     constexpr int LDS = T_TR * 64 * 4 + 2 * (T_TR * 64 / 32) * 4 + T_TR * 4 + T_TR * 8 + T_TR * 2 + 17 * 4 + 60;
-    static bool attr_set[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return DZ_ERR_HIP;
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_tiles<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            set_error("dz_build_tiles: cannot reserve %d bytes of LDS", LDS);
-            return DZ_ERR_HIP;
-        }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_build_tiles<NT>), LDS, lds_done, "dz_build_tiles")) return rc_;
     hipLaunchKernelGGL((k_build_tiles<NT>), dim3(ceil_div(cap_out, T_TR)), dim3(NT), LDS, stream, nbr, d_m_out, cap_out, kvol,
                        (int)dz_build_tiles_halo_stride(kvol), halo, tinfo, ltab, rowmap);
     DZ_LAUNCH_CHECK();

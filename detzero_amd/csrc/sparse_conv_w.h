@@ -342,23 +342,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
 template <int CIN, int COUT, int G, class M, int WAVES, int OCC>
 static int launch_spconv_w(const SpConvHArgs &a, hipStream_t stream) {
     const int lds = a.kvol * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_w<CIN, COUT, G, M, WAVES, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                27 * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4) != hipSuccess) {
-            set_error("dz_spconv_forward_split: cannot reserve %d bytes of LDS", lds);
-            return DZ_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceFlags lds_done;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_spconv_w<CIN, COUT, G, M, WAVES, OCC>), 27 * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4, lds_done, "dz_spconv_forward_split")) return rc_;
     // persistent workgroups: as many as fit on the chip, a multiple of 8 for the XCD schedule
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DZ_ERR_HIP;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     const int per_cu = (4 * OCC) / WAVES > 0 ? (4 * OCC) / WAVES : 1;
     int grid = cus * per_cu;
     const int need = ceil_div(ceil_div(a.cap, 32), WAVES);

@@ -95,6 +95,8 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
             cnts.append(c.reshape(-1))
     boxes = torch.cat(outs, dim=0)
     counts = torch.cat(cnts, dim=0).to(torch.int32)
+    if hasattr(pipeline, 'check_overflow'):            # calibrated level capacities: a dropped site must not go unnoticed (one sync per chunk)
+        pipeline.check_overflow()
     if world == 1:
         all_b, all_c = boxes[None], counts[None]
     else:

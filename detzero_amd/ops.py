@@ -109,6 +109,7 @@ def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxel
                                   L.ptr(lvl.prefix), L.ptr(lvl.coords), L.ptr(lvl.d_m), cap, L.ptr(feats), c_dst, storage_math(math),
                                   L.ptr(ws), ws.numel(), L.stream())
     L.check(rc, 'dz_voxelize_to_level')
+    lvl.prefix_partial = True
     return lvl, feats
 
 
@@ -179,6 +180,9 @@ class SparseLevel:
         self.d_m = torch.zeros((1,), dtype=torch.int32, device=device)
         self.ws = _ws(lib.dz_index_workspace_bytes(self.batch, *self.shape, self.layout))
         self._m_host = None
+        # True for levels written by dz_voxelize_to_level: prefix[] is valid only at words that hold a bit, so only ACTIVE cells may
+        # be ranked (csrc/common.h: bitmap_rank contract); build_from_coords / downsample write the full prefix
+        self.prefix_partial = False
 
     def num_active(self):
         """Host copy of the active-site count (one sync; cached)."""
@@ -197,6 +201,7 @@ class SparseLevel:
                                       L.ptr(rank), L.ptr(self.ws), self.ws.numel(), L.stream())
         L.check(rc, 'dz_index_from_coords')
         self._m_host = None
+        self.prefix_partial = False
         return rank
 
     def downsample(self, k, s, p, cap=None):

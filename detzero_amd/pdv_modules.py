@@ -161,8 +161,17 @@ def index_lookup(coords_bzyx, level):
     return out[:n]
 
 
+def _full_prefix(level, who):
+    if getattr(level, 'prefix_partial', False):
+        raise L.DetZeroHipError('%s ranks cells that may be inactive: it needs a level with a full prefix (ops.SparseLevel.build_from_coords), '
+                                'not one written by dz_voxelize_to_level (prefix only at occupied words)' % who)
+    if level.layout != ops.LAYOUT_LINEAR:
+        raise L.DetZeroHipError('%s walks cells in the linear key order: the level must use LAYOUT_LINEAR' % who)
+
+
 def ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample):
     """-> idx (M, nsample) int32 (within-batch indices, padded with the first hit, zeros for an empty ball), cnt (M,) int32."""
+    _full_prefix(level, 'dz_pdv_ball_query')
     mq = new_xyz.shape[0]
     dev = new_xyz.device
     idx = torch.empty((max(mq, 1), nsample), dtype=torch.int32, device=dev)
@@ -175,6 +184,7 @@ def ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample):
 
 
 def group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, row_stride):
+    _full_prefix(level, 'dz_pdv_group_features')
     mq, nsample = idx.shape
     rows = torch.empty((max(mq * nsample, 1), row_stride), dtype=torch.float32, device=new_xyz.device)
     cells = level.shape[0] * level.shape[1] * level.shape[2]
@@ -362,6 +372,13 @@ class PDVHead(_Cached):
         glob = rotate_points_along_z(local.clone(), rois[:, 6]) + rois[:, 0:3].unsqueeze(dim=1)
         return glob, local
 
+    def stack_math(self):
+        """Arithmetic of this head's MLP / FC stacks = the head's own math mode (set_math), NOT the refiner's global one: 'f32'
+        pins them to the exact-fp32 engine; the opt-in 'f16' detector mode runs them as f16 pairs (there is no single-product
+        linear kernel)."""
+        m = int(getattr(self, 'math', 0) or 0)
+        return 1 if m == 3 else m
+
     def roi_grid_pool(self, batch_dict):
         p = self.plan()
         batch_size = batch_dict['batch_size']
@@ -379,9 +396,14 @@ class PDVHead(_Cached):
             level.build_from_coords(coords, want_rank=False)      # rank of a centroid's cell = its row (rows are in cell-key order)
             layer = self.roi_grid_pool_layers[k]
             for s, (radius, nsample) in enumerate(zip(layer.radii, layer.nsamples)):
+                if xyz.shape[0] == 0:          # no centroid on an active cell (empty / out-of-range frame): every ball is empty
+                    couts = p['pool'][k][s]['stack'][-1]['cout']
+                    pooled.append(new_xyz.new_zeros((new_xyz.shape[0], couts)))
+                    balls.append(torch.zeros((new_xyz.shape[0], nsample), dtype=torch.int32, device=new_xyz.device))
+                    continue
                 idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
                 rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
-                out, _ = _run_stack(rows, p['pool'][k][s]['stack'])
+                out, _ = _run_stack(rows, p['pool'][k][s]['stack'], math=self.stack_math())
                 pooled.append(ops.group_max(out, new_xyz.shape[0], nsample))
                 balls.append(idx)
         all_pooled = torch.cat(pooled, dim=-1).view(-1, g ** 3, self.c_out)
@@ -407,7 +429,7 @@ class PDVHead(_Cached):
         pos_in = positional_input.reshape(r * l, -1).float()
         pos_rows = pos_in.new_zeros((r * l, 16))
         pos_rows[:, :pos_in.shape[1]] = pos_in
-        pos, _ = _run_stack(pos_rows, p['pos'])
+        pos, _ = _run_stack(pos_rows, p['pos'], math=self.stack_math())
         empty = key_padding_mask.all(-1)                                   # RoIs without any point: left untouched (:31-44)
         add_pos = (~key_padding_mask) & (~empty)[:, None]
         src = torch.where(add_pos.reshape(r * l, 1), feats + pos, feats)
@@ -452,9 +474,9 @@ class PDVHead(_Cached):
         if self.pool_cfg.ATTENTION.get('COMBINE'):
             att = pooled + att
         rows = att.reshape(att.shape[0], -1).contiguous()                   # (RoI, 216 * C): the shared FC's columns were permuted to match
-        shared, _ = _run_stack(rows, p['shared'])
-        rcnn_reg, _ = _run_stack(shared, p['reg'])
-        rcnn_cls, _ = _run_stack(shared, p['cls'])
+        shared, _ = _run_stack(rows, p['shared'], math=self.stack_math())
+        rcnn_reg, _ = _run_stack(shared, p['reg'], math=self.stack_math())
+        rcnn_cls, _ = _run_stack(shared, p['cls'], math=self.stack_math())
         cls_preds, box_preds = self.generate_predicted_boxes(batch_dict['batch_size'], batch_dict['rois'], rcnn_cls.contiguous(), rcnn_reg.contiguous())
         batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = cls_preds, box_preds
         batch_dict['cls_preds_normalized'] = False

@@ -247,13 +247,14 @@ def _split_w(l, m, key='w'):
     return l[ck]
 
 
-def _splittable(layers, rows):
-    return bool(_REFINE_MATH[0]) and rows >= SPLIT_MIN_ROWS and all(l['cout'] % 32 == 0 for l in layers[:-1])
+def _splittable(layers, rows, math=None):
+    m = _REFINE_MATH[0] if math is None else math
+    return bool(m) and rows >= SPLIT_MIN_ROWS and all(l['cout'] % 32 == 0 for l in layers[:-1])
 
 
-def _run_stack_split(xp, layers, keep_pair=False):
+def _run_stack_split(xp, layers, keep_pair=False, math=None):
     """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair."""
-    m = _REFINE_MATH[0]
+    m = _REFINE_MATH[0] if math is None else math
     outs = []
     for li, l in enumerate(layers):
         last = li == len(layers) - 1
@@ -263,11 +264,14 @@ def _run_stack_split(xp, layers, keep_pair=False):
     return xp, outs
 
 
-def _run_stack(x, layers, upto=None):
+def _run_stack(x, layers, upto=None, math=None):
+    """math: None = the refiner's global mode (set_refine_math); an explicit mode (0 = fp32 engine, 1 / 2 = split pairs) pins the
+    stack's arithmetic whatever the refiner is set to (the PDV head passes its own)."""
     layers = layers if upto is None else layers[:upto]
-    if _splittable(layers, x.shape[0]):
-        xp = ops.pair16_from_f32(x, c_dst=_r32(x.shape[1]), math=_REFINE_MATH[0])
-        return _run_stack_split(xp, layers)
+    if _splittable(layers, x.shape[0], math):
+        m = _REFINE_MATH[0] if math is None else math
+        xp = ops.pair16_from_f32(x, c_dst=_r32(x.shape[1]), math=m)
+        return _run_stack_split(xp, layers, math=m)
     outs = []
     for li, l in enumerate(layers):
         x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])

@@ -1,7 +1,7 @@
-"""detzero_utils.config_utils (utils/detzero_utils/config_utils.py:1-97): the global ``cfg``, yaml loading with
-``_BASE_CONFIG_`` includes resolved against the CWD like the reference (its tools run from detection/tools),
-``cfg_from_list`` command-line overrides, ``log_config_to_file``."""
-from ast import literal_eval
+"""detzero_utils.config_utils - the global ``cfg`` and the three functions the reference's tools call (test.py:1-19):
+cfg_from_yaml_file (with ``_BASE_CONFIG_`` includes, resolved against the working directory because the reference's tools run
+from detection/tools), cfg_from_list (``KEY.SUB value`` overrides from the command line) and log_config_to_file."""
+import ast
 
 import yaml
 
@@ -10,61 +10,73 @@ from detzero_amd.config import AttrDict
 EasyDict = AttrDict
 
 
+def _walk(node, prefix):
+    """(dotted path, value, is a section) for every entry, depth first in insertion order."""
+    for key, val in node.items():
+        path = '%s.%s' % (prefix, key)
+        section = isinstance(val, AttrDict)
+        yield path, val, section
+        if section:
+            yield from _walk(val, path)
+
+
 def log_config_to_file(cfg, pre='cfg', logger=None):
-    """config_utils.py:6-12."""
-    for key, val in cfg.items():
-        if isinstance(cfg[key], AttrDict):
-            logger.info('\n%s.%s = edict()' % (pre, key))
-            log_config_to_file(cfg[key], pre=pre + '.' + key, logger=logger)
-            continue
-        logger.info('%s.%s: %s' % (pre, key, val))
+    for path, val, section in _walk(cfg, pre):
+        logger.info('\n%s = edict()' % path if section else '%s: %s' % (path, val))
+
+
+def _parse(text):
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def _override(section, key, text):
+    """One command-line override: the new value takes the type of the entry it replaces."""
+    old, new = section[key], _parse(text)
+    if isinstance(old, AttrDict) and not isinstance(new, dict):               # "a:1,b:2" into a sub-section
+        for item in str(text).split(','):
+            k, v = item.split(':')
+            old[k] = type(old[k])(v)
+    elif isinstance(old, list) and not isinstance(new, list):                 # "1,2,3" into a list
+        section[key] = [type(old[0])(x) for x in str(text).split(',')]
+    elif type(new) is type(old):
+        section[key] = new
+    else:
+        raise AssertionError('type %s does not match original type %s' % (type(new), type(old)))
 
 
 def cfg_from_list(cfg_list, config):
-    """config_utils.py:24-56: ``KEY.SUBKEY value`` pairs; dict-valued and list-valued keys take ``a:1,b:2`` / ``1,2`` strings."""
-    assert len(cfg_list) % 2 == 0
-    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
-        key_list = k.split('.')
-        d = config
-        for subkey in key_list[:-1]:
-            assert subkey in d, 'NotFoundKey: %s' % subkey
-            d = d[subkey]
-        subkey = key_list[-1]
-        assert subkey in d, 'NotFoundKey: %s' % subkey
-        try:
-            value = literal_eval(v)
-        except Exception:
-            value = v
-        if type(value) != type(d[subkey]) and isinstance(d[subkey], AttrDict):
-            for src in value.split(','):
-                cur_key, cur_val = src.split(':')
-                d[subkey][cur_key] = type(d[subkey][cur_key])(cur_val)
-        elif type(value) != type(d[subkey]) and isinstance(d[subkey], list):
-            d[subkey] = [type(d[subkey][0])(x) for x in value.split(',')]
-        else:
-            assert type(value) == type(d[subkey]), 'type {} does not match original type {}'.format(type(value), type(d[subkey]))
-            d[subkey] = value
+    if len(cfg_list) % 2:
+        raise AssertionError('overrides come in KEY VALUE pairs')
+    for dotted, text in zip(cfg_list[0::2], cfg_list[1::2]):
+        *parents, leaf = dotted.split('.')
+        section = config
+        for name in parents:
+            assert name in section, 'NotFoundKey: %s' % name
+            section = section[name]
+        assert leaf in section, 'NotFoundKey: %s' % leaf
+        _override(section, leaf, text)
 
 
 def merge_new_config(config, new_config):
-    """config_utils.py:59-76 (the include path is opened relative to the CWD, as in the reference)."""
-    if '_BASE_CONFIG_' in new_config:
-        with open(new_config['_BASE_CONFIG_'], 'r') as f:
+    """Deep-merge a loaded yaml dict into `config`; a ``_BASE_CONFIG_`` entry is loaded first, underneath."""
+    base = new_config.get('_BASE_CONFIG_')
+    if base is not None:
+        with open(base) as f:
             config.update(AttrDict(yaml.safe_load(f)))
     for key, val in new_config.items():
-        if not isinstance(val, dict):
+        if isinstance(val, dict):
+            merge_new_config(config.setdefault(key, AttrDict()), val)
+        else:
             config[key] = val
-            continue
-        if key not in config:
-            config[key] = AttrDict()
-        merge_new_config(config[key], val)
     return config
 
 
 def cfg_from_yaml_file(cfg_file, config):
-    with open(cfg_file, 'r') as f:
-        merge_new_config(config=config, new_config=yaml.safe_load(f))
-    return config
+    with open(cfg_file) as f:
+        return merge_new_config(config, yaml.safe_load(f))
 
 
 cfg = AttrDict()

@@ -1,8 +1,8 @@
-"""The evaluation loop the plugin surface is driven by: the contract of detection/tools/eval_utils.py:28-146 restated
+"""TEST HARNESS (not part of the product): a driver with the contract of the reference's detection/tools/eval_utils.py:28-146
 (recall bookkeeping :13-25, per-batch ``load_data_to_gpu`` -> ``model(batch_dict)`` -> ``generate_prediction_dicts``,
-``result.pkl``, ``dataset.evaluation``).  The reference's own file runs unchanged against the shims
-(tests/test_shim.py drives both over the same loader and compares the pickles); this copy exists so that the loop can also
-be run where the reference tree is not checked out."""
+``result.pkl``, ``dataset.evaluation``) for machines where /root/reference is absent (the GPU box).  Where the tree exists the
+reference's own file is loaded by path and runs unchanged against the shim packages; tests/test_shim.py drives both over the
+same loader and compares the pickles."""
 import pickle
 import time
 

@@ -90,6 +90,38 @@ def scene(seed=0):
             's4': np.array(s4), 'rois': np.stack(rois), 'roi_scores': scores, 'roi_labels': labels}
 
 
+RANGE_BIG = np.array([-75.2, -75.2, -2.0, 75.2, 75.2, 4.0], np.float32)
+N_ROI_BIG = 320
+
+
+def scene_big(seed=0):
+    """The bench shape (tools/bench_pdv.py: a full-range frame, hundreds of RoIs): one 120k-point frame over the whole Waymo range,
+    320 RoIs on the point cloud.  Everything is a function of the seed, so the fixture stores outputs only."""
+    from detzero_amd.synth import synth_waymo_frame
+    from oracle import sparse as osp, voxelize as ov
+    rng = np.random.default_rng(1000 + seed)
+    p = synth_waymo_frame(90 + seed, 120000)
+    p = p[np.all((p[:, :3] > RANGE_BIG[:3] + 0.05) & (p[:, :3] < RANGE_BIG[3:] - 0.05), axis=1)]
+    pts = np.concatenate([np.zeros((p.shape[0], 1), np.float32), p], 1)
+    _, czyx, _ = ov.hard_voxelize(p, RANGE_BIG, VOXEL, 5, 200000)
+    coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    shape = [41, 1504, 1504]
+    coords = coords[osp.canonical_order(coords, shape)]
+    K3, S2 = (3, 3, 3), (2, 2, 2)
+    l2, s2 = osp.conv_out_coords(coords, shape, K3, S2, (1, 1, 1))
+    l3, s3 = osp.conv_out_coords(l2, s2, K3, S2, (1, 1, 1))
+    l4, s4 = osp.conv_out_coords(l3, s3, K3, S2, (0, 1, 1))
+    centres = p[rng.choice(p.shape[0], N_ROI_BIG, replace=False), :3]
+    r = np.zeros((1, N_ROI_BIG, 7), np.float32)
+    r[0, :, :3] = centres + rng.normal(0, 0.2, (N_ROI_BIG, 3))
+    r[0, :, 3:6] = rng.uniform([1.5, 0.8, 1.2], [5.0, 2.4, 2.2], (N_ROI_BIG, 3))
+    r[0, :, 6] = rng.uniform(-np.pi, np.pi, N_ROI_BIG)
+    f3 = rng.standard_normal((l3.shape[0], 64)).astype(np.float32)
+    f4 = rng.standard_normal((l4.shape[0], 128)).astype(np.float32)
+    return {'points': pts, 'c3': l3.astype(np.int32), 'f3': f3, 's3': np.array(s3), 'c4': l4.astype(np.int32), 'f4': f4, 's4': np.array(s4),
+            'rois': r, 'roi_scores': rng.uniform(0.1, 0.9, (1, N_ROI_BIG)).astype(np.float32), 'roi_labels': rng.integers(1, 4, (1, N_ROI_BIG)).astype(np.int64)}
+
+
 def install_reference():
     import gen_golden as gg
     gg.install_stubs()                                   # numba, torch_scatter, iou3d_nms_utils.nms_gpu, detzero_det.utils.{centernet,model_nms}_utils
@@ -183,5 +215,41 @@ def main():
     print('saved', os.path.getsize(os.path.join(HERE, 'pdv_golden.npz')) // 1024, 'KiB')
 
 
+def main_big():
+    """pdv_big_golden.npz: the reference's PDVHead over scene_big() - final boxes / confidences of all 320 RoIs, the key-padding
+    mask, and the pooled / attended features of a few RoIs."""
+    import time
+    from detzero_amd.synth import synth_state_dict
+    pdv = install_reference()
+    sc = scene_big()
+    head = pdv.PDVHead(512, roi_head_cfg(), RANGE_BIG, VOXEL, num_class=1).eval()
+    head.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in head.state_dict().items()}, seed=WEIGHT_SEED), strict=True)
+    t = torch.from_numpy
+    bd = {'batch_size': 1, 'points': t(sc['points']), 'rois': t(sc['rois']), 'roi_scores': t(sc['roi_scores']), 'roi_labels': t(sc['roi_labels']),
+          'has_class_labels': True, 'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8},
+          'multi_scale_3d_features': {'x_conv3': SparseStub(t(sc['c3']), t(sc['f3']), sc['s3'], 1), 'x_conv4': SparseStub(t(sc['c4']), t(sc['f4']), sc['s4'], 1)}}
+    t0 = time.time()
+    with torch.no_grad():
+        pf, pc = head.get_point_voxel_features(bd)
+        bd['point_features'], bd['point_coords'] = pf, pc
+        pooled, g_pts, l_pts, ball = head.roi_grid_pool(bd)
+        pos = head.get_positional_input(bd['points'], bd['rois'], l_pts)
+        mask = (ball == 0).all(-1)
+        att = head.attention_head(pooled, pos, mask)
+        res = head({k: v for k, v in bd.items() if k not in ('point_features', 'point_coords')})
+    sub = np.array([0, 211])
+    small = {'n_points': np.array(sc['points'].shape[0]), 'n_c3': np.array(sc['c3'].shape[0]), 'n_c4': np.array(sc['c4'].shape[0]),
+             'n_centroids3': np.array(pc['x_conv3'].shape[0]), 'n_centroids4': np.array(pc['x_conv4'].shape[0]),
+             'key_padding_mask': np.packbits(mask.numpy()), 'roi_subset': sub, 'pooled': pooled.numpy()[sub].astype(np.float32),
+             'attention': att.numpy()[sub].astype(np.float32), 'ball_row_sums': ball.numpy().astype(np.int64).sum(axis=(1, 2)),
+             'batch_cls_preds': res['batch_cls_preds'].numpy(), 'batch_box_preds': res['batch_box_preds'].numpy()}
+    print('reference PDVHead on %d points, %d RoIs: %.0f s; masked grid points %.1f %%' % (sc['points'].shape[0], N_ROI_BIG, time.time() - t0, 100 * mask.numpy().mean()))
+    np.savez_compressed(os.path.join(HERE, 'pdv_big_golden.npz'), **small)
+    print('saved', os.path.getsize(os.path.join(HERE, 'pdv_big_golden.npz')) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    main()
+    if '--big' in sys.argv:
+        main_big()
+    else:
+        main()

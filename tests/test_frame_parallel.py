@@ -105,3 +105,37 @@ def test_boxes_to_annos_format():
     assert a['sequence_name'] == 's' and a['frame_id'] == 3
     e = fp.boxes_to_annos(b, 0, ['Vehicle'])
     assert e['boxes_lidar'].shape[0] == 0
+
+
+def _merge_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import detzero_amd.shim as shim
+    shim.install()
+    from detzero_utils import common_utils
+    n = 7                                               # 7 frames over 2 ranks: rank 1's shard ends with the wrap-around frame 0
+    part = [{'frame_id': i, 'boxes_lidar': np.full((2, 7), i, np.float32)} for i in fp.shard_indices(n, rank, world)]
+    merged = common_utils.merge_results_dist(part, n, tmpdir='/nonexistent/never-created')
+    assert common_utils.get_dist_info() == (rank, world)
+    q.put((rank, None if merged is None else [m['frame_id'] for m in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_merge_results_dist_is_a_collective_world2():
+    """The shim's merge_results_dist (the name eval_utils.eval_one_epoch calls) over gloo, world size 2: rank 0 gets the records in
+    dataset order with the sampler's wrap-around padding cut, rank 1 gets None, and no file is written (the reference's version
+    goes through per-rank pickle files, common_utils.py:119-140)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == list(range(7)) and got[1] is None
+    assert not os.path.exists('/nonexistent')

@@ -277,9 +277,25 @@ def test_calibrated_capacities_and_overflow_flag(small, device):
     for i in range(2):
         k = int(n0[i].item())
         assert torch.equal(o0[i, :k], o1[i, :k])
+    assert not cal.overflow_seen()
     cal.level_caps = [64, 64, 64, 64]
     cal(frames)
     assert bool(cal.last_overflow.item())
+    # the counter is sticky: a later pass that fits does not hide the overflow of an earlier one, and the check raises once
+    cal.level_caps = caps
+    cal(frames)
+    assert not bool(cal.last_overflow.item())
+    from detzero_amd.lib import DetZeroHipError
+    with pytest.raises(DetZeroHipError):
+        cal.check_overflow()
+    cal.check_overflow()                                   # read and cleared
+    # the multi-GPU driver checks once per chunk
+    from detzero_amd import frame_parallel as fp
+    cal.level_caps = [64, 64, 64, 64]
+    with pytest.raises(DetZeroHipError):
+        fp.run_frame_parallel(cal, frames, ['Vehicle', 'Pedestrian', 'Cyclist'], batch=2)
+    cal.level_caps = caps
+    assert len(fp.run_frame_parallel(cal, frames, ['Vehicle', 'Pedestrian', 'Cyclist'], batch=2)) == 2
 
 
 @pytest.mark.parametrize('math', ['f32', 'f16x2'])

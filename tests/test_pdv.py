@@ -158,6 +158,37 @@ def test_final_boxes_and_confidences(device, g):
 
 
 @pytest.mark.gpu
+def test_pdv_head_at_bench_size(device, golden_dir):
+    """PDVHead at the shape tools/bench_pdv.py and the `pdv` leg of bench.py time: a full-range 120k-point frame, 320 RoIs
+    (69 120 grid points against ~40 k voxel centroids per location).  Golden = the reference's own PDVHead over the same seeded
+    scene (gen_pdv_golden.py --big; 133 s on the CPU): the ball-query index sums of every RoI exactly, the key-padding mask, the
+    pooled / attended features of two RoIs, and the final boxes and confidences of all 320 RoIs within 1e-3."""
+    from detzero_amd.pdv_modules import PDVHead
+    g = np.load(os.path.join(golden_dir, 'pdv_big_golden.npz'))
+    sc = gen.scene_big()
+    assert sc['points'].shape[0] == int(g['n_points']) > 100000 and sc['c3'].shape[0] == int(g['n_c3']) and sc['rois'].shape[1] == 320
+    head = PDVHead(512, gen.roi_head_cfg(), gen.RANGE_BIG, gen.VOXEL, num_class=1).eval()
+    head.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in head.state_dict().items()}, seed=gen.WEIGHT_SEED), strict=True)
+    head = head.to(device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)        # noqa: E731
+    bd = {'batch_size': 1, 'points': t(sc['points']), 'rois': t(sc['rois']), 'roi_scores': t(sc['roi_scores']), 'roi_labels': t(sc['roi_labels']),
+          'has_class_labels': True, 'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8},
+          'multi_scale_3d_features': {'x_conv3': _Sparse(t(sc['c3']), t(sc['f3']), sc['s3'], 1), 'x_conv4': _Sparse(t(sc['c4']), t(sc['f4']), sc['s4'], 1)}}
+    out = head(bd)
+    r = head.forward_ret_dict
+    np.testing.assert_array_equal(r['ball_idxs'].cpu().numpy().astype(np.int64).sum(axis=(1, 2)), g['ball_row_sums'])      # exact indices (checksum per RoI)
+    mask = np.unpackbits(g['key_padding_mask'])[:320 * 216].reshape(320, 216).astype(bool)
+    np.testing.assert_array_equal(r['key_padding_mask'].cpu().numpy(), mask)
+    sub = g['roi_subset']
+    torch.testing.assert_close(r['pooled_features'][sub].cpu(), torch.from_numpy(g['pooled']), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r['attention_output'][sub].cpu(), torch.from_numpy(g['pooled'] + g['attention']), rtol=2e-3, atol=2e-3)
+    eb = float((out['batch_box_preds'].cpu() - torch.from_numpy(g['batch_box_preds'])).abs().max())
+    ec = float((out['batch_cls_preds'].cpu() - torch.from_numpy(g['batch_cls_preds'])).abs().max())
+    print('PDV at bench size: boxes max abs err %.2e, confidences %.2e' % (eb, ec))
+    assert tuple(out['batch_box_preds'].shape) == (1, 320, 7) and eb <= 1e-3 and ec <= 1e-3
+
+
+@pytest.mark.gpu
 def test_centerpoint_with_second_stage_end_to_end(device):
     """centerpoint_pdv_3sweeps-shaped model (DynamicMeanVFE, 6 point features, SECOND_STAGE): dense head -> RoIs -> PDVHead ->
     post_processing's second-stage branch.  Checks the plumbing (keys, shapes, score rule) on a two-frame batch."""

@@ -208,10 +208,10 @@ def _stub_cfg():
 
 @pytest.mark.skipif(not has_ref, reason='reference tree not present')
 def test_reference_eval_loop_equals_restated_loop(tmp_path):
-    """The reference's eval_utils.eval_one_epoch (by path) and detzero_amd/shim/eval_utils.py over the same loader and model:
+    """The reference's eval_utils.eval_one_epoch (by path) and tests/eval_loop.py over the same loader and model:
     identical result.pkl, identical recall dictionary."""
     ref_eval = _reference_eval_utils()
-    from detzero_amd.shim import eval_utils as my_eval
+    from tests import eval_loop as my_eval
     ds = _StubDataset()
     loader = torch.utils.data.DataLoader(ds, batch_size=2, collate_fn=ds.collate_batch)
     logger = logging.getLogger('shim-eval')
@@ -239,7 +239,7 @@ def test_eval_one_epoch_drives_the_hip_detector(device, tmp_path):
     from detzero_amd.centerpoint import FramePipeline, SyntheticDatasetInfo, synth_detector
     from detzero_amd.synth import VOXEL_SIZE_02
     from oracle import cref
-    ev = _reference_eval_utils() if has_ref else __import__('detzero_amd.shim.eval_utils', fromlist=['x'])
+    ev = _reference_eval_utils() if has_ref else __import__('tests.eval_loop', fromlist=['x'])
     root = str(tmp_path / 'waymo')
     infos = _write_dataset(root)
     cfg = _dataset_cfg(root)
