@@ -412,11 +412,14 @@ class FramePipeline:
     def backbone_stage(self, prep):
         """The 21 sparse convolutions -> {name: (rows, SparseLevel)}."""
         self.last_overflow = prep.get('overflow', None)          # flag of THIS pass (device bool); the counter below is sticky
+        res = self.model.backbone3d.run_pyramid(prep)
         if self.last_overflow is not None:
+            # (after run_pyramid: the flag is written on the index-pyramid side stream, and the main stream has by now waited for
+            # the last stage's event, which covers it)
             if self._overflow_acc is None:                       # (first pass is an eager warm-up: never allocated inside a capture)
                 self._overflow_acc = torch.zeros((), dtype=torch.int32, device=self.last_overflow.device)
             self._overflow_acc |= self.last_overflow.to(torch.int32)
-        return self.model.backbone3d.run_pyramid(prep)
+        return res
 
     @torch.no_grad()
     def dense_stage(self, res, nb):
