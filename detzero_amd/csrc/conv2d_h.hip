@@ -125,6 +125,54 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
             return;
         }
     }
+    if constexpr (OUT_F32) {
+        if (p.group_max) {
+            // Fused max over row groups (PointNet: torch.max over the points of an object, geometry_transformer.py:124,137): the tile's
+            // rows belong to ONE group (group_rows % BP == 0, checked by the launcher), so the wave reduces its PT fragments in
+            // registers, the 32 rows of a fragment with shuffles, and issues one atomic max per (wave, channel) on the fp32 result
+            // (pre-filled with -inf).  The (rows x cout) activation is never written: 2 x rows x cout x 4 bytes of HBM traffic less.
+            const long grow = row0 / p.group_rows;
+            float *const orow = p.out + (size_t)grow * p.out_cstride + ooff;
+#pragma unroll
+            for (int ct = 0; ct < T::CT; ++ct) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wc * T::CT * 32 + ct * 32 + 8 * j + 4 * h;
+                    float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                    for (int pt = 0; pt < T::PT; ++pt) {
+                        const int lr = wp * T::PT * 32 + pt * 32 + (lane & 31);
+                        if (out_pix[lr] < 0 || col >= gcout) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sc = p.scale ? p.scale[grp * p.cout_pad + col + e] : 1.f;
+                            const float sh = p.shift ? p.shift[grp * p.cout_pad + col + e] : 0.f;
+                            float a = acc[ct][pt][4 * j + e];
+                            if (p.group_shift) a += p.group_shift[(size_t)grow * p.cout_pad + col + e];
+                            a = fmaf(a, sc, sh);
+                            if (p.relu) a = fmaxf(a, 0.f);
+                            v[e] = fmaxf(v[e], a);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int d = 1; d < 32; d <<= 1) v[e] = fmaxf(v[e], __shfl_xor(v[e], d, 64));
+                    }
+                    if ((lane & 31) == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e >= gcout || v[e] == -INFINITY) continue;
+                            // float max through integer atomics: non-negative values order like ints, negative ones inversely like uints
+                            if (v[e] >= 0.f) atomicMax(reinterpret_cast<int *>(orow + col + e), __float_as_int(v[e]));
+                            else atomicMin(reinterpret_cast<unsigned int *>(orow + col + e), __float_as_uint(v[e]));
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int pt = 0; pt < T::PT; ++pt) {
         const int lr = wp * T::PT * 32 + pt * 32 + (lane & 31);
@@ -264,18 +312,25 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
 
 int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
                             const float *shift, const float *group_shift, int group_rows, int relu, float *y, int y_stride, int math,
-                            int out_f32, void *stream_) {
+                            int out_f32, int group_max, void *stream_) {
     DZ_CHECK_ARG(rows >= 0 && x_stride >= cin && y_stride >= cout && cin % 32 == 0 && cout_pad % 32 == 0 && cout <= cout_pad,
                  "dz_linear_forward_split: bad sizes (cin and cout_pad in multiples of 32)");
+    if (group_max) {
+        // y = (rows / group_rows, y_stride) fp32: max over every group's rows, fused into the layer's epilogue
+        DZ_CHECK_ARG(out_f32 && group_rows >= 128 && group_rows % 128 == 0 && rows % group_rows == 0 && y_stride % 4 == 0 && ((uintptr_t)y & 15u) == 0,
+                     "dz_linear_forward_split: group_max needs fp32 output, group_rows %% 128 == 0 (got %d), rows %% group_rows == 0, a 16-byte aligned result", group_rows);
+        const int rc = fill_u32(y, 0xFF800000u, (size_t)(rows / group_rows) * y_stride, (hipStream_t)stream_);        // -inf
+        if (rc) return rc;
+    }
     if (group_rows < 1) group_rows = 1;
     // the rows are fetched through 32-bit buffer offsets: at most ~2 GiB of them per launch
     long max_rows = (long)(0x7FF00000ull / ((size_t)x_stride * sizeof(float)));
-    if (group_shift) max_rows = max_rows / group_rows * group_rows;
+    if (group_shift || group_max) max_rows = max_rows / group_rows * group_rows;
     DZ_CHECK_ARG(max_rows >= 1, "dz_linear_forward_split: one row group exceeds the 2 GiB addressing window");
     for (long r0 = 0; r0 < rows; r0 += max_rows) {
         const int n = (int)((rows - r0) < max_rows ? (rows - r0) : max_rows);
         dz_conv2d_desc d = {};
-        d.in = x + (size_t)r0 * x_stride; d.out = y + (size_t)r0 * y_stride; d.w = w; d.scale = scale; d.shift = shift;
+        d.in = x + (size_t)r0 * x_stride; d.out = y + (size_t)(group_max ? r0 / group_rows : r0) * y_stride; d.w = w; d.scale = scale; d.shift = shift;
         d.batch = 1; d.ho = 1; d.wo = n;
         d.in_hp = 1; d.in_wp = n; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin;
         d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
@@ -284,6 +339,7 @@ int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, co
         d.groups = 1; d.cout_pad = cout_pad; d.g_cout[0] = cout; d.g_ooff[0] = 0; d.relu = relu;
         d.group_shift = group_shift ? group_shift + (size_t)(r0 / group_rows) * cout_pad : nullptr;
         d.group_rows = group_rows;
+        d.group_max = group_max ? 1 : 0;
         const int rc = dz_conv2d_forward_split(&d, math, out_f32, stream_);
         if (rc) return rc;
     }

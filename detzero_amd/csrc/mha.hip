@@ -23,7 +23,8 @@ namespace dz {
 
 constexpr int HD = 32;  // head dim of every DetZero refiner config (256 / 8 heads)
 
-template <bool MASK>
+// HDT: head dim (32 for the refiner's heads; 64 .. 256 for the single wide head of the PDV encoder layer, dz_attention_single_head)
+template <bool MASK, int HDT = HD>
 __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, const float *__restrict__ k,
                                                   const float *__restrict__ v, const uint8_t *__restrict__ kpm,
                                                   int batch, int lq, int lk, int heads, float scale,
@@ -37,22 +38,25 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
     const int qt = (int)(item % qtiles);
     const int h = (int)((item / qtiles) % heads);
     const int b = (int)(item / ((long)qtiles * heads));
-    const int e_dim = heads * HD;
+    const int e_dim = heads * HDT;
+    constexpr int NS = HDT / 16;                    // 16-channel slices of a head
 
     // B operand of S^T: Q[query r][d = 16*s + 4g + e] * scale
     const int qi = qt * 16 + r;
-    float qreg[2][4];
+    float qreg[NS][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qi < lq) t = *reinterpret_cast<const float4 *>(q + ((size_t)b * lq + qi) * e_dim + h * HD + s * 16 + g * 4);
+        if (qi < lq) t = *reinterpret_cast<const float4 *>(q + ((size_t)b * lq + qi) * e_dim + h * HDT + s * 16 + g * 4);
         qreg[s][0] = t.x * scale; qreg[s][1] = t.y * scale; qreg[s][2] = t.z * scale; qreg[s][3] = t.w * scale;
     }
 
-    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 o[NS];
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;   // per query column r (replicated over g)
-    const float *kb = k + (size_t)b * lk * e_dim + h * HD;
-    const float *vb = v + (size_t)b * lk * e_dim + h * HD;
+    const float *kb = k + (size_t)b * lk * e_dim + h * HDT;
+    const float *vb = v + (size_t)b * lk * e_dim + h * HDT;
     const uint8_t *mb = kpm ? kpm + (size_t)b * lk : nullptr;
 
     for (int key0 = 0; key0 < lk; key0 += 16) {
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
         const int krow = key0 + r;                      // A operand row = key
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
+        for (int sl = 0; sl < NS; ++sl) {
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (krow < lk) kv = *reinterpret_cast<const float4 *>(kb + (size_t)krow * e_dim + sl * 16 + g * 4);
             s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qreg[sl][0], s, 0, 0, 0);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
         l_run = l_run * alpha + (p[0] + p[1] + p[2] + p[3]);   // in-lane partial; reduced over g at the end
         m_run = m_new;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < NS; ++dt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
         // ---- O^T += V^T . P^T
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
         for (int e = 0; e < 4; ++e) {
             const int key = key0 + g * 4 + e;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = 0; dt < NS; ++dt) {
                 const float vv = (key < lk) ? vb[(size_t)key * e_dim + dt * 16 + r] : 0.f;
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p[e], o[dt], 0, 0, 0);
             }
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(256) void k_mha_core(const float *__restrict__ q, c
     // o[dt][e] = O^T[d = dt*16 + 4g + e][query r]
     if (qi < lq) {
         const float inv = 1.f / l_run;               // fully masked row -> NaN, as torch.softmax gives
-        float *dst = out + ((size_t)b * lq + qi) * e_dim + h * HD;
+        float *dst = out + ((size_t)b * lq + qi) * e_dim + h * HDT;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < NS; ++dt) {
             float4 w = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
             *reinterpret_cast<float4 *>(dst + dt * 16 + g * 4) = w;
         }
@@ -276,6 +280,27 @@ __global__ __launch_bounds__(512) void k_mha_block(const float *__restrict__ q, 
             for (int dt = 0; dt < 2; ++dt)
                 *reinterpret_cast<float4 *>(dst + dt * 16 + g * 4) = make_float4(o[t][dt][0] * inv, o[t][dt][1] * inv, o[t][dt][2] * inv, o[t][dt][3] * inv);
         }
+    }
+}
+
+// One wide head (the PDV encoder layer: R sequences of L = 216 tokens, E = 192): k_mha_core with head dim E - one wave per 16 queries,
+// keys streamed from L2, scores and probabilities in registers.  Returns false when E has no instance (the caller's VALU kernel runs).
+template <int E>
+static void launch_1h(const float *q, const float *k, const float *v, const unsigned char *mask, int r, int l, float scale, float *out, hipStream_t stream) {
+    const long items = (long)r * ((l + 15) / 16);
+    if (mask)
+        hipLaunchKernelGGL((k_mha_core<true, E>), dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, mask, r, l, l, 1, scale, out);
+    else
+        hipLaunchKernelGGL((k_mha_core<false, E>), dim3(ceil_div(items, 4)), dim3(256), 0, stream, q, k, v, mask, r, l, l, 1, scale, out);
+}
+bool attention_1h_mfma(const float *q, const float *k, const float *v, const unsigned char *mask, int r, int l, int e, float scale, float *out,
+                       hipStream_t stream) {
+    switch (e) {
+        case 64: launch_1h<64>(q, k, v, mask, r, l, scale, out, stream); return true;
+        case 128: launch_1h<128>(q, k, v, mask, r, l, scale, out, stream); return true;
+        case 192: launch_1h<192>(q, k, v, mask, r, l, scale, out, stream); return true;
+        case 256: launch_1h<256>(q, k, v, mask, r, l, scale, out, stream); return true;
+        default: return false;
     }
 }
 

@@ -18,9 +18,14 @@
 //     nsample hits are exactly the reference's - a few hundred bitmap probes per grid point instead of 50 000 distance tests.
 //   * Grouping, the KDE of the grouped offsets and the feature gather are one kernel writing the rows the shared MLP (dz_linear_forward)
 //     consumes; the max over samples is dz_group_max.  The per-part point counts are one pass over the points with atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dz {
+
+bool attention_1h_mfma(const float *q, const float *k, const float *v, const unsigned char *mask, int r, int l, int e, float scale, float *out,
+                       hipStream_t stream);      // mha.hip
 
 // ------------------------------------------------------------------------------------------------ voxel centroids
 struct CentroidGeom {
@@ -480,6 +485,12 @@ int dz_attention_single_head(const float *q, const float *k, const float *v, con
     DZ_CHECK_ARG(r >= 0 && l >= 1 && l <= 256 && e >= 4 && e <= 256 && e % 4 == 0, "dz_attention_single_head: L <= 256, E <= 256, E %% 4 == 0 (got %d, %d)", l, e);
     if (r == 0) return DZ_OK;
     DZ_CHECK_ARG(q && k && v && out, "dz_attention_single_head: null pointer");
+    // the matrix-core kernel (mha.hip: k_mha_core with head dim E, r03: 1.93 ms -> ~0.3 ms for 487 x 216 x 192) whenever E has an instance
+    static const bool valu_only = getenv("DZ_TUNE_ATT1H_VALU") != nullptr;
+    if (!valu_only && attention_1h_mfma(q, k, v, key_padding_mask, r, l, e, scale, out, stream)) {
+        DZ_LAUNCH_CHECK();
+        return DZ_OK;
+    }
     const int qblocks = (l + ATT_QB - 1) / ATT_QB;
     hipLaunchKernelGGL(k_attention_1h, dim3(r * qblocks), dim3(256), (size_t)ATT_QB * (e + l) * sizeof(float), stream, q, k, v, key_padding_mask, l, e, scale, out);
     DZ_LAUNCH_CHECK();

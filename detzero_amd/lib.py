@@ -36,7 +36,7 @@ class Conv2dDesc(ctypes.Structure):
         ('groups', c_int), ('cout_pad', c_int),
         ('g_cout', _I8), ('g_ooff', _I8),
         ('relu', c_int),
-        ('group_shift', c_void_p), ('group_rows', c_int),
+        ('group_shift', c_void_p), ('group_rows', c_int), ('group_max', c_int),
     ]
 
 
@@ -83,7 +83,7 @@ _SIGS = {
     'dz_merge_sweeps_workspace_bytes': (c_size_t, [c_int]),
     'dz_merge_sweeps': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dz_linear_forward_split': (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                        c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dz_tile_masks_words': (c_int, [c_int]),
     'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

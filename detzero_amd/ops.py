@@ -469,9 +469,11 @@ def linear(x, w, scale, shift, relu, cout, out=None, group_shift=None, group_row
     return out
 
 
-def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shift=None, group_rows=0):
+def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shift=None, group_rows=0, group_max=False):
     """dz_linear_forward_split: x (rows, >= cin words) pair16 @ w (cout_pad, cin) pair16 -> (rows, cout) fp32 when out_f32,
-    else (rows, cout) pair16 (cout % 32 == 0 so that the result can feed the next layer)."""
+    else (rows, cout) pair16 (cout % 32 == 0 so that the result can feed the next layer).
+    group_max: -> (rows / group_rows, cout) fp32, the maximum over each group of `group_rows` consecutive rows, taken in the layer's
+    epilogue (the PointNet max over an object's points; the (rows, cout) activation is never written)."""
     lib = L.load()
     L.require_cuda(x, w, scale, shift, group_shift)
     rows = x.shape[0]
@@ -480,10 +482,12 @@ def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shif
         raise L.DetZeroHipError('linear_split: a pair16 result needs cout %% 32 == 0 (got %d)' % cout)
     if group_shift is not None and group_shift.shape[1] != cout_pad:
         raise L.DetZeroHipError('linear_split: group_shift rows must be cout_pad = %d wide' % cout_pad)
-    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    if group_max and (group_rows < 128 or group_rows % 128 or rows % group_rows):
+        raise L.DetZeroHipError('linear_split: group_max needs groups of a multiple of 128 rows (got %d rows in groups of %d)' % (rows, group_rows))
+    out = torch.empty((rows // group_rows if group_max else rows, cout), dtype=torch.float32, device=x.device)
     rc = lib.dz_linear_forward_split(L.ptr(x), rows, cin, x.stride(0), L.ptr(w), cout, cout_pad, L.ptr(scale), L.ptr(shift),
                                      L.ptr(group_shift), int(group_rows), 1 if relu else 0, L.ptr(out), out.stride(0), int(math),
-                                     1 if out_f32 else 0, L.stream())
+                                     1 if (out_f32 or group_max) else 0, 1 if group_max else 0, L.stream())
     L.check(rc, 'dz_linear_forward_split')
     return out
 

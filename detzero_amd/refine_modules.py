@@ -252,30 +252,44 @@ def _splittable(layers, rows, math=None):
     return bool(m) and rows >= SPLIT_MIN_ROWS and all(l['cout'] % 32 == 0 for l in layers[:-1])
 
 
-def _run_stack_split(xp, layers, keep_pair=False, math=None):
-    """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair."""
+def _gmax_ok(gmax):
+    return gmax is not None and gmax[1] >= 128 and gmax[1] % 128 == 0
+
+
+def _run_stack_split(xp, layers, keep_pair=False, math=None, gmax=None):
+    """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair.
+    gmax = (groups, rows per group): the max over each group's rows is fused into the last layer (-> (groups, cout) fp32)."""
     m = _REFINE_MATH[0] if math is None else math
     outs = []
     for li, l in enumerate(layers):
         last = li == len(layers) - 1
         w = _split_w(l, m)
-        xp = ops.linear_split(xp, w, l['scale32'], l['shift32'], l['relu'], l['cout'], m, out_f32=last and not keep_pair)
+        if last and gmax is not None:
+            if _gmax_ok(gmax):
+                xp = ops.linear_split(xp, w, l['scale32'], l['shift32'], l['relu'], l['cout'], m, group_rows=gmax[1], group_max=True)
+            else:
+                xp = ops.group_max(ops.linear_split(xp, w, l['scale32'], l['shift32'], l['relu'], l['cout'], m, out_f32=True), gmax[0], gmax[1])
+        else:
+            xp = ops.linear_split(xp, w, l['scale32'], l['shift32'], l['relu'], l['cout'], m, out_f32=last and not keep_pair)
         outs.append(xp)
     return xp, outs
 
 
-def _run_stack(x, layers, upto=None, math=None):
+def _run_stack(x, layers, upto=None, math=None, gmax=None):
     """math: None = the refiner's global mode (set_refine_math); an explicit mode (0 = fp32 engine, 1 / 2 = split pairs) pins the
     stack's arithmetic whatever the refiner is set to (the PDV head passes its own)."""
     layers = layers if upto is None else layers[:upto]
     if _splittable(layers, x.shape[0], math):
         m = _REFINE_MATH[0] if math is None else math
         xp = ops.pair16_from_f32(x, c_dst=_r32(x.shape[1]), math=m)
-        return _run_stack_split(xp, layers, math=m)
+        return _run_stack_split(xp, layers, math=m, gmax=gmax)
     outs = []
     for li, l in enumerate(layers):
         x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
         outs.append(x)
+    if gmax is not None:
+        x = ops.group_max(x, gmax[0], gmax[1])
+        outs[-1] = x
     return x, outs
 
 
@@ -392,8 +406,7 @@ class _PointNetPlan:
         if _splittable(self.enc + self.mlp, pts_rows.shape[0]) and self.mlp[0]['cout'] % 32 == 0:
             m = _REFINE_MATH[0]
             xp = ops.pair16_from_f32(pts_rows, c_dst=_r32(self.cin_pad), math=m)
-            feat, outs = _run_stack_split(xp, self.enc)                               # feat fp32, the tapped layer pair16
-            pooled = ops.group_max(feat, groups, length)
+            pooled, outs = _run_stack_split(xp, self.enc, gmax=(groups, length))      # max over the points fused; the tapped layer pair16
             gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])
             l0 = self.mlp[0]
             w0 = _split_w(l0, m)
@@ -457,8 +470,7 @@ class GeometryTransformer(_Cached):
         memory = p['memory'].forward(m_pts.reshape(b * lm, cm), b, lm)                        # (B*Lm, E)
         q_pts = data_dict['geo_query_points'].float()
         _, pp, npts, cq = q_pts.shape
-        qf, _ = _run_stack(_pad_cols(q_pts.reshape(b * pp * npts, cq), _pad16(cq)), p['q_enc'])
-        qf = ops.group_max(qf, b * pp, npts)
+        qf, _ = _run_stack(_pad_cols(q_pts.reshape(b * pp * npts, cq), _pad16(cq)), p['q_enc'], gmax=(b * pp, npts))
         qf, _ = _run_stack(qf, p['q_mlp'])                                                       # (B*pp, E)
         qpos = data_dict['geo_query_boxes'][..., 3:6].float().reshape(b * pp, 3).contiguous()
         out = decoder_layer_forward(p['layer'], qf, memory, qpos, b, pp, lm)
@@ -536,8 +548,7 @@ class PositionTransformer(_Cached):
         if gp != self.MEM_PTS_PER_BOX:
             raise DetZeroHipError('PositionTransformer: %d memory points per box (the reference hard-codes 48)' % gp)
         e = self.embed_dims
-        qf, _ = _run_stack(_pad_cols(local_pts.reshape(b * nb * npts, cq), _pad16(cq)), p['q_enc'])
-        qf = ops.group_max(qf, b * nb, npts)
+        qf, _ = _run_stack(_pad_cols(local_pts.reshape(b * nb * npts, cq), _pad16(cq)), p['q_enc'], gmax=(b * nb, npts))
         qf, _ = _run_stack(qf, p['q_mlp'])                                                       # (B*nb, E)
         qpos = torch.cat([traj[..., :3], traj[..., 6:]], dim=-1).reshape(b * nb, -1).contiguous()
         lk = nb * gp

@@ -181,6 +181,8 @@ typedef struct dz_conv2d_desc {
     int relu;
     const float *group_shift; /* optional (n_row_groups, cout_pad): added to the accumulator BEFORE scale/shift, */
     int group_rows;           /* row group = output row / group_rows (per-object bias of the PointNet concat)   */
+    int group_max;            /* dz_linear_forward_split only: out = (row groups, out_cstride) fp32 pre-filled with -inf, the max over each
+                                 group's rows is taken in the epilogue (no (rows, cout) result is written)          */
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
@@ -248,10 +250,13 @@ int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m
 int dz_conv2d_forward_split(const dz_conv2d_desc *h_desc, int math, int out_f32, void *stream);
 const char *dz_conv2d_variant_split(const dz_conv2d_desc *h_desc);
 /* dz_linear_forward on pair16 rows: x (rows, x_stride words) pair16, w (cout_pad, cin) pair16 (cin, cout_pad % 32 == 0), y pair16
- * rows or, with out_f32 != 0, fp32 rows; group_shift (row groups, cout_pad) fp32 as in dz_linear_forward. */
+ * rows or, with out_f32 != 0, fp32 rows; group_shift (row groups, cout_pad) fp32 as in dz_linear_forward.
+ * group_max != 0 (with out_f32): the torch.max over the points of an object that follows the PointNet encoders
+ * (geometry_transformer.py:124,137, position_transformer.py:108,117) fused into the layer: y = (rows / group_rows, y_stride) fp32,
+ * the maximum over each group's rows; the (rows, cout) activation is not written.  group_rows % 128 == 0. */
 int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
                             const float *shift, const float *group_shift, int group_rows, int relu, float *y, int y_stride, int math,
-                            int out_f32, void *stream);
+                            int out_f32, int group_max, void *stream);
 const char *dz_spconv_variant_split(int cin, int cout);
 
 /* ---------------------------------------------------------------------------------------------

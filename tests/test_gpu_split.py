@@ -296,3 +296,26 @@ def test_math_mode_selection_by_activation_range(device, gain, expect):
         bad = _stage_features(model, info, pts, 'f16x2')
         worst = max(float((bad[n] - ref[n]).abs().max()) / float(ref[n].abs().max()) for n in ref)
         assert worst > 1e-2, worst
+
+
+@pytest.mark.parametrize('name,mid', MODES)
+@pytest.mark.parametrize('cin,cout,groups,length,relu,shift_rows', [(128, 512, 6, 4096, True, False), (128, 256, 37, 256, True, False),
+                                                                   (32, 128, 5, 384, False, True), (128, 512, 3, 9600, True, True)])
+def test_linear_with_fused_group_max(device, name, mid, cin, cout, groups, length, relu, shift_rows):
+    """dz_linear_forward_split(group_max): the max over each object's points taken in the layer's epilogue (integer atomics on the
+    fp32 bits) equals dz_group_max over the layer's fp32 output BIT FOR BIT - with and without ReLU (negative maxima), with the
+    per-object addend of the PointNet concat, for the GRM (4096), PRM query (256) and PRM memory (9600) group lengths."""
+    from detzero_amd import ops
+    rng = np.random.default_rng(cin + cout + groups)
+    rows = groups * length
+    x = ops.pair16_from_f32(_t(rng.standard_normal((rows, cin)).astype(np.float32), device), cin, mid)
+    w = ops.pack_weight_split(_t((rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32), device), mid)
+    scale = _t(rng.uniform(0.5, 1.5, w.shape[0]).astype(np.float32), device)
+    shift = _t((rng.standard_normal(w.shape[0]) - (0.0 if relu else 12.0)).astype(np.float32), device)       # relu off: every maximum negative
+    gs = _t(rng.standard_normal((groups, w.shape[0])).astype(np.float32), device) if shift_rows else None
+    full = ops.linear_split(x, w, scale, shift, relu, cout, mid, out_f32=True, group_shift=gs, group_rows=length)
+    want = ops.group_max(full, groups, length)
+    got = ops.linear_split(x, w, scale, shift, relu, cout, mid, group_shift=gs, group_rows=length, group_max=True)
+    assert tuple(got.shape) == (groups, cout) and torch.equal(got, want)
+    if not relu:
+        assert float(want.max()) < 0
