@@ -256,10 +256,24 @@ def _gmax_ok(gmax):
     return gmax is not None and gmax[1] >= 128 and gmax[1] % 128 == 0
 
 
-def _run_stack_split(xp, layers, keep_pair=False, math=None, gmax=None):
+FUSED_POINTNET = [True]       # development switch: the fused encoder kernel (csrc/pointnet.hip) vs layer-by-layer launches
+
+
+def _pointnet3_ok(xp, layers, gmax, m):
+    return (FUSED_POINTNET[0] and m in (1, 2) and gmax is not None and gmax[1] % 32 == 0 and len(layers) == 3 and xp.shape[1] == 32
+            and layers[0]['cout'] == 128 and layers[1]['cout'] == 128 and layers[2]['cout'] in (128, 256, 512)
+            and all(l['relu'] for l in layers))
+
+
+def _run_stack_split(xp, layers, keep_pair=False, math=None, gmax=None, tap=False):
     """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair.
-    gmax = (groups, rows per group): the max over each group's rows is fused into the last layer (-> (groups, cout) fp32)."""
+    gmax = (groups, rows per group): the max over each group's rows is fused into the last layer (-> (groups, cout) fp32); a
+    32 -> 128 -> 128 -> C PointNet encoder runs as ONE kernel (dz_pointnet3_forward; outs[1] = the second layer's rows)."""
     m = _REFINE_MATH[0] if math is None else math
+    if _pointnet3_ok(xp, layers, gmax, m):
+        trip = [(_split_w(l, m), l['scale32'], l['shift32']) for l in layers]
+        pooled, tap = ops.pointnet3(xp, trip, gmax[1], m, want_tap=tap)
+        return pooled, [None, tap, pooled]
     outs = []
     for li, l in enumerate(layers):
         last = li == len(layers) - 1
@@ -406,7 +420,7 @@ class _PointNetPlan:
         if _splittable(self.enc + self.mlp, pts_rows.shape[0]) and self.mlp[0]['cout'] % 32 == 0:
             m = _REFINE_MATH[0]
             xp = ops.pair16_from_f32(pts_rows, c_dst=_r32(self.cin_pad), math=m)
-            pooled, outs = _run_stack_split(xp, self.enc, gmax=(groups, length))      # max over the points fused; the tapped layer pair16
+            pooled, outs = _run_stack_split(xp, self.enc, gmax=(groups, length), tap=True)      # max over the points fused; the tapped layer pair16
             gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])
             l0 = self.mlp[0]
             w0 = _split_w(l0, m)

@@ -319,3 +319,47 @@ def test_linear_with_fused_group_max(device, name, mid, cin, cout, groups, lengt
     assert tuple(got.shape) == (groups, cout) and torch.equal(got, want)
     if not relu:
         assert float(want.max()) < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,mid', [('f16x2', 1), ('bf16x2', 2)])
+@pytest.mark.parametrize('cin,c3,groups,length', [(29, 256, 5, 4096), (30, 512, 37, 256), (32, 512, 3, 9600), (8, 128, 200, 32)])
+def test_fused_pointnet_encoder(device, name, mid, cin, c3, groups, length):
+    """dz_pointnet3_forward (three point-wise layers + max over an object's points in one kernel, the activations in registers;
+    geometry_transformer.py:34-67, position_transformer.py:43-124) against (a) the same layers run one launch each through
+    dz_linear_forward_split + dz_group_max and (b) float64 on the host.  The tapped second layer must be the layer-by-layer rows."""
+    from detzero_amd import ops
+    rng = np.random.default_rng(cin * 7 + c3 + groups)
+    rows = groups * length
+    xf = rng.standard_normal((rows, cin)).astype(np.float32)
+    dims = [(cin, 128), (128, 128), (128, c3)]
+    ws = [(rng.standard_normal(d) / np.sqrt(d[0])).astype(np.float32) for d in dims]
+    ss = [rng.uniform(0.5, 1.5, d[1]).astype(np.float32) for d in dims]
+    bs = [(0.3 * rng.standard_normal(d[1])).astype(np.float32) for d in dims]
+    x = ops.pair16_from_f32(_t(xf, device), 32, mid)
+    trip = []
+    for w, s, b in zip(ws, ss, bs):
+        wp = np.zeros(((w.shape[0] + 31) // 32 * 32, w.shape[1]), np.float32)
+        wp[:w.shape[0]] = w
+        trip.append((ops.pack_weight_split(_t(wp, device), mid), _t(s, device), _t(b, device)))
+    got, tap = ops.pointnet3(x, trip, length, mid, want_tap=True)
+    got2, none = ops.pointnet3(x, trip, length, mid)
+    assert none is None and torch.equal(got, got2)
+    h = x
+    for li, (w, s, b) in enumerate(trip):
+        h = ops.linear_split(h, w, s, b, True, w.shape[0], mid, out_f32=li == 2)
+        if li == 1:
+            tap_want = h
+    want = ops.group_max(h, groups, length)
+    tw, tg = ops.pair16_to_f32(tap_want, mid), ops.pair16_to_f32(tap, mid)
+    e_tap = float((tw - tg).abs().max())
+    e_pool = float((want - got).abs().max())
+    ref = xf.astype(np.float64)
+    for w, s, b in zip(ws, ss, bs):
+        ref = np.maximum(ref @ w.astype(np.float64) * s + b, 0.0)
+    ref = ref.reshape(groups, length, c3).max(1)
+    e_ref = float(np.abs(got.cpu().numpy() - ref).max())
+    tol = 2e-5 if mid == 1 else 2e-4
+    print('pointnet3 %s cin %d c3 %d: |tap - layered| %.2e, |pool - layered| %.2e, |pool - f64| %.2e' % (name, cin, c3, e_tap, e_pool, e_ref))
+    assert tuple(got.shape) == (groups, c3)
+    assert e_tap <= tol and e_pool <= tol and e_ref <= 10 * tol
