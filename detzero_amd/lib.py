@@ -113,6 +113,9 @@ _SIGS = {
     'dz_conv2d_forward_split': (c_int, [ctypes.POINTER(Conv2dDesc), c_int, c_int, c_void_p]),
     'dz_conv2d_variant_split': (ctypes.c_char_p, [ctypes.POINTER(Conv2dDesc)]),
     'dz_spconv_variant_split': (ctypes.c_char_p, [c_int, c_int]),
+    'dz_xattn_folded_supported': (c_int, [c_int, c_int, c_int]),
+    'dz_xattn_folded_workspace_bytes': (ctypes.c_size_t, [c_int, c_int]),
+    'dz_xattn_folded': (c_int, [c_void_p] * 6 + [c_int] * 5 + [ctypes.c_float, c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     'dz_pointnet3_forward': (c_int, [c_void_p, ctypes.c_long] + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'dz_centerhead_decode_workspace_bytes': (c_size_t, [c_int] * 4),
     'dz_centerhead_decode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,

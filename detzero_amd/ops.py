@@ -657,6 +657,27 @@ def mha_core(q, k, v, key_padding_mask, heads, scale):
     return out
 
 
+def xattn_folded_supported(lq, e, heads):
+    return bool(L.load().dz_xattn_folded_supported(int(lq), int(e), int(heads)))
+
+
+def xattn_folded(q, mem, key_padding_mask, wk_oi, wv_io, bv, heads, scale):
+    """dz_xattn_folded: q (B,Lq,E) projected queries, mem (B,Lk,E) RAW memory rows, wk_oi = Wk (out, in), wv_io = Wv^T (in, out), bv (E)
+    -> (B,Lq,E) attention output before out_proj; the key / value projections of the memory are never formed."""
+    lib = L.load()
+    L.require_cuda(q, mem, wk_oi, wv_io, bv)
+    b, lq, e = q.shape
+    lk = mem.shape[1]
+    m8 = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    nbytes = lib.dz_xattn_folded_workspace_bytes(b, lk)
+    ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=q.device)
+    out = torch.empty_like(q)
+    rc = lib.dz_xattn_folded(L.ptr(q), L.ptr(mem), L.ptr(m8), L.ptr(wk_oi), L.ptr(wv_io), L.ptr(bv), b, lq, lk, e, int(heads), float(scale),
+                             L.ptr(ws), nbytes, L.ptr(out), L.stream())
+    L.check(rc, 'dz_xattn_folded')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # per-launch profiling hook (bench.py): HIP events on the stream the kernels are launched on
 # ------------------------------------------------------------------------------------------------

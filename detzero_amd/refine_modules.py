@@ -256,6 +256,8 @@ def _gmax_ok(gmax):
     return gmax is not None and gmax[1] >= 128 and gmax[1] % 128 == 0
 
 
+FOLDED_XATTN = [True]         # development switch: dz_xattn_folded for few-query cross-attention vs projecting the memory to K and V
+FOLD_MIN_KEYS = 256
 FUSED_POINTNET = [True]       # development switch: the fused encoder kernel (csrc/pointnet.hip) vs layer-by-layer launches
 
 
@@ -319,7 +321,7 @@ def _mha_plan(m):
     e = m.embed_dim
     w, b = m.in_proj_weight.detach().float(), m.in_proj_bias.detach().float()
     one = torch.ones(e, device=w.device)
-    return {'wq': w[:e].t().contiguous(), 'wk': w[e:2 * e].t().contiguous(), 'wv': w[2 * e:].t().contiguous(),
+    return {'wq': w[:e].t().contiguous(), 'wk': w[e:2 * e].t().contiguous(), 'wv': w[2 * e:].t().contiguous(), 'wk_oi': w[e:2 * e].contiguous(),
             'bq': b[:e].contiguous(), 'bk': b[e:2 * e].contiguous(), 'bv': b[2 * e:].contiguous(),
             'wo': m.out_proj.weight.detach().float().t().contiguous(), 'bo': m.out_proj.bias.detach().float().contiguous(),
             'one': one, 'heads': m.num_heads, 'scale': float(m.head_dim) ** -0.5, 'e': e}
@@ -329,6 +331,10 @@ def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask):
     """rows are (B*L, E) channel-last.  multi_head_attention.py:199-288."""
     e = p['e']
     q = ops.linear(q_rows, p['wq'], p['one'], p['bq'], False, e)
+    if FOLDED_XATTN[0] and k_rows is v_rows and lk >= FOLD_MIN_KEYS and ops.xattn_folded_supported(lq, e, p['heads']):
+        # a few queries over a long memory (GRM: 3 x 4096): the key / value projections fold into the queries, the memory is read once
+        o = ops.xattn_folded(q.view(b, lq, e), k_rows.view(b, lk, e), key_padding_mask, p['wk_oi'], p['wv'], p['bv'], p['heads'], p['scale'])
+        return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
     m = _REFINE_MATH[0]
     if m and k_rows is v_rows and k_rows.shape[0] >= SPLIT_MIN_ROWS and e % 32 == 0:
         # key / value projections of a long memory: one conversion of the memory rows, two split GEMMs

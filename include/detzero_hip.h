@@ -258,6 +258,17 @@ int dz_linear_forward_split(const float *x, long rows, int cin, int x_stride, co
                             const float *shift, const float *group_shift, int group_rows, int relu, float *y, int y_stride, int math,
                             int out_f32, int group_max, void *stream);
 const char *dz_spconv_variant_split(int cin, int cout);
+/* Cross-attention of a few queries over a long memory with the key / value projections folded into the queries (csrc/xattn_fold.hip;
+ * multi_head_attention.py:199-288 as called by decoder.py:79-84 for the geometry refiner: 3 queries x 4096 memory points x 8 heads).
+ * Equal to  out = softmax(scale * (q_h) . (Wk_h m + bk_h)) (Wv_h m + bv_h)  per head, computed WITHOUT projecting the memory:
+ * q (b, lq, e) fp32 = the projected queries (Wq x + bq, NOT yet scaled); mem (b, lk, e) fp32 = the raw memory rows; wk_oi (e, e) = Wk as
+ * stored by torch (rows = output channel); wv_io (e, e) = Wv^T (rows = input channel); bv (e); key_padding_mask (b, lk) bytes or NULL
+ * (non-zero = ignore); out (b, lq, e) fp32 = the heads' outputs before out_proj.  bk cancels in the softmax.  fp32 throughout.
+ * Supported (dz_xattn_folded_supported) when e == 256, e % heads == 0 and heads * lq <= 32; workspace from dz_xattn_folded_workspace_bytes. */
+int dz_xattn_folded_supported(int lq, int e, int heads);
+size_t dz_xattn_folded_workspace_bytes(int b, int lk);
+int dz_xattn_folded(const float *q, const float *mem, const uint8_t *key_padding_mask, const float *wk_oi, const float *wv_io, const float *bv,
+                    int b, int lq, int lk, int e, int heads, float scale, float *workspace, size_t workspace_bytes, float *out, void *stream);
 /* Fused PointNet encoder (csrc/pointnet.hip; geometry_transformer.py:34-67,118-140, position_transformer.py:43-124): three
  * point-wise layers 32 -> 128 -> 128 -> c3 (c3 in {128, 256, 512}; BatchNorm scale / shift + ReLU after each) and the max over
  * every group of group_rows consecutive rows (group_rows % 32 == 0, rows % group_rows == 0) in one kernel; the activations never
