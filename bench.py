@@ -121,6 +121,9 @@ def parse():
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
     ap.add_argument('--sparse-engine', default='gather', choices=['gather', 'tiles'], help='sparse-backbone engine of the headline run')
+    ap.add_argument('--sweeps', type=int, default=1, choices=[1, 2],
+                    help='2: run the multisweep shape (BASELINE configs[4]) as the main workload - for profiling that leg on its own; the '
+                         'metric of the printed line is then NOT the headline one (config.workload says so)')
     ap.add_argument('--no-refine', action='store_true', help='skip the refiner leg (BASELINE configs[3])')
     ap.add_argument('--no-pdv', action='store_true', help='skip the two-stage (PDV) leg')
     ap.add_argument('--stub', action='store_true',
@@ -450,7 +453,7 @@ def main():
 
     torch.set_num_threads(min(usable_cores(), 32))
     log('rank', rank, 'of', world, 'usable host cores', usable_cores())
-    case = Case(args, dev, rank, args.math, args.batch, engine=args.sparse_engine)
+    case = Case(args, dev, rank, args.math, args.batch, engine=args.sparse_engine, sweeps=args.sweeps)
     if case.caps is not None:
         log('calibrated level capacities per frame:', case.caps)
     B = case.B
@@ -495,9 +498,11 @@ def main():
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_names[args.math], 'data': 'synthetic',
             'ranks_seen': tinfo.get('ranks_seen', 1), 'gather_ms': tinfo.get('gather_ms', 0.0),
-            'config': {'workload': 'BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
-                                   '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
-                                   '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points,
+            'config': {'workload': ('BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
+                                    '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
+                                    '+ CenterHead + decode + rotated NMS, frames resident in HBM' % args.points) if args.sweeps == 1 else
+                                   ('NOT the headline workload (--sweeps 2): BASELINE configs[4] shape, two merged sweeps per frame (2 x %d points), '
+                                    'DynamicMeanVFE + 3-sweep model' % args.points),
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'parallelism': 'frame-parallel x%d' % world,
                        'launch': graph_note, 'math': args.math, 'sparse_engine': args.sparse_engine,
                        'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',
