@@ -641,7 +641,12 @@ def main():
                                  'unit': 'TFLOP/s', 'frac': round(r32['mha_core_prm_tflops'] / PEAK_F32_MFMA_TFLOPS, 4),
                                  'avg_launch_us': r32['mha_core_prm_us'],
                                  'note': 'PRM cross-attention core: 96 tracks x 8 heads, 200 queries x 9600 keys x 32, exact fp32 on v_mfma_f32_16x16x4_f32; '
-                                         'algorithmic FLOP = 4 * Lq * Lk * d per track'}}
+                                         'algorithmic FLOP = 4 * Lq * Lk * d per track'},
+                    'roofline_grm': None if 'xattn_folded_grm_gbs' not in r32 else {
+                        'bound': 'hbm', 'kernel': 'k_xattn_fold', 'achieved': r32['xattn_folded_grm_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(r32['xattn_folded_grm_gbs'] / PEAK_HBM_GBS, 4), 'avg_launch_us': r32['xattn_folded_grm_us'],
+                        'note': 'GRM cross-attention, 128 objects x 3 queries x 4096 memory rows x 256 channels x 8 heads with the key / value projections folded '
+                                'into the queries (fold + attend + merge launches together): algorithmic bytes = the memory rows, read once'}}
                 log('refine GRM %.0f / %.0f objects/s, PRM %.0f / %.0f tracks/s (f32 / f16x2)' % (
                     r32['grm_objects_per_s'], r16['grm_objects_per_s'], r32['prm_objects_per_s'], r16['prm_objects_per_s']))
             except Exception as e:

@@ -195,6 +195,30 @@ def group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, row_stride):
     return rows[:mq * nsample]
 
 
+FUSED_SA = [True]            # development switch: dz_pdv_sa_pool (group + MLP + max in one kernel) vs group_features + layer launches
+
+
+def sa_pool_supported(c, stack, nsample):
+    return (FUSED_SA[0] and len(stack) == 2 and
+            bool(L.load().dz_pdv_sa_pool_supported(int(c), stack[0]['w'].shape[0], stack[0]['cout'], stack[1]['cout'], int(nsample),
+                                                   int(stack[0]['relu']), int(stack[1]['relu']))))
+
+
+def sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack):
+    """dz_pdv_sa_pool: grouping + the two layers of `stack` + max over the ball -> (M, cout) fp32."""
+    _full_prefix(level, 'dz_pdv_sa_pool')
+    mq, nsample = idx.shape
+    l1, l2 = stack
+    out = torch.empty((mq, l2['cout']), dtype=torch.float32, device=new_xyz.device)
+    cells = level.shape[0] * level.shape[1] * level.shape[2]
+    with torch.cuda.device(new_xyz.device):
+        rc = L.load().dz_pdv_sa_pool(L.ptr(new_xyz), mq, per_batch, L.ptr(xyz), L.ptr(feats), feats.shape[1], L.ptr(level.bitmap), L.ptr(level.prefix), cells,
+                                     L.ptr(idx), L.ptr(cnt), nsample, L.ptr(l1['w']), l1['w'].shape[1], L.ptr(l1['scale']), L.ptr(l1['shift']), l1['cout'],
+                                     L.ptr(l2['w']), l2['w'].shape[1], L.ptr(l2['scale']), L.ptr(l2['shift']), l2['cout'], l1['w'].shape[0], L.ptr(out), L.stream())
+    L.check(rc, 'dz_pdv_sa_pool')
+    return out
+
+
 def part_counts(points_b, rois, grid_size, max_num_boxes):
     """density_utils.find_num_points_per_part_multi -> (B, O, G, G, G) int32."""
     b, o = rois.shape[0], rois.shape[1]
@@ -402,9 +426,13 @@ class PDVHead(_Cached):
                     balls.append(torch.zeros((new_xyz.shape[0], nsample), dtype=torch.int32, device=new_xyz.device))
                     continue
                 idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
-                rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
-                out, _ = _run_stack(rows, p['pool'][k][s]['stack'], math=self.stack_math())
-                pooled.append(ops.group_max(out, new_xyz.shape[0], nsample))
+                stack = p['pool'][k][s]['stack']
+                if self.stack_math() == 0 and sa_pool_supported(feats.shape[1], stack, nsample):
+                    pooled.append(sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack))    # group + MLP + max in one kernel
+                else:
+                    rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
+                    out, _ = _run_stack(rows, stack, math=self.stack_math())
+                    pooled.append(ops.group_max(out, new_xyz.shape[0], nsample))
                 balls.append(idx)
         all_pooled = torch.cat(pooled, dim=-1).view(-1, g ** 3, self.c_out)
         all_balls = torch.cat(balls, dim=-1).view(-1, g ** 3, sum(b.shape[1] for b in balls))

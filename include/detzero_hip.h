@@ -474,6 +474,15 @@ int dz_pdv_ball_query(const float *new_xyz, int mq, int per_batch, const float *
 int dz_pdv_group_features(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, int c,
                           const uint32_t *bitmap, const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt,
                           int nsample, float *rows, int row_stride, void *stream);
+/* One branch of StackSAModuleMSGAttention in one kernel (csrc/pdv_sa.hip; pointnet2_modules.py:31-158): grouping as dz_pdv_group_features,
+ * two point-wise layers (Conv2d 1x1 + folded BatchNorm + ReLU; w1 (cin_pad, ldw1) / w2 (h1, ldw2) fp32, rows = input channel, scale / shift
+ * per output channel) and the max over the ball's nsample rows -> out (mq, h2) fp32.  Exact fp32 (v_mfma_f32_16x16x4_f32).  Instances
+ * (dz_pdv_sa_pool_supported): nsample 16, (cin_pad, h1, h2) = (80, 32, 32) or (144, 64, 64), c % 4 == 0, c + 4 <= cin_pad, ReLU on both layers. */
+int dz_pdv_sa_pool_supported(int c, int cin_pad, int h1, int h2, int nsample, int relu1, int relu2);
+int dz_pdv_sa_pool(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, int c, const uint32_t *bitmap,
+                   const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt, int nsample, const float *w1, int ldw1,
+                   const float *s1, const float *b1, int h1, const float *w2, int ldw2, const float *s2, const float *b2, int h2, int cin_pad,
+                   float *out, void *stream);
 /* density_utils.find_num_points_per_part_multi (:52-109) on points_in_multi_boxes (roiaware_pool3d_kernel.cu:377-404): counts
  * (batch, o, grid, grid, grid) int32 of the points (n, stride) [b, x, y, z, ...] per cell of every RoI (batch, o, 7), a point
  * counting for the first max_boxes RoIs (in RoI order) that contain it. */

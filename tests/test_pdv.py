@@ -222,3 +222,27 @@ def test_centerpoint_with_second_stage_end_to_end(device):
         assert d['pred_boxes'].shape == (n, 7) and n > 0 and torch.isfinite(d['pred_boxes']).all()
         exp = torch.sqrt(torch.sigmoid(bd['batch_cls_preds'][b].reshape(-1)) * bd['roi_scores'][b])[bd['roi_labels'][b] != 0]
         assert torch.equal(d['pred_scores'], exp) and set(d['pred_labels'].cpu().tolist()) <= {1, 2, 3}
+
+
+@pytest.mark.gpu
+def test_fused_grid_pooling_equals_the_layered_path(device, g):
+    """dz_pdv_sa_pool (grouping + two layers + max over the ball in one kernel, pointnet2_modules.py:31-158) against the same branch run
+    as dz_pdv_group_features + two dz_linear_forward + dz_group_max: both are exact-fp32 MFMA arithmetic, only the summation order of
+    the 68 / 132 input channels differs."""
+    from detzero_amd import pdv_modules as pm
+    head = _head().to(device)
+    outs = []
+    for fused in (True, False):
+        pm.FUSED_SA[0] = fused
+        try:
+            bd = _batch(g, device)
+            bd['point_features'], bd['point_coords'] = head.get_point_voxel_features(bd)
+            outs.append(head.roi_grid_pool(bd)[0])
+        finally:
+            pm.FUSED_SA[0] = True
+    for k, layer in enumerate(head.roi_grid_pool_layers):      # every branch of this config has an instance of the fused kernel
+        for s, ns in enumerate(layer.nsamples):
+            assert pm.sa_pool_supported(head.plan()['pool'][k][s]['stack'][0]['w'].shape[0] - 16 + 12, head.plan()['pool'][k][s]['stack'], ns)
+    err = float((outs[0] - outs[1]).abs().max())
+    print('fused grid pooling vs layered: max |diff| %.2e (max |value| %.2f)' % (err, float(outs[1].abs().max())))
+    assert tuple(outs[0].shape) == tuple(outs[1].shape) and err <= 2e-5

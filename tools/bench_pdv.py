@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def measure(dev, points=160000, reps=10, math='f32'):
+def measure(dev, points=160000, reps=10, math='f32', phases=False):
     """Two-stage detector on one merged 2-sweep frame -> dict (also the `pdv` leg of bench.py)."""
     from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
     from detzero_amd.config import centerpoint_pdv_cfg
@@ -50,6 +50,39 @@ def measure(dev, points=160000, reps=10, math='f32'):
         return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[1])) if timed else None
     for _ in range(3):
         run(False)
+    if phases:                   # per-method device time of the second stage (events around the head's own methods)
+        head, acc = model.roi_head, {}
+
+        def wrap(name):
+            fn = getattr(head, name)
+
+            def timed(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **k)
+                e1.record()
+                acc.setdefault(name, []).append((e0, e1))
+                return out
+            setattr(head, name, timed)
+        for name in ('get_point_voxel_features', 'proposal_layer', 'roi_grid_pool', 'get_positional_input', 'attention', 'generate_predicted_boxes'):
+            wrap(name)
+        from detzero_amd import pdv_modules as pm
+        for name in ('ball_query', 'group_features', 'voxel_centroids'):
+            fn = getattr(pm, name)
+
+            def timed(*a, _fn=fn, _name=name, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _fn(*a, **k)
+                e1.record()
+                acc.setdefault('  ' + _name, []).append((e0, e1))
+                return out
+            setattr(pm, name, timed)
+        for _ in range(reps):
+            run(False)
+        torch.cuda.synchronize()
+        for k, v in acc.items():
+            print('%-32s %8.3f ms per frame (%d calls)' % (k, sum(a.elapsed_time(b) for a, b in v) / reps, len(v) // reps), file=sys.stderr)
     t1 = t2 = 0.0
     n_roi = 0
     for _ in range(reps):
@@ -67,8 +100,9 @@ def main():
     ap.add_argument('--points', type=int, default=160000, help='points per sweep (two sweeps are merged per frame)')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--math', default='f32')
+    ap.add_argument('--phases', action='store_true', help='also print the device time of the second stage per method (stderr)')
     args = ap.parse_args()
-    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math)))
+    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math, args.phases)))
 
 
 if __name__ == '__main__':

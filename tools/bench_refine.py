@@ -79,6 +79,19 @@ def measure(dev, objects=1024, chunk=128, steps=3, math='f32', with_crop=True):
     out['mha_core_prm_us'] = round(t * 1e6, 1)
     del q, k, v
 
+    # GRM cross-attention without projecting the memory (dz_xattn_folded): 3 queries x 4096 memory rows x 256 channels per object; the
+    # memory rows are its compulsory HBM bytes (read once)
+    if ops.xattn_folded_supported(3, 256, 8):
+        q = torch.randn((b, 3, 256), generator=gen).to(dev)
+        mem = torch.randn((b, 4096, 256), generator=gen).to(dev)
+        wk = (torch.randn((256, 256), generator=gen) / 16).to(dev)
+        wv = (torch.randn((256, 256), generator=gen) / 16).to(dev)
+        bv = torch.zeros(256, device=dev)
+        t = timed(lambda: ops.xattn_folded(q, mem, None, wk, wv, bv, 8, 32 ** -0.5), 10)
+        out['xattn_folded_grm_us'] = round(t * 1e6, 1)
+        out['xattn_folded_grm_gbs'] = round(b * 4096 * 256 * 4 / t / 1e9, 1)
+        del q, mem
+
     if with_crop:       # object crop mask
         from detzero_amd import roiaware_pool3d_utils
         pts = torch.from_numpy(synth_waymo_frame(0, 180000)[:, :3]).to(dev)[None].contiguous()
