@@ -92,7 +92,10 @@ class CenterPoint(nn.Module):
         recall_dict = {}
         if self.second_stage:                                # centerpoint.py:214-281 (the single-class-NMS branch of the PDV configs)
             if post_process_cfg.get('NMS_CONFIG', {}).get('MULTI_CLASSES_NMS', False):
-                raise DetZeroHipError('post_processing: MULTI_CLASSES_NMS is not used by the DetZero configs and not provided')
+                # the reference's own branch cannot run either: it reads `cls_preds` before assigning it (centerpoint.py:221-222,
+                # UnboundLocalError on the first frame); no DetZero config sets the flag
+                raise DetZeroHipError('post_processing: MULTI_CLASSES_NMS is not provided (the reference branch, centerpoint.py:221-245, '
+                                      'fails on an unassigned `cls_preds`; no DetZero config sets the flag)')
             pred_dicts = []
             for index in range(batch_dict['batch_size']):
                 box_preds = batch_dict['batch_box_preds'][index]
@@ -286,6 +289,9 @@ class FramePipeline:
         self.mode = mode
         self.dynamic = dynamic
         self.head = model.dense_head
+        if len(self.head.class_names_each_head) != 1:
+            raise DetZeroHipError('FramePipeline: the batched route packs ONE head\'s detections (the layout of every DetZero config); a '
+                                  'multi-head CenterHead runs through the module API (CenterPoint.forward)')
         post = self.head.model_cfg.POST_PROCESSING
         self.k = post.MAX_OBJ_PER_SAMPLE
         self.post_max = post.NMS_CONFIG.NMS_POST_MAXSIZE

@@ -533,6 +533,43 @@ __global__ void k_crop_gather(const int *__restrict__ pairs, const int *__restri
 
 using namespace dz;
 
+// ------------------------------------------------------------------------------------------------ RoI features from the BEV map
+// center_head.py:408-432,461-486 (get_box_center with num_point = 5, absl_to_relative, centernet_utils.bilinear_interpolate_torch:233-262):
+// per first-stage box the BEV features at its centre and at the middles of its front / back / left / right edges, bilinear with
+// the reference's clamped corner indices (the weights use the CLAMPED x1 / y1, as the reference does), concatenated channel-wise.
+__global__ __launch_bounds__(256) void k_roi_bev_features(const float *__restrict__ boxes, int n, const float *__restrict__ bev, long row_stride,
+                                                          long pix_stride, int h, int w, int c, float x_lo, float y_lo, float sx, float sy,
+                                                          float fstride, float *__restrict__ out) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const float *b = boxes + (size_t)i * 7;
+    const float cx = b[0], cy = b[1], hx = b[3] * 0.5f, hy = b[4] * 0.5f;
+    const float cs = cosf(b[6]), sn = sinf(b[6]);
+    // corners 0..3 of box_utils.boxes_to_corners_3d (template (+,+), (+,-), (-,-), (-,+)) rotated about z and shifted
+    const float tx[4] = {hx, hx, -hx, -hx}, ty[4] = {hy, -hy, -hy, hy};
+    float kx[4], ky[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        kx[k] = __fadd_rn(__fadd_rn(__fmul_rn(tx[k], cs), __fmul_rn(ty[k], -sn)), cx);
+        ky[k] = __fadd_rn(__fadd_rn(__fmul_rn(tx[k], sn), __fmul_rn(ty[k], cs)), cy);
+    }
+    const float px[5] = {cx, (kx[0] + kx[1]) / 2.f, (kx[2] + kx[3]) / 2.f, (kx[0] + kx[3]) / 2.f, (kx[1] + kx[2]) / 2.f};
+    const float py[5] = {cy, (ky[0] + ky[1]) / 2.f, (ky[2] + ky[3]) / 2.f, (ky[0] + ky[3]) / 2.f, (ky[1] + ky[2]) / 2.f};
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const float x = __fdiv_rn(__fdiv_rn(__fsub_rn(px[p], x_lo), sx), fstride), y = __fdiv_rn(__fdiv_rn(__fsub_rn(py[p], y_lo), sy), fstride);
+        const float fx = floorf(x), fy = floorf(y);
+        const long x0 = min(max((long)fx, 0l), (long)w - 1), x1 = min(max((long)fx + 1, 0l), (long)w - 1);
+        const long y0 = min(max((long)fy, 0l), (long)h - 1), y1 = min(max((long)fy + 1, 0l), (long)h - 1);
+        const float wa = __fmul_rn((float)x1 - x, (float)y1 - y), wb = __fmul_rn((float)x1 - x, y - (float)y0);
+        const float wc = __fmul_rn(x - (float)x0, (float)y1 - y), wd = __fmul_rn(x - (float)x0, y - (float)y0);
+        const float *ia = bev + y0 * row_stride + x0 * pix_stride, *ib = bev + y1 * row_stride + x0 * pix_stride;
+        const float *ic = bev + y0 * row_stride + x1 * pix_stride, *id = bev + y1 * row_stride + x1 * pix_stride;
+        for (int ch = threadIdx.x; ch < c; ch += 256)
+            out[((size_t)i * 5 + p) * c + ch] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ia[ch], wa), __fmul_rn(ib[ch], wb)), __fmul_rn(ic[ch], wc)), __fmul_rn(id[ch], wd));
+    }
+}
+
 extern "C" {
 
 static size_t crop_layout(int m, int t, int cap, size_t *o_pf, size_t *o_pairs, size_t *o_sw, size_t *sw_bytes, int *row_words) {
@@ -719,6 +756,17 @@ int dz_points_in_boxes_v2(const float *boxes, const float *pts, int batch, int t
     if (batch == 0 || t == 0 || m == 0) return DZ_OK;
     DZ_CHECK_ARG(boxes && pts && mask, "dz_points_in_boxes_v2: null pointer");
     hipLaunchKernelGGL(k_points_in_boxes, dim3(ceil_div(m, 256), batch), dim3(256), 0, stream, boxes, pts, t, m, mask);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_roi_bev_features(const float *boxes, int n, const float *bev, long row_stride, long pix_stride, int h, int w, int c, float x_lo, float y_lo,
+                        float voxel_x, float voxel_y, int stride, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n >= 0 && h >= 1 && w >= 1 && c >= 1 && voxel_x > 0.f && voxel_y > 0.f && stride >= 1, "dz_roi_bev_features: bad sizes");
+    if (n == 0) return DZ_OK;
+    DZ_CHECK_ARG(boxes && bev && out, "dz_roi_bev_features: null pointer");
+    hipLaunchKernelGGL(k_roi_bev_features, dim3(n), dim3(256), 0, stream, boxes, n, bev, row_stride, pix_stride, h, w, c, x_lo, y_lo, voxel_x, voxel_y, (float)stride, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -722,8 +722,8 @@ class CenterHead(_Cached):
                 torch.from_numpy(np.array([self.class_names.index(x) for x in cur_class_names if x in class_names])))
         total_classes = sum(len(x) for x in self.class_names_each_head)
         assert total_classes == len(self.class_names), f'class_names_each_head={self.class_names_each_head}'
-        if len(self.class_names_each_head) != 1:
-            raise DetZeroHipError('CenterHead: the HIP backend implements the single-head layout of the DetZero configs')
+        if max(len(x) for x in self.class_names_each_head) > 3 or min(len(x) for x in self.class_names_each_head) < 1:
+            raise DetZeroHipError('CenterHead: 1 to 3 classes per head (the decode kernel keeps the heat map in columns 9:12)')
         use_bias = self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)
         self.shared_conv = nn.Sequential(
             nn.Conv2d(input_channels, self.model_cfg.SHARED_CONV_CHANNEL, 3, stride=1, padding=1, bias=use_bias),
@@ -738,7 +738,7 @@ class CenterHead(_Cached):
         self.head_names = list(self.heads_list[0].sep_head_dict.keys())
         for name in self.head_names:
             cfgd = self.heads_list[0].sep_head_dict[name]
-            if name not in self.COLS or cfgd['num_conv'] != 2 or cfgd['out_channels'] != self.COLS[name][1]:
+            if name not in self.COLS or cfgd['num_conv'] != 2 or (cfgd['out_channels'] != self.COLS[name][1] and name != 'hm'):
                 raise DetZeroHipError('CenterHead: unsupported branch %s %s' % (name, dict(cfgd)))
         if sorted(self.head_names) != sorted(self.COLS):
             raise DetZeroHipError('CenterHead: branches must be %s (got %s)' % (sorted(self.COLS), self.head_names))
@@ -753,55 +753,73 @@ class CenterHead(_Cached):
         s_scale, s_shift = fold_bn(sbn, sc.bias)
         c = self.model_cfg.SHARED_CONV_CHANNEL
         order = ['center', 'center_z', 'dim', 'rot', 'iou', 'hm']      # fixed column layout of the decode kernel
-        head = self.heads_list[0]
-        w1, sc1, sh1, w2, b2 = [], [], [], [], []
-        for name in order:
-            fc = getattr(head, name)
-            conv1, bn1, conv2 = fc[0][0], fc[0][1], fc[1]
-            a, b = fold_bn(bn1, conv1.bias)
-            w1.append(_conv_weight_taps(conv1.weight)); sc1.append(a); sh1.append(b)
-            w2.append(_conv_weight_taps(conv2.weight, 16))
-            b2.append(_pad_vec(conv2.bias.detach().float(), 16))
+        heads = []
+        for head, names in zip(self.heads_list, self.class_names_each_head):
+            w1, sc1, sh1, w2, b2 = [], [], [], [], []
+            for name in order:
+                fc = getattr(head, name)
+                conv1, bn1, conv2 = fc[0][0], fc[0][1], fc[1]
+                a, b = fold_bn(bn1, conv1.bias)
+                w1.append(_conv_weight_taps(conv1.weight)); sc1.append(a); sh1.append(b)
+                w2.append(_conv_weight_taps(conv2.weight, 16))
+                b2.append(_pad_vec(conv2.bias.detach().float(), 16))
+            g_cout = [len(names) if n == 'hm' else self.COLS[n][1] for n in order]
+            heads.append({
+                'hidden': {'w': torch.cat(w1, dim=2).contiguous(), 'scale': torch.cat(sc1).contiguous(),
+                           'shift': torch.cat(sh1).contiguous()},
+                'final': {'w': torch.stack(w2, dim=0).contiguous(),          # (6, 9, 64, 16)
+                          'shift': torch.cat(b2).contiguous(),
+                          # the split engine works on 32-channel fragments: biases padded per group to 32
+                          'shift32': torch.cat([_pad_vec(b, 32) for b in b2]).contiguous(),
+                          'g_cout': g_cout, 'g_ooff': [self.COLS[n][0] for n in order]}})
         self._plan = {
             'shared': {'w': _conv_weight_taps(sc.weight), 'scale': s_scale, 'shift': s_shift, 'cin': sc.in_channels},
-            'hidden': {'w': torch.cat(w1, dim=2).contiguous(), 'scale': torch.cat(sc1).contiguous(),
-                       'shift': torch.cat(sh1).contiguous()},
-            'final': {'w': torch.stack(w2, dim=0).contiguous(),          # (6, 9, 64, 16)
-                      'shift': torch.cat(b2).contiguous(),
-                      # the split engine works on 32-channel fragments: biases padded per group to 32
-                      'shift32': torch.cat([_pad_vec(b, 32) for b in b2]).contiguous(),
-                      'g_cout': [self.COLS[n][1] for n in order], 'g_ooff': [self.COLS[n][0] for n in order]},
+            'heads': heads, 'hidden': heads[0]['hidden'], 'final': heads[0]['final'],
             'c': c, 'order': order,
         }
         return self._plan
 
-    def run_convs(self, concat, batch):
-        """concat (B,H+2,W+2,Cin) zero-bordered -> head map (B, H*W, 12) channel-last."""
+    def run_shared(self, concat, batch):
+        """concat (B,H+2,W+2,Cin) zero-bordered -> the shared 3x3 conv's map (B,H+2,W+2,C), zero-bordered (center_head.py:443)."""
         p = self.plan()
-        dev = concat.device
         hp, wp = concat.shape[1], concat.shape[2]
+        c = p['c']
+        shared = bordered_zeros('head.shared', (batch, hp, wp, c), concat.device)
+        conv_layer(concat, (hp, wp), self._w(p['shared']), p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
+                   cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=hp - 2, wo=wp - 2, batch=batch,
+                   math=self.math)
+        return shared
+
+    def run_head(self, shared, batch, index=0):
+        """One SeparateHead (center_head.py:13-48, :445-447) on the shared map -> head map (B, H*W, 12) channel-last: its six
+        branches as one 64 -> 384 conv and one grouped 384 -> 12 conv; a head with fewer than 3 classes leaves columns 9 + n .. 11 unwritten."""
+        p = self.plan()
+        hp_ = p['heads'][index]
+        dev = shared.device
+        hp, wp = shared.shape[1], shared.shape[2]
         h, w = hp - 2, wp - 2
         c = p['c']
         mm = self.math
-        shared = bordered_zeros('head.shared', (batch, hp, wp, c), dev)
-        conv_layer(concat, (hp, wp), self._w(p['shared']), p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
-                   cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=h, wo=w, batch=batch,
-                   math=mm)
         hidden = bordered_zeros('head.hidden', (batch, hp, wp, 6 * c), dev)
-        conv_layer(shared, (hp, wp), self._w(p['hidden']), p['hidden']['scale'], p['hidden']['shift'], True, hidden, (hp, wp),
+        conv_layer(shared, (hp, wp), self._w(hp_['hidden']), hp_['hidden']['scale'], hp_['hidden']['shift'], True, hidden, (hp, wp),
                    cin=c, in_cstride=c, out_cstride=6 * c, out_d=(1, 1), ho=h, wo=w, batch=batch, math=mm)
         head = torch.empty((batch, h * w, 12), dtype=torch.float32, device=dev)
-        conv_layer(hidden, (hp, wp), self._w(p['final']), None, p['final']['shift32' if mm else 'shift'], False, head, (h, w),
+        conv_layer(hidden, (hp, wp), self._w(hp_['final']), None, hp_['final']['shift32' if mm else 'shift'], False, head, (h, w),
                    cin=c, in_cstride=6 * c, out_cstride=12, out_d=(0, 0), groups=6, cout_pad=32 if mm else 16,
-                   g_cout=p['final']['g_cout'], g_ooff=p['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
+                   g_cout=hp_['final']['g_cout'], g_ooff=hp_['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
         return head, h, w
+
+    def run_convs(self, concat, batch):
+        """concat (B,H+2,W+2,Cin) zero-bordered -> head map (B, H*W, 12) channel-last of the FIRST head (the single-head layout of
+        every DetZero config; FramePipeline's route)."""
+        return self.run_head(self.run_shared(concat, batch), batch, 0)
 
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
         """center_head.py:202-260 (host-side, like the reference's)."""
         from .target_assign import assign_targets
         return assign_targets(self, gt_boxes, feature_map_size)
 
-    def decode_batched_nosync(self, head, h, w):
+    def decode_batched_nosync(self, head, h, w, index=0):
         """head (B,H*W,12) -> boxes (B,K,7), scores (B,K), labels (B,K) i32 (0-based), keep (B,K) i32, d_nk (B,) i32:
         top-K decode and rotated NMS of all frames in one launch sequence, counts stay on the device."""
         post = self.model_cfg.POST_PROCESSING
@@ -814,24 +832,29 @@ class CenterHead(_Cached):
         if k > nms.NMS_PRE_MAXSIZE:
             raise DetZeroHipError('MAX_OBJ_PER_SAMPLE > NMS_PRE_MAXSIZE is not supported')
         boxes, scores, labels, counts = ops.centerhead_decode(
-            head, h, w, len(self.class_names_each_head[0]), k, post.SCORE_THRESH, post.POST_CENTER_LIMIT_RANGE,
+            head, h, w, len(self.class_names_each_head[index]), k, post.SCORE_THRESH, post.POST_CENTER_LIMIT_RANGE,
             self.point_cloud_range, self.voxel_size, self.feature_map_stride, use_iou=self.iou_weight > 0)
         keep, d_nk = ops.nms_rotated_batched_nosync(boxes, counts, nms.NMS_THRESH, nms.NMS_POST_MAXSIZE)
         return boxes, scores, labels, keep, d_nk
 
-    def decode_nosync(self, head, h, w):
-        boxes, scores, labels, keep, d_nk = self.decode_batched_nosync(head, h, w)
+    def decode_nosync(self, head, h, w, index=0):
+        boxes, scores, labels, keep, d_nk = self.decode_batched_nosync(head, h, w, index)
         return [(boxes[b], scores[b], labels[b], keep[b], d_nk[b:b + 1]) for b in range(head.shape[0])]
 
-    def generate_predicted_boxes(self, head, h, w):
-        mapping = self.class_id_mapping_each_head[0].to(head.device)
-        ret = []
-        for boxes, scores, labels, keep, d_nk in self.decode_nosync(head, h, w):
-            nk = int(d_nk.item())
-            sel = keep[:nk].long()
-            ret.append({'pred_boxes': boxes[sel], 'pred_scores': scores[sel],
-                        'pred_labels': mapping[labels[sel].long()] + 1})
-        return ret
+    def generate_predicted_boxes(self, heads, h, w):
+        """center_head.py:315-385: every head decodes and suppresses on its own; a frame's result is the heads' boxes one after the
+        other, labels mapped through the head's class list.  `heads`: one head map or a list (one per head)."""
+        heads = heads if isinstance(heads, (list, tuple)) else [heads]
+        ret = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(heads[0].shape[0])]
+        for index, head in enumerate(heads):
+            mapping = self.class_id_mapping_each_head[index].to(head.device)
+            for b, (boxes, scores, labels, keep, d_nk) in enumerate(self.decode_nosync(head, h, w, index)):
+                nk = int(d_nk.item())
+                sel = keep[:nk].long()
+                ret[b]['pred_boxes'].append(boxes[sel])
+                ret[b]['pred_scores'].append(scores[sel])
+                ret[b]['pred_labels'].append(mapping[labels[sel].long()] + 1)
+        return [{k: (v[0] if len(v) == 1 else torch.cat(v, dim=0)) for k, v in d.items()} for d in ret]
 
     def forward(self, data_dict):
         _inference_only(self)
@@ -841,23 +864,44 @@ class CenterHead(_Cached):
             if concat is None:
                 concat, enc = nchw_to_padded_nhwc(data_dict['spatial_features_2d'].float()), 0
             concat = _recode(concat, enc, self.math)
-            head, h, w = self.run_convs(concat, concat.shape[0])
-            pred = {n: head.view(head.shape[0], h, w, 12)[..., o:o + c].permute(0, 3, 1, 2)
-                    for n, (o, c) in self.COLS.items()}
+            shared = self.run_shared(concat, concat.shape[0])
+            heads, preds = [], []
+            for index, names in enumerate(self.class_names_each_head):
+                head, h, w = self.run_head(shared, concat.shape[0], index)
+                heads.append(head)
+                preds.append({n: head.view(head.shape[0], h, w, 12)[..., o:o + (len(names) if n == 'hm' else c)].permute(0, 3, 1, 2)
+                              for n, (o, c) in self.COLS.items()})
             if data_dict.get('gt_boxes', None) is not None:              # center_head.py:448-453
                 self.forward_ret_dict['target_dicts'] = self.assign_targets(data_dict['gt_boxes'], feature_map_size=(h, w))
-            self.forward_ret_dict['pred_dicts'] = [pred]
-            pred_dicts = self.generate_predicted_boxes(head, h, w)
+            self.forward_ret_dict['pred_dicts'] = preds
+            pred_dicts = self.generate_predicted_boxes(heads, h, w)
             data_dict['final_box_dicts'] = pred_dicts
             if self.predict_boxes_when_training:         # second stage (center_head.py:461-486): first-stage boxes become the RoIs
                 rois, roi_scores, roi_labels = self.reorder_rois(data_dict['batch_size'], pred_dicts)
                 data_dict.update({'rois': rois, 'roi_scores': roi_scores, 'roi_labels': roi_labels, 'has_class_labels': True})
+                if 'spatial_features_2d' in data_dict:              # center_head.py:461-486: BEV features at five points of every box
+                    data_dict['roi_features'] = self.roi_features(data_dict['spatial_features_2d'], pred_dicts, rois.shape[1])
         return data_dict
+
+    def roi_features(self, spatial_features_2d, pred_dicts, num_max_rois):
+        """center_head.py:408-432,461-486 + reorder_rois_for_refining_features:388-406: (B, max boxes, 5 * C) bilinear BEV features at
+        the centre and the four edge middles of every first-stage box (num_point = 5, :69), zero rows behind a frame's boxes."""
+        b, c = spatial_features_2d.shape[0], spatial_features_2d.shape[1]
+        out = spatial_features_2d.new_zeros((b, num_max_rois, 5 * c), dtype=torch.float32)
+        hwc = spatial_features_2d.float().permute(0, 2, 3, 1)
+        if hwc.stride(3) != 1:
+            hwc = hwc.contiguous()
+        for i, d in enumerate(pred_dicts):
+            n = d['pred_boxes'].shape[0]
+            if n:
+                out[i, :n] = ops.roi_bev_features(d['pred_boxes'][:, :7], hwc[i], self.point_cloud_range[0], self.point_cloud_range[1],
+                                                  self.voxel_size[0], self.voxel_size[1], self.feature_map_stride)
+        return out
 
     @staticmethod
     def reorder_rois(batch_size, pred_dicts):
-        """center_head.py:388-406 without ``roi_features`` (bilinear BEV samples at five box points: no DetZero second stage reads
-        them - PDVHead pools from x_conv3 / x_conv4): (B, max boxes, 7) RoIs padded with zero rows, scores, 1-based labels."""
+        """center_head.py:388-406 (the ``roi_features`` of :398-406 come from `roi_features` above): (B, max boxes, 7) RoIs padded with
+        zero rows, scores, 1-based labels."""
         num_max_rois = max(1, max(len(d['pred_boxes']) for d in pred_dicts))
         ref = pred_dicts[0]['pred_boxes']
         rois = ref.new_zeros((batch_size, num_max_rois, ref.shape[-1]))

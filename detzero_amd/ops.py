@@ -657,6 +657,22 @@ def mha_core(q, k, v, key_padding_mask, heads, scale):
     return out
 
 
+def roi_bev_features(boxes, bev_hwc, x_lo, y_lo, voxel_x, voxel_y, stride):
+    """dz_roi_bev_features: boxes (n, 7) of one frame, bev_hwc (H, W, C) view with channel stride 1 -> (n, 5 * C) bilinear BEV features at
+    the box centre and the four edge middles (center_head.py:408-432,461-486)."""
+    lib = L.load()
+    if not boxes.is_cuda or not bev_hwc.is_cuda or bev_hwc.stride(2) != 1:
+        raise L.DetZeroHipError('roi_bev_features: device tensors, BEV map as an (H, W, C) view with contiguous channels')
+    boxes = boxes.float().contiguous()
+    n = boxes.shape[0]
+    h, w, c = bev_hwc.shape
+    out = torch.empty((n, 5 * c), dtype=torch.float32, device=boxes.device)
+    rc = lib.dz_roi_bev_features(L.ptr(boxes), n, bev_hwc.data_ptr(), bev_hwc.stride(0), bev_hwc.stride(1), h, w, c, float(x_lo), float(y_lo), float(voxel_x),
+                                 float(voxel_y), int(stride), L.ptr(out), L.stream())
+    L.check(rc, 'dz_roi_bev_features')
+    return out
+
+
 def xattn_folded_supported(lq, e, heads):
     return bool(L.load().dz_xattn_folded_supported(int(lq), int(e), int(heads)))
 

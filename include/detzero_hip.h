@@ -292,6 +292,12 @@ int dz_centerhead_decode(const float *head, int batch, int h, int w, int ncls, i
                          int use_iou, float *boxes, float *scores, int *labels, int *d_counts, void *ws,
                          size_t ws_bytes, void *stream);
 
+/* RoI features of the first-stage boxes (center_head.py:408-432,461-486: get_box_center with num_point 5 + absl_to_relative +
+ * centernet_utils.bilinear_interpolate_torch:233-262): boxes (n, 7) of ONE frame; bev = that frame's (h, w, c) map, channel stride 1,
+ * pixel / row strides in floats; map cell of a point = (p - lo) / voxel / stride; out (n, 5 * c) = [centre | front | back | left | right]. */
+int dz_roi_bev_features(const float *boxes, int n, const float *bev, long row_stride, long pix_stride, int h, int w, int c, float x_lo, float y_lo,
+                        float voxel_x, float voxel_y, int stride, float *out, void *stream);
+
 /* iou3d_nms_cuda.nms_gpu (iou3d_nms.cpp:114-160 + nms_kernel iou3d_nms_kernel.cu:386-430), with the
  * suppression sweep done on the device.  boxes (n_cap,7) already in descending score order;
  * *d_n of them valid (d_n may be NULL).  keep (n_cap) i32 receives kept indices in order,

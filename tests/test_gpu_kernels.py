@@ -651,3 +651,67 @@ def test_voxelize_to_level_equals_voxelize_index_scatter(device, math, layout):
     assert torch.equal(lvl.bitmap, ref.bitmap) and torch.equal(lvl.prefix[nz], ref.prefix[nz])
     assert torch.equal(lvl.coords[:m], ref.coords[:m])
     assert torch.equal(x[:m].view(torch.int32), xr[:m].view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_roi_bev_features_match_reference_golden(device, golden_dir):
+    """dz_roi_bev_features / CenterHead.roi_features against the reference's own get_box_center + absl_to_relative +
+    bilinear_interpolate_torch + reorder_rois_for_refining_features (center_head.py:388-432,461-486; tests/golden/gen_roi_feat_golden.py):
+    boxes on and over the map border included (clamped corner indices), an empty frame gives zero rows."""
+    from detzero_amd import ops
+    g = np.load(os.path.join(golden_dir, 'roi_feat_golden.npz'))
+    bev = _t(g['bev'], device)
+    boxes = _t(g['boxes0'], device)
+    pcr, vs, stride = g['point_cloud_range'], g['voxel_size'], int(g['stride'])
+    got = ops.roi_bev_features(boxes, bev[0].permute(1, 2, 0).contiguous(), pcr[0], pcr[1], vs[0], vs[1], stride)
+    want = g['roi_features'][0]
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    print('roi_features: max |diff| %.2e on values up to %.2f' % (err, float(np.abs(want).max())))
+    assert tuple(got.shape) == want.shape and err <= 2e-5
+
+    class Host:
+        point_cloud_range, voxel_size, feature_map_stride = [float(v) for v in pcr], [float(v) for v in vs], stride
+    from detzero_amd.det_modules import CenterHead
+    pred = [{'pred_boxes': boxes}, {'pred_boxes': boxes[:0]}]
+    full = CenterHead.roi_features(Host(), bev, pred, 37)
+    assert tuple(full.shape) == g['roi_features'].shape and float(full[1].abs().max()) == 0.0
+    np.testing.assert_allclose(full.cpu().numpy(), g['roi_features'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('math', ['f32', 'f16x2'])
+def test_two_head_center_head_matches_reference_golden(device, golden_dir, math):
+    """CLASS_NAMES_EACH_HEAD with two heads ([Vehicle], [Pedestrian, Cyclist]; center_head.py:81-102, 315-385) against the reference
+    class itself (tests/golden/gen_multihead_golden.py): every head's six maps, and per frame the heads' suppressed boxes one head
+    after the other with the labels mapped through the head's class list."""
+    import sys
+    from tests.util import match_boxes
+    from detzero_amd.config import AttrDict
+    from detzero_amd.det_modules import CenterHead
+    from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_02
+    from oracle import voxelize as ov
+    sys.path.insert(0, golden_dir)
+    from gen_multihead_golden import head_cfg
+    g = np.load(os.path.join(golden_dir, 'multihead_golden.npz'))
+    head = CenterHead(AttrDict(head_cfg()), 64, 3, ['Vehicle', 'Pedestrian', 'Cyclist'], ov.grid_size_of(POINT_CLOUD_RANGE, VOXEL_SIZE_02),
+                      POINT_CLOUD_RANGE, VOXEL_SIZE_02)
+    head.load_state_dict({k[len('head_dense_head.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('head_dense_head.')}, strict=True)
+    head = head.to(device).eval().set_math(math)
+    dd = head({'spatial_features_2d': _t(g['head_in'], device), 'batch_size': 2})
+    worst_map = 0.0
+    for i, pred in enumerate(head.forward_ret_dict['pred_dicts']):
+        assert pred['hm'].shape[1] == (1, 2)[i]
+        for name in ('center', 'center_z', 'dim', 'rot', 'iou', 'hm'):
+            worst_map = max(worst_map, float((pred[name].cpu() - torch.from_numpy(g['pred%d_%s' % (i, name)])).abs().max()))
+    assert worst_map <= 2e-5, worst_map                    # observed 1.4e-6
+    for i, fb in enumerate(dd['final_box_dicts']):
+        ref_b, ref_s, ref_l = g['boxes_%d' % i], g['scores_%d' % i], g['labels_%d' % i]
+        got_b, got_s, got_l = fb['pred_boxes'].cpu().numpy(), fb['pred_scores'].cpu().numpy(), fb['pred_labels'].cpu().numpy()
+        assert got_b.shape == ref_b.shape, (got_b.shape, ref_b.shape)
+        n0 = int((ref_l == 1).sum())                                   # head 0 (Vehicle) first, then head 1
+        assert np.all(got_l[:n0] == 1) and np.all(got_l[n0:] >= 2)
+        nm, worst = match_boxes(ref_b, ref_s, got_b, got_s, tol=1e-3)
+        assert nm == ref_b.shape[0], (nm, ref_b.shape[0], worst)
+        assert sorted(got_l.tolist()) == sorted(ref_l.tolist())
+    print('two-head CenterHead [%s]: maps within %.2e, %d + %d boxes' % (math, worst_map, dd['final_box_dicts'][0]['pred_boxes'].shape[0],
+                                                                        dd['final_box_dicts'][1]['pred_boxes'].shape[0]))
