@@ -511,6 +511,31 @@ def pointnet3(x, layers, group_rows, math, want_tap=False):
     return out, tap
 
 
+def mlp_chain(x, la, lb, group_shift, group_rows, math, kv=None):
+    """dz_mlp_chain_forward: x (rows, 128) pair16 through la = (w (512, 128) pair16, scale, shift) with the per-group pre-BatchNorm addend
+    group_shift (groups, >= 512) and lb = (w (256, 512) pair16, scale, shift), both with ReLU -> memory (rows, 256) fp32; with
+    kv = (wk (256, 256) pair16, bk, wv, bv) also the key / value projections of the memory -> (memory, k, v)."""
+    lib = L.load()
+    (wa, sa, ba), (wb, sb, bb) = la, lb
+    L.require_cuda(x, wa, sa, ba, wb, sb, bb)
+    rows = x.shape[0]
+    if tuple(wa.shape) != (512, 128) or tuple(wb.shape) != (256, 512) or x.shape[1] != 128:
+        raise L.DetZeroHipError('mlp_chain: expects 128 -> 512 -> 256 layers on (rows, 128) pair16 rows (got %s, %s on %s)' % (
+            tuple(wa.shape), tuple(wb.shape), tuple(x.shape)))
+    mem = torch.empty((rows, 256), dtype=torch.float32, device=x.device)
+    k = v = wk = bk = wv = bv = None
+    if kv is not None:
+        wk, bk, wv, bv = kv
+        if tuple(wk.shape) != (256, 256) or tuple(wv.shape) != (256, 256):
+            raise L.DetZeroHipError('mlp_chain: key / value projections must be 256 -> 256')
+        k, v = torch.empty_like(mem), torch.empty_like(mem)
+    ldg = 0 if group_shift is None else group_shift.stride(0)
+    rc = lib.dz_mlp_chain_forward(L.ptr(x), rows, L.ptr(wa), L.ptr(sa), L.ptr(ba), L.ptr(group_shift), ldg, int(group_rows), L.ptr(wb), L.ptr(sb), L.ptr(bb),
+                                  L.ptr(wk), L.ptr(bk), L.ptr(wv), L.ptr(bv), L.ptr(mem), L.ptr(k), L.ptr(v), storage_math(math), L.stream())
+    L.check(rc, 'dz_mlp_chain_forward')
+    return (mem, k, v) if kv is not None else mem
+
+
 def group_max(x, groups, length):
     """x (groups*length, c) -> (groups, c) max over each group's rows."""
     lib = L.load()

@@ -258,6 +258,7 @@ def _gmax_ok(gmax):
 
 FOLDED_XATTN = [True]         # development switch: dz_xattn_folded for few-query cross-attention vs projecting the memory to K and V
 FOLD_MIN_KEYS = 256
+FUSED_CHAIN = [True]          # development switch: dz_mlp_chain_forward (memory MLP + K / V in one kernel) vs one launch per layer
 FUSED_POINTNET = [True]       # development switch: the fused encoder kernel (csrc/pointnet.hip) vs layer-by-layer launches
 
 
@@ -327,10 +328,14 @@ def _mha_plan(m):
             'one': one, 'heads': m.num_heads, 'scale': float(m.head_dim) ** -0.5, 'e': e}
 
 
-def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask):
-    """rows are (B*L, E) channel-last.  multi_head_attention.py:199-288."""
+def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask, kv=None):
+    """rows are (B*L, E) channel-last.  multi_head_attention.py:199-288.  kv: the key / value projections of the memory when the
+    caller already has them (dz_mlp_chain_forward produces them with the memory rows)."""
     e = p['e']
     q = ops.linear(q_rows, p['wq'], p['one'], p['bq'], False, e)
+    if kv is not None:
+        o = ops.mha_core(q.view(b, lq, e), kv[0].view(b, lk, e), kv[1].view(b, lk, e), key_padding_mask, p['heads'], p['scale'])
+        return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
     if FOLDED_XATTN[0] and k_rows is v_rows and lk >= FOLD_MIN_KEYS and ops.xattn_folded_supported(lq, e, p['heads']):
         # a few queries over a long memory (GRM: 3 x 4096): the key / value projections fold into the queries, the memory is read once
         o = ops.xattn_folded(q.view(b, lq, e), k_rows.view(b, lk, e), key_padding_mask, p['wk_oi'], p['wv'], p['bv'], p['heads'], p['scale'])
@@ -365,7 +370,7 @@ def decoder_layer_plan(layer):
     }
 
 
-def decoder_layer_forward(p, query, memory, query_pos, b, lq, lk, sa_mask=None, ca_mask=None):
+def decoder_layer_forward(p, query, memory, query_pos, b, lq, lk, sa_mask=None, ca_mask=None, memory_kv=None):
     """decoder.py:48-92.  query (B*Lq, C), memory (B*Lk, C), query_pos (B*Lq, pos_dims) -> (B*Lq, C)."""
     pos, _ = _run_stack(_pad_cols(query_pos, 16), p['pos'])
     if p['sa'] is not None:
@@ -374,7 +379,7 @@ def decoder_layer_forward(p, query, memory, query_pos, b, lq, lk, sa_mask=None, 
         g, be, eps = p['ln'][0]
         query = ops.add_layernorm(query, q2, g, be, eps)
     qp = ops.add_layernorm(query, pos, None, None, norm=False)
-    q2 = _mha_forward(p['ca'], qp, memory, memory, b, lq, lk, ca_mask)
+    q2 = _mha_forward(p['ca'], qp, memory, memory, b, lq, lk, ca_mask, kv=memory_kv)
     g, be, eps = p['ln'][1]
     query = ops.add_layernorm(query, q2, g, be, eps)
     h = ops.linear(query, p['w1'], p['one1'], p['b1'], True, p['w1'].shape[1])
@@ -422,7 +427,20 @@ class _PointNetPlan:
         self.ones = torch.ones(w.shape[1], device=w.device)
         self.zeros = torch.zeros(w.shape[1], device=w.device)
 
-    def forward(self, pts_rows, groups, length):
+    def _chain_ok(self, rows, length, m):
+        """dz_mlp_chain_forward applies: 128 -> 512 -> 256 with ReLU on both layers, whole 32-row tiles per object."""
+        return (FUSED_CHAIN[0] and m in (1, 2) and len(self.mlp) == 2 and self.mlp[0]['w'].shape[0] == 128 and self.mlp[0]['cout'] == 512 and
+                self.mlp[1]['cout'] == 256 and self.mlp[0]['relu'] and self.mlp[1]['relu'] and length % 32 == 0 and rows * 1024 < 2 ** 31)
+
+    def forward(self, pts_rows, groups, length, kv_plan=None):
+        """-> memory rows (groups * length, E); with kv_plan (the cross-attention's _mha_plan) -> (memory, (K, V) or None): the key /
+        value projections come out of the same kernel as the memory rows when dz_mlp_chain_forward applies."""
+        mem = self._forward(pts_rows, groups, length, kv_plan)
+        if kv_plan is None:
+            return mem[0] if isinstance(mem, tuple) else mem
+        return mem if isinstance(mem, tuple) else (mem, None)
+
+    def _forward(self, pts_rows, groups, length, kv_plan):
         if _splittable(self.enc + self.mlp, pts_rows.shape[0]) and self.mlp[0]['cout'] % 32 == 0:
             m = _REFINE_MATH[0]
             xp = ops.pair16_from_f32(pts_rows, c_dst=_r32(self.cin_pad), math=m)
@@ -430,6 +448,17 @@ class _PointNetPlan:
             gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])
             l0 = self.mlp[0]
             w0 = _split_w(l0, m)
+            if outs[1] is not None and self._chain_ok(pts_rows.shape[0], length, m):
+                l1 = self.mlp[1]
+                w1 = _split_w(l1, m)
+                kv = None
+                if kv_plan is not None and kv_plan['e'] == 256:
+                    if 'kv_split%d' % m not in kv_plan:
+                        kv_plan['kv_split%d' % m] = (ops.pack_weight_split(kv_plan['wk'], m), ops.pack_weight_split(kv_plan['wv'], m))
+                    wk, wv = kv_plan['kv_split%d' % m]
+                    kv = (wk, kv_plan['bk'], wv, kv_plan['bv'])
+                res = ops.mlp_chain(outs[1], (w0, l0['scale32'], l0['shift32']), (w1, l1['scale32'], l1['shift32']), gshift, length, m, kv=kv)
+                return (res[0], (res[1], res[2])) if kv is not None else res
             only = len(self.mlp) == 1
             y = ops.linear_split(outs[1], w0, l0['scale32'], l0['shift32'], l0['relu'], l0['cout'], m, out_f32=only,
                                  group_shift=gshift, group_rows=length)
@@ -572,10 +601,15 @@ class PositionTransformer(_Cached):
         qf, _ = _run_stack(qf, p['q_mlp'])                                                       # (B*nb, E)
         qpos = torch.cat([traj[..., :3], traj[..., 6:]], dim=-1).reshape(b * nb, -1).contiguous()
         lk = nb * gp
-        memory = p['memory'].forward(global_pts.reshape(b * lk, global_pts.shape[3]), b, lk)     # (B*Lk, E)
+        # (B*Lk, E); the cross-attention's K / V come with it when the fused chain runs, unless the attention folds them away
+        fold = FOLDED_XATTN[0] and lk >= FOLD_MIN_KEYS and ops.xattn_folded_supported(nb, e, p['layer']['ca']['heads'])
+        if fold:
+            memory, mkv = p['memory'].forward(global_pts.reshape(b * lk, global_pts.shape[3]), b, lk), None
+        else:
+            memory, mkv = p['memory'].forward(global_pts.reshape(b * lk, global_pts.shape[3]), b, lk, kv_plan=p['layer']['ca'])
         kpm = data_dict['padding_mask'].to(torch.bool)
         ca = kpm.reshape(b, nb, 1).repeat(1, 1, gp).reshape(b, -1)
-        out = decoder_layer_forward(p['layer'], qf, memory, qpos, b, nb, lk, sa_mask=kpm, ca_mask=ca)
+        out = decoder_layer_forward(p['layer'], qf, memory, qpos, b, nb, lk, sa_mask=kpm, ca_mask=ca, memory_kv=mkv)
         preds = {k: v.view(b, nb, -1) for k, v in ffn_forward(p['ffn'], out).items()}
         preds['size_reg'] = traj[:, :, 3:6]
         data_dict['query'] = qf.view(b, nb, e).permute(0, 2, 1)

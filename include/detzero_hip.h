@@ -269,6 +269,15 @@ int dz_xattn_folded_supported(int lq, int e, int heads);
 size_t dz_xattn_folded_workspace_bytes(int b, int lk);
 int dz_xattn_folded(const float *q, const float *mem, const uint8_t *key_padding_mask, const float *wk_oi, const float *wv_io, const float *bv,
                     int b, int lq, int lk, int e, int heads, float scale, float *workspace, size_t workspace_bytes, float *out, void *stream);
+/* The refiner's memory branch behind its PointNet encoder in one kernel (csrc/mlp_chain.hip; geometry_transformer.py:56-67,126-133,
+ * position_transformer.py:60-72,108-117, multi_head_attention.py:199-236):  h = ReLU(sa * (Wa x + group_shift[row / group_rows]) + ba)
+ * (128 -> 512), mem = ReLU(sb * (Wb h) + bb) (512 -> 256), and - when wk is not NULL - K = Wk mem + bk, V = Wv mem + bv (256 -> 256).
+ * x (rows, 128) pair16 (the tapped encoder layer); wa (512, 128), wb (256, 512), wk / wv (256, 256) pair16, rows = output channel;
+ * group_shift (rows / group_rows, ldg >= 512) fp32 or NULL; mem / k / v (rows, 256) fp32.  Split math only; group_rows % 32 == 0;
+ * rows * 1024 < 2 GiB.  Bit-identical to the same layers run one dz_linear_forward_split each. */
+int dz_mlp_chain_forward(const float *x, long rows, const float *wa, const float *sa, const float *ba, const float *group_shift, int ldg, int group_rows,
+                         const float *wb, const float *sb, const float *bb, const float *wk, const float *bk, const float *wv, const float *bv,
+                         float *mem, float *k, float *v, int math, void *stream);
 /* Fused PointNet encoder (csrc/pointnet.hip; geometry_transformer.py:34-67,118-140, position_transformer.py:43-124): three
  * point-wise layers 32 -> 128 -> 128 -> c3 (c3 in {128, 256, 512}; BatchNorm scale / shift + ReLU after each) and the max over
  * every group of group_rows consecutive rows (group_rows % 32 == 0, rows % group_rows == 0) in one kernel; the activations never

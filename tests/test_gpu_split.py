@@ -363,3 +363,39 @@ def test_fused_pointnet_encoder(device, name, mid, cin, c3, groups, length):
     print('pointnet3 %s cin %d c3 %d: |tap - layered| %.2e, |pool - layered| %.2e, |pool - f64| %.2e' % (name, cin, c3, e_tap, e_pool, e_ref))
     assert tuple(got.shape) == (groups, c3)
     assert e_tap <= tol and e_pool <= tol and e_ref <= 10 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,mid', [('f16x2', 1), ('bf16x2', 2)])
+@pytest.mark.parametrize('groups,length,kv', [(3, 4096, False), (2, 9600, True), (37, 32, True), (1, 160, False)])
+def test_fused_memory_chain(device, name, mid, groups, length, kv):
+    """dz_mlp_chain_forward (128 -> 512 with the per-object addend -> 256, then the key / value projections, one kernel, the 512-wide
+    hidden layer never leaving the registers; geometry_transformer.py:56-67, position_transformer.py:60-72, multi_head_attention.py:
+    199-236) against the same layers run one dz_linear_forward_split each: the same products in the same order -> the same bits."""
+    from detzero_amd import ops
+    rng = np.random.default_rng(groups * 31 + length)
+    rows = groups * length
+    x = ops.pair16_from_f32(_t(np.maximum(rng.standard_normal((rows, 128)), 0).astype(np.float32), device), 128, mid)
+    dims = [(128, 512), (512, 256), (256, 256), (256, 256)]
+    ws = [ops.pack_weight_split(_t((rng.standard_normal(d) / np.sqrt(d[0])).astype(np.float32), device), mid) for d in dims]
+    sc = [_t(rng.uniform(0.5, 1.5, d[1]).astype(np.float32), device) for d in dims[:2]]
+    sh = [_t((0.3 * rng.standard_normal(d[1])).astype(np.float32), device) for d in dims]
+    gs = _t(rng.standard_normal((groups, 512)).astype(np.float32), device)
+    one = torch.ones(256, device=device)
+    res = ops.mlp_chain(x, (ws[0], sc[0], sh[0]), (ws[1], sc[1], sh[1]), gs, length, mid, kv=(ws[2], sh[2], ws[3], sh[3]) if kv else None)
+    mem = res[0] if kv else res
+    h = ops.linear_split(x, ws[0], sc[0], sh[0], True, 512, mid, group_shift=gs, group_rows=length)
+    want = ops.linear_split(h, ws[1], sc[1], sh[1], True, 256, mid, out_f32=True)
+    assert tuple(mem.shape) == (rows, 256) and torch.equal(mem, want), float((mem - want).abs().max())
+    if kv:
+        mp = ops.pair16_from_f32(want, 256, mid)
+        for got, w, b in ((res[1], ws[2], sh[2]), (res[2], ws[3], sh[3])):
+            assert torch.equal(got, ops.linear_split(mp, w, one, b, False, 256, mid, out_f32=True))
+    # and against float64 on the host (the split arithmetic itself)
+    xf = ops.pair16_to_f32(x, mid).cpu().numpy().astype(np.float64)[:64]
+    wf = [ops.pair16_to_f32(w, mid).cpu().numpy().astype(np.float64) for w in ws[:2]]
+    hh = np.maximum((xf @ wf[0].T + gs.cpu().numpy()[np.arange(64) // length]) * sc[0].cpu().numpy() + sh[0].cpu().numpy(), 0)
+    mm = np.maximum((hh @ wf[1].T) * sc[1].cpu().numpy() + sh[1].cpu().numpy(), 0)
+    err = float(np.abs(mem[:64].cpu().numpy() - mm).max())
+    print('memory chain %s %d x %d: bit-identical to the layered path; |mem - f64| %.2e' % (name, groups, length, err))
+    assert err <= (3e-5 if mid == 1 else 2e-4)                     # observed 2.9e-6 / 2.0e-5
