@@ -664,8 +664,9 @@ def crop_points_in_boxes_nosync(xyz, boxes, payload, cap):
     return out, index, offsets, d_total
 
 
-def mha_core(q, k, v, key_padding_mask, heads, scale):
-    """q (B,Lq,E), k/v (B,Lk,E), mask (B,Lk) bool/uint8 or None -> (B,Lq,E)."""
+def mha_core(q, k, v, key_padding_mask, heads, scale, math=0):
+    """q (B,Lq,E), k/v (B,Lk,E), mask (B,Lk) bool/uint8 or None -> (B,Lq,E).  math 0: exact fp32 (dz_mha_core); 1 / 2: operands as
+    16-bit pairs on the 16-bit matrix cores (dz_mha_core_split)."""
     lib = L.load()
     L.require_cuda(q, k, v)
     b, lq, e = q.shape
@@ -676,6 +677,10 @@ def mha_core(q, k, v, key_padding_mask, heads, scale):
     if key_padding_mask is not None:
         m8 = key_padding_mask.to(torch.uint8).contiguous()
     out = torch.empty_like(q)
+    if math:
+        rc = lib.dz_mha_core_split(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(m8), b, lq, lk, heads, float(scale), L.ptr(out), storage_math(math), L.stream())
+        L.check(rc, 'dz_mha_core_split')
+        return out
     rc = lib.dz_mha_core(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(m8), b, lq, lk, heads, float(scale), L.ptr(out),
                          L.stream())
     L.check(rc, 'dz_mha_core')

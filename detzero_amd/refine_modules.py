@@ -258,6 +258,8 @@ def _gmax_ok(gmax):
 
 FOLDED_XATTN = [True]         # development switch: dz_xattn_folded for few-query cross-attention vs projecting the memory to K and V
 FOLD_MIN_KEYS = 256
+SPLIT_ATTENTION = [True]      # development switch: dz_mha_core_split for long key lists in the split math modes vs the fp32 core
+SPLIT_ATTN_MIN_KEYS = 1024
 FUSED_CHAIN = [True]          # development switch: dz_mlp_chain_forward (memory MLP + K / V in one kernel) vs one launch per layer
 FUSED_POINTNET = [True]       # development switch: the fused encoder kernel (csrc/pointnet.hip) vs layer-by-layer launches
 
@@ -333,8 +335,9 @@ def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask, kv=None
     caller already has them (dz_mlp_chain_forward produces them with the memory rows)."""
     e = p['e']
     q = ops.linear(q_rows, p['wq'], p['one'], p['bq'], False, e)
+    am = _REFINE_MATH[0] if (SPLIT_ATTENTION[0] and lk >= SPLIT_ATTN_MIN_KEYS and _REFINE_MATH[0] in (1, 2)) else 0   # long key lists only
     if kv is not None:
-        o = ops.mha_core(q.view(b, lq, e), kv[0].view(b, lk, e), kv[1].view(b, lk, e), key_padding_mask, p['heads'], p['scale'])
+        o = ops.mha_core(q.view(b, lq, e), kv[0].view(b, lk, e), kv[1].view(b, lk, e), key_padding_mask, p['heads'], p['scale'], math=am)
         return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
     if FOLDED_XATTN[0] and k_rows is v_rows and lk >= FOLD_MIN_KEYS and ops.xattn_folded_supported(lq, e, p['heads']):
         # a few queries over a long memory (GRM: 3 x 4096): the key / value projections fold into the queries, the memory is read once
@@ -352,7 +355,7 @@ def _mha_forward(p, q_rows, k_rows, v_rows, b, lq, lk, key_padding_mask, kv=None
     else:
         k = ops.linear(k_rows, p['wk'], p['one'], p['bk'], False, e)
         v = ops.linear(v_rows, p['wv'], p['one'], p['bv'], False, e)
-    o = ops.mha_core(q.view(b, lq, e), k.view(b, lk, e), v.view(b, lk, e), key_padding_mask, p['heads'], p['scale'])
+    o = ops.mha_core(q.view(b, lq, e), k.view(b, lk, e), v.view(b, lk, e), key_padding_mask, p['heads'], p['scale'], math=am)
     return ops.linear(o.view(b * lq, e), p['wo'], p['one'], p['bo'], False, e)
 
 

@@ -360,6 +360,11 @@ int dz_crop_points_in_boxes(const float *xyz, int m, const float *boxes, int t, 
  * key_padding_mask (B,Lk) u8 (1 = ignore) or NULL; out (B,Lq,E).  softmax(q*scale . k^T) . v */
 int dz_mha_core(const float *q, const float *k, const float *v, const uint8_t *key_padding_mask, int batch,
                 int lq, int lk, int heads, float scale, float *out, void *stream);
+/* The same core on the 16-bit matrix cores with q, k, v and the probabilities carried as (hi, lo) 16-bit pairs (csrc/mha_h.hip; three
+ * MFMAs per product, fp32 accumulation and softmax): the arithmetic class of dz_linear_forward_split, for long key lists (PRM's
+ * cross-attention: 200 queries x 9600 keys).  Same arguments; math = DZ_MATH_F16X2 or DZ_MATH_BF16X2; head dim 32. */
+int dz_mha_core_split(const float *q, const float *k, const float *v, const uint8_t *key_padding_mask, int batch, int lq, int lk, int heads,
+                      float scale, float *out, int math, void *stream);
 
 /* y (rows, cout) = relu?( x (rows, cin) . W (cin, cout_pad) * scale + shift ) — the 1x1 Conv1d/Conv2d
  * + BatchNorm + ReLU stacks of the GRM/PRM PointNet encoders

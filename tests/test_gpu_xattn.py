@@ -86,3 +86,45 @@ def test_folded_cross_attention_refuses_what_it_cannot_fold(device):
     with pytest.raises(DetZeroHipError):
         ops.xattn_folded(x, torch.zeros((1, 64, 256), device=device), None, torch.zeros((256, 256), device=device), torch.zeros((256, 256), device=device),
                          torch.zeros(256, device=device), 8, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,mid,tol', [('f16x2', 1, 1.2e-5), ('bf16x2', 2, 3e-4)])       # 10x the observed 1.2e-6 / 2.9e-5
+@pytest.mark.parametrize('b,lq,lk,heads,masked', [(3, 200, 9600, 8, True), (2, 37, 1000, 8, False), (1, 300, 130, 4, True), (2, 5, 64, 8, True)])
+def test_attention_core_on_split_operands(device, name, mid, tol, b, lq, lk, heads, masked):
+    """dz_mha_core_split (q, k, v and the probabilities as 16-bit pairs on the 16-bit matrix cores; multi_head_attention.py:207-288) against
+    float64 on the host and against the exact-fp32 core (dz_mha_core) on the same inputs, key padding masks with whole dead blocks,
+    ragged query / key counts."""
+    from detzero_amd import ops
+    e = heads * 32
+    rng = np.random.default_rng(lq * 7 + lk)
+    q = rng.standard_normal((b, lq, e))
+    k = rng.standard_normal((b, lk, e))
+    v = rng.standard_normal((b, lk, e)) * 2.0
+    mask = None
+    if masked:
+        mask = (rng.random((b, lk)) < 0.35).astype(np.uint8)
+        if lk >= 256:
+            mask[0, 64 * (lk // 128):64 * (lk // 128) + 64] = 1      # a whole staged block without a live key
+        mask[-1, :min(70, lk - 1)] = 1                                # ... and at the start (running maximum still -inf)
+        mask[:, lk - 1] = 0                                           # (a fully masked row is NaN in both: tested for dz_xattn_folded)
+    scale = 32 ** -0.5
+    qq = q.reshape(b, lq, heads, 32).transpose(0, 2, 1, 3) * scale
+    kk = k.reshape(b, lk, heads, 32).transpose(0, 2, 1, 3)
+    vv = v.reshape(b, lk, heads, 32).transpose(0, 2, 1, 3)
+    s = qq @ kk.transpose(0, 1, 3, 2)
+    if mask is not None:
+        s = np.where(mask[:, None, None, :] != 0, -np.inf, s)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    want = ((p / p.sum(-1, keepdims=True)) @ vv).transpose(0, 2, 1, 3).reshape(b, lq, e)
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    tm = None if mask is None else torch.from_numpy(mask).to(device)
+    got = ops.mha_core(t(q), t(k), t(v), tm, heads, scale, math=mid)
+    ref = ops.mha_core(t(q), t(k), t(v), tm, heads, scale)
+    torch.cuda.synchronize()
+    err, err32 = float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(ref.cpu().numpy() - want).max())
+    print('attention core %s b %d lq %d lk %d heads %d: |split - f64| %.2e, |fp32 core - f64| %.2e' % (name, b, lq, lk, heads, err, err32))
+    assert err <= tol

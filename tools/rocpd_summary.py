@@ -8,6 +8,7 @@ import sys
 
 
 def short(name):
+    name = name.replace('(anonymous namespace)::', '')
     name = re.sub(r'\(.*', '', name)
     name = name.replace('void ', '').replace('dz::', '')
     name = re.sub(r'TileCfg<(\d+), (\d+), (\d+), \d+, \d+>', r'\1x\2x\3', name)
