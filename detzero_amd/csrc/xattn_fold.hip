@@ -38,32 +38,30 @@ __device__ __forceinline__ void xf_load16_lds(unsigned int lds_base, unsigned in
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(b), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
-// Qf[b][h * lq + qi][c] = scale * sum_d q[b][qi][h * hd + d] * Wk[h * hd + d][c]; rows >= heads * lq are zero
+// Qf[b][h * lq + qi][c] = scale * sum_d q[b][qi][h * hd + d] * Wk[h * hd + d][c]; rows >= heads * lq are zero.  Grid (heads + 1, B):
+// one workgroup per (object, head) - the head's hd rows of Wk are read once per workgroup, coalesced - and one for the padding rows
 __global__ __launch_bounds__(XF_THREADS) void k_fold_queries(const float *__restrict__ q, const float *__restrict__ wk_oi, int lq, int heads,
                                                               float scale, float *__restrict__ qf) {
-    __shared__ float qs[4 * XF_E];
-    const int b = blockIdx.x, c = threadIdx.x, hd = XF_E / heads;
+    __shared__ float qs[XF_ROWS * XF_E];                 // the head's slice of the queries [qi][d]: lq * hd <= (32 / heads) * (256 / heads)
+    const int hh = blockIdx.x, b = blockIdx.y, c = threadIdx.x, hd = XF_E / heads;
     float *dst = qf + (size_t)b * XF_ROWS * XF_E;
-    for (int q0 = 0; q0 < lq; q0 += 4) {               // 4 queries at a time through 4 KB of LDS
-        __syncthreads();
-        for (int i = c; i < 4 * XF_E; i += XF_THREADS) {
-            const int qi = q0 + i / XF_E;
-            qs[i] = qi < lq ? q[((size_t)b * lq + qi) * XF_E + i % XF_E] * scale : 0.f;
-        }
-        __syncthreads();
-        for (int h = 0; h < heads; ++h) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int d = 0; d < hd; ++d) {
-                const float w = wk_oi[(size_t)(h * hd + d) * XF_E + c];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(qs[j * XF_E + h * hd + d], w, acc[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q0 + j < lq) dst[(size_t)(h * lq + q0 + j) * XF_E + c] = acc[j];
-        }
+    if (hh == heads) {
+        for (int r = heads * lq; r < XF_ROWS; ++r) dst[(size_t)r * XF_E + c] = 0.f;
+        return;
     }
-    for (int r = heads * lq; r < XF_ROWS; ++r) dst[(size_t)r * XF_E + c] = 0.f;
+    for (int i = c; i < lq * hd; i += XF_THREADS) qs[i] = q[((size_t)b * lq + i / hd) * XF_E + hh * hd + i % hd] * scale;
+    __syncthreads();
+    for (int q0 = 0; q0 < lq; q0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < hd; ++d) {
+            const float w = wk_oi[(size_t)(hh * hd + d) * XF_E + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(qs[min(q0 + j, lq - 1) * hd + d], w, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q0 + j < lq) dst[(size_t)(hh * lq + q0 + j) * XF_E + c] = acc[j];
+    }
 }
 
 template <bool MASK>
@@ -231,13 +229,16 @@ __global__ __launch_bounds__(XF_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
 }
 
-// out[b][qi][h * hd + d] = bv + sum_c ctx[h * lq + qi][c] * Wv[h * hd + d][c]; ctx = merged and normalised partials
+// out[b][qi][h * hd + d] = bv + sum_c ctx[h * lq + qi][c] * Wv[h * hd + d][c]; ctx = merged and normalised partials.  Grid (heads, B):
+// a workgroup merges the lq rows of its head, then thread (d = t % hd, part = t / hd) sums its share of the 256 channels
 __global__ __launch_bounds__(XF_THREADS) void k_fold_out(const float *__restrict__ part, const float *__restrict__ pm, const float *__restrict__ pl,
                                                          const float *__restrict__ wv_io, const float *__restrict__ bv, int lq, int heads, int splits,
                                                          float *__restrict__ out) {
-    __shared__ float cn[XF_ROWS * XF_E];
-    const int b = blockIdx.x, t = threadIdx.x, rows = heads * lq, hd = XF_E / heads;
-    for (int row = 0; row < rows; ++row) {
+    __shared__ float cn[XF_ROWS * XF_E];                 // the head's lq <= 32 / heads merged rows
+    __shared__ float red[XF_THREADS];
+    const int hh = blockIdx.x, b = blockIdx.y, t = threadIdx.x, hd = XF_E / heads;
+    for (int qi = 0; qi < lq; ++qi) {
+        const int row = hh * lq + qi;
         float mx = -INFINITY;
         for (int s = 0; s < splits; ++s) mx = fmaxf(mx, pm[((size_t)b * splits + s) * XF_ROWS + row]);
         float acc = 0.f, l = 0.f;
@@ -248,20 +249,21 @@ __global__ __launch_bounds__(XF_THREADS) void k_fold_out(const float *__restrict
             l += f * pl[slot];
             acc += f * part[slot * XF_E + t];
         }
-        cn[row * XF_E + t] = acc / l;                  // every key masked: 0 / 0 = NaN, as torch.softmax gives
+        cn[qi * XF_E + t] = acc / l;                   // every key masked: 0 / 0 = NaN, as torch.softmax gives
     }
     __syncthreads();
-    const int h = t / hd;
-    for (int q0 = 0; q0 < lq; q0 += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < XF_E; ++c) {
-            const float w = wv_io[(size_t)c * XF_E + t];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(cn[min(h * lq + q0 + j, rows - 1) * XF_E + c], w, acc[j]);
+    const int d = t % hd, pr = t / hd, nparts = XF_THREADS / hd, span = XF_E / nparts;
+    for (int qi = 0; qi < lq; ++qi) {
+        float acc = 0.f;
+        for (int c = pr * span; c < (pr + 1) * span; ++c) acc = fmaf(cn[qi * XF_E + c], wv_io[(size_t)c * XF_E + hh * hd + d], acc);
+        red[t] = acc;
+        __syncthreads();
+        if (pr == 0) {
+            float v = bv[hh * hd + d];
+            for (int k = 0; k < nparts; ++k) v += red[k * hd + d];
+            out[((size_t)b * lq + qi) * XF_E + hh * hd + d] = v;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (q0 + j < lq) out[((size_t)b * lq + q0 + j) * XF_E + t] = acc[j] + bv[t];
+        __syncthreads();
     }
 }
 
@@ -298,7 +300,7 @@ int dz_xattn_folded(const float *q, const float *mem, const uint8_t *key_padding
     hipStream_t st = (hipStream_t)stream;
     const int splits = xf_splits(b, lk);
     float *qf = workspace, *part = qf + (size_t)b * XF_ROWS * XF_E, *pm = part + (size_t)b * splits * XF_ROWS * XF_E, *pl = pm + (size_t)b * splits * XF_ROWS;
-    hipLaunchKernelGGL(k_fold_queries, dim3(b), dim3(XF_THREADS), 0, st, q, wk_oi, lq, heads, scale, qf);
+    hipLaunchKernelGGL(k_fold_queries, dim3(heads + 1, b), dim3(XF_THREADS), 0, st, q, wk_oi, lq, heads, scale, qf);
     int rc;
     if (key_padding_mask) {
         static PerDeviceFlags done;
@@ -309,7 +311,7 @@ int dz_xattn_folded(const float *q, const float *mem, const uint8_t *key_padding
         if ((rc = reserve_lds(reinterpret_cast<const void *>(&k_xattn_fold<false>), XF_LDS, done, "dz_xattn_folded"))) return rc;
         hipLaunchKernelGGL(k_xattn_fold<false>, dim3(splits, b), dim3(XF_THREADS), XF_LDS, st, qf, mem, (const uint8_t *)nullptr, lk, splits, part, pm, pl);
     }
-    hipLaunchKernelGGL(k_fold_out, dim3(b), dim3(XF_THREADS), 0, st, part, pm, pl, wv_io, bv, lq, heads, splits, out);
+    hipLaunchKernelGGL(k_fold_out, dim3(heads, b), dim3(XF_THREADS), 0, st, part, pm, pl, wv_io, bv, lq, heads, splits, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
