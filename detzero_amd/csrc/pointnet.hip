@@ -46,6 +46,7 @@ struct PointNetArgs {
     long rows;
     int c3, group_rows;
     unsigned int x_bytes, w3_bytes;
+    int x_cols_f32;                // 0: x is pair16; 16 / 32: x is (rows, x_cols_f32) fp32 and is split on the way in
 };
 
 template <class M>
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const long group = live ? (tile * 32) / a.group_rows : -1;
         if (group != cur_group) { flush(); cur_group = group; }
         // ---- input rows: 128 bytes = 4 groups of (16 hi | 16 lo); k-step s takes groups 2 s + h
-        {
+        if (a.x_cols_f32 == 0) {
             const unsigned int off = rok ? (unsigned int)(row * (PN_CIN * 4)) + (unsigned int)(h * 32) : OOB_OFFSET;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -157,6 +158,29 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+        } else {
+            // fp32 rows: k-step s takes channels 16 s + 8 h .. + 7 = 32 contiguous bytes, split here (the same bits dz_pair16_from_f32
+            // would have written); a 16-column input has no second k-step (reads past the row come back as zeros: out-of-range offset)
+            const unsigned int rb = (unsigned int)a.x_cols_f32 * 4u;
+            v4u lo4[2], hi4[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned int off = (rok && s * 16 + h * 8 < a.x_cols_f32) ? (unsigned int)row * rb + (unsigned int)((s * 16 + h * 8) * 4) : OOB_OFFSET;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(lo4[s]) : "v"(off), "s"(xrsrc));
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(hi4[s]) : "v"(off), "s"(xrsrc));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                asm volatile("" : "+v"(lo4[s]), "+v"(hi4[s]));
+                const float f0[4] = {__uint_as_float(lo4[s].x), __uint_as_float(lo4[s].y), __uint_as_float(lo4[s].z), __uint_as_float(lo4[s].w)};
+                const float f1[4] = {__uint_as_float(hi4[s].x), __uint_as_float(hi4[s].y), __uint_as_float(hi4[s].z), __uint_as_float(hi4[s].w)};
+                uint2 h0, l0, h1, l1;
+                split4<M>(f0, h0, l0);
+                split4<M>(f1, h1, l1);
+                xh[s] = v4u{h0.x, h0.y, h1.x, h1.y};
+                xl[s] = v4u{l0.x, l0.y, l1.x, l1.y};
+            }
         }
         // ---- layers 1 and 2: D[channel x row], then BatchNorm + ReLU + split + completion of the 8-channel groups
         f32x16 acc[4];
@@ -268,18 +292,19 @@ extern "C" {
 
 int dz_pointnet3_forward(const float *x, long rows, const float *w1, const float *s1, const float *b1, const float *w2, const float *s2,
                          const float *b2, const float *w3, const float *s3, const float *b3, int c3, int group_rows, float *tap, float *out,
-                         int math, void *stream_) {
+                         int x_cols_f32, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(rows >= 0 && (c3 == 256 || c3 == 512 || c3 == 128) && group_rows >= 32 && group_rows % 32 == 0,
                  "dz_pointnet3_forward: c3 in {128, 256, 512}, group_rows a multiple of 32 (got %d, %d)", c3, group_rows);
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_pointnet3_forward: math %d is not a split mode", math);
     if (rows == 0) return DZ_OK;
     DZ_CHECK_ARG(x && w1 && w2 && w3 && out && rows % group_rows == 0, "dz_pointnet3_forward: null pointer / rows not a multiple of group_rows");
-    const size_t x_bytes = (size_t)rows * PN_CIN * 4;
+    DZ_CHECK_ARG(x_cols_f32 == 0 || x_cols_f32 == 16 || x_cols_f32 == 32, "dz_pointnet3_forward: fp32 input rows of 16 or 32 columns (got %d)", x_cols_f32);
+    const size_t x_bytes = (size_t)rows * (x_cols_f32 ? x_cols_f32 : PN_CIN) * 4;
     if (x_bytes >= 0x80000000ull) { set_error("dz_pointnet3_forward: input of %zu bytes exceeds the 2 GiB buffer-addressing limit", x_bytes); return DZ_ERR_UNSUPPORTED; }
     int rc = fill_u32(out, 0xFF800000u, (size_t)(rows / group_rows) * c3, stream);       // -inf
     if (rc) return rc;
-    PointNetArgs a{x, w1, w2, w3, s1, b1, s2, b2, s3, b3, tap, out, rows, c3, group_rows, (unsigned int)x_bytes, (unsigned int)((size_t)c3 * PN_HID * 4)};
+    PointNetArgs a{x, w1, w2, w3, s1, b1, s2, b2, s3, b3, tap, out, rows, c3, group_rows, (unsigned int)x_bytes, (unsigned int)((size_t)c3 * PN_HID * 4), x_cols_f32};
     const long ntiles = (rows + 31) / 32;
     int grid = device_cus();
     if ((long)grid * PN_WAVES > ntiles) grid = (int)((ntiles + PN_WAVES - 1) / PN_WAVES);

@@ -122,7 +122,7 @@ _SIGS = {
     'dz_pdv_sa_pool': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_mlp_chain_forward': (c_int, [c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_int, c_void_p]),
-    'dz_pointnet3_forward': (c_int, [c_void_p, ctypes.c_long] + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'dz_pointnet3_forward': (c_int, [c_void_p, ctypes.c_long] + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'dz_centerhead_decode_workspace_bytes': (c_size_t, [c_int] * 4),
     'dz_centerhead_decode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

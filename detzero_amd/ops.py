@@ -492,21 +492,22 @@ def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shif
     return out
 
 
-def pointnet3(x, layers, group_rows, math, want_tap=False):
-    """dz_pointnet3_forward: x (rows, 32) pair16 through three (w (cout_pad, cin) pair16, scale, shift) layers 32 -> 128 -> 128 -> c3 with
-    ReLU and the max over every `group_rows` rows -> (pooled (rows / group_rows, c3) fp32, tap (rows, 128) pair16 or None)."""
+def pointnet3(x, layers, group_rows, math, want_tap=False, x_f32=False):
+    """dz_pointnet3_forward: x (rows, 32) pair16 - or, with x_f32, (rows, 16 | 32) fp32 rows split inside the kernel - through three
+    (w (cout_pad, cin) pair16, scale, shift) layers 32 -> 128 -> 128 -> c3 with ReLU and the max over every `group_rows` rows ->
+    (pooled (rows / group_rows, c3) fp32, tap (rows, 128) pair16 or None)."""
     lib = L.load()
     (w1, s1, b1), (w2, s2, b2), (w3, s3, b3) = layers
     L.require_cuda(x, w1, w2, w3, s1, b1, s2, b2, s3, b3)
     rows = x.shape[0]
     c3 = w3.shape[0]
-    if tuple(w1.shape) != (128, 32) or tuple(w2.shape) != (128, 128) or w3.shape[1] != 128 or x.shape[1] != 32 or rows % group_rows:
+    if tuple(w1.shape) != (128, 32) or tuple(w2.shape) != (128, 128) or w3.shape[1] != 128 or x.shape[1] not in ((16, 32) if x_f32 else (32,)) or rows % group_rows:
         raise L.DetZeroHipError('pointnet3: expects 32 -> 128 -> 128 -> c3 layers on (rows, 32) pair16 input (got %s, %s, %s on %s)' % (
             tuple(w1.shape), tuple(w2.shape), tuple(w3.shape), tuple(x.shape)))
     out = torch.empty((rows // group_rows, c3), dtype=torch.float32, device=x.device)
     tap = torch.empty((rows, 128), dtype=torch.float32, device=x.device) if want_tap else None
     rc = lib.dz_pointnet3_forward(L.ptr(x), rows, L.ptr(w1), L.ptr(s1), L.ptr(b1), L.ptr(w2), L.ptr(s2), L.ptr(b2), L.ptr(w3), L.ptr(s3), L.ptr(b3),
-                                  c3, int(group_rows), L.ptr(tap), L.ptr(out), storage_math(math), L.stream())
+                                  c3, int(group_rows), L.ptr(tap), L.ptr(out), x.shape[1] if x_f32 else 0, storage_math(math), L.stream())
     L.check(rc, 'dz_pointnet3_forward')
     return out, tap
 

@@ -264,20 +264,24 @@ FUSED_CHAIN = [True]          # development switch: dz_mlp_chain_forward (memory
 FUSED_POINTNET = [True]       # development switch: the fused encoder kernel (csrc/pointnet.hip) vs layer-by-layer launches
 
 
-def _pointnet3_ok(xp, layers, gmax, m):
-    return (FUSED_POINTNET[0] and m in (1, 2) and gmax is not None and gmax[1] % 32 == 0 and len(layers) == 3 and xp.shape[1] == 32
+def _pointnet3_ok(xp, layers, gmax, m, x_f32=False):
+    """x_f32: xp is still the fp32 rows (16 or 32 columns, contiguous) - the kernel splits them itself, no conversion pass."""
+    cols_ok = (xp.shape[1] in (16, 32) and xp.is_contiguous()) if x_f32 else xp.shape[1] == 32
+    return (FUSED_POINTNET[0] and m in (1, 2) and gmax is not None and gmax[1] % 32 == 0 and len(layers) == 3 and cols_ok
             and layers[0]['cout'] == 128 and layers[1]['cout'] == 128 and layers[2]['cout'] in (128, 256, 512)
             and all(l['relu'] for l in layers))
 
 
-def _run_stack_split(xp, layers, keep_pair=False, math=None, gmax=None, tap=False):
+def _run_stack_split(xp, layers, keep_pair=False, math=None, gmax=None, tap=False, x_f32=False):
     """xp: pair16 rows.  Hidden layers stay pair16; the last one returns fp32 unless keep_pair.
     gmax = (groups, rows per group): the max over each group's rows is fused into the last layer (-> (groups, cout) fp32); a
     32 -> 128 -> 128 -> C PointNet encoder runs as ONE kernel (dz_pointnet3_forward; outs[1] = the second layer's rows)."""
     m = _REFINE_MATH[0] if math is None else math
-    if _pointnet3_ok(xp, layers, gmax, m):
+    if x_f32 and not _pointnet3_ok(xp, layers, gmax, m, True):          # fp32 rows the fused encoder cannot take as they are
+        xp, x_f32 = ops.pair16_from_f32(xp, c_dst=_r32(xp.shape[1]), math=m), False
+    if _pointnet3_ok(xp, layers, gmax, m, x_f32):
         trip = [(_split_w(l, m), l['scale32'], l['shift32']) for l in layers]
-        pooled, tap = ops.pointnet3(xp, trip, gmax[1], m, want_tap=tap)
+        pooled, tap = ops.pointnet3(xp, trip, gmax[1], m, want_tap=tap, x_f32=x_f32)
         return pooled, [None, tap, pooled]
     outs = []
     for li, l in enumerate(layers):
@@ -300,8 +304,7 @@ def _run_stack(x, layers, upto=None, math=None, gmax=None):
     layers = layers if upto is None else layers[:upto]
     if _splittable(layers, x.shape[0], math):
         m = _REFINE_MATH[0] if math is None else math
-        xp = ops.pair16_from_f32(x, c_dst=_r32(x.shape[1]), math=m)
-        return _run_stack_split(xp, layers, math=m, gmax=gmax)
+        return _run_stack_split(x.contiguous(), layers, math=m, gmax=gmax, x_f32=True)      # (converted there unless the fused encoder takes fp32 rows)
     outs = []
     for li, l in enumerate(layers):
         x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
@@ -446,8 +449,8 @@ class _PointNetPlan:
     def _forward(self, pts_rows, groups, length, kv_plan):
         if _splittable(self.enc + self.mlp, pts_rows.shape[0]) and self.mlp[0]['cout'] % 32 == 0:
             m = _REFINE_MATH[0]
-            xp = ops.pair16_from_f32(pts_rows, c_dst=_r32(self.cin_pad), math=m)
-            pooled, outs = _run_stack_split(xp, self.enc, gmax=(groups, length), tap=True)      # max over the points fused; the tapped layer pair16
+            # max over the points fused; the tapped layer pair16; 16- / 32-column fp32 rows go in as they are
+            pooled, outs = _run_stack_split(pts_rows.contiguous(), self.enc, gmax=(groups, length), tap=True, x_f32=True)
             gshift = ops.linear(pooled, self.w_pool, self.ones, self.zeros, False, self.w_pool.shape[1])
             l0 = self.mlp[0]
             w0 = _split_w(l0, m)

@@ -281,11 +281,12 @@ int dz_mlp_chain_forward(const float *x, long rows, const float *wa, const float
 /* Fused PointNet encoder (csrc/pointnet.hip; geometry_transformer.py:34-67,118-140, position_transformer.py:43-124): three
  * point-wise layers 32 -> 128 -> 128 -> c3 (c3 in {128, 256, 512}; BatchNorm scale / shift + ReLU after each) and the max over
  * every group of group_rows consecutive rows (group_rows % 32 == 0, rows % group_rows == 0) in one kernel; the activations never
- * leave the registers.  x (rows, 32) pair16; w1 (128, 32), w2 (128, 128), w3 (c3, 128) pair16; out (rows / group_rows, c3) fp32;
+ * leave the registers.  x (rows, 32) pair16 - or, with x_cols_f32 = 16 / 32, (rows, x_cols_f32) fp32 rows split on the way in (columns
+ * beyond x_cols_f32 count as zero); w1 (128, 32), w2 (128, 128), w3 (c3, 128) pair16; out (rows / group_rows, c3) fp32;
  * tap (rows, 128) pair16 or NULL = the second layer's output (the reference reads it through a forward hook).  Split math only. */
 int dz_pointnet3_forward(const float *x, long rows, const float *w1, const float *s1, const float *b1, const float *w2, const float *s2,
                          const float *b2, const float *w3, const float *s3, const float *b3, int c3, int group_rows, float *tap, float *out,
-                         int math, void *stream);
+                         int x_cols_f32, int math, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CenterHead decode + NMS (center_head.py:315-368, centernet_utils.py:138-230,

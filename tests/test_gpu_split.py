@@ -345,6 +345,12 @@ def test_fused_pointnet_encoder(device, name, mid, cin, c3, groups, length):
     got, tap = ops.pointnet3(x, trip, length, mid, want_tap=True)
     got2, none = ops.pointnet3(x, trip, length, mid)
     assert none is None and torch.equal(got, got2)
+    # fp32 rows split inside the kernel: the same bits as the converted input
+    cp = 16 if cin <= 16 else 32
+    xpad = np.zeros((rows, cp), np.float32)
+    xpad[:, :cin] = xf
+    got3, tap3 = ops.pointnet3(_t(xpad, device), trip, length, mid, want_tap=True, x_f32=True)
+    assert torch.equal(got3, got) and torch.equal(tap3, tap)
     h = x
     for li, (w, s, b) in enumerate(trip):
         h = ops.linear_split(h, w, s, b, True, w.shape[0], mid, out_f32=li == 2)
