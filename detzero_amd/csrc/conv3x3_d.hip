@@ -38,7 +38,7 @@ constexpr int D_LDS_BYTES = D_OFF_SS + 2 * D_BC * 4;
 
 // 16 bytes per lane from a buffer straight into LDS at lds_base + lane * 16 (lds_base wave-uniform)
 __device__ __forceinline__ void load_to_lds(unsigned int lds_base, unsigned int voff, srsrc_t rsrc, unsigned int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 
 template <class M>

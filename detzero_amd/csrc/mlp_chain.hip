@@ -13,9 +13,10 @@
 //   * the 512-wide hidden layer never exists as a whole: it is produced in four slices of 128 channels, and each slice is contracted
 //     into the 256 accumulators of the next layer at once (k ascending, so the sums are those of the layered path, bit for bit);
 //   * one wave per SIMD with the whole register file (128 fp32 accumulators of the 256-wide layer + 64 of the slice + operands);
-//   * weights stream through LDS in 64 KB slices (128 output x 128 input channels), double buffered, loaded with
-//     `buffer_load_dwordx4 ... lds` (no staging registers) into an XOR-swizzled layout that is conflict-free for the fragment reads;
-//     20 slices per 128 rows (12 without K / V), one workgroup barrier per slice = per 96 MFMAs of a wave;
+//   * weights stream through LDS in 32 KB slices (64 output x 128 input channels) through a ring of four buffers, THREE slices in flight
+//     (every workgroup of the launch walks the same 1.3 MB of weights in step: with one slice of look-ahead a third of the time went
+//     into waiting for L2), loaded with `buffer_load_dwordx4 ... lds` (no staging registers) into an XOR-swizzled layout that is
+//     conflict-free for the fragment reads; 40 slices per 128 rows (24 without K / V), one workgroup barrier per slice = per 48 MFMAs;
 //   * fp32 results leave through a wave-private LDS window (a lane stores 64 contiguous bytes of a row).
 // HBM traffic: the tap rows in (512 B each), memory / K / V rows out (1 KB each) - nothing else.
 #include <stdlib.h>
@@ -28,9 +29,9 @@ namespace dz {
 namespace {
 
 constexpr int MC_THREADS = 256, MC_WAVES = 4;
-constexpr int MC_SLICE = 128 * 128 * 4;                    // one weight slice: 128 rows x 128 channels of pair16
+constexpr int MC_SLICE = 64 * 128 * 4, MC_NBUF = 4;        // one weight slice: 64 rows x 128 channels of pair16; ring of four, three in flight
 constexpr int MC_WIN_ROW = 144, MC_WIN = 32 * MC_WIN_ROW;  // fp32 window of a 32 x 32 fragment
-constexpr int MC_OFF_W = 0, MC_OFF_WIN = 2 * MC_SLICE, MC_OFF_V = MC_OFF_WIN + MC_WAVES * MC_WIN;
+constexpr int MC_OFF_W = 0, MC_OFF_WIN = MC_NBUF * MC_SLICE, MC_OFF_V = MC_OFF_WIN + MC_WAVES * MC_WIN;
 constexpr int MC_C1 = 512, MC_C2 = 256, MC_CIN = 128;
 constexpr int MC_NVEC = 2 * MC_C1 + 2 * MC_C2 + 2 * MC_C2;            // sA bA | sB bB | bK bV
 constexpr int MC_LDS = MC_OFF_V + MC_NVEC * 4;
@@ -49,7 +50,7 @@ struct ChainArgs {
 
 __device__ __forceinline__ void mc_load16_lds(unsigned int lds_base, unsigned int voff, srsrc_t rsrc) {
     const unsigned int b = __builtin_amdgcn_readfirstlane(lds_base);
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(b), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(b), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 
 template <class M, bool KV>
@@ -70,41 +71,43 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     const srsrc_t xrsrc = make_srsrc(a.x, a.x_bytes);
 
-    // ---- the slice stream of a tile: j = 0 .. NSL-1
-    //   j = 3 sa + 0: W_a rows [128 sa, +128), all 128 input channels;  j = 3 sa + 1 / + 2: W_b rows [0, 128) / [128, 256), input channels [128 sa, +128)
-    //   j = 12 + 2 c + kk: W_k rows [128 c, +128), input channels [128 kk, +128);  j = 16 + 2 c + kk: W_v likewise
-    constexpr int NSL = KV ? 20 : 12;
-    // unit u = i * 256 + tid of a slice = 16 bytes at LDS offset u * 16: chunk (32 channels) u >> 10, row (u >> 3) & 127, stored piece u & 7
+    // ---- the slice stream of a tile: j = 0 .. NSL-1, 64 output rows x 128 input channels each
+    //   j = 6 sa + hf (hf = 0, 1): W_a rows [128 sa + 64 hf, +64), all 128 input channels
+    //   j = 6 sa + 2 + qd (qd = 0 .. 3): W_b rows [64 qd, +64), input channels [128 sa, +128)
+    //   j = 24 + 8 pj + 2 qd + kk: W_k (pj = 0) / W_v (pj = 1) rows [64 qd, +64), input channels [128 kk, +128)
+    constexpr int NSL = KV ? 40 : 24;
+    static_assert(NSL % MC_NBUF == 0, "slice j of every tile lives in buffer j % 4");
+    // unit u = i * 256 + tid of a slice = 16 bytes at LDS offset u * 16: chunk (32 channels) u >> 9, row (u >> 3) & 63, stored piece u & 7
     // holds source piece (u & 7) ^ ((row >> 1) & 7)
     auto issue_slice = [&](int j, int buf) {
         // (the slice index may be a run-time value: the descriptor is built from scalar selects, never indexed from memory)
         const float *wbase;
         unsigned int n0, k0, rowb, wbytes;
-        if (j < 12) {
-            const int sa = j / 3, part = j % 3;
-            wbase = part == 0 ? a.wa : a.wb;
-            wbytes = part == 0 ? MC_C1 * MC_CIN * 4 : MC_C2 * MC_C1 * 4;
-            n0 = part == 0 ? sa * 128 : (part - 1) * 128;
-            k0 = part == 0 ? 0 : sa * 128;
-            rowb = part == 0 ? MC_CIN * 4 : MC_C1 * 4;
+        if (j < 24) {
+            const int sa = j / 6, r = j % 6;
+            wbase = r < 2 ? a.wa : a.wb;
+            wbytes = r < 2 ? MC_C1 * MC_CIN * 4 : MC_C2 * MC_C1 * 4;
+            n0 = r < 2 ? sa * 128 + r * 64 : (r - 2) * 64;
+            k0 = r < 2 ? 0 : sa * 128;
+            rowb = r < 2 ? MC_CIN * 4 : MC_C1 * 4;
         } else {
-            const int jj = j - 12, c = (jj >> 1) & 1, kk = jj & 1;
-            wbase = jj < 4 ? a.wk : a.wv;
+            const int jj = j - 24, r = jj & 7;
+            wbase = jj < 8 ? a.wk : a.wv;
             wbytes = MC_C2 * MC_C2 * 4;
-            n0 = c * 128; k0 = kk * 128; rowb = MC_C2 * 4;
+            n0 = (r >> 1) * 64; k0 = (r & 1) * 128; rowb = MC_C2 * 4;
         }
         const srsrc_t rs = make_srsrc(wbase, wbytes);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int chunk = i >> 2, n = (i & 3) * 32 + (tid >> 3), pc = (tid & 7) ^ ((n >> 1) & 7);
+        for (int i = 0; i < 8; ++i) {
+            const int chunk = i >> 1, n = (i & 1) * 32 + (tid >> 3), pc = (tid & 7) ^ ((n >> 1) & 7);
             mc_load16_lds((unsigned int)(MC_OFF_W + buf * MC_SLICE + (i * MC_THREADS + wid * 64) * 16),
                           (n0 + n) * rowb + (k0 + chunk * 32) * 4 + pc * 16, rs);
         }
     };
     // weight fragment: k-step s (16 channels: chunk s >> 1, pieces 4 (s & 1) + 2 h, + 1) of rows [r0, r0 + 32) of the slice in `buf`.
-    // Rows r0 + l31 with r0 a multiple of 32 share the swizzle of l31, so a fragment address is one of 8 lane-dependent bases (buffer x
-    // (s & 1) x hi / lo) plus a compile-time offset below 64 KB; the bases are kept opaque, or the compiler materialises (and spills)
-    // a register per (buffer, chunk, fragment) instead of using the offset field of ds_read_b128
+    // Rows r0 + l31 with r0 a multiple of 32 share the swizzle of l31, so a fragment address is one of 8 lane-dependent bases (buffer
+    // pair x (s & 1) x hi / lo) plus a compile-time offset below 64 KB; the bases are kept opaque, or the compiler materialises (and
+    // spills) a register per (buffer, chunk, fragment) instead of using the offset field of ds_read_b128
     unsigned int wb[2][2][2];                            // (32-bit LDS offsets: a laundered POINTER loses its address space)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -113,21 +116,24 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
                 const int sw = (l31 >> 1) & 7, pc = par * 4 + h * 2 + hl;
-                wb[b][par][hl] = (unsigned int)(MC_OFF_W + b * MC_SLICE + (l31 << 7) + ((pc ^ sw) << 4));
+                wb[b][par][hl] = (unsigned int)(MC_OFF_W + b * 2 * MC_SLICE + (l31 << 7) + ((pc ^ sw) << 4));
                 asm volatile("" : "+v"(wb[b][par][hl]));
             }
     auto wfrag = [&](int buf, int r0, int s, v4u &hi, v4u &lo) {
-        const int off = ((s >> 1) * 128 + r0) << 7;
-        hi = *reinterpret_cast<const v4u *>(smem_raw + wb[buf][s & 1][0] + off);
-        lo = *reinterpret_cast<const v4u *>(smem_raw + wb[buf][s & 1][1] + off);
+        const int off = (buf & 1) * MC_SLICE + (((s >> 1) * 64 + r0) << 7);
+        hi = *reinterpret_cast<const v4u *>(smem_raw + wb[buf >> 1][s & 1][0] + off);
+        lo = *reinterpret_cast<const v4u *>(smem_raw + wb[buf >> 1][s & 1][1] + off);
     };
-    static_assert(NSL % 2 == 0, "slice j of every tile lives in buffer j & 1");
-    // the current slice has landed in every wave's view; the other buffer is free: start the next slice into it
-    auto begin_slice = [&](int j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Slice j has landed in every wave's view once the wave's own loads for it are back and the workgroup has met.  Its loads went out
+    // three slices ago; the two slices issued since stay in flight (8 loads per thread each; loads return in order) - unless result
+    // stores were issued in between, which retire on their own schedule: then everything is drained (`drain`).  The buffer of slice
+    // j - 1 is free after the barrier: slice j + 3 goes into it.
+    auto begin_slice = [&](int j, bool drain) {
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __syncthreads();
-        issue_slice(j + 1 < NSL ? j + 1 : 0, (j + 1) & 1);
-        return j & 1;
+        issue_slice((j + 3) % NSL, (j + 3) & 3);
+        return j & 3;
     };
 
     // accumulator fragment (32 channels x 32 rows) -> BatchNorm (+ addend) + optional ReLU; lane (l31, h): acc[4 q + e] = channel 8 q + 4 h + e
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // 32 finished channels x 32 rows -> global fp32 rows through the wave's window: lane (row = lane >> 1, half) stores 64 contiguous bytes.
     // Buffer stores with a 32-bit offset (rows past the end carry the out-of-range offset: dropped by the hardware, no branches)
     unsigned char *const win = smem_raw + MC_OFF_WIN + wid * MC_WIN;
-    auto store_f32 = [&](const float (&v)[16], srsrc_t rs, unsigned int off) {
+    auto store_f32 = [&](const float (&v)[16], __amdgpu_buffer_rsrc_t rs, unsigned int off) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(win + l31 * MC_WIN_ROW + (q * 8 + h * 4) * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -187,15 +193,15 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const v4u *src = reinterpret_cast<const v4u *>(win + (lane >> 1) * MC_WIN_ROW + (lane & 1) * 64);
         const v4u t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(t0), "v"(off), "s"(rs) : "memory");
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:16" ::"v"(t1), "v"(off), "s"(rs) : "memory");
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32" ::"v"(t2), "v"(off), "s"(rs) : "memory");
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:48" ::"v"(t3), "v"(off), "s"(rs) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128(t0, rs, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t1, rs, (int)off + 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t2, rs, (int)off + 32, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t3, rs, (int)off + 48, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
     const unsigned int out_bytes = (unsigned int)((size_t)a.rows * MC_C2 * 4);
-    const srsrc_t rsMem = make_srsrc(a.mem, out_bytes);
+    const __amdgpu_buffer_rsrc_t rsMem = make_rsrc(a.mem, out_bytes);
 
     const long ntiles = (a.rows + 31) / 32;
     const long nwaves = (long)gridDim.x * MC_WAVES;
@@ -203,6 +209,8 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const long t_begin = ((long)blockIdx.x * MC_WAVES + wid) * per;
     __syncthreads();
     issue_slice(0, 0);
+    issue_slice(1, 1);
+    issue_slice(2, 2);
 
     for (long it = 0; it < per; ++it) {
         const long tile = t_begin + it, row0 = tile * 32;
@@ -227,55 +235,66 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accB[ct][e] = 0.f;
-#pragma unroll 1                     // (unrolled, the compiler hoists the four slices' addend loads to the top of the tile: 300 spilled registers)
-        for (int sa = 0; sa < 4; ++sa) {
-            // ---- 128 channels of the hidden layer
-            int buf = begin_slice(3 * sa);                                   // (its vmcnt(0) also covers the tap loads)
-            if (sa == 0) {
+#pragma unroll 1                     // (fully unrolled, the compiler hoists the four slices' addend loads to the top of the tile: 300 spilled registers)
+        for (int sa2 = 0; sa2 < 2; ++sa2) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
-            }
-            f32x16 accA[4];
+            for (int u = 0; u < 2; ++u) {                                    // (two slices of the hidden layer per trip: buffer indices stay compile-time)
+                const int sa = 2 * sa2 + u;
+                // ---- 128 channels of the hidden layer, 64 per slice
+                f32x16 accA[4];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+                for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) accA[ct][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) accA[ct][e] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+                for (int hf = 0; hf < 2; ++hf) {
+                    // (the first slice of a tile follows the previous tile's result stores and my row loads: drain)
+                    const int buf = (6 * u + hf) & 3;
+                    begin_slice(12 * sa2 + 6 * u + hf, sa == 0 && hf == 0);
+                    if (u == 0 && hf == 0 && sa2 == 0) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            v4u whi, wlo;
+                            wfrag(buf, ct * 32, s, whi, wlo);
+                            f32x16 &acc = accA[hf * 2 + ct];
+                            acc = M::mma(wlo, xh[s], acc);
+                            acc = M::mma(whi, xl[s], acc);
+                            acc = M::mma(whi, xh[s], acc);
+                        }
+                        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                v4u sh_[8], sl_[8];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    v4u whi, wlo;
-                    wfrag(buf, ct * 32, s, whi, wlo);
-                    accA[ct] = M::mma(wlo, xh[s], accA[ct]);
-                    accA[ct] = M::mma(whi, xl[s], accA[ct]);
-                    accA[ct] = M::mma(whi, xh[s], accA[ct]);
+                    float v[16];
+                    const int c0 = sa * 128 + ct * 32;
+                    finish(accA[ct], sA + c0, bA + c0, gs ? gs + c0 : nullptr, true, v);
+                    to_operands(v, sh_[2 * ct], sl_[2 * ct], sh_[2 * ct + 1], sl_[2 * ct + 1]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            v4u sh_[8], sl_[8];
+                // ---- their contribution to the 256 channels of the second layer, 64 output channels per slice
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                float v[16];
-                const int c0 = sa * 128 + ct * 32;
-                finish(accA[ct], sA + c0, bA + c0, gs ? gs + c0 : nullptr, true, v);
-                to_operands(v, sh_[2 * ct], sl_[2 * ct], sh_[2 * ct + 1], sl_[2 * ct + 1]);
-            }
-            // ---- their contribution to the 256 channels of the second layer, 128 output channels per slice
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int buf = (6 * u + 2 + qd) & 3;
+                    begin_slice(12 * sa2 + 6 * u + 2 + qd, false);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                buf = begin_slice(3 * sa + 1 + half);
+                    for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        v4u whi, wlo;
-                        wfrag(buf, ct * 32, s, whi, wlo);
-                        f32x16 &acc = accB[half * 4 + ct];
-                        acc = M::mma(wlo, sh_[s], acc);
-                        acc = M::mma(whi, sl_[s], acc);
-                        acc = M::mma(whi, sh_[s], acc);
+                        for (int ct = 0; ct < 2; ++ct) {
+                            v4u whi, wlo;
+                            wfrag(buf, ct * 32, s, whi, wlo);
+                            f32x16 &acc = accB[qd * 2 + ct];
+                            acc = M::mma(wlo, sh_[s], acc);
+                            acc = M::mma(whi, sl_[s], acc);
+                            acc = M::mma(whi, sh_[s], acc);
+                        }
+                        if (s & 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -291,29 +310,31 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if constexpr (KV) {
 #pragma unroll 1
             for (int pj = 0; pj < 2; ++pj) {                                 // K, then V
-                const srsrc_t rsOut = make_srsrc(pj ? a.v : a.k, out_bytes);
+                const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(pj ? a.v : a.k, out_bytes);
                 f32x16 acc[8];
 #pragma unroll
                 for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        const int buf = begin_slice(12 + pj * 4 + c * 2 + kk);
+                        // (the first slice of K / V follows the stores of the memory / K rows: drain)
+                        const int buf = (2 * qd + kk) & 3;
+                        begin_slice(24 + 8 * pj + 2 * qd + kk, qd == 0 && kk == 0);
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                            for (int ct = 0; ct < 4; ++ct) {
+                            for (int ct = 0; ct < 2; ++ct) {
                                 v4u whi, wlo;
                                 wfrag(buf, ct * 32, s, whi, wlo);
-                                f32x16 &d = acc[c * 4 + ct];
+                                f32x16 &d = acc[qd * 2 + ct];
                                 d = M::mma(wlo, mh[kk * 8 + s], d);
                                 d = M::mma(whi, ml[kk * 8 + s], d);
                                 d = M::mma(whi, mh[kk * 8 + s], d);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
+                            if (s & 1) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slice issued for a tile that does not come
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slices issued for a tile that does not come
 }
 
 template <class M>

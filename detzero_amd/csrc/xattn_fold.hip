@@ -35,7 +35,7 @@ static_assert(XF_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ void xf_load16_lds(unsigned int lds_base, unsigned int voff, srsrc_t rsrc, unsigned int soff) {
     const unsigned int b = __builtin_amdgcn_readfirstlane(lds_base), so = __builtin_amdgcn_readfirstlane(soff);
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(b), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(b), "v"(voff), "s"(rsrc), "s"(so) : "memory", "m0");
 }
 
 // Qf[b][h * lq + qi][c] = scale * sum_d q[b][qi][h * hd + d] * Wk[h * hd + d][c]; rows >= heads * lq are zero.  Grid (heads + 1, B):
