@@ -229,7 +229,15 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         // fp32 output rows: lane (row0 + lane / 2, 64-byte half lane & 1); out of range = dropped (outputs are < 2 GiB, host-checked)
         const unsigned int rowoff = (live && row0 + (lane >> 1) < a.rows) ? (unsigned int)((row0 + (lane >> 1)) * (MC_C2 * 4)) + (unsigned int)((lane & 1) * 64) : OOB_OFFSET;
-        const float *gs = (a.gshift && live) ? a.gshift + (size_t)(row0 / a.group_rows) * a.ldg : nullptr;
+        // the tile's row of per-object addends (512 floats) rides into the wave's window (idle until the result stores): read from
+        // global inside the slice stream, every load of it would make the compiler wait for the weight slices in flight behind it
+        const bool has_gs = a.gshift != nullptr;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        if (has_gs && live) {
+            const float4 *gp = reinterpret_cast<const float4 *>(a.gshift + (size_t)(row0 / a.group_rows) * a.ldg);
+            g0 = gp[lane]; g1 = gp[64 + lane];
+        }
+        const float *gs = has_gs ? reinterpret_cast<const float *>(win) : nullptr;
         f32x16 accB[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
@@ -254,19 +262,27 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     if (u == 0 && hf == 0 && sa2 == 0) {
 #pragma unroll
                         for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+                        if (has_gs) {
+                            reinterpret_cast<float4 *>(win)[lane] = g0;
+                            reinterpret_cast<float4 *>(win)[64 + lane] = g1;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
                     }
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
+                        // (term-major over the two fragments: with one wave per SIMD a dependent MFMA issued back to back waits for
+                        // its predecessor; every accumulator still receives lo.hi, hi.lo, hi.hi in that order)
+                        v4u whi[2], wlo[2];
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            v4u whi, wlo;
-                            wfrag(buf, ct * 32, s, whi, wlo);
-                            f32x16 &acc = accA[hf * 2 + ct];
-                            acc = M::mma(wlo, xh[s], acc);
-                            acc = M::mma(whi, xl[s], acc);
-                            acc = M::mma(whi, xh[s], acc);
-                        }
-                        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+                        for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(wlo[ct], xh[s], accA[hf * 2 + ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(whi[ct], xl[s], accA[hf * 2 + ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(whi[ct], xh[s], accA[hf * 2 + ct]);
                     }
                 }
                 v4u sh_[8], sl_[8];
@@ -284,16 +300,15 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     begin_slice(12 * sa2 + 6 * u + 2 + qd, false);
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
+                        v4u whi[2], wlo[2];
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            v4u whi, wlo;
-                            wfrag(buf, ct * 32, s, whi, wlo);
-                            f32x16 &acc = accB[qd * 2 + ct];
-                            acc = M::mma(wlo, sh_[s], acc);
-                            acc = M::mma(whi, sl_[s], acc);
-                            acc = M::mma(whi, sh_[s], acc);
-                        }
-                        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+                        for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(wlo[ct], sh_[s], accB[qd * 2 + ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(whi[ct], sl_[s], accB[qd * 2 + ct]);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(whi[ct], sh_[s], accB[qd * 2 + ct]);
                     }
                 }
             }
@@ -325,15 +340,15 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         begin_slice(24 + 8 * pj + 2 * qd + kk, qd == 0 && kk == 0);
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
+                            v4u whi[2], wlo[2];
 #pragma unroll
-                            for (int ct = 0; ct < 2; ++ct) {
-                                v4u whi, wlo;
-                                wfrag(buf, ct * 32, s, whi, wlo);
-                                f32x16 &d = acc[qd * 2 + ct];
-                                d = M::mma(wlo, mh[kk * 8 + s], d);
-                                d = M::mma(whi, ml[kk * 8 + s], d);
-                                d = M::mma(whi, mh[kk * 8 + s], d);
-                            }
+                            for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(wlo[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(whi[ct], ml[kk * 8 + s], acc[qd * 2 + ct]);
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(whi[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
                             if (s & 1) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
