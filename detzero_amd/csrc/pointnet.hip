@@ -29,13 +29,16 @@
 namespace dz {
 
 constexpr int PN_THREADS = 512, PN_WAVES = 8, PN_HID = 128, PN_CIN = 32;
-constexpr int PN_ROWB = 144;                               // LDS row of a 32-channel weight chunk: 128 bytes + 16 pad (conflict-free ds_read_b128)
+constexpr int PN_ROWB = 144;                               // W1's LDS row (a 32-channel chunk): 128 bytes + 16 pad (conflict-free ds_read_b128)
 constexpr int PN_W1 = PN_HID * PN_ROWB;                    // [128 rows][144]
-constexpr int PN_W2 = 4 * PN_HID * PN_ROWB;                // [4 chunks][128 rows][144]
-constexpr int PN_W3S = 4 * 32 * PN_ROWB;                   // a slice of 32 output channels: [4 chunks][32 rows][144]
-constexpr int PN_OFF_W1 = 0, PN_OFF_W2 = PN_W1, PN_OFF_W3 = PN_OFF_W2 + PN_W2, PN_OFF_SS = PN_OFF_W3 + 2 * PN_W3S;
-constexpr int PN_OFF_RUN = PN_OFF_SS + 4 * PN_HID * 4;                  // (scale / shift of layers 1 and 2)
+// W2 and the W3 ring: unpadded 128-byte rows, the 16-byte piece p of row n stored at p ^ ((n >> 1) & 7) (conflict-free for the 16-lane
+// groups ds_read_b128 is served in) - padded they would not leave room for a third slice in flight
+constexpr int PN_W2 = 4 * PN_HID * 128;                    // [4 chunks][128 rows][128]
+constexpr int PN_W3S = 4 * 32 * 128, PN_RING = 3;          // a slice of 32 output channels: [4 chunks][32 rows][128]; ring of three
+constexpr int PN_OFF_W1 = 0, PN_OFF_W2 = PN_W1, PN_OFF_W3 = PN_OFF_W2 + PN_W2, PN_OFF_SS = PN_OFF_W3 + PN_RING * PN_W3S;
+constexpr int PN_OFF_RUN = PN_OFF_SS + (4 * PN_HID + 2 * 512) * 4;      // (scale / shift of layers 1 and 2, then of layer 3)
 constexpr int PN_LDS = PN_OFF_RUN + PN_WAVES * 16 * 32 * 4;             // + running maxima: [wave][slice][channel of the slice]
+static_assert(PN_LDS <= 160 * 1024, "LDS");
 
 struct PointNetArgs {
     const float *x;                // (rows, 32) pair16
@@ -66,7 +69,11 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const v4u *g2 = reinterpret_cast<const v4u *>(a.w2);
         for (int i = tid; i < PN_HID * 32; i += PN_THREADS) {                // 32 pieces per row: chunk = piece / 8
             const int n = i >> 5, pc = i & 31;
-            *reinterpret_cast<v4u *>(smem_raw + PN_OFF_W2 + ((pc >> 3) * PN_HID + n) * PN_ROWB + (pc & 7) * 16) = g2[i];
+            *reinterpret_cast<v4u *>(smem_raw + PN_OFF_W2 + (((pc >> 3) * PN_HID + n) << 7) + (((pc & 7) ^ ((n >> 1) & 7)) << 4)) = g2[i];
+        }
+        for (int i = tid; i < 512; i += PN_THREADS) {
+            ss[4 * PN_HID + i] = (a.s3 && i < a.c3) ? a.s3[i] : 1.f;
+            ss[4 * PN_HID + 512 + i] = (a.b3 && i < a.c3) ? a.b3[i] : 0.f;
         }
         if (tid < PN_HID) {
             ss[tid] = a.s1 ? a.s1[tid] : 1.f;
@@ -84,31 +91,30 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const long per = (ntiles + nwaves - 1) / nwaves;
     const long t_begin = ((long)blockIdx.x * PN_WAVES + wid) * per;
 
-    // W3 slice staging: 16 KB per slice = 2 pieces of 16 bytes per thread: piece i = j * 512 + tid -> row n = i / 32 of the slice,
-    // 16-byte piece pc = i % 32 of its 512-byte row
-    auto w3_issue = [&](int slice, v4u (&st)[2]) {
+    // W3 slices (32 output channels x 128 inputs = 16 KB) stream through a ring of three with `buffer_load_dwordx4 ... lds`: two 16-byte
+    // units per thread, unit u = j * 512 + tid at LDS offset u * 16 = chunk u >> 8, row (u >> 3) & 31, stored piece u & 7
+    auto w3_issue = [&](int slice, int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int i = j * PN_THREADS + tid;
-            const unsigned int off = (unsigned int)(((slice * 32 + (i >> 5)) * PN_HID * 4) + (i & 31) * 16);
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[j]) : "v"(off), "s"(w3rsrc));
+            const int u = j * PN_THREADS + tid, chunk = u >> 8, n = (u >> 3) & 31, pc = (u & 7) ^ ((n >> 1) & 7);
+            const unsigned int off = (unsigned int)((slice * 32 + n) * (PN_HID * 4) + chunk * 128 + pc * 16);
+            const unsigned int base = __builtin_amdgcn_readfirstlane((unsigned int)(PN_OFF_W3 + buf * PN_W3S + (j * PN_THREADS + wid * 64) * 16));
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(base), "v"(off), "s"(w3rsrc) : "memory", "m0");
         }
     };
-    auto w3_store = [&](int buf, v4u (&st)[2]) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            asm volatile("" : "+v"(st[j]));
-            const int i = j * PN_THREADS + tid;
-            const int n = i >> 5, pc = i & 31;
-            *reinterpret_cast<v4u *>(smem_raw + PN_OFF_W3 + buf * PN_W3S + ((pc >> 3) * 32 + n) * PN_ROWB + (pc & 7) * 16) = st[j];
-        }
-    };
-    // weight fragment of k-step s (16 channels) for the 32 rows [r0, r0 + 32) of a [chunk][rows][144] tile
+    // weight fragment of k-step s (16 channels) for the 32 rows [r0, r0 + 32) of a [chunk][rows][144] tile (W1)
     auto wfrag = [&](int base, int rows_per_chunk, int r0, int s, v4u &hi, v4u &lo) {
         const unsigned char *p = smem_raw + base + ((s >> 1) * rows_per_chunk + r0 + l31) * PN_ROWB + ((s & 1) * 4 + h * 2) * 16;
         hi = *reinterpret_cast<const v4u *>(p);
         lo = *reinterpret_cast<const v4u *>(p + 16);
+    };
+    // ... and of an unpadded, swizzled [chunk][rows][128] tile (W2, the W3 ring); r0 a multiple of 32: the swizzle is that of l31
+    const int sw = (l31 >> 1) & 7;
+    auto wfrag_u = [&](int base, int rows_per_chunk, int r0, int s, v4u &hi, v4u &lo) {
+        const unsigned char *p = smem_raw + base + (((s >> 1) * rows_per_chunk + r0 + l31) << 7);
+        const int p0 = (s & 1) * 4 + h * 2;
+        hi = *reinterpret_cast<const v4u *>(p + ((p0 ^ sw) << 4));
+        lo = *reinterpret_cast<const v4u *>(p + (((p0 + 1) ^ sw) << 4));
     };
 
     // running maximum of output channel (slice cb, column l31) over the rows of the current group: LDS, private to the wave
@@ -132,10 +138,9 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     };
 
     __syncthreads();
-    v4u st[2];
-    w3_issue(0, st);
-    w3_store(0, st);
-    __syncthreads();
+    w3_issue(0, 0);
+    w3_issue(nsl > 1 ? 1 : 0, 1);
+    int ring = 0;                                        // buffer of the slice about to be consumed (wave-uniform)
 
     // operand registers of a layer's input: k-step s -> (hi, lo) of channels 16 s + 8 h .. + 7 of my row
     v4u xh[2], xl[2];
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // ---- layers 1 and 2: D[channel x row], then BatchNorm + ReLU + split + completion of the 8-channel groups
         f32x16 acc[4];
         auto hidden_layer = [&](int wbase, auto ks_t, const v4u *bh, const v4u *bl, const float *sc, const float *sh) {
-            constexpr int KSTEPS = decltype(ks_t)::value;
+            constexpr int KSTEPS = decltype(ks_t)::value;           // 2: layer 1 (W1, padded rows); 8: layer 2 (W2, swizzled rows)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     v4u whi, wlo;
-                    wfrag(wbase, PN_HID, ct * 32, s, whi, wlo);
+                    if constexpr (KSTEPS == 2) wfrag(wbase, PN_HID, ct * 32, s, whi, wlo);
+                    else wfrag_u(wbase, PN_HID, ct * 32, s, whi, wlo);
                     if constexpr (M::TERMS != 1) {
                         acc[ct] = M::mma(wlo, bh[s], acc[ct]);
                         acc[ct] = M::mma(whi, bl[s], acc[ct]);
@@ -249,16 +255,27 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         // ---- layer 3, transposed: D^T[row x channel] per slice of 32 channels, max over the rows into the running maximum
         for (int cb = 0; cb < nsl; ++cb) {
-            const int n = (int)(it * nsl) + cb;                              // position in this workgroup's slice stream
-            const int nxt = cb + 1 < nsl ? cb + 1 : 0;
-            w3_issue(nxt, st);                                               // (the next iteration starts with slice 0 again)
+            // slice cb has landed once my loads for it are back and the workgroup has met; its loads went out two slices ago, the
+            // slice issued since (2 loads per thread; loads return in order) stays in flight.  The buffer of the previous slice is
+            // free after the barrier: the slice after next goes into it (the next tile walks the same slices again)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();
+            {
+                int nxt = cb + 2;
+                if (nxt >= nsl) nxt -= nsl;
+                if (nxt >= nsl) nxt -= nsl;                                  // (nsl = 1)
+                int nb = ring + 2;
+                if (nb >= PN_RING) nb -= PN_RING;
+                w3_issue(nxt, nb);
+            }
             f32x16 d;
 #pragma unroll
             for (int e = 0; e < 16; ++e) d[e] = 0.f;
+            const int wbase3 = PN_OFF_W3 + ring * PN_W3S;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 v4u whi, wlo;
-                wfrag(PN_OFF_W3 + (n & 1) * PN_W3S, 32, 0, s, whi, wlo);
+                wfrag_u(wbase3, 32, 0, s, whi, wlo);
                 if constexpr (M::TERMS != 1) {
                     d = M::mma(hl[s], whi, d);
                     d = M::mma(hh[s], wlo, d);
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
             // lane: channel cb * 32 + l31, rows 8 (e >> 2) + 4 h + (e & 3)
             const int ch = cb * 32 + l31;
-            const float sc = a.s3 ? a.s3[ch] : 1.f, sh = a.b3 ? a.b3[ch] : 0.f;
+            const float sc = ss[4 * PN_HID + ch], sh = ss[4 * PN_HID + 512 + ch];
             float m = -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -277,10 +294,10 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             if (h == 0) run[cb * 32] = fmaxf(run[cb * 32], m);
-            w3_store((n + 1) & 1, st);
-            __syncthreads();
+            ring = ring + 1 == PN_RING ? 0 : ring + 1;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slices issued for a tile that does not come
     flush();
 }
 
