@@ -25,6 +25,10 @@
 
 #include "hgemm.h"
 
+#ifndef DZ_CHAIN_DIAG
+#define DZ_CHAIN_DIAG 0        // timing experiments only (results are garbage): 1 = no workgroup barriers, 2 = no weight loads, 8 = no vmcnt waits,
+#endif                          // 16 = weight fragments from registers instead of LDS, 32 = no MFMAs, 64 = no result stores
+
 namespace dz {
 namespace {
 
@@ -51,6 +55,12 @@ struct ChainArgs {
 __device__ __forceinline__ void mc_load16_lds(unsigned int lds_base, unsigned int voff, srsrc_t rsrc) {
     const unsigned int b = __builtin_amdgcn_readfirstlane(lds_base);
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(b), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+template <class M>
+__device__ __forceinline__ f32x16 mc_mma(v4u a, v4u b, f32x16 c) {
+    if (DZ_CHAIN_DIAG & 32) { c[0] += __uint_as_float(a.x ^ b.x); return c; }
+    return M::mma(a, b, c);
 }
 
 template <class M, bool KV>
@@ -120,6 +130,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 asm volatile("" : "+v"(wb[b][par][hl]));
             }
     auto wfrag = [&](int buf, int r0, int s, v4u &hi, v4u &lo) {
+        if (DZ_CHAIN_DIAG & 16) { hi = v4u{0x3c003c00u + (unsigned)s, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + (unsigned)r0}; lo = hi; return; }
         const int off = (buf & 1) * MC_SLICE + (((s >> 1) * 64 + r0) << 7);
         hi = *reinterpret_cast<const v4u *>(smem_raw + wb[buf >> 1][s & 1][0] + off);
         lo = *reinterpret_cast<const v4u *>(smem_raw + wb[buf >> 1][s & 1][1] + off);
@@ -129,10 +140,12 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // stores were issued in between, which retire on their own schedule: then everything is drained (`drain`).  The buffer of slice
     // j - 1 is free after the barrier: slice j + 3 goes into it.
     auto begin_slice = [&](int j, bool drain) {
-        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __syncthreads();
-        issue_slice((j + 3) % NSL, (j + 3) & 3);
+        if (!(DZ_CHAIN_DIAG & 8)) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
+        if (!(DZ_CHAIN_DIAG & 1)) __syncthreads();
+        if (!(DZ_CHAIN_DIAG & 2)) issue_slice((j + 3) % NSL, (j + 3) & 3);
         return j & 3;
     };
 
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const v4u *src = reinterpret_cast<const v4u *>(win + (lane >> 1) * MC_WIN_ROW + (lane & 1) * 64);
         const v4u t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+        if (DZ_CHAIN_DIAG & 64) return;
         __builtin_amdgcn_raw_buffer_store_b128(t0, rs, (int)off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(t1, rs, (int)off + 16, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(t2, rs, (int)off + 32, 0, 0);
@@ -278,11 +292,11 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(wlo[ct], xh[s], accA[hf * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = mc_mma<M>(wlo[ct], xh[s], accA[hf * 2 + ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(whi[ct], xl[s], accA[hf * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = mc_mma<M>(whi[ct], xl[s], accA[hf * 2 + ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = M::mma(whi[ct], xh[s], accA[hf * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accA[hf * 2 + ct] = mc_mma<M>(whi[ct], xh[s], accA[hf * 2 + ct]);
                     }
                 }
                 v4u sh_[8], sl_[8];
@@ -304,11 +318,11 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(wlo[ct], sh_[s], accB[qd * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = mc_mma<M>(wlo[ct], sh_[s], accB[qd * 2 + ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(whi[ct], sl_[s], accB[qd * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = mc_mma<M>(whi[ct], sl_[s], accB[qd * 2 + ct]);
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = M::mma(whi[ct], sh_[s], accB[qd * 2 + ct]);
+                        for (int ct = 0; ct < 2; ++ct) accB[qd * 2 + ct] = mc_mma<M>(whi[ct], sh_[s], accB[qd * 2 + ct]);
                     }
                 }
             }
@@ -344,11 +358,11 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                             for (int ct = 0; ct < 2; ++ct) wfrag(buf, ct * 32, s, whi[ct], wlo[ct]);
 #pragma unroll
-                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(wlo[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = mc_mma<M>(wlo[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
 #pragma unroll
-                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(whi[ct], ml[kk * 8 + s], acc[qd * 2 + ct]);
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = mc_mma<M>(whi[ct], ml[kk * 8 + s], acc[qd * 2 + ct]);
 #pragma unroll
-                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = M::mma(whi[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
+                            for (int ct = 0; ct < 2; ++ct) acc[qd * 2 + ct] = mc_mma<M>(whi[ct], mh[kk * 8 + s], acc[qd * 2 + ct]);
                             if (s & 1) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
