@@ -173,3 +173,23 @@ def test_math_modes_and_their_tensor_encoding():
     assert torch.equal(ops.pair16_pack(x, 3), ops.pair16_pack(x, 1))
     with pytest.raises(Exception):
         ops.math_id('fp8')
+
+
+def test_capability_queries_answer_without_a_gpu():
+    """The `*_supported` / workspace entry points of the fused refiner and PDV kernels are host code: they must answer on a machine
+    without a GPU (the Python side uses them to choose between the fused kernel and the layer-by-layer path)."""
+    from detzero_amd import lib as L
+    lib = L.load()
+    # folded cross-attention: E = 256, heads * queries <= 32
+    assert lib.dz_xattn_folded_supported(3, 256, 8) == 1
+    assert lib.dz_xattn_folded_supported(4, 256, 8) == 1
+    assert lib.dz_xattn_folded_supported(5, 256, 8) == 0          # 40 folded rows
+    assert lib.dz_xattn_folded_supported(3, 128, 4) == 0
+    assert lib.dz_xattn_folded_supported(200, 256, 8) == 0        # PRM: keeps K / V + the attention core
+    assert lib.dz_xattn_folded_workspace_bytes(128, 4096) >= 128 * 32 * 256 * 4
+    # PDV grid pooling: the two instances of the centerpoint_pdv configs
+    assert lib.dz_pdv_sa_pool_supported(64, 80, 32, 32, 16, 1, 1) == 1
+    assert lib.dz_pdv_sa_pool_supported(128, 144, 64, 64, 16, 1, 1) == 1
+    assert lib.dz_pdv_sa_pool_supported(128, 144, 64, 64, 32, 1, 1) == 0
+    assert lib.dz_pdv_sa_pool_supported(128, 144, 64, 64, 16, 1, 0) == 0
+    assert lib.dz_pdv_sa_pool_supported(126, 144, 64, 64, 16, 1, 1) == 0
