@@ -26,6 +26,10 @@
 
 #include "hgemm.h"
 
+#ifndef DZ_PN_DIAG
+#define DZ_PN_DIAG 0           // timing experiments only (results are garbage): 1 = no workgroup barriers, 2 = no W3 loads, 4 = no layer-3 epilogue,
+#endif                          // 8 = no vmcnt waits in the slice loop, 16 = weight fragments from registers, 32 = no hidden-layer epilogues
+
 namespace dz {
 
 constexpr int PN_THREADS = 512, PN_WAVES = 8, PN_HID = 128, PN_CIN = 32;
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // ... and of an unpadded, swizzled [chunk][rows][128] tile (W2, the W3 ring); r0 a multiple of 32: the swizzle is that of l31
     const int sw = (l31 >> 1) & 7;
     auto wfrag_u = [&](int base, int rows_per_chunk, int r0, int s, v4u &hi, v4u &lo) {
+        if (DZ_PN_DIAG & 16) { hi = v4u{0x3c003c00u + (unsigned)s, 0x3c003c00u, 0x3c003c00u + (unsigned)base, 0x3c003c00u + (unsigned)r0}; lo = hi; return; }
         const unsigned char *p = smem_raw + base + (((s >> 1) * rows_per_chunk + r0 + l31) << 7);
         const int p0 = (s & 1) * 4 + h * 2;
         hi = *reinterpret_cast<const v4u *>(p + ((p0 ^ sw) << 4));
@@ -209,8 +214,15 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     acc[ct] = M::mma(whi, bh[s], acc[ct]);
                 }
             }
+            if (DZ_PN_DIAG & 32) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { hh[s] = v4u{__float_as_uint(acc[s >> 1][0]), 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; hl[s] = hh[s]; }
+                return;
+            }
             // lane (row l31, half h) holds channels 32 ct + 8 q + 4 h + {0..3} in acc[ct][4 q ..]: it keeps the groups g = 4 ct + q with
-            // (q & 1) == h, sends the other two to lane ^ 32 and receives their missing halves from it
+            // (q & 1) == h, sends the other two to lane ^ 32 and receives their missing halves from it.  (The four fragments finish
+            // together and the matrix pipe idles during this epilogue - a quarter of the kernel by the DZ_PN_DIAG measurements; finishing
+            // them one or two at a time so that the next ones' MFMAs could cover it was measured: 1927 / 1843 us against 1840)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 uint2 ghi[4], glo[4];
@@ -258,9 +270,9 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // slice cb has landed once my loads for it are back and the workgroup has met; its loads went out two slices ago, the
             // slice issued since (2 loads per thread; loads return in order) stays in flight.  The buffer of the previous slice is
             // free after the barrier: the slice after next goes into it (the next tile walks the same slices again)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __syncthreads();
-            {
+            if (!(DZ_PN_DIAG & 8)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (!(DZ_PN_DIAG & 1)) __syncthreads();
+            if (!(DZ_PN_DIAG & 2)) {
                 int nxt = cb + 2;
                 if (nxt >= nsl) nxt -= nsl;
                 if (nxt >= nsl) nxt -= nsl;                                  // (nsl = 1)
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
                 d = M::mma(hh[s], whi, d);
             }
+            if (DZ_PN_DIAG & 4) { if (h == 0) run[cb * 32] = d[0]; ring = ring + 1 == PN_RING ? 0 : ring + 1; continue; }
             // lane: channel cb * 32 + l31, rows 8 (e >> 2) + 4 h + (e & 3)
             const int ch = cb * 32 + l31;
             const float sc = ss[4 * PN_HID + ch], sh = ss[4 * PN_HID + 512 + ch];
