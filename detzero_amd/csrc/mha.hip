@@ -17,6 +17,8 @@
 //       B = P^T: MFMA number e takes k-slot g' <-> key 4g'+e, which is exactly register e of
 //       lane (g', r): the probabilities feed the second GEMM without leaving their lane.
 //       A = V[key 4g+e][d] loaded per lane (16 lanes read 64 contiguous bytes).
+#include <stdlib.h>
+
 #include "igemm.h"
 
 namespace dz {
@@ -283,6 +285,154 @@ __global__ __launch_bounds__(512) void k_mha_block(const float *__restrict__ q, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One WIDE head per sequence (the PDV encoder layer: R RoIs x L = 216 grid points x E = 192 channels).  k_mha_core<.., E> lets each of the
+// 14 waves of a RoI stream the RoI's K and V (2 x 166 KB) from L2 on its own; here a workgroup owns the RoI (up to 8 waves x 32 queries)
+// and stages K / V once, in blocks of 64 keys: K as rows [key][E + 4], V transposed [channel][64 + 4] (the A operand of the second
+// product is then one 16-byte LDS read).  Single buffer (102 KB at E = 192), two barriers per block; a wave carries two 16-query tiles
+// so that every K / V fragment read feeds two MFMAs.  Same fp32 arithmetic and online softmax as k_mha_block.
+// ------------------------------------------------------------------------------------------------
+template <bool MASK, int E>
+__global__ __launch_bounds__(512) void k_attn1h_block(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                      const uint8_t *__restrict__ kpm, int l, float scale, float *__restrict__ out) {
+    constexpr int NS = E / 16, KSTR = E + 4, VSTR = MB_KEYS + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm1h[];
+    float *const ks = sm1h;                              // [64][KSTR]
+    float *const vt = sm1h + MB_KEYS * KSTR;             // [E][VSTR]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
+    const int r = lane & 15, g = lane >> 4;
+    const size_t seq = (size_t)blockIdx.x * l;
+    const int qbase = wid * 32;
+    float qreg[2][NS][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = qbase + t * 16 + r;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < l) x = *reinterpret_cast<const float4 *>(q + (seq + qi) * E + sl * 16 + g * 4);
+            const float sc2 = scale * 1.44269504088896340736f;       // scores in units of log2(e): the softmax runs on v_exp_f32
+            qreg[t][sl][0] = x.x * sc2; qreg[t][sl][1] = x.y * sc2; qreg[t][sl][2] = x.z * sc2; qreg[t][sl][3] = x.w * sc2;
+        }
+    }
+    f32x4 o[2][NS];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < NS; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *kb = k + seq * E, *vb = v + seq * E;
+    const uint8_t *mb = MASK ? kpm + seq : nullptr;
+    const int nblocks = (l + MB_KEYS - 1) / MB_KEYS;
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int key0 = blk * MB_KEYS;
+        __syncthreads();                                 // every wave is done with the previous block
+        for (int i = tid; i < MB_KEYS * (E / 4); i += nthr) {
+            const int key = i / (E / 4), c4 = i % (E / 4);
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (key0 + key < l) {
+                kk = *reinterpret_cast<const float4 *>(kb + (size_t)(key0 + key) * E + c4 * 4);
+                vv = *reinterpret_cast<const float4 *>(vb + (size_t)(key0 + key) * E + c4 * 4);
+            }
+            *reinterpret_cast<float4 *>(ks + key * KSTR + c4 * 4) = kk;
+            float *vd = vt + (c4 * 4) * VSTR + key;
+            vd[0] = vv.x; vd[VSTR] = vv.y; vd[2 * VSTR] = vv.z; vd[3 * VSTR] = vv.w;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kt = 0; kt < MB_KEYS / 16; ++kt) {
+            if (key0 + kt * 16 >= l) break;              // (workgroup-uniform)
+            f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const float4 kv = *reinterpret_cast<const float4 *>(ks + (kt * 16 + r) * KSTR + sl * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qreg[t][sl][0], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qreg[t][sl][1], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qreg[t][sl][2], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qreg[t][sl][3], s[t], 0, 0, 0);
+                }
+            }
+            bool dead[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = key0 + kt * 16 + g * 4 + e;
+                dead[e] = key >= l;
+                if (MASK) dead[e] = dead[e] | (mb[min(key, l - 1)] != 0);
+            }
+            float p[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float sv[4], tmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sv[e] = dead[e] ? -INFINITY : s[t][e]; tmax = fmaxf(tmax, sv[e]); }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[t], tmax);
+                float alpha = 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[t][e] = 0.f;
+                if (m_new != -INFINITY) {
+                    alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[t][e] = __builtin_amdgcn_exp2f(sv[e] - m_new);
+                }
+                l_run[t] = l_run[t] * alpha + (p[t][0] + p[t][1] + p[t][2] + p[t][3]);
+                m_run[t] = m_new;
+                if (!__all(alpha == 1.f)) {
+#pragma unroll
+                    for (int dt = 0; dt < NS; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[t][dt][e] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < NS; ++dt) {
+                const float4 vv = *reinterpret_cast<const float4 *>(vt + (dt * 16 + r) * VSTR + kt * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p[t][0], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p[t][1], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p[t][2], o[t][dt], 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p[t][3], o[t][dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float lsum = l_run[t];
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const int qi = qbase + t * 16 + r;
+        if (qi < l) {
+            const float inv = 1.f / lsum;              // fully masked row -> NaN, as torch.softmax gives
+            float *dst = out + (seq + qi) * E;
+#pragma unroll
+            for (int dt = 0; dt < NS; ++dt)
+                *reinterpret_cast<float4 *>(dst + dt * 16 + g * 4) = make_float4(o[t][dt][0] * inv, o[t][dt][1] * inv, o[t][dt][2] * inv, o[t][dt][3] * inv);
+        }
+    }
+}
+
+template <int E>
+static bool launch_1h_block(const float *q, const float *k, const float *v, const unsigned char *mask, int r, int l, float scale, float *out, hipStream_t stream) {
+    constexpr int LDS = (MB_KEYS * (E + 4) + E * (MB_KEYS + 4)) * 4;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    const int nw = (l + 31) / 32;
+    if (nw > 8) return false;
+    static PerDeviceFlags done_m, done_u;
+    if (mask) {
+        if (reserve_lds(reinterpret_cast<const void *>(&k_attn1h_block<true, E>), LDS, done_m, "dz_attention_single_head")) return false;
+        hipLaunchKernelGGL((k_attn1h_block<true, E>), dim3(r), dim3(64 * nw), LDS, stream, q, k, v, mask, l, scale, out);
+    } else {
+        if (reserve_lds(reinterpret_cast<const void *>(&k_attn1h_block<false, E>), LDS, done_u, "dz_attention_single_head")) return false;
+        hipLaunchKernelGGL((k_attn1h_block<false, E>), dim3(r), dim3(64 * nw), LDS, stream, q, k, v, (const uint8_t *)nullptr, l, scale, out);
+    }
+    return true;
+}
+
 // One wide head (the PDV encoder layer: R sequences of L = 216 tokens, E = 192): k_mha_core with head dim E - one wave per 16 queries,
 // keys streamed from L2, scores and probabilities in registers.  Returns false when E has no instance (the caller's VALU kernel runs).
 template <int E>
@@ -295,6 +445,11 @@ static void launch_1h(const float *q, const float *k, const float *v, const unsi
 }
 bool attention_1h_mfma(const float *q, const float *k, const float *v, const unsigned char *mask, int r, int l, int e, float scale, float *out,
                        hipStream_t stream) {
+    static const bool no_block = getenv("DZ_TUNE_ATT1H_NOBLOCK") != nullptr;
+    if (!no_block && l > 64 && l <= 256) {             // K / V staged once per sequence
+        if (e == 192 && launch_1h_block<192>(q, k, v, mask, r, l, scale, out, stream)) return true;
+        if (e == 128 && launch_1h_block<128>(q, k, v, mask, r, l, scale, out, stream)) return true;
+    }
     switch (e) {
         case 64: launch_1h<64>(q, k, v, mask, r, l, scale, out, stream); return true;
         case 128: launch_1h<128>(q, k, v, mask, r, l, scale, out, stream); return true;

@@ -128,3 +128,31 @@ def test_attention_core_on_split_operands(device, name, mid, tol, b, lq, lk, hea
     err, err32 = float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(ref.cpu().numpy() - want).max())
     print('attention core %s b %d lq %d lk %d heads %d: |split - f64| %.2e, |fp32 core - f64| %.2e' % (name, b, lq, lk, heads, err, err32))
     assert err <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('r,l,e', [(9, 216, 192), (3, 100, 192), (5, 256, 128), (4, 40, 192), (2, 216, 64)])
+def test_single_head_attention_of_the_pdv_encoder(device, r, l, e):
+    """dz_attention_single_head (nn.MultiheadAttention with one head over the grid points of a RoI, attention_utils.py:17-52): the
+    workgroup-per-sequence kernel with K / V staged in LDS (64 < L <= 256, E = 192 / 128), and the per-wave kernel it falls back to,
+    against float64 on the host; key padding masks with fully dead 16-key tiles."""
+    from detzero_amd import pdv_modules as pm
+    rng = np.random.default_rng(r * 100 + l)
+    q, k, v = (rng.standard_normal((r, l, e)) for _ in range(3))
+    mask = (rng.random((r, l)) < 0.3).astype(np.uint8)
+    mask[0, 16:48] = 1
+    mask[-1, :min(20, l - 1)] = 1
+    mask[:, l - 1] = 0
+    scale = float(e) ** -0.5
+    s = (q * scale) @ k.transpose(0, 2, 1)
+    s = np.where(mask[:, None, :] != 0, -np.inf, s)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    want = (p / p.sum(-1, keepdims=True)) @ v
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    got = pm.attention_single_head(t(q), t(k), t(v), torch.from_numpy(mask.astype(bool)).to(device), scale)
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    print('single-head attention r %d l %d e %d: |got - f64| %.2e' % (r, l, e, err))
+    assert err <= 2e-5
