@@ -189,6 +189,23 @@ static int conv2d_dispatch(const dz_conv2d_desc &p, hipStream_t stream) {
 
 using namespace dz;
 
+namespace dz {
+// y[r][n] = act(scale[n] * sum over the splits of part[r][s * cout_pad + n] + shift[n]): the second half of dz_linear_forward_splitk
+__global__ void k_splitk_reduce(const float *__restrict__ part, int rows, int cout, int cout_pad, int splits, const float *__restrict__ scale,
+                                const float *__restrict__ shift, int relu, float *__restrict__ y, int y_stride) {
+    const long total = (long)rows * cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / cout), n = (int)(idx % cout);
+        const float *p = part + (size_t)r * splits * cout_pad + n;
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += p[(size_t)s * cout_pad];
+        float v = fmaf(a, scale ? scale[n] : 1.f, shift ? shift[n] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)r * y_stride + n] = v;
+    }
+}
+}  // namespace dz
+
 extern "C" {
 
 int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
@@ -237,6 +254,38 @@ int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const flo
         const int rc = dz_conv2d_forward(&d, stream_);
         if (rc) return rc;
     }
+    return DZ_OK;
+}
+
+// A few rows against a very long input (the PDV head's first FC layer: 487 RoIs x 41 472 inputs -> 256): as one GEMM that is 32 workgroups
+// walking 2 592 k-steps each.  Here the input channels are cut into `splits` (<= 8) groups that run as the groups of ONE grouped 1 x 1
+// convolution (each group's weight rows are contiguous in w) into a (rows, splits * cout_pad) workspace; a second pass sums them
+// and applies scale / shift / ReLU.  fp32 sums in a different order than dz_linear_forward.
+size_t dz_linear_splitk_workspace_bytes(int rows, int cout_pad, int splits) { return (size_t)rows * cout_pad * splits * sizeof(float); }
+
+int dz_linear_forward_splitk(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
+                             const float *shift, int relu, float *y, int y_stride, int splits, float *workspace, size_t workspace_bytes,
+                             void *stream_) {
+    DZ_CHECK_ARG(rows >= 0 && x_stride >= cin && y_stride >= cout && splits >= 1 && splits <= 8 && cin % (splits * 32) == 0,
+                 "dz_linear_forward_splitk: 1..8 splits of a multiple of 32 channels each (cin %d, splits %d)", cin, splits);
+    if (rows == 0) return DZ_OK;
+    DZ_CHECK_ARG(workspace && workspace_bytes >= dz_linear_splitk_workspace_bytes(rows, cout_pad, splits), "dz_linear_forward_splitk: workspace too small");
+    DZ_CHECK_ARG((size_t)rows * x_stride * sizeof(float) < 0x7FF00000ull, "dz_linear_forward_splitk: input beyond the 2 GiB addressing window");
+    dz_conv2d_desc d = {};
+    d.in = x; d.out = workspace; d.w = w; d.scale = nullptr; d.shift = nullptr;
+    d.batch = 1; d.ho = 1; d.wo = rows;
+    d.in_hp = 1; d.in_wp = rows; d.in_cstride = x_stride; d.in_coff = 0; d.cin = cin / splits;
+    d.kh = 1; d.kw = 1; d.stride = 1; d.in_off = 0;
+    d.out_hp = 1; d.out_wp = rows; d.out_cstride = splits * cout_pad; d.out_coff = 0;
+    d.out_sy = 1; d.out_sx = 1; d.out_dy = 0; d.out_dx = 0;
+    d.groups = splits; d.cout_pad = cout_pad; d.relu = 0; d.group_rows = 1;
+    for (int g = 0; g < splits; ++g) { d.g_cout[g] = cout_pad; d.g_ooff[g] = g * cout_pad; }
+    const int rc = dz_conv2d_forward(&d, stream_);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(stream_grid((long)rows * cout, 256)), dim3(256), 0, stream, workspace, rows, cout, cout_pad, splits, scale, shift,
+                       relu, y, y_stride);
+    DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 

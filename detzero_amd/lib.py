@@ -117,6 +117,9 @@ _SIGS = {
     'dz_xattn_folded_workspace_bytes': (ctypes.c_size_t, [c_int, c_int]),
     'dz_xattn_folded': (c_int, [c_void_p] * 6 + [c_int] * 5 + [ctypes.c_float, c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     'dz_roi_bev_features': (c_int, [c_void_p, c_int, c_void_p, ctypes.c_long, ctypes.c_long, c_int, c_int, c_int] + [ctypes.c_float] * 4 + [c_int, c_void_p, c_void_p]),
+    'dz_linear_splitk_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
+    'dz_linear_forward_splitk': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                         ctypes.c_size_t, c_void_p]),
     'dz_mha_core_split': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p, c_int, c_void_p]),
     'dz_pdv_sa_pool_supported': (c_int, [c_int] * 7),
     'dz_pdv_sa_pool': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

@@ -469,6 +469,29 @@ def linear(x, w, scale, shift, relu, cout, out=None, group_shift=None, group_row
     return out
 
 
+SPLITK_MAX_ROWS, SPLITK_MIN_CIN = 2048, 4096
+
+
+def linear_splitk_ok(rows, cin):
+    return 0 < rows <= SPLITK_MAX_ROWS and cin >= SPLITK_MIN_CIN and cin % 256 == 0
+
+
+def linear_splitk(x, w, scale, shift, relu, cout, splits=8):
+    """dz_linear_forward_splitk: ops.linear for a few rows against a very long input (cin % (splits * 32) == 0): the input channels in
+    `splits` groups side by side, summed in a second pass."""
+    lib = L.load()
+    L.require_cuda(x, w, scale, shift)
+    rows, cin = x.shape
+    cout_pad = w.shape[1]
+    nbytes = lib.dz_linear_splitk_workspace_bytes(rows, cout_pad, splits)
+    ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=x.device)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    rc = lib.dz_linear_forward_splitk(L.ptr(x), rows, cin, x.stride(0), L.ptr(w), cout, cout_pad, L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(out),
+                                      out.stride(0), int(splits), L.ptr(ws), nbytes, L.stream())
+    L.check(rc, 'dz_linear_forward_splitk')
+    return out
+
+
 def linear_split(x, w, scale, shift, relu, cout, math, out_f32=False, group_shift=None, group_rows=0, group_max=False):
     """dz_linear_forward_split: x (rows, >= cin words) pair16 @ w (cout_pad, cin) pair16 -> (rows, cout) fp32 when out_f32,
     else (rows, cout) pair16 (cout % 32 == 0 so that the result can feed the next layer).

@@ -307,7 +307,10 @@ def _run_stack(x, layers, upto=None, math=None, gmax=None):
         return _run_stack_split(x.contiguous(), layers, math=m, gmax=gmax, x_f32=True)      # (converted there unless the fused encoder takes fp32 rows)
     outs = []
     for li, l in enumerate(layers):
-        x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
+        if ops.linear_splitk_ok(x.shape[0], x.shape[1]) and x.shape[1] == l['w'].shape[0]:       # a few rows, a very long input
+            x = ops.linear_splitk(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
+        else:
+            x = ops.linear(x, l['w'], l['scale'], l['shift'], l['relu'], l['cout'])
         outs.append(x)
     if gmax is not None:
         x = ops.group_max(x, gmax[0], gmax[1])

@@ -374,6 +374,14 @@ int dz_linear_forward(const float *x, int rows, int cin, int x_stride, const flo
                       const float *scale, const float *shift, const float *group_shift, int group_rows, int relu,
                       float *y, int y_stride, void *stream);
 
+/* dz_linear_forward for a few rows against a very long input (the PDV head's first FC layer, pdv_head.py:154-172: 41 472 -> 256 for
+ * some hundred RoIs): the input channels are cut into `splits` (1..8, cin % (splits * 32) == 0) groups that run side by side (one
+ * grouped launch into the workspace) and are summed in a second pass with scale / shift / ReLU.  Same arguments otherwise. */
+size_t dz_linear_splitk_workspace_bytes(int rows, int cout_pad, int splits);
+int dz_linear_forward_splitk(const float *x, int rows, int cin, int x_stride, const float *w, int cout, int cout_pad, const float *scale,
+                             const float *shift, int relu, float *y, int y_stride, int splits, float *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* out (groups, c) = max over the `len` rows of each group of x (groups*len, c): the point-wise max pooling of
  * the GRM/PRM PointNet encoders (geometry_transformer.py:124,137; position_transformer.py:108,117). */
 int dz_group_max(const float *x, int groups, int len, int c, float *out, void *stream);

@@ -715,3 +715,26 @@ def test_two_head_center_head_matches_reference_golden(device, golden_dir, math)
         assert sorted(got_l.tolist()) == sorted(ref_l.tolist())
     print('two-head CenterHead [%s]: maps within %.2e, %d + %d boxes' % (math, worst_map, dd['final_box_dicts'][0]['pred_boxes'].shape[0],
                                                                         dd['final_box_dicts'][1]['pred_boxes'].shape[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cin,cout,relu', [(487, 41472, 256, True), (3, 4096, 19, False), (1000, 8192, 64, True)])
+def test_linear_split_over_the_input_channels(device, rows, cin, cout, relu):
+    """dz_linear_forward_splitk (the PDV head's 41 472 -> 256 FC layer for a few hundred RoIs, pdv_head.py:154-172) against float64 on the
+    host and against dz_linear_forward: the same products, summed in eight groups."""
+    from detzero_amd import ops
+    rng = np.random.default_rng(rows + cin)
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    cp = (cout + 15) // 16 * 16
+    w = np.zeros((cin, cp), np.float32)
+    w[:, :cout] = rng.standard_normal((cin, cout)).astype(np.float32) / np.sqrt(cin)
+    sc, sh = rng.uniform(0.5, 1.5, cp).astype(np.float32), (0.2 * rng.standard_normal(cp)).astype(np.float32)
+    assert ops.linear_splitk_ok(rows, cin)
+    got = ops.linear_splitk(_t(x, device), _t(w, device), _t(sc, device), _t(sh, device), relu, cout)
+    ref = ops.linear(_t(x, device), _t(w, device), _t(sc, device), _t(sh, device), relu, cout)
+    want = x.astype(np.float64) @ w[:, :cout].astype(np.float64) * sc[:cout] + sh[:cout]
+    if relu:
+        want = np.maximum(want, 0)
+    e1, e2 = float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(ref.cpu().numpy() - want).max())
+    print('split-k linear %d x %d -> %d: |split - f64| %.2e, |one pass - f64| %.2e' % (rows, cin, cout, e1, e2))
+    assert tuple(got.shape) == (rows, cout) and e1 <= 2e-5

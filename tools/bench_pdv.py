@@ -67,7 +67,7 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False):
         for name in ('get_point_voxel_features', 'proposal_layer', 'roi_grid_pool', 'get_positional_input', 'attention', 'generate_predicted_boxes'):
             wrap(name)
         from detzero_amd import pdv_modules as pm
-        for name in ('ball_query', 'group_features', 'voxel_centroids'):
+        for name in ('ball_query', 'group_features', 'voxel_centroids', 'sa_pool', '_run_stack', 'part_counts', 'attention_single_head'):
             fn = getattr(pm, name)
 
             def timed(*a, _fn=fn, _name=name, **k):
