@@ -656,7 +656,10 @@ def main():
             try:
                 import bench_pdv
                 out['pdv'] = bench_pdv.measure(dev, args.points, 8, 'f32')
-                log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs)' % (out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois']))
+                p16 = bench_pdv.measure(dev, args.points, 8, 'f16x2')
+                out['pdv']['f16x2'] = {k: p16[k] for k in ('first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
+                log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs); f16x2: %.2f + %.2f ms' % (
+                    out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois'], p16['first_stage_ms'], p16['second_stage_ms']))
             except Exception as e:
                 out['pdv'] = {'error': str(e).split('\n')[0][:200]}
             torch.cuda.empty_cache()

@@ -427,7 +427,7 @@ class PDVHead(_Cached):
                     continue
                 idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
                 stack = p['pool'][k][s]['stack']
-                if self.stack_math() == 0 and sa_pool_supported(feats.shape[1], stack, nsample):
+                if sa_pool_supported(feats.shape[1], stack, nsample):     # (exact fp32 in every math mode)
                     pooled.append(sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack))    # group + MLP + max in one kernel
                 else:
                     rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
