@@ -237,7 +237,11 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
         if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);       // 4 waves of 32 x 32 (r01d)
-        return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);                    // 8 waves of 32 x 32
+        if (t64 == 2) return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);      // 8 waves of 32 x 32 (r01e-r03b)
+        // 8 waves of 64 x 32 over 256 rows: 12 instead of 16 fragment reads per 12 MFMAs, the weight slice fetched once per 256 rows
+        // (r03: LDS fragment reads had become the largest single item of the diag breakdown of the 128-channel kernel, -31 %; inside
+        // the detector, A/B on one box, two rounds: 861.2 / 861.9 against 855.3 / 853.3 frames/s, +0.2 % on another box)
+        return launch_spconv_h<HTile<256, 64, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);
     }
     if ((a.cin == 64 || a.cin == 128) && a.cout_pad == 128) {
 #ifdef DZ_SPCONV_DIAG
@@ -256,6 +260,10 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
 #endif
         if (t128 == 1) return launch_spconv_h<HTile<64, 128, 32, 2, 2>, M, 3>(a, stream, !(a.cin == 128 && a.kvol == 27));   // 4 waves (r01d)
         if (t128 == 2) return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 3, 2, 2>(a, stream);    // three register stages (r01e-r02f)
+        // 8 waves of 64 x 64 over 256 rows, two register stages (240 registers): 16 instead of 24 fragment reads per 24 MFMAs.  r03,
+        // A/B inside the detector: -0.2 % / -0.45 % of a pass on two boxes, +3 % together with the 256-row 64-channel tile on a third:
+        // not the default
+        if (t128 == 3) return launch_spconv_h<HTile<256, 128, 32, 4, 2>, M, 2, 2, 2, 2>(a, stream);
         // 8 waves of 32 x 64, four register stages with the ring (202 registers at two waves per SIMD): +0.3 % of a pass over three,
         // A/B inside the detector on one box (tools/gpu_ab_env.sh) - gather latency is not what limits this kernel
         return launch_spconv_h<HTile<128, 128, 32, 4, 2>, M, 3, 4, 2, 2>(a, stream);
