@@ -320,8 +320,10 @@ const char *dz_spconv_variant_split(int cin, int cout) {
     }
     if (cin == 16 && cout_pad == 32) return "k_spconv_h<128x32x16>";
     if (cin == 32 && cout_pad == 32) return "k_spconv_h<128x32x32>";
-    if ((cin == 32 || cin == 64) && cout_pad == 64) return "k_spconv_h<128x64x32>";
-    if ((cin == 64 || cin == 128) && cout_pad == 128) return "k_spconv_h<128x128x32>";
+    if ((cin == 32 || cin == 64) && cout_pad == 64)
+        return tune("DZ_TUNE_SPCONV64", 0) == 2 ? "k_spconv_h<128x64x32>" : "k_spconv_h<256x64x32>";
+    if ((cin == 64 || cin == 128) && cout_pad == 128)
+        return tune("DZ_TUNE_SPCONV128", 0) == 3 ? "k_spconv_h<256x128x32>" : "k_spconv_h<128x128x32>";
     return "none";
 }
 
