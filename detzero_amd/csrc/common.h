@@ -169,9 +169,10 @@ int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream);
 size_t bitmap_scan_workspace_bytes(size_t nwords);
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
-                hipStream_t stream, bool nonzero_only = false);     // nonzero_only (modes 0, 2): prefix[] valid only at words with a bit set
+                hipStream_t stream, bool nonzero_only = false,      // nonzero_only (modes 0, 2): prefix[] valid only at words with a bit set
+                const unsigned char *line_flags = nullptr);         // optional: one byte per 32 words, 0 = the line holds no bit (not read)
 // scan of a level's bitmap, coordinates [b,z,y,x] emitted at their rank in the level's key layout
 int level_scan(const uint32_t *bitmap, const LevelGeom &lg, uint32_t *prefix, int *d_total, int *coords_out, int cap_out, void *ws,
-               size_t ws_bytes, hipStream_t stream, bool nonzero_only);
+               size_t ws_bytes, hipStream_t stream, bool nonzero_only, const unsigned char *line_flags = nullptr);
 
 }  // namespace dz

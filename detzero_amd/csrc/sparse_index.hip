@@ -47,42 +47,70 @@ int fill_u32(void *ptr, uint32_t value, size_t nwords, hipStream_t stream) {
 // WPT = bitmap words per thread (a workgroup covers 256 * WPT words).  Large, mostly empty bitmaps use WPT = 4
 // (fewer partial sums); small / dense ones WPT = 1: the coordinate emission walks the set bits of a thread's words
 // serially, so a dense level needs many threads rather than long per-thread chains.
+// line_flags (optional, one byte per 32 words = 128-byte line): lines whose flag is 0 hold no bit and are not read - a thread's
+// WPT <= 4 aligned words lie in one line.
 template <int WPT>
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *__restrict__ bitmap, size_t nwords,
-                                                     uint32_t *__restrict__ partial) {
+                                                     uint32_t *__restrict__ partial, const unsigned char *__restrict__ line_flags) {
     __shared__ uint32_t lds[4];
     const size_t base = (size_t)blockIdx.x * (256 * WPT) + (size_t)threadIdx.x * WPT;
     uint32_t s = 0;
+    if (!line_flags || (base < nwords && line_flags[base >> 5])) {
 #pragma unroll
-    for (int j = 0; j < WPT; ++j)
-        if (base + j < nwords) s += __popc(bitmap[base + j]);
+        for (int j = 0; j < WPT; ++j)
+            if (base + j < nwords) s += __popc(bitmap[base + j]);
+    }
     uint32_t total;
     block_excl_scan_256(s, lds, total);
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of `partial` in place (PPT entries per thread per trip), total -> d_total.
-// Large bitmaps (a batch of 16 level-1 grids = 45k partials) take the 32-per-thread instance: 6 trips instead of 22.
-template <int PPT>
-__global__ __launch_bounds__(256) void k_scan_partials(uint32_t *__restrict__ partial, int nblocks,
-                                                       int *__restrict__ d_total) {
-    __shared__ uint32_t lds[4];
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 256 * PPT) {
-        const int i0 = base + threadIdx.x * PPT;
+// single block of 1024 threads: exclusive scan of `partial` in place, total -> d_total.  8192 entries per trip: loaded with
+// coalesced accesses (entry j * 1024 + t), transposed through LDS so that a thread scans 8 CONSECUTIVE entries (a thread-
+// contiguous global access pattern keeps one CU's address pipe busy with 64 cache lines per load: 46 us for the 45k partial sums
+// of a batch of 16 level-1 grids), one block scan of the thread sums, and back; the next trip's loads are issued before the
+// scan of the current one.
+__global__ __launch_bounds__(1024) void k_scan_partials(uint32_t *__restrict__ partial, int nblocks, int *__restrict__ d_total) {
+    constexpr int PPT = 8, TRIP = 1024 * PPT;
+    __shared__ uint32_t buf[TRIP + TRIP / 32];          // (one pad word per 32: the 8-word thread stride stays conflict-light)
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    auto slot = [](int i) { return i + (i >> 5); };
+    uint32_t carry = 0, nxt[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) nxt[j] = (j * 1024 + t < nblocks) ? partial[j * 1024 + t] : 0u;
+    for (int base = 0; base < nblocks; base += TRIP) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) buf[slot(j * 1024 + t)] = nxt[j];
+        if (base + TRIP < nblocks) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) { const int i = base + TRIP + j * 1024 + t; nxt[j] = i < nblocks ? partial[i] : 0u; }
+        }
+        __syncthreads();
         uint32_t v[PPT], s = 0;
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) { v[j] = (i0 + j < nblocks) ? partial[i0 + j] : 0u; s += v[j]; }
-        uint32_t total;
-        uint32_t run = carry + block_excl_scan_256(s, lds, total);
+        for (int j = 0; j < PPT; ++j) { v[j] = buf[slot(t * PPT + j)]; s += v[j]; }
+        uint32_t incl = s;
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            if (i0 + j < nblocks) partial[i0 + j] = run;
-            run += v[j];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
         }
-        carry += total;
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; if (w < wid) woff += x; tot += x; }
+        uint32_t run = carry + woff + incl - s;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) { buf[slot(t * PPT + j)] = run; run += v[j]; }
+        carry += tot;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) { const int i = base + j * 1024 + t; if (i < nblocks) partial[i] = buf[slot(j * 1024 + t)]; }
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *d_total = (int)carry;
+    if (t == 0) *d_total = (int)carry;
 }
 
 // exact n / d, n % d for 32-bit n through one fp64 multiply + one fix-up (d > 0)
@@ -103,15 +131,23 @@ template <int MODE, int WPT, bool NZ = false>
 __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ bitmap, size_t nwords,
                                                    const uint32_t *__restrict__ partial,
                                                    uint32_t *__restrict__ prefix, ScanDecode dec,
-                                                   int *__restrict__ coords_out, int cap_out) {
+                                                   int *__restrict__ coords_out, int cap_out,
+                                                   const unsigned char *__restrict__ line_flags, const int *__restrict__ d_total) {
     constexpr int CHUNK = 256 * WPT;
+    if (NZ) {
+        // a chunk without a bit (half of the chunks of a level-1 grid) has nothing to write: its count is the difference of two
+        // scanned partial sums
+        const uint32_t p0 = partial[blockIdx.x], p1 = blockIdx.x + 1 < gridDim.x ? partial[blockIdx.x + 1] : (uint32_t)*d_total;
+        if (p0 == p1) return;
+    }
     __shared__ uint32_t lds[4];
     __shared__ __attribute__((aligned(16))) uint32_t w_s[CHUNK];
     __shared__ __attribute__((aligned(16))) uint32_t p_s[CHUNK];
     const size_t base = (size_t)blockIdx.x * CHUNK + (size_t)threadIdx.x * WPT;
     uint32_t wv[WPT];
+    const bool live = !line_flags || (base < nwords && line_flags[base >> 5]);         // (an unflagged line holds no bit: not read)
 #pragma unroll
-    for (int j = 0; j < WPT; ++j) wv[j] = (base + j < nwords) ? bitmap[base + j] : 0u;
+    for (int j = 0; j < WPT; ++j) wv[j] = (live && base + j < nwords) ? bitmap[base + j] : 0u;
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) s += __popc(wv[j]);
@@ -184,36 +220,34 @@ size_t bitmap_scan_workspace_bytes(size_t nwords) {
 
 template <int WPT>
 static void launch_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode, const ScanDecode &dec,
-                        int *coords_out, int cap_out, uint32_t *partial, hipStream_t stream, bool nonzero_only) {
+                        int *coords_out, int cap_out, uint32_t *partial, hipStream_t stream, bool nonzero_only,
+                        const unsigned char *lf) {
     const int nblocks = (int)((nwords + 256 * WPT - 1) / (256 * WPT));
-    hipLaunchKernelGGL(k_scan_reduce<WPT>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial);
-    if (nblocks > 4096)
-        hipLaunchKernelGGL(k_scan_partials<32>, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
-    else
-        hipLaunchKernelGGL(k_scan_partials<8>, dim3(1), dim3(256), 0, stream, partial, nblocks, d_total);
+    hipLaunchKernelGGL(k_scan_reduce<WPT>, dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, lf);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, stream, partial, nblocks, d_total);
     if (mode == 0 && nonzero_only)
         hipLaunchKernelGGL((k_scan_down<0, WPT, true>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
     else if (mode == 0)
         hipLaunchKernelGGL((k_scan_down<0, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
     else if (mode == 1)
         hipLaunchKernelGGL((k_scan_down<1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
     else if (mode == 2 && nonzero_only)
         hipLaunchKernelGGL((k_scan_down<2, WPT, true>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
     else if (mode == 2)
         hipLaunchKernelGGL((k_scan_down<2, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
     else
         hipLaunchKernelGGL((k_scan_down<-1, WPT>), dim3(nblocks), dim3(256), 0, stream, bitmap, nwords, partial, prefix, dec,
-                           coords_out, cap_out);
+                           coords_out, cap_out, lf, d_total);
 }
 
 int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_total, int mode,
                 ScanDims dims, int *coords_out, int cap_out, void *ws, size_t ws_bytes,
-                hipStream_t stream, bool nonzero_only) {
+                hipStream_t stream, bool nonzero_only, const unsigned char *line_flags) {
     if (ws_bytes < bitmap_scan_workspace_bytes(nwords)) {
         set_error("bitmap_scan: workspace %zu < %zu", ws_bytes, bitmap_scan_workspace_bytes(nwords));
         return DZ_ERR_WORKSPACE;
@@ -224,9 +258,10 @@ int bitmap_scan(const uint32_t *bitmap, size_t nwords, uint32_t *prefix, int *d_
     dec.d1 = FastDiv{(uint32_t)(dims.d1 > 0 ? dims.d1 : 1), 1.0 / (double)(dims.d1 > 0 ? dims.d1 : 1)};
     dec.d2 = FastDiv{(uint32_t)(dims.d2 > 0 ? dims.d2 : 1), 1.0 / (double)(dims.d2 > 0 ? dims.d2 : 1)};
     if (nwords <= ((size_t)1 << 21))
-        launch_scan<1>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only);
-    else
-        launch_scan<4>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only);
+        launch_scan<1>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only, line_flags);
+    else            // (16 words per thread - 11k partial sums for a batch of level-1 grids - was measured: the reduce pass 34 -> 113 us,
+                    // the emit pass 76 -> 142 us: a thread's 64 contiguous bytes are no longer one coalesced vector load per wavefront)
+        launch_scan<4>(bitmap, nwords, prefix, d_total, mode, dec, coords_out, cap_out, partial, stream, nonzero_only, line_flags);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
@@ -304,8 +339,181 @@ __global__ void k_mark_outputs(const int *__restrict__ coords_in, const int *__r
     }
 }
 
-// nbr[t*cap + o] for every output row o and tap t; one thread per (o, tz, ty) row of kW taps so
-// that the kW lookups of a thread share bitmap/prefix words.
+// k_mark_outputs for windows that feed at most two outputs per dimension (every strided stage of the backbone: k 3 / s 2, and
+// conv_out's (3,1,1) / (2,1,1)).  Atomics on this part resolve at the memory side (the bitmap is shared by the 8 XCDs' L2s) and
+// bound the kernel; the inputs arrive in key order, so the 64 inputs of a wavefront mostly feed the same few output words: a
+// lane keeps one (word, bits) per (z, y) output row, the lanes of a run of equal words OR their bits together in registers
+// (segmented scan over the wavefront) and only the run's last lane tests the word and issues the atomic.
+__global__ __launch_bounds__(256) void k_mark_outputs_w(const int *__restrict__ coords_in, const int *__restrict__ d_m_in, int cap_in,
+                                                        ConvGeom g, LevelGeom lo, uint32_t *__restrict__ bitmap_out) {
+    const int m = min(*d_m_in, cap_in);
+    const int m_pad = (m + 63) & ~63;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m_pad; i += gridDim.x * blockDim.x) {
+        uint32_t widx[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, wbits[4] = {0u, 0u, 0u, 0u};
+        if (i < m) {
+            const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
+            int wz[3], wy[3], wx[3];
+            const int nz = outs_of(c.y, g.k[0], g.s[0], g.p[0], g.od, wz);
+            const int ny = outs_of(c.z, g.k[1], g.s[1], g.p[1], g.oh, wy);
+            const int nx = outs_of(c.w, g.k[2], g.s[2], g.p[2], g.ow, wx);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (a >= nz || b >= ny || nx < 1) continue;
+                    const uint32_t k0 = lo.key(c.x, wz[a], wy[b], wx[0]);
+                    uint32_t w = k0 >> 5, bits = 1u << (k0 & 31u);
+                    if (nx > 1) {
+                        const uint32_t k1 = lo.key(c.x, wz[a], wy[b], wx[1]);
+                        if ((k1 >> 5) == w) bits |= 1u << (k1 & 31u);
+                        else atomicOr(&bitmap_out[k1 >> 5], 1u << (k1 & 31u));      // the second x candidate opens another word (1 input in 32)
+                    }
+                    widx[a * 2 + b] = w;
+                    wbits[a * 2 + b] = bits;
+                }
+        }
+        bool last[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const uint32_t w = widx[sl];
+            uint32_t bits = wbits[sl];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t wp = (uint32_t)__shfl_up((int)w, d, 64), bp = (uint32_t)__shfl_up((int)bits, d, 64);
+                if (lane >= d && wp == w) bits |= bp;
+            }
+            const uint32_t wn = (uint32_t)__shfl_down((int)w, 1, 64);
+            last[sl] = bits && (lane == 63 || wn != w);
+            wbits[sl] = bits;
+        }
+        // ~8 inputs feed every output: test before the atomic (a stale read only costs a redundant atomicOr); the four tests of a lane
+        // are loaded together
+        uint32_t seen[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) seen[sl] = last[sl] ? __builtin_nontemporal_load(&bitmap_out[widx[sl]]) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (last[sl] && (seen[sl] & wbits[sl]) != wbits[sl]) atomicOr(&bitmap_out[widx[sl]], wbits[sl]);
+    }
+}
+
+// nbr[t*cap + o] for every output row o and tap t.
+//
+// k_build_neighbors_rows (linear key layout, x window of 3 around an always-valid centre cell, or of 1): ONE thread per output
+// row.  The x taps of a (tz, ty) row are consecutive cells of one bitmap row, and ranks follow the key order, so the bitmap and
+// prefix words around the centre cell answer all of them: with r = number of active cells below the centre cell, the left
+// neighbour (when its bit is set) is row r - 1, the centre r, the right one r + centre_bit; when the centre sits at bit 0 / 31
+// the outer cell is bit 31 / 0 of the adjacent word (rank from that word's own prefix - a prefix entry is only valid where the
+// word holds a bit, common.h).  A thread fetches the THREE words around the centre with one 12-byte load each from the bitmap
+// and the prefix array: 2 * K0 * K1 independent, unconditional loads in flight together, no divergent second lookups (with 64
+// lanes nearly every wavefront has a lane at bit 0 or 31, and 18 serialised two-load lookups were most of the kernel's time).
+// A lane's tap mask is OR-reduced over its 32-row group in registers and stored - no atomics, no zero-fill of the mask words
+// (rows past the count store 0).
+#ifndef DZ_NBR_DIAG
+#define DZ_NBR_DIAG 0       // development builds (tools/gpu_nbr_diag.sh): 1 no bitmap / prefix loads, 2 no table stores, 4 nontemporal stores
+#endif
+struct __attribute__((packed, aligned(4))) Words3 { uint32_t a, b, c; };
+template <int K0, int K1, int KW, bool XCD>
+__global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restrict__ coords_out, const int *__restrict__ d_m_out,
+                                                              int cap_out, const uint32_t *__restrict__ bitmap_in,
+                                                              const uint32_t *__restrict__ prefix_in, LevelGeom li, ConvGeom g,
+                                                              int *__restrict__ nbr, uint32_t *__restrict__ tile_masks, int mask_rows,
+                                                              uint32_t last_base) {
+    const int m = min(*d_m_out, cap_out);
+    // every 32-row group of the mask buffer is visited (mask_rows = 32 x its words): whole wavefronts run the same trip count
+    const int total = tile_masks ? mask_rows : ((m + 63) & ~63);
+    // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): XCD x takes the x-th CONTIGUOUS eighth of the live
+    // rows, so that the bitmap / prefix lines of a row's y and z neighbours (hundreds to thousands of rows away in key order)
+    // are fetched into the L2 that fetched them for the row itself, not into all eight (gridDim.x is a multiple of 8)
+    const int live = min(total, (m + 63) & ~63);
+    const int span = XCD ? ((live + 511) / 512) * 64 : live;
+    const int lo = XCD ? (int)(blockIdx.x & 7u) * span : 0, hi = XCD ? min(live, lo + span) : live;
+    const int first = lo + (XCD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * (int)blockDim.x + (int)threadIdx.x;
+    const int step = (XCD ? (int)(gridDim.x >> 3) : (int)gridDim.x) * (int)blockDim.x;
+    if (tile_masks)             // mask words past the live rows: zero
+        for (int o = live + blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x)
+            if ((threadIdx.x & 31) == 0) tile_masks[o >> 5] = 0u;
+    for (int o = first; o < hi; o += step) {
+        uint32_t bits = 0u;
+        if (o < m) {
+            const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
+            const int uxc = c.w * g.s[2] - g.p[2] + (KW == 3 ? 1 : 0);       // centre cell: inside the grid (checked by the launcher)
+            Words3 word[K0 * K1], pref[K0 * K1];
+            uint32_t kc[K0 * K1], base[K0 * K1];
+            bool ok[K0 * K1];
+#pragma unroll
+            for (int tz = 0; tz < K0; ++tz)
+#pragma unroll
+                for (int ty = 0; ty < K1; ++ty) {
+                    const int r = tz * K1 + ty;
+                    const int uz = c.y * g.s[0] - g.p[0] + tz, uy = c.z * g.s[1] - g.p[1] + ty;
+                    ok[r] = (unsigned)uz < (unsigned)li.d && (unsigned)uy < (unsigned)li.h;
+                    kc[r] = ok[r] ? (uint32_t)(((c.x * li.d + uz) * li.h + uy) * li.w + uxc) : 32u;
+                    const uint32_t wc = kc[r] >> 5;
+                    base[r] = min(wc > 0u ? wc - 1u : 0u, last_base);       // words base .. base + 2 (inside the arrays)
+#if DZ_NBR_DIAG & 1
+                    if (KW == 3) { word[r] = Words3{kc[r], kc[r] * 3u, kc[r] * 5u}; pref[r] = Words3{kc[r] >> 3, kc[r] >> 4, kc[r] >> 5}; } else {
+#else
+                    if (KW == 3) {
+                        word[r] = *reinterpret_cast<const Words3 *>(bitmap_in + base[r]);
+                        pref[r] = *reinterpret_cast<const Words3 *>(prefix_in + base[r]);  // (unwritten where a word is empty: not used)
+                    } else {
+#endif
+                        word[r].b = bitmap_in[wc];
+                        pref[r].b = prefix_in[wc];
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < K0 * K1; ++r) {
+                const uint32_t wc = kc[r] >> 5, bc = kc[r] & 31u;
+                const int ci = KW == 3 ? (int)(wc - base[r]) : 1;            // position of the centre word among the three (1 but at the ends)
+                uint32_t w = ci == 1 ? word[r].b : (ci == 0 ? word[r].a : word[r].c);
+                const uint32_t pw = ci == 1 ? pref[r].b : (ci == 0 ? pref[r].a : pref[r].c);
+                if (!ok[r]) w = 0u;
+                const int rank = (int)(pw + __popc(w & ((1u << bc) - 1u)));
+                const uint32_t cbit = (w >> bc) & 1u;
+                const int vc = cbit ? rank : -1;
+                if (KW == 1) {
+                    nbr[(size_t)r * cap_out + o] = vc;
+                    if (vc >= 0) bits |= 1u << r;
+                } else {
+                    // the words before / after the centre word (bit 0 / 31 only; absent at the ends of the array)
+                    const uint32_t lw = ci == 1 ? word[r].a : (ci == 2 ? word[r].b : 0u), lp = ci == 1 ? pref[r].a : pref[r].b;
+                    const uint32_t rw = ci == 1 ? word[r].c : (ci == 0 ? word[r].b : 0u), rp = ci == 1 ? pref[r].c : pref[r].b;
+                    int vl = -1, vr = -1;
+                    if (bc != 0u) { if ((w >> (bc - 1u)) & 1u) vl = rank - 1; }
+                    else if (lw >> 31) vl = (int)(lp + __popc(lw)) - 1;
+                    if (bc != 31u) { if ((w >> (bc + 1u)) & 1u) vr = rank + (int)cbit; }
+                    else if (rw & 1u) vr = (int)rp;
+                    if (!ok[r] || uxc == 0) vl = -1;            // (the cell before the centre then belongs to the previous grid row)
+                    if (!ok[r] || uxc + 1 >= li.w) vr = -1;
+                    const int tap = r * 3;
+#if DZ_NBR_DIAG & 2
+                    bits ^= (uint32_t)(vl + vc + vr) & 0x8000000u;
+#elif DZ_NBR_DIAG & 4
+                    __builtin_nontemporal_store(vl, &nbr[(size_t)tap * cap_out + o]);
+                    __builtin_nontemporal_store(vc, &nbr[(size_t)(tap + 1) * cap_out + o]);
+                    __builtin_nontemporal_store(vr, &nbr[(size_t)(tap + 2) * cap_out + o]);
+#else
+                    nbr[(size_t)tap * cap_out + o] = vl;
+                    nbr[(size_t)(tap + 1) * cap_out + o] = vc;
+                    nbr[(size_t)(tap + 2) * cap_out + o] = vr;
+#endif
+                    bits |= ((vl >= 0 ? 1u : 0u) | (vc >= 0 ? 2u : 0u) | (vr >= 0 ? 4u : 0u)) << tap;
+                }
+            }
+        }
+        if (tile_masks) {
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, d, 64);
+            if ((threadIdx.x & 31) == 0) tile_masks[o >> 5] = bits;
+        }
+    }
+}
+
+// general form (brick key layout, other kernel widths / paddings): one thread per (o, tz, ty) row of kW taps; the tap masks are
+// collected with atomics into zero-filled words.
 __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__ coords_out,
                                                          const int *__restrict__ d_m_out, int cap_out,
                                                          const uint32_t *__restrict__ bitmap_in,
@@ -387,11 +595,13 @@ static bool geom_from(const int *k3, const int *s3, const int *p3, int d, int h,
 
 // scan of a level's bitmap with coordinate emission in the level's key layout
 int level_scan(const uint32_t *bitmap, const LevelGeom &lg, uint32_t *prefix, int *d_total, int *coords_out, int cap_out, void *ws,
-               size_t ws_bytes, hipStream_t stream, bool nonzero_only) {
+               size_t ws_bytes, hipStream_t stream, bool nonzero_only, const unsigned char *line_flags) {
     const size_t nwords = align_up((lg.cells() + 31) / 32, 8);        // = dz_index_words
     if (lg.layout == 0)
-        return bitmap_scan(bitmap, nwords, prefix, d_total, 0, ScanDims{lg.d, lg.h, lg.w}, coords_out, cap_out, ws, ws_bytes, stream, nonzero_only);
-    return bitmap_scan(bitmap, nwords, prefix, d_total, 2, ScanDims{lg.d, lg.nby, lg.nbx}, coords_out, cap_out, ws, ws_bytes, stream, nonzero_only);
+        return bitmap_scan(bitmap, nwords, prefix, d_total, 0, ScanDims{lg.d, lg.h, lg.w}, coords_out, cap_out, ws, ws_bytes, stream,
+                           nonzero_only, line_flags);
+    return bitmap_scan(bitmap, nwords, prefix, d_total, 2, ScanDims{lg.d, lg.nby, lg.nbx}, coords_out, cap_out, ws, ws_bytes, stream,
+                       nonzero_only, line_flags);
 }
 
 }  // namespace dz
@@ -469,7 +679,12 @@ int dz_index_downsample(const int *coords_in, const int *d_m_in, int cap_in, int
     const size_t nwords = dz_index_words(b, g.od, g.oh, g.ow, layout);
     rc = fill_u32(bitmap_out, 0u, nwords, stream);
     if (rc) return rc;
-    if (cap_in > 0)
+    static const int plain = getenv("DZ_TUNE_MARK_PLAIN") ? atoi(getenv("DZ_TUNE_MARK_PLAIN")) : 0;     // development knob
+    const bool two = (g.k[0] + g.s[0] - 1) / g.s[0] <= 2 && (g.k[1] + g.s[1] - 1) / g.s[1] <= 2 && (g.k[2] + g.s[2] - 1) / g.s[2] <= 2;
+    if (cap_in > 0 && two && !plain)
+        hipLaunchKernelGGL(k_mark_outputs_w, dim3(stream_grid(cap_in, 256)), dim3(256), 0, stream, coords_in, d_m_in,
+                           cap_in, g, lo, bitmap_out);
+    else if (cap_in > 0)
         hipLaunchKernelGGL(k_mark_outputs, dim3(stream_grid(cap_in, 256)), dim3(256), 0, stream, coords_in, d_m_in,
                            cap_in, g, lo, bitmap_out);
     rc = level_scan(bitmap_out, lo, prefix_out, d_m_out, coords_out, cap_out, ws, ws_bytes, stream, false);
@@ -489,13 +704,33 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
     DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_build_neighbors: bad kernel/stride/padding");
     DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_build_neighbors: bad layout %d", layout);
     if (cap_out == 0) return DZ_OK;
+    const LevelGeom li = make_level(b, d, h, w, layout);
+    // the per-row kernel: linear keys, three z taps, and an x window whose centre cell is inside the input grid for every output
+    // (3 wide with padding 1: centre = x * s <= w - 1 because ow = (w - 1) / s + 1; 1 wide without padding: centre = x * s)
+    static const int generic = getenv("DZ_TUNE_NBR_GENERIC") ? atoi(getenv("DZ_TUNE_NBR_GENERIC")) : 0;    // development knob
+    const bool kw3 = g.k[2] == 3 && g.p[2] == 1 && (long)(g.ow - 1) * g.s[2] <= w - 1;
+    const bool kw1 = g.k[2] == 1 && g.p[2] == 0 && (long)(g.ow - 1) * g.s[2] <= w - 1;
+    if (!generic && layout == DZ_LAYOUT_LINEAR && g.k[0] == 3 && ((g.k[1] == 3 && kw3) || (g.k[1] == 1 && kw1))) {
+        const int mask_rows = tile_masks_words(cap_out) * 32;
+        const uint32_t last_base = (uint32_t)(dz_index_words(b, d, h, w, layout) - 3);      // (>= 8 words: padded to whole 32-byte units)
+        const dim3 grid((stream_grid(tile_masks ? mask_rows : cap_out, 256) + 7) & ~7);
+        static const int flat = getenv("DZ_TUNE_NBR_FLAT") ? atoi(getenv("DZ_TUNE_NBR_FLAT")) : 0;             // development knob
+#define DZ_NBR_ROWS(K1_, KW_, X_)                                                                                                   \
+    hipLaunchKernelGGL((k_build_neighbors_rows<3, K1_, KW_, X_>), grid, dim3(256), 0, stream, coords_out, d_m_out, cap_out, bitmap_in, \
+                       prefix_in, li, g, nbr, tile_masks, mask_rows, last_base)
+        if (g.k[1] == 3) { if (flat) DZ_NBR_ROWS(3, 3, false); else DZ_NBR_ROWS(3, 3, true); }
+        else { if (flat) DZ_NBR_ROWS(1, 1, false); else DZ_NBR_ROWS(1, 1, true); }
+#undef DZ_NBR_ROWS
+        DZ_LAUNCH_CHECK();
+        return DZ_OK;
+    }
     if (tile_masks) {
         const int rc = fill_u32(tile_masks, 0u, (size_t)tile_masks_words(cap_out), stream);
         if (rc) return rc;
     }
     const long work = (long)cap_out * g.k[0] * g.k[1];
     hipLaunchKernelGGL(k_build_neighbors, dim3(stream_grid(work, 256)), dim3(256), 0, stream, coords_out, d_m_out,
-                       cap_out, bitmap_in, prefix_in, make_level(b, d, h, w, layout), g, nbr, tile_masks);
+                       cap_out, bitmap_in, prefix_in, li, g, nbr, tile_masks);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -59,14 +59,24 @@ __global__ void k_hard_keys(const float *__restrict__ pts, int n, int c, VoxGeom
 // {slot, carried value}, every index is offered to slot 0, so slot 0 ends as the minimum and everything else has been offered to
 // slot 1, and by induction slot q holds the (q+1)-th smallest.  An empty slot (0x7f7f7f7f) ends a point's walk: typically one or
 // two atomics per point instead of the max_points full passes (rank lookup + atomicMin each) of the round-by-round version.
+// Points arrive in scan order, so the lanes of a wavefront often hold runs of points of ONE voxel (their indices ascending): a
+// point with p run-mates before it has p smaller indices in its voxel and can never sit above slot p - it starts its walk there
+// (the induction still holds: the value of overall rank r starts at a slot <= r, and slot q keeps the minimum of what reaches
+// it), and a point with max_points run-mates before it is dropped at once.
 __global__ void k_hard_insert(const uint32_t *__restrict__ keys, int n, const uint32_t *__restrict__ bitmap,
                               const uint32_t *__restrict__ prefix, int *__restrict__ mins, int cap, int max_points) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t key = keys[i];
-        if (key == KEY_INVALID) continue;
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 63) & ~63;               // whole wavefronts run the same trip count (the run positions use a ballot)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+        const uint32_t key = i < n ? keys[i] : KEY_INVALID;
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || prev != key);
+        const int first = 63 - __clzll(heads & (~0ull >> (63 - lane)));      // first lane of this lane's run
+        const int q0 = lane - first;
+        if (key == KEY_INVALID || q0 >= max_points) continue;
         const int v = bitmap_rank(bitmap, prefix, key);
         int val = i;
-        for (int q = 0; q < max_points; ++q) {
+        for (int q = q0; q < max_points; ++q) {
             const int old = atomicMin(&mins[(size_t)q * cap + v], val);
             if (old == 0x7f7f7f7f) break;
             val = max(old, val);
@@ -168,18 +178,36 @@ __global__ void k_hard_emit_mean(const float *__restrict__ pts, int c, const int
 // ((b*D + z)*H + y)*W + x, the scan writes the level's prefix / canonical coordinates / count, and the voxel means go
 // to the voxel's canonical row directly (zero-padded to the backbone's input width, optionally as pair16).  The
 // first-appearance ordering, the voxel list, dz_index_from_coords and dz_scatter_rows all disappear.
+// line_flags (optional): one byte per 32 bitmap words (a 128-byte line), set for every line that receives a bit - the scan that
+// follows skips the lines (> 75 % of a level-1 grid) that were never touched.
+// Atomics on the bitmap resolve at the memory side and bound this kernel; points arrive in scan order, so the lanes of a
+// wavefront hold runs of points of the same bitmap word: the run's bits are ORed together in registers (segmented scan) and its
+// last lane issues ONE atomic (half the atomics on lidar-ordered points; any order stays correct).
 __global__ void k_level_keys(const float *__restrict__ pts, int n, int c, VoxGeom g, int n_per, LevelGeom lg,
-                             uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *p = pts + (size_t)i * c;
-        const float xyz[3] = {p[0], p[1], p[2]};
-        int cx, cy, cz;
+                             uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap, unsigned char *__restrict__ line_flags) {
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
         uint32_t key = KEY_INVALID;
-        if (voxel_coord(xyz, g, cx, cy, cz)) {
-            key = lg.key(i / n_per, cz, cy, cx);
-            atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+        if (i < n) {
+            const float *p = pts + (size_t)i * c;
+            const float xyz[3] = {p[0], p[1], p[2]};
+            int cx, cy, cz;
+            if (voxel_coord(xyz, g, cx, cy, cz)) key = lg.key(i / n_per, cz, cy, cx);
+            keys[i] = key;
         }
-        keys[i] = key;
+        const uint32_t w = key == KEY_INVALID ? KEY_INVALID : key >> 5;
+        uint32_t bits = key == KEY_INVALID ? 0u : 1u << (key & 31u);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t wp = (uint32_t)__shfl_up((int)w, d, 64), bp = (uint32_t)__shfl_up((int)bits, d, 64);
+            if (lane >= d && wp == w) bits |= bp;
+        }
+        const uint32_t wn = (uint32_t)__shfl_down((int)w, 1, 64);
+        if (bits && (lane == 63 || wn != w)) {
+            atomicOr(&bitmap[w], bits);
+            if (line_flags) line_flags[w >> 5] = 1;
+        }
     }
 }
 
@@ -427,19 +455,23 @@ int dz_voxelize_hard_mean_batched(const float *points, int n_per_frame, int batc
                               ws_bytes, (hipStream_t)stream_);
 }
 
-static size_t level_ws_layout(long n, int max_points, int cap, size_t nwords, size_t *o_min, size_t *o_sw, size_t *sw_bytes) {
+static size_t level_ws_layout(long n, int max_points, int cap, size_t nwords, size_t *o_min, size_t *o_sw, size_t *sw_bytes, size_t *o_lf,
+                              size_t *lf_words) {
     size_t off = align_up((size_t)(n < 1 ? 1 : n) * 4, 256);                 // keys first
     *o_min = off;
     off += align_up((size_t)max_points * (cap < 1 ? 1 : cap) * 4, 256);
     *sw_bytes = bitmap_scan_workspace_bytes(nwords);
     *o_sw = off;
     off += align_up(*sw_bytes, 256);
+    *lf_words = align_up((nwords + 31) / 32, 16) / 4;                         // one byte per 32-word line, as whole 16-byte units
+    *o_lf = off;
+    off += align_up(*lf_words * 4, 256);
     return off;
 }
 
 size_t dz_voxelize_to_level_workspace_bytes(int n_per_frame, int batch, int max_points, int cap, int d, int h, int w, int layout) {
-    size_t a, b, c;
-    return level_ws_layout((long)n_per_frame * batch, max_points, cap, dz_index_words(batch, d, h, w, layout), &a, &b, &c);
+    size_t a, b, c, e, f;
+    return level_ws_layout((long)n_per_frame * batch, max_points, cap, dz_index_words(batch, d, h, w, layout), &a, &b, &c, &e, &f);
 }
 
 int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c, const float *h_range6, const float *h_vsize3,
@@ -465,19 +497,23 @@ int dz_voxelize_to_level(const float *points, int n_per_frame, int batch, int c,
     const LevelGeom lg = make_level(batch, level_d, g.g[1], g.g[0], layout);
     if (lg.cells() >= 0xFFFFFFFFull) { set_error("dz_voxelize_to_level: grid x batch too large for 32-bit keys"); return DZ_ERR_UNSUPPORTED; }
     const size_t nwords = dz_index_words(batch, level_d, g.g[1], g.g[0], layout);
-    size_t o_min, o_sw, sw_bytes;
-    const size_t need = level_ws_layout(n, max_points, cap, nwords, &o_min, &o_sw, &sw_bytes);
+    size_t o_min, o_sw, sw_bytes, o_lf, lf_words;
+    const size_t need = level_ws_layout(n, max_points, cap, nwords, &o_min, &o_sw, &sw_bytes, &o_lf, &lf_words);
     if (ws_bytes < need) { set_error("dz_voxelize_to_level: workspace %zu < %zu", ws_bytes, need); return DZ_ERR_WORKSPACE; }
     uint32_t *keys = (uint32_t *)ws;
     int *mins = (int *)((char *)ws + o_min);
+    static const int use_flags = getenv("DZ_TUNE_LINE_FLAGS") ? atoi(getenv("DZ_TUNE_LINE_FLAGS")) : 1;      // development knob
+    unsigned char *line_flags = use_flags ? (unsigned char *)ws + o_lf : nullptr;
     int rc = fill_u32(bitmap, 0u, nwords, stream);
     if (!rc) rc = fill_u32(mins, 0x7f7f7f7fu, (size_t)max_points * cap, stream);
+    if (!rc && line_flags) rc = fill_u32(line_flags, 0u, lf_words, stream);
     if (rc) return rc;
-    if (n == 0) return level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true);
+    if (n == 0) return level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true, line_flags);
     DZ_CHECK_ARG(points, "dz_voxelize_to_level: null points");
     const int grid_n = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, lg, keys, bitmap);
-    rc = level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true);
+    hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(256), 0, stream, points, (int)n, c, g, n_per_frame, lg, keys, bitmap,
+                       line_flags);
+    rc = level_scan(bitmap, lg, prefix, d_m, coords_out, cap, (char *)ws + o_sw, sw_bytes, stream, true, line_flags);
     if (rc) return rc;
     hipLaunchKernelGGL(k_hard_insert, dim3(grid_n), dim3(256), 0, stream, keys, (int)n, bitmap, prefix, mins, cap, max_points);
     const dim3 ge(stream_grid((long)cap * (c_dst / 8), 256));

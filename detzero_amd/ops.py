@@ -101,7 +101,7 @@ def voxelize_to_level(points, batch, pc_range, voxel_size, max_points, max_voxel
     grid = grid_size_of(pc_range, voxel_size)
     assert [int(level_shape[1]), int(level_shape[2])] == [int(grid[1]), int(grid[0])], (level_shape, grid)
     cap = batch * max(min(int(max_voxels), n_per), 1)
-    lvl = SparseLevel(batch, level_shape, cap, points.device, layout=layout)
+    lvl = SparseLevel(batch, level_shape, cap, points.device, layout=layout, zero_count=False)
     feats = torch.empty((cap, c_dst), dtype=torch.float32, device=points.device)
     ws = _ws(lib.dz_voxelize_to_level_workspace_bytes(n_per, batch, max_points, cap, *lvl.shape, lvl.layout))
     rc = lib.dz_voxelize_to_level(L.ptr(points), n_per, batch, c, L.f6(pc_range), L.f3(voxel_size), L.i3(grid),
@@ -167,7 +167,7 @@ class SparseLevel:
     layout: the cell key that orders the rows (include/detzero_hip.h: DZ_LAYOUT_LINEAR = ascending (b, z, y, x), the canonical
     order of the parity statements; DZ_LAYOUT_BRICK = 8 x 8 columns of the (y, x) plane, the order the backbone computes in)."""
 
-    def __init__(self, batch, shape, cap, device, layout=LAYOUT_LINEAR):
+    def __init__(self, batch, shape, cap, device, layout=LAYOUT_LINEAR, zero_count=True):
         lib = L.load()
         self.batch = int(batch)
         self.shape = [int(s) for s in shape]           # (D, H, W)
@@ -177,7 +177,8 @@ class SparseLevel:
         self.bitmap = torch.empty((nwords,), dtype=torch.int32, device=device)
         self.prefix = torch.empty((nwords,), dtype=torch.int32, device=device)
         self.coords = torch.empty((max(self.cap, 1), 4), dtype=torch.int32, device=device)
-        self.d_m = torch.zeros((1,), dtype=torch.int32, device=device)
+        # (zero_count=False: the caller builds the level right away - every build ends with the scan writing the count)
+        self.d_m = (torch.zeros if zero_count else torch.empty)((1,), dtype=torch.int32, device=device)
         self.ws = _ws(lib.dz_index_workspace_bytes(self.batch, *self.shape, self.layout))
         self._m_host = None
         # True for levels written by dz_voxelize_to_level: prefix[] is valid only at words that hold a bit, so only ACTIVE cells may
@@ -214,7 +215,7 @@ class SparseLevel:
             for i in range(3):
                 per_in *= (k[i] + s[i] - 1) // s[i]
             cap = min(cells, self.cap * per_in)
-        out = SparseLevel(self.batch, oshape, cap, self.coords.device, layout=self.layout)
+        out = SparseLevel(self.batch, oshape, cap, self.coords.device, layout=self.layout, zero_count=False)
         rc = lib.dz_index_downsample(L.ptr(self.coords), L.ptr(self.d_m), self.cap, self.batch, *self.shape, self.layout,
                                      L.i3(k), L.i3(s), L.i3(p), L.ptr(out.bitmap), L.ptr(out.prefix),
                                      L.ptr(out.coords), L.ptr(out.d_m), out.cap, L.ptr(out.ws), out.ws.numel(),
