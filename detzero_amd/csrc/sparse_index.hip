@@ -8,6 +8,7 @@
 // site its rank in ascending linear-key order, so feature rows are stored spatially sorted
 // (x-neighbours are adjacent rows -> coalesced gathers) and a neighbour lookup is two loads +
 // one popcount, no probing, no atomics on the read side.
+#include <algorithm>
 #include <stdarg.h>
 #include <string.h>
 
@@ -411,15 +412,46 @@ __global__ __launch_bounds__(256) void k_mark_outputs_w(const int *__restrict__ 
 // A lane's tap mask is OR-reduced over its 32-row group in registers and stored - no atomics, no zero-fill of the mask words
 // (rows past the count store 0).
 #ifndef DZ_NBR_DIAG
-#define DZ_NBR_DIAG 0       // development builds (tools/gpu_nbr_diag.sh): 1 no bitmap / prefix loads, 2 no table stores, 4 nontemporal stores
+#define DZ_NBR_DIAG 0       // development builds (tools/gpu_nbr_diag.sh): 1 no bitmap / prefix loads, 2 no table stores
 #endif
-struct __attribute__((packed, aligned(4))) Words3 { uint32_t a, b, c; };
+typedef unsigned int nbr_u3 __attribute__((ext_vector_type(3)));
+
+// the three x taps of one (tz, ty) row from the bitmap / prefix words around the centre cell.  EDGE = false: the centre word is
+// w.y (words w.x / w.z before / after it); EDGE = true (the centre word is the first or last of the array): it is component ci.
+template <bool EDGE>
+__device__ __forceinline__ void nbr_row3(nbr_u3 w, nbr_u3 p, int ci, uint32_t bc, bool ok, bool lv, bool rv, int &vl, int &vc, int &vr) {
+    uint32_t wc_ = w.y, pc_ = p.y, lw = w.x, lp = p.x, rw = w.z, rp = p.z;
+    if (EDGE) {
+        wc_ = ci == 1 ? w.y : (ci == 0 ? w.x : w.z);
+        pc_ = ci == 1 ? p.y : (ci == 0 ? p.x : p.z);
+        lw = ci == 1 ? w.x : (ci == 2 ? w.y : 0u); lp = ci == 1 ? p.x : p.y;
+        rw = ci == 1 ? w.z : (ci == 0 ? w.y : 0u); rp = ci == 1 ? p.z : p.y;
+    }
+    if (!ok) wc_ = lw = rw = 0u;
+    const int rank = (int)(pc_ + __popc(wc_ & ((1u << bc) - 1u)));         // active cells below the centre cell
+    const uint32_t cbit = (wc_ >> bc) & 1u;
+    vc = cbit ? rank : -1;
+    // left / right cell: bit bc -+ 1 of the centre word, or bit 31 / 0 of the adjacent word (ranked from that word's own prefix)
+    const bool lbit = bc != 0u ? ((wc_ >> (bc - 1u)) & 1u) != 0u : (lw >> 31) != 0u;
+    const bool rbit = bc != 31u ? ((wc_ >> (bc + 1u)) & 1u) != 0u : (rw & 1u) != 0u;
+    const int lrank = bc != 0u ? rank - 1 : (int)(lp + __popc(lw)) - 1;
+    const int rrank = bc != 31u ? rank + (int)cbit : (int)rp;
+    vl = lbit && lv ? lrank : -1;
+    vr = rbit && rv ? rrank : -1;
+}
+
 template <int K0, int K1, int KW, bool XCD>
 __global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restrict__ coords_out, const int *__restrict__ d_m_out,
                                                               int cap_out, const uint32_t *__restrict__ bitmap_in,
                                                               const uint32_t *__restrict__ prefix_in, LevelGeom li, ConvGeom g,
                                                               int *__restrict__ nbr, uint32_t *__restrict__ tile_masks, int mask_rows,
-                                                              uint32_t last_base) {
+                                                              uint32_t last_base, uint32_t index_bytes, uint32_t nbr_bytes) {
+    // table, bitmap and prefix array through buffer descriptors: a scalar base (+ the tap's scalar row offset) and ONE 32-bit
+    // per-lane byte offset, instead of a 64-bit address per access (the table is written through K0 * K1 * KW row pointers)
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(nbr, 0, nbr_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bmr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(bitmap_in), 0, index_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pfr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(prefix_in), 0, index_bytes, 0x00020000);
+    const uint32_t row_bytes = (uint32_t)cap_out * 4u;
     const int m = min(*d_m_out, cap_out);
     // every 32-row group of the mask buffer is visited (mask_rows = 32 x its words): whole wavefronts run the same trip count
     const int total = tile_masks ? mask_rows : ((m + 63) & ~63);
@@ -436,72 +468,70 @@ __global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restr
             if ((threadIdx.x & 31) == 0) tile_masks[o >> 5] = 0u;
     for (int o = first; o < hi; o += step) {
         uint32_t bits = 0u;
-        if (o < m) {
-            const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
-            const int uxc = c.w * g.s[2] - g.p[2] + (KW == 3 ? 1 : 0);       // centre cell: inside the grid (checked by the launcher)
-            Words3 word[K0 * K1], pref[K0 * K1];
-            uint32_t kc[K0 * K1], base[K0 * K1];
-            bool ok[K0 * K1];
+        int4 c = make_int4(0, 0, 0, 0);
+        if (o < m) c = reinterpret_cast<const int4 *>(coords_out)[o];
+        const uint32_t voff = (uint32_t)o * 4u;
+        const int uxc = c.w * g.s[2] - g.p[2] + (KW == 3 ? 1 : 0);       // centre cell: inside the grid (checked by the launcher)
+        const bool lv = uxc > 0, rv = uxc + 1 < li.w;
+        const int uz0 = c.y * g.s[0] - g.p[0], uy0 = c.z * g.s[1] - g.p[1];
+        const uint32_t key00 = (uint32_t)(((c.x * li.d + uz0) * li.h + uy0) * li.w + uxc);
+        // one z slab (K1 rows) at a time: the loads of slab tz + 1 are issued before the taps of slab tz are computed and stored
+        struct Slab { nbr_u3 word[K1], pref[K1]; uint32_t kc[K1], base[K1]; bool ok[K1], edge; } sl[K0];
+        auto fetch = [&](int tz, Slab &q) {
+            q.edge = false;
 #pragma unroll
-            for (int tz = 0; tz < K0; ++tz)
-#pragma unroll
-                for (int ty = 0; ty < K1; ++ty) {
-                    const int r = tz * K1 + ty;
-                    const int uz = c.y * g.s[0] - g.p[0] + tz, uy = c.z * g.s[1] - g.p[1] + ty;
-                    ok[r] = (unsigned)uz < (unsigned)li.d && (unsigned)uy < (unsigned)li.h;
-                    kc[r] = ok[r] ? (uint32_t)(((c.x * li.d + uz) * li.h + uy) * li.w + uxc) : 32u;
-                    const uint32_t wc = kc[r] >> 5;
-                    base[r] = min(wc > 0u ? wc - 1u : 0u, last_base);       // words base .. base + 2 (inside the arrays)
+            for (int ty = 0; ty < K1; ++ty) {
+                q.ok[ty] = o < m && (unsigned)(uz0 + tz) < (unsigned)li.d && (unsigned)(uy0 + ty) < (unsigned)li.h;
+                q.kc[ty] = q.ok[ty] ? key00 + (uint32_t)((tz * li.h + ty) * li.w) : 32u;
+                const uint32_t wc = q.kc[ty] >> 5;
+                q.edge |= wc - 1u > last_base;                                   // first or last word of the arrays
+                q.base[ty] = min(wc > 0u ? wc - 1u : 0u, last_base);             // words base .. base + 2 (inside the arrays)
 #if DZ_NBR_DIAG & 1
-                    if (KW == 3) { word[r] = Words3{kc[r], kc[r] * 3u, kc[r] * 5u}; pref[r] = Words3{kc[r] >> 3, kc[r] >> 4, kc[r] >> 5}; } else {
+                q.word[ty] = nbr_u3{q.kc[ty], q.kc[ty] * 3u, q.kc[ty] * 5u}; q.pref[ty] = nbr_u3{q.kc[ty] >> 3, q.kc[ty] >> 4, q.kc[ty] >> 5};
 #else
-                    if (KW == 3) {
-                        word[r] = *reinterpret_cast<const Words3 *>(bitmap_in + base[r]);
-                        pref[r] = *reinterpret_cast<const Words3 *>(prefix_in + base[r]);  // (unwritten where a word is empty: not used)
-                    } else {
-#endif
-                        word[r].b = bitmap_in[wc];
-                        pref[r].b = prefix_in[wc];
-                    }
-                }
-#pragma unroll
-            for (int r = 0; r < K0 * K1; ++r) {
-                const uint32_t wc = kc[r] >> 5, bc = kc[r] & 31u;
-                const int ci = KW == 3 ? (int)(wc - base[r]) : 1;            // position of the centre word among the three (1 but at the ends)
-                uint32_t w = ci == 1 ? word[r].b : (ci == 0 ? word[r].a : word[r].c);
-                const uint32_t pw = ci == 1 ? pref[r].b : (ci == 0 ? pref[r].a : pref[r].c);
-                if (!ok[r]) w = 0u;
-                const int rank = (int)(pw + __popc(w & ((1u << bc) - 1u)));
-                const uint32_t cbit = (w >> bc) & 1u;
-                const int vc = cbit ? rank : -1;
-                if (KW == 1) {
-                    nbr[(size_t)r * cap_out + o] = vc;
-                    if (vc >= 0) bits |= 1u << r;
+                if (KW == 3) {
+                    q.word[ty] = __builtin_amdgcn_raw_buffer_load_b96(bmr, q.base[ty] * 4u, 0, 0);
+                    q.pref[ty] = __builtin_amdgcn_raw_buffer_load_b96(pfr, q.base[ty] * 4u, 0, 0);   // (unwritten where a word is empty: not used)
                 } else {
-                    // the words before / after the centre word (bit 0 / 31 only; absent at the ends of the array)
-                    const uint32_t lw = ci == 1 ? word[r].a : (ci == 2 ? word[r].b : 0u), lp = ci == 1 ? pref[r].a : pref[r].b;
-                    const uint32_t rw = ci == 1 ? word[r].c : (ci == 0 ? word[r].b : 0u), rp = ci == 1 ? pref[r].c : pref[r].b;
-                    int vl = -1, vr = -1;
-                    if (bc != 0u) { if ((w >> (bc - 1u)) & 1u) vl = rank - 1; }
-                    else if (lw >> 31) vl = (int)(lp + __popc(lw)) - 1;
-                    if (bc != 31u) { if ((w >> (bc + 1u)) & 1u) vr = rank + (int)cbit; }
-                    else if (rw & 1u) vr = (int)rp;
-                    if (!ok[r] || uxc == 0) vl = -1;            // (the cell before the centre then belongs to the previous grid row)
-                    if (!ok[r] || uxc + 1 >= li.w) vr = -1;
-                    const int tap = r * 3;
-#if DZ_NBR_DIAG & 2
-                    bits ^= (uint32_t)(vl + vc + vr) & 0x8000000u;
-#elif DZ_NBR_DIAG & 4
-                    __builtin_nontemporal_store(vl, &nbr[(size_t)tap * cap_out + o]);
-                    __builtin_nontemporal_store(vc, &nbr[(size_t)(tap + 1) * cap_out + o]);
-                    __builtin_nontemporal_store(vr, &nbr[(size_t)(tap + 2) * cap_out + o]);
-#else
-                    nbr[(size_t)tap * cap_out + o] = vl;
-                    nbr[(size_t)(tap + 1) * cap_out + o] = vc;
-                    nbr[(size_t)(tap + 2) * cap_out + o] = vr;
-#endif
-                    bits |= ((vl >= 0 ? 1u : 0u) | (vc >= 0 ? 2u : 0u) | (vr >= 0 ? 4u : 0u)) << tap;
+                    q.word[ty].y = __builtin_amdgcn_raw_buffer_load_b32(bmr, wc * 4u, 0, 0);
+                    q.pref[ty].y = __builtin_amdgcn_raw_buffer_load_b32(pfr, wc * 4u, 0, 0);
                 }
+#endif
+            }
+        };
+        fetch(0, sl[0]);
+#pragma unroll
+        for (int tz = 0; tz < K0; ++tz) {
+            if (tz + 1 < K0) fetch(tz + 1, sl[tz + 1]);
+            const Slab &q = sl[tz];
+            const bool any_edge = KW == 3 && __any(q.edge);
+#pragma unroll
+            for (int ty = 0; ty < K1; ++ty) {
+                const int r = tz * K1 + ty;
+                const uint32_t bc = q.kc[ty] & 31u;
+                int vl, vc, vr;
+                if (KW == 1) {
+                    const uint32_t w = q.ok[ty] ? q.word[ty].y : 0u;
+                    vc = (w >> bc) & 1u ? (int)(q.pref[ty].y + __popc(w & ((1u << bc) - 1u))) : -1;
+#if !(DZ_NBR_DIAG & 2)
+                    if (o < m) __builtin_amdgcn_raw_buffer_store_b32(vc, tab, voff, (uint32_t)r * row_bytes, 0);
+#endif
+                    if (vc >= 0) bits |= 1u << r;
+                    continue;
+                }
+                if (any_edge) nbr_row3<true>(q.word[ty], q.pref[ty], (int)((q.kc[ty] >> 5) - q.base[ty]), bc, q.ok[ty], lv, rv, vl, vc, vr);
+                else nbr_row3<false>(q.word[ty], q.pref[ty], 1, bc, q.ok[ty], lv, rv, vl, vc, vr);
+                const int tap = r * 3;
+#if DZ_NBR_DIAG & 2
+                bits ^= (uint32_t)(vl + vc + vr) & 0x8000000u;
+#else
+                if (o < m) {
+                    __builtin_amdgcn_raw_buffer_store_b32(vl, tab, voff, (uint32_t)tap * row_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(vc, tab, voff, (uint32_t)(tap + 1) * row_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(vr, tab, voff, (uint32_t)(tap + 2) * row_bytes, 0);
+                }
+#endif
+                bits |= ((vl >= 0 ? 1u : 0u) | (vc >= 0 ? 2u : 0u) | (vr >= 0 ? 4u : 0u)) << tap;
             }
         }
         if (tile_masks) {
@@ -710,14 +740,18 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
     static const int generic = getenv("DZ_TUNE_NBR_GENERIC") ? atoi(getenv("DZ_TUNE_NBR_GENERIC")) : 0;    // development knob
     const bool kw3 = g.k[2] == 3 && g.p[2] == 1 && (long)(g.ow - 1) * g.s[2] <= w - 1;
     const bool kw1 = g.k[2] == 1 && g.p[2] == 0 && (long)(g.ow - 1) * g.s[2] <= w - 1;
-    if (!generic && layout == DZ_LAYOUT_LINEAR && g.k[0] == 3 && ((g.k[1] == 3 && kw3) || (g.k[1] == 1 && kw1))) {
+    const size_t table_bytes = (size_t)g.k[0] * g.k[1] * g.k[2] * cap_out * sizeof(int);         // (descriptor-addressed: below 4 GiB)
+    if (!generic && layout == DZ_LAYOUT_LINEAR && g.k[0] == 3 && ((g.k[1] == 3 && kw3) || (g.k[1] == 1 && kw1)) &&
+        table_bytes < 0xFFFFFFFFull) {
         const int mask_rows = tile_masks_words(cap_out) * 32;
-        const uint32_t last_base = (uint32_t)(dz_index_words(b, d, h, w, layout) - 3);      // (>= 8 words: padded to whole 32-byte units)
-        const dim3 grid((stream_grid(tile_masks ? mask_rows : cap_out, 256) + 7) & ~7);
+        const size_t index_words = dz_index_words(b, d, h, w, layout);                       // (>= 8 words: padded to whole 32-byte units)
+        const uint32_t last_base = (uint32_t)(index_words - 3);
+        static const int gmax = getenv("DZ_TUNE_NBR_GRID") ? atoi(getenv("DZ_TUNE_NBR_GRID")) : 2048;           // development knob
+        const dim3 grid((std::min(stream_grid(tile_masks ? mask_rows : cap_out, 256), gmax) + 7) & ~7);
         static const int flat = getenv("DZ_TUNE_NBR_FLAT") ? atoi(getenv("DZ_TUNE_NBR_FLAT")) : 0;             // development knob
 #define DZ_NBR_ROWS(K1_, KW_, X_)                                                                                                   \
     hipLaunchKernelGGL((k_build_neighbors_rows<3, K1_, KW_, X_>), grid, dim3(256), 0, stream, coords_out, d_m_out, cap_out, bitmap_in, \
-                       prefix_in, li, g, nbr, tile_masks, mask_rows, last_base)
+                       prefix_in, li, g, nbr, tile_masks, mask_rows, last_base, (uint32_t)(index_words * 4), (uint32_t)table_bytes)
         if (g.k[1] == 3) { if (flat) DZ_NBR_ROWS(3, 3, false); else DZ_NBR_ROWS(3, 3, true); }
         else { if (flat) DZ_NBR_ROWS(1, 1, false); else DZ_NBR_ROWS(1, 1, true); }
 #undef DZ_NBR_ROWS

@@ -69,6 +69,43 @@ def test_voxelize_hard_edges(device):
     assert v1.shape[0] == 0
 
 
+def test_voxelize_hard_runs_of_one_voxel(device):
+    """Point orders that exercise the wave-level shortcuts of the key and insertion kernels: runs of one voxel longer than a
+    wavefront (positions past max_points are dropped at once, the others start their walk at their run position), the same voxel
+    in separate runs of one wavefront and of different wavefronts with SMALLER-index points arriving in later runs' neighbours,
+    strictly alternating voxels (no runs), and runs that cross wavefront boundaries - against the oracle, bit for bit, through
+    the list route and the level route."""
+    from detzero_amd import ops
+    from oracle import voxelize as ov
+    rng = np.random.default_rng(11)
+    cells = np.array([[762, 772, 16], [763, 772, 16], [451, 852, 20], [1152, 551, 6], [762, 773, 16]], np.float32)       # (x, y, z)
+    vs = np.array(VOXEL_SIZE_01, np.float32)
+    centres = np.array(POINT_CLOUD_RANGE[:3], np.float32) + (cells + 0.5) * vs
+    seq = [0] * 150 + [1, 0] * 40 + [2] * 7 + [0] * 3 + [3] * 61 + [1] * 5 + [2] * 70 + [4, 3, 4, 3, 4] + [0] * 130 + [1] * 64 + [4] * 64
+    seq = np.array(seq + list(rng.integers(0, 5, size=700)))
+    pts = np.zeros((seq.size, 5), np.float32)
+    pts[:, :3] = centres[seq] + (rng.uniform(-0.3, 0.3, size=(seq.size, 3)) * vs).astype(np.float32)
+    pts[:, 3] = np.arange(seq.size)
+    pts[:, 4] = rng.random(seq.size)
+    v0, c0, n0 = ov.hard_voxelize(pts, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    assert v0.shape[0] == 5 and list(n0) == [5] * 5
+    v1, c1, n1 = ops.voxelize_hard(_t(pts, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    assert np.array_equal(c1.cpu().numpy(), c0) and np.array_equal(n1.cpu().numpy(), n0) and np.array_equal(v1.cpu().numpy(), v0)
+    # level route (keys with merged bitmap atomics + line flags, insertion, mean): two copies of the frame as a batch
+    grid = ov.grid_size_of(POINT_CLOUD_RANGE, VOXEL_SIZE_01)
+    shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
+    both = _t(np.concatenate([pts, pts[::-1].copy()], 0), device)
+    lvl, x = ops.voxelize_to_level(both, 2, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 200000, shape, 8, math=0, xy_range_mask=True)
+    assert lvl.num_active() == 10
+    got = lvl.coords[:10].cpu().numpy()
+    order = np.lexsort((c0[:, 2], c0[:, 1], c0[:, 0]))
+    assert np.array_equal(got[:5, 1:], c0[order]) and np.array_equal(got[5:, 1:], c0[order]) and list(got[:, 0]) == [0] * 5 + [1] * 5
+    assert np.array_equal(x[:5, :5].cpu().numpy(), ov.mean_vfe(v0, n0)[order])
+    vr, cr, nr = ov.hard_voxelize(pts[::-1].copy(), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
+    order_r = np.lexsort((cr[:, 2], cr[:, 1], cr[:, 0]))
+    assert np.array_equal(x[5:10, :5].cpu().numpy(), ov.mean_vfe(vr, nr)[order_r])
+
+
 def test_mean_vfe(device, golden_dir):
     from detzero_amd import ops
     g = np.load(os.path.join(golden_dir, 'det_golden.npz'))
@@ -164,6 +201,48 @@ def test_index_and_rulebooks_bit_exact(device, seed, n, vs, batch, layout):
         ref = osp.neighbor_table(cur, cur_shape, oc, k, s, p)
         assert np.array_equal(canon_table(nbr[:, :oc.shape[0]].cpu().numpy(), nxt_order, cur_order), ref)
         cur, cur_shape, cur_lvl, cur_order = oc, oshape, nxt, nxt_order
+
+
+@pytest.mark.parametrize('shape,fill', [([5, 9, 70], 0.5), ([4, 8, 64], 0.9), ([3, 5, 33], 0.25)])
+def test_rulebooks_on_dense_small_grids(device, shape, fill):
+    """The per-row neighbour kernel and the wave-merged output marking where their special cases are dense: grids whose rows do not
+    start on bitmap-word boundaries (x windows that straddle two words at bit 0 / 31), the first and the last word of the bitmap
+    (grid corners occupied), x = 0 / W - 1, paddings that put whole (z, y) rows outside the grid - every stage shape of the
+    backbone, against the oracle; the per-32-row tap masks must equal the table's own occupancy and be zero past the rows."""
+    from detzero_amd import ops
+    from oracle import sparse as osp
+    rng = np.random.default_rng(shape[2])
+    batch = 2
+    cells = shape[0] * shape[1] * shape[2]
+    lin = np.nonzero(rng.random(batch * cells) < fill)[0]
+    lin = np.unique(np.concatenate([lin, [0, 31, 32, batch * cells - 1, batch * cells - 33]]))
+    coords = np.stack([lin // cells, (lin % cells) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    lvl = ops.SparseLevel(batch, shape, coords.shape[0] + 5, device)
+    lvl.build_from_coords(_t(coords, device), want_rank=False)
+    assert lvl.num_active() == coords.shape[0]
+    # (np.nonzero order = ascending linear key = the canonical order of the rows)
+
+    def check(nbr, ref, m):
+        got = nbr[:, :m].cpu().numpy()
+        assert np.array_equal(got, ref)
+        masks = nbr.tile_masks.cpu().numpy().astype(np.uint32)
+        for gi in range(masks.shape[0]):
+            blk = ref[:, gi * 32:(gi + 1) * 32]
+            want = 0
+            for t in range(ref.shape[0]):
+                if blk.shape[1] and (blk[t] >= 0).any():
+                    want |= 1 << t
+            assert int(masks[gi]) == want, (gi, hex(int(masks[gi])), hex(want))
+
+    K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    check(lvl.neighbors_to(lvl, K3, S1, P1), osp.neighbor_table(coords, shape, coords, K3, S1, P1), coords.shape[0])
+    for k, s, p in [(K3, (2, 2, 2), (1, 1, 1)), (K3, (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]:
+        nxt = lvl.downsample(k, s, p)
+        oc, oshape = osp.conv_out_coords(coords, shape, k, s, p)
+        assert nxt.shape == list(oshape) and nxt.num_active() == oc.shape[0]
+        assert np.array_equal(nxt.coords[:oc.shape[0]].cpu().numpy(), oc)
+        check(lvl.neighbors_to(nxt, k, s, p), osp.neighbor_table(coords, shape, oc, k, s, p), oc.shape[0])
+        check(nxt.neighbors_to(nxt, K3, S1, P1), osp.neighbor_table(oc, list(oshape), oc, K3, S1, P1), oc.shape[0])
 
 
 def _random_level(rng, shape, n, batch, device, layout, dense_block=False):

@@ -52,4 +52,6 @@ echo "==== two-stage detector (PDV second stage)"
 timeout 300 python tools/bench_pdv.py 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv.json; cat $O/${TAG}_bench_pdv.json
 rm -rf $O/trace_pdv; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_pdv -o pdv -- python $GRAFT_REPO_ROOT/tools/bench_pdv.py --reps 5 > $O/trace_pdv_stdout.txt 2>&1 )
 python tools/rocpd_summary.py $O/trace_pdv/pdv_results.db > $O/${TAG}_kernel_trace_pdv.txt; head -12 $O/${TAG}_kernel_trace_pdv.txt
+echo "==== voxelize + index chain on its own"
+timeout 300 python tools/bench_index.py 2>/dev/null | tail -1 > $O/${TAG}_bench_index.json; cat $O/${TAG}_bench_index.json
 find $O -name "*.db" -delete
