@@ -273,19 +273,31 @@ __global__ void k_mean_vfe(const float *__restrict__ voxels, const int *__restri
 }
 
 // ---- dynamic voxelization ----------------------------------------------------------------------
+// (bitmap atomics merged per run of equal words over the wavefront, as in k_level_keys)
 __global__ void k_dyn_keys(const float *__restrict__ pts, int n, int stride, VoxGeom g, int batch,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ bitmap) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *p = pts + (size_t)i * stride;
-        const float xyz[3] = {p[1], p[2], p[3]};
-        int cx, cy, cz;
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
         uint32_t key = KEY_INVALID;
-        const int b = (int)p[0];
-        if ((unsigned)b < (unsigned)batch && voxel_coord(xyz, g, cx, cy, cz)) {
-            key = (uint32_t)(((b * g.g[0] + cx) * g.g[1] + cy) * g.g[2] + cz);
-            atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+        if (i < n) {
+            const float *p = pts + (size_t)i * stride;
+            const float xyz[3] = {p[1], p[2], p[3]};
+            int cx, cy, cz;
+            const int b = (int)p[0];
+            if ((unsigned)b < (unsigned)batch && voxel_coord(xyz, g, cx, cy, cz))
+                key = (uint32_t)(((b * g.g[0] + cx) * g.g[1] + cy) * g.g[2] + cz);
+            keys[i] = key;
         }
-        keys[i] = key;
+        const uint32_t w = key == KEY_INVALID ? KEY_INVALID : key >> 5;
+        uint32_t bits = key == KEY_INVALID ? 0u : 1u << (key & 31u);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t wp = (uint32_t)__shfl_up((int)w, d, 64), bp = (uint32_t)__shfl_up((int)bits, d, 64);
+            if (lane >= d && wp == w) bits |= bp;
+        }
+        const uint32_t wn = (uint32_t)__shfl_down((int)w, 1, 64);
+        if (bits && (lane == 63 || wn != w)) atomicOr(&bitmap[w], bits);
     }
 }
 
@@ -294,20 +306,34 @@ __global__ void k_dyn_keys(const float *__restrict__ pts, int n, int stride, Vox
 // order the atomics land in (fp32 atomics, as torch_scatter uses them in the reference, give run-to-run differences).
 constexpr float DYN_FIX = 268435456.f;        // 2^28
 
+// One thread per point.  Points arrive in scan order: the lanes of a wavefront hold runs of points of one voxel, whose fixed-point
+// values are summed in registers (segmented scan; integer addition, so the result is the same in any grouping) - the run's last
+// lane ranks the voxel and issues ONE atomic per channel and one for the count.
 __global__ void k_dyn_accumulate(const float *__restrict__ pts, int n, int c, const uint32_t *__restrict__ keys,
                                  const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ prefix, int cap,
                                  unsigned long long *__restrict__ acc, int *__restrict__ counts) {
-    const long total = (long)n * c;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(idx / c), ch = (int)(idx % c);
-        const uint32_t key = keys[i];
-        if (key == KEY_INVALID) continue;
-        const int v = bitmap_rank(bitmap, prefix, key);
-        if (v >= cap) continue;
-        const long long q = __float2ll_rn(pts[(size_t)i * (c + 1) + 1 + ch] * DYN_FIX);
-        atomicAdd(&acc[(size_t)v * c + ch], (unsigned long long)q);          // two's complement: wrap-around addition is signed addition
-        if (ch == 0) atomicAdd(&counts[v], 1);
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+        const uint32_t key = i < n ? keys[i] : KEY_INVALID;
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64), next = (uint32_t)__shfl_down((int)key, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || prev != key);
+        const int first = 63 - __clzll(heads & (~0ull >> (63 - lane)));           // first lane of this lane's run (runs are contiguous)
+        const int run = lane - first + 1;                                         // points of the run up to this lane
+        const bool last = key != KEY_INVALID && (lane == 63 || next != key);
+        int v = cap;
+        if (last) v = bitmap_rank(bitmap, prefix, key);
+        for (int ch = 0; ch < c; ++ch) {
+            long long q = key != KEY_INVALID ? __float2ll_rn(pts[(size_t)i * (c + 1) + 1 + ch] * DYN_FIX) : 0ll;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int lo = __shfl_up((int)(unsigned int)q, 1 << j, 64), hi = __shfl_up((int)(q >> 32), 1 << j, 64);
+                if (lane - (1 << j) >= first) q += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+            }
+            // two's complement: wrap-around addition is signed addition
+            if (v < cap) atomicAdd(&acc[(size_t)v * c + ch], (unsigned long long)q);
+        }
+        if (v < cap) atomicAdd(&counts[v], run);
     }
 }
 
@@ -592,7 +618,7 @@ int dz_voxelize_dynamic_mean(const float *points_b, int n, int c, const float *h
                          base + o_sw, sw_bytes, stream);
     if (rc) return rc;
     if (n > 0 && cap > 0) {
-        hipLaunchKernelGGL(k_dyn_accumulate, dim3(stream_grid((long)n * c, 256)), dim3(256), 0, stream, points_b, n, c,
+        hipLaunchKernelGGL(k_dyn_accumulate, dim3(stream_grid((long)n, 256)), dim3(256), 0, stream, points_b, n, c,
                            keys, bitmap, prefix, cap, acc, counts);
         hipLaunchKernelGGL(k_dyn_divide, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream, acc, feats, counts,
                            d_num_voxels, cap, c);

@@ -104,6 +104,14 @@ def test_voxelize_hard_runs_of_one_voxel(device):
     vr, cr, nr = ov.hard_voxelize(pts[::-1].copy(), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 100)
     order_r = np.lexsort((cr[:, 2], cr[:, 1], cr[:, 0]))
     assert np.array_equal(x[5:10, :5].cpu().numpy(), ov.mean_vfe(vr, nr)[order_r])
+    # dynamic route (run-merged fixed-point sums and counts): against the oracle, and bit-equal to the same points shuffled
+    pb = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts], 1)
+    fd0, cd0 = ov.dynamic_mean_vfe(pb, POINT_CLOUD_RANGE, VOXEL_SIZE_01)
+    fd1, cd1 = ops.voxelize_dynamic(_t(pb, device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 1)
+    assert np.array_equal(cd1.cpu().numpy(), cd0)
+    np.testing.assert_allclose(fd1.cpu().numpy(), fd0, rtol=1e-5, atol=1e-5)
+    fd2, cd2 = ops.voxelize_dynamic(_t(pb[rng.permutation(pb.shape[0])], device), POINT_CLOUD_RANGE, VOXEL_SIZE_01, 1)
+    assert torch.equal(cd2, cd1) and torch.equal(fd2, fd1)
 
 
 def test_mean_vfe(device, golden_dir):
