@@ -88,6 +88,37 @@ __global__ void k_sparse_to_bev_split(const unsigned short *__restrict__ feats, 
     }
 }
 
+// The same hand-over written DENSE for two z slabs (the encoded tensor of VoxelResBackBone8x): one thread per (pixel, group of 8
+// output channels) looks the pixel's two cells up in the level's bitmap and writes the group - 4 channels of the z = 0 row
+// interleaved with 4 of the z = 1 row (channel ch * 2 + z), zeros where a cell is empty or the pixel is border.  Every byte of
+// the image is written once with 16-byte stores: no zero-fill pass over the 591 MB canvas and no 2-byte scatter stores.
+__global__ __launch_bounds__(256) void k_sparse_to_bev_split_dense2(const uint2 *__restrict__ feats, const uint32_t *__restrict__ bitmap,
+                                                                     const uint32_t *__restrict__ prefix, LevelGeom lg, int c, int pad,
+                                                                     uint4 *__restrict__ bev) {
+    const int hp = lg.h + 2 * pad, wp = lg.w + 2 * pad;
+    const int groups = c * 2 / 8, in_groups = c / 8;
+    const long total = (long)lg.b * hp * wp * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int og = (int)(idx % groups);
+        const long pix = idx / groups;
+        const int xp = (int)(pix % wp), yp = (int)((pix / wp) % hp), b = (int)(pix / ((long)wp * hp));
+        const int x = xp - pad, y = yp - pad;
+        uint2 h0 = make_uint2(0u, 0u), l0 = h0, h1 = h0, l1 = h0;
+        if ((unsigned)x < (unsigned)lg.w && (unsigned)y < (unsigned)lg.h) {
+            const int r0 = bitmap_find(bitmap, prefix, lg.key(b, 0, y, x)), r1 = bitmap_find(bitmap, prefix, lg.key(b, 1, y, x));
+            // input group og / 2 (16 B hi | 16 B lo = four uint2), its channels (og & 1) * 4 .. + 3
+            if (r0 >= 0) { const uint2 *s = feats + ((size_t)r0 * in_groups + (og >> 1)) * 4 + (og & 1); h0 = s[0]; l0 = s[2]; }
+            if (r1 >= 0) { const uint2 *s = feats + ((size_t)r1 * in_groups + (og >> 1)) * 4 + (og & 1); h1 = s[0]; l1 = s[2]; }
+        }
+        auto zip = [](uint2 a, uint2 z) {       // 16-bit interleave: a0 z0 a1 z1 a2 z2 a3 z3
+            return make_uint4((a.x & 0xFFFFu) | (z.x << 16), (a.x >> 16) | (z.x & 0xFFFF0000u), (a.y & 0xFFFFu) | (z.y << 16),
+                              (a.y >> 16) | (z.y & 0xFFFF0000u));
+        };
+        bev[idx * 2] = zip(h0, h1);
+        bev[idx * 2 + 1] = zip(l0, l1);
+    }
+}
+
 }  // namespace dz
 
 using namespace dz;
@@ -151,6 +182,21 @@ int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m
     hipLaunchKernelGGL(k_sparse_to_bev_split, dim3(stream_grid((long)cap * c, 256)), dim3(256), 0, stream,
                        reinterpret_cast<const unsigned short *>(feats), coords, d_m, cap, c, d, h, w, pad,
                        reinterpret_cast<unsigned short *>(bev));
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_sparse_to_bev_split_dense(const float *feats, const uint32_t *bitmap, const uint32_t *prefix, int batch, int c, int d, int h,
+                                 int w, int layout, int pad, float *bev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(feats && bitmap && prefix && bev && batch > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0 && pad >= 0,
+                 "dz_sparse_to_bev_split_dense: bad argument");
+    if (d != 2) { set_error("dz_sparse_to_bev_split_dense: %d z slabs (the dense form interleaves exactly 2)", d); return DZ_ERR_UNSUPPORTED; }
+    DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_sparse_to_bev_split_dense: bad layout %d", layout);
+    const LevelGeom lg = make_level(batch, d, h, w, layout);
+    const long total = (long)batch * (h + 2 * pad) * (w + 2 * pad) * (c * 2 / 8);
+    hipLaunchKernelGGL(k_sparse_to_bev_split_dense2, dim3(stream_grid(total, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint2 *>(feats), bitmap, prefix, lg, c, pad, reinterpret_cast<uint4 *>(bev));
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

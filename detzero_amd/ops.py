@@ -7,6 +7,7 @@ returns tensors sliced to the exact size (one host sync, reference-compatible), 
 returns capacity-sized tensors plus the device count (graph-capturable).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -329,12 +330,21 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     return out
 
 
+BEV_DENSE = not os.environ.get('DZ_BEV_SCATTER')   # development switch: False = zero-fill + scatter (dz_sparse_to_bev_split) for two-slab levels too
+
+
 def sparse_to_bev(feats, level, c, pad=1, out=None, math=0):
     """-> (B, H+2p, W+2p, C*D) channel-last zero-bordered BEV image (pair16 in, pair16 out when math != 0)."""
     lib = L.load()
     d, h, w = level.shape
     if out is None:
         out = torch.empty((level.batch, h + 2 * pad, w + 2 * pad, c * d), dtype=torch.float32, device=feats.device)
+    if math and d == 2 and c % 8 == 0 and BEV_DENSE:
+        # two z slabs (the backbone's encoded tensor): the whole image, zeros included, written once from the level's own index
+        rc = lib.dz_sparse_to_bev_split_dense(L.ptr(feats), L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, c, d, h, w, level.layout,
+                                              pad, L.ptr(out), L.stream())
+        L.check(rc, 'dz_sparse_to_bev_split_dense')
+        return out
     out.zero_()
     fn = lib.dz_sparse_to_bev_split if math else lib.dz_sparse_to_bev
     rc = fn(L.ptr(feats), L.ptr(level.coords), L.ptr(level.d_m), level.cap, c, d, h, w, pad, L.ptr(out), L.stream())

@@ -106,6 +106,21 @@ def test_sparse_to_bev_split(device):
     ref = osp.to_bev(ops.pair16_to_f32(fp, 1).cpu(), coords, shape, 2)         # the halves are moved, not re-rounded
     assert torch.equal(plain[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).cpu(), ref)
     assert float(plain[:, 0].abs().max()) == 0 and float(plain[:, :, -1].abs().max()) == 0
+    # the two-slab level goes through the dense writer (every byte of the image, zeros included, from the level's index): the
+    # same bits as zero-fill + scatter, into a buffer that held garbage, and in the brick key layout
+    dirty = torch.full_like(bev, float('nan'))
+    assert torch.equal(ops.sparse_to_bev(fp, lvl, 128, pad=1, out=dirty, math=1).view(torch.int32), bev.view(torch.int32))
+    ops.BEV_DENSE = False
+    try:
+        scat = ops.sparse_to_bev(fp, lvl, 128, pad=1, math=1)
+    finally:
+        ops.BEV_DENSE = True
+    assert torch.equal(scat.view(torch.int32), bev.view(torch.int32))
+    lvl_b = ops.SparseLevel(2, shape, n, device, layout=1)
+    rank_b = lvl_b.build_from_coords(_t(coords, device))
+    fp_b = torch.empty_like(fp)
+    fp_b[rank_b.long()] = fp                                                    # rows in the brick order
+    assert torch.equal(ops.sparse_to_bev(fp_b, lvl_b, 128, pad=1, math=1).view(torch.int32), bev.view(torch.int32))
 
 
 @pytest.mark.parametrize('name,mid', MODES)
