@@ -112,7 +112,7 @@ def parse():
                          'f16 = one fp16 MFMA per product on the same tensors (fast mode, not fp32-class)')
     ap.add_argument('--overlap', action='store_true',
                     help='two-stage streaming pipeline (StreamingDetector: stage A of batch i+1 under stage B of batch i, results one step later) instead of '
-                         'one graph per step; +0.8 .. +1.4 % on MI355X (r03e build, A/B on one box), not the default')
+                         'one graph per step; +0.8 .. +1.4 %% on MI355X (r03e build, A/B on one box), not the default')
     ap.add_argument('--no-calibrate', action='store_true', help='keep worst-case level capacities (limits the batch to ~4 frames)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
