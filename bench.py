@@ -376,7 +376,8 @@ class Case:
         ch = list(self.model.backbone3d.channels) + [self.model.backbone3d.channels[-1]]     # channels of levels 0..4
 
         def pairs_of(nbr, m):
-            return int((nbr[:, :m] >= 0).sum().item())
+            from detzero_amd import ops
+            return ops.table_pairs(nbr, m)
 
         def conv(n_in, cin, m, cout, kvol, pairs, residual):
             return 4.0 * (n_in * cin + m * cout * (2 if residual else 1) + kvol * cin * cout) + 8.0 * pairs

@@ -281,6 +281,15 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
 
 using namespace dz;
 
+template <class M>
+static int spconv_w_packed_dispatch(const SpConvHArgs &a, hipStream_t stream) {
+    if (a.cin == 16 && a.cout == 16) return launch_spconv_w<16, 16, 4, M, 6, 3, true>(a, stream);
+    if (a.cin == 16 && a.cout == 32) return launch_spconv_w<16, 32, 3, M, 6, 3, true>(a, stream);
+    if (a.cin == 32 && a.cout == 32) return launch_spconv_w<32, 32, 2, M, 12, 3, true>(a, stream);
+    set_error("dz_spconv_forward_split_packed: %d -> %d channels (the packed table feeds the 16 -> 16, 16 -> 32 and 32 -> 32 kernels)", a.cin, a.cout);
+    return DZ_ERR_UNSUPPORTED;
+}
+
 extern "C" {
 
 int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nbr, const uint32_t *tile_masks, int kvol, int cap_out,
@@ -309,6 +318,27 @@ int dz_spconv_forward_split(const float *in, int in_rows, int cin, const int *nb
 #endif
     if (math == DZ_MATH_F16) return spconv_h_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? spconv_h_dispatch<MathF16>(a, stream) : spconv_h_dispatch<MathBF16>(a, stream);
+}
+
+int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const int *nbr_packed, const uint32_t *tile_masks, int cap_out,
+                                   const int *d_m_out, const float *w, const float *scale, const float *shift, const float *residual,
+                                   int relu, float *out, int cout, int math, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(in && nbr_packed && tile_masks && d_m_out && w && out, "dz_spconv_forward_split_packed: null pointer");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_spconv_forward_split_packed: math %d is not a split mode", math);
+    if (cap_out == 0) return DZ_OK;
+    const int kvol = 27, cout_pad = 32;
+    const size_t in_bytes = (size_t)in_rows * cin * sizeof(float);
+    const size_t w_bytes = (size_t)kvol * cout_pad * cin * sizeof(float);
+    const size_t nbr_bytes = (size_t)9 * cap_out * sizeof(int);
+    if (in_rows < 0 || in_bytes >= 0x80000000ull || nbr_bytes >= 0x80000000ull) {
+        set_error("dz_spconv_forward_split_packed: input of %zu / table of %zu bytes exceeds the 2 GiB buffer-addressing limit", in_bytes, nbr_bytes);
+        return DZ_ERR_UNSUPPORTED;
+    }
+    SpConvHArgs a{in, nbr_packed, tile_masks, d_m_out, w, scale, shift, residual, out, cin, cout, cout_pad, kvol, cap_out, relu,
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, (unsigned int)tile_masks_words(cap_out) * 4u, 0};
+    if (math == DZ_MATH_F16) return spconv_w_packed_dispatch<MathF16H>(a, stream);
+    return math == DZ_MATH_F16X2 ? spconv_w_packed_dispatch<MathF16>(a, stream) : spconv_w_packed_dispatch<MathBF16>(a, stream);
 }
 
 const char *dz_spconv_variant_split(int cin, int cout) {

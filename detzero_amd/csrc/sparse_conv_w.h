@@ -55,7 +55,7 @@ struct WChunk {
     unsigned int rowoff[2];   // per lane: byte offset of its row of each 16-pixel half in one tap of the table (or out of range)
 };
 
-template <int CIN, int COUT, int G, class M, int WAVES, int OCC>
+template <int CIN, int COUT, int G, class M, int WAVES, int OCC, bool PK = false>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC))) void k_spconv_w(SpConvHArgs a) {
     constexpr int KS = CIN / 16;            // 32-deep MFMA steps per tap (16 channels x (hi, lo))
     constexpr int KG = CIN / 8;             // 8-channel groups of a row
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
     auto issue_idx = [&](const WChunk &c, int (&dst)[G][2]) {
 #pragma unroll
         for (int s = 0; s < G; ++s) {
-            unsigned int toff = ((c.taps >> (5 * s)) & 31u) * nbr_tap_bytes;      // scalar: rides in the instruction's soffset
+            // scalar: rides in the instruction's soffset.  PK: the packed table has one row per (tz, ty) = tap / 3 (the entry is loaded
+            // once per slot all the same: a second load of it hits the line, and the hand-counted load stream keeps its shape)
+            unsigned int toff = (PK ? ((c.taps >> (5 * s)) & 31u) / 3u : ((c.taps >> (5 * s)) & 31u)) * nbr_tap_bytes;
 #ifdef DZ_SPCONV_DIAG
             if (a.diag == 3) toff = 0u;                        // every index load reads tap 0 (cache hits)
 #endif
@@ -191,6 +193,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 asm volatile("" : "+v"(ix[s][h]));
+                if (PK) {
+                    // packed entry (DZ_NBR_PACKED): r = active cells below the centre of the x window (bits 0..28), presence of the
+                    // left / centre / right tap (bits 29..31): left = r - 1, centre = r, right = r + centre.  Branch-free: the tap's
+                    // position in its window is wave-uniform, so its shift / offset / centre mask are scalars
+                    const unsigned int tx = ((c.taps >> (5 * s)) & 31u) % 3u;
+                    const unsigned int sh = 29u + tx, cm = tx >> 1;                     // cm = 1 for the right tap
+                    const int dl = (int)((tx + 2u) / 3u) - 1;                           // -1 for the left tap, else 0
+                    const unsigned int e = (unsigned int)ix[s][h];
+                    const int keep = __builtin_amdgcn_sbfe((int)e, sh, 1u);              // 0 / -1: the tap's presence bit, sign-extended
+                    const int v = (int)(e & 0x1FFFFFFFu) + dl + (int)((e >> 30) & cm);
+                    ix[s][h] = (v & keep) | ~keep;
+                }
                 if (__ballot(ix[s][h] >= 0) != 0ull) pres |= 1u << (2 * s + h);
                 unsigned int base = (unsigned int)ix[s][h] * (unsigned int)ROWB + (unsigned int)(kg * 16);
 #ifdef DZ_SPCONV_DIAG
@@ -339,11 +353,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(OCC)
     asm volatile("s_waitcnt vmcnt(0)");
 }
 
-template <int CIN, int COUT, int G, class M, int WAVES, int OCC>
+template <int CIN, int COUT, int G, class M, int WAVES, int OCC, bool PK = false>
 static int launch_spconv_w(const SpConvHArgs &a, hipStream_t stream) {
     const int lds = a.kvol * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4;
     static PerDeviceFlags lds_done;
-    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_spconv_w<CIN, COUT, G, M, WAVES, OCC>), 27 * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4, lds_done, "dz_spconv_forward_split")) return rc_;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_spconv_w<CIN, COUT, G, M, WAVES, OCC, PK>), 27 * (COUT / 16) * (CIN / 8) * 2 * 16 * 16 + 64 * 4, lds_done, "dz_spconv_forward_split")) return rc_;
     // persistent workgroups: as many as fit on the chip, a multiple of 8 for the XCD schedule
     const int cus = device_cus();
     const int per_cu = (4 * OCC) / WAVES > 0 ? (4 * OCC) / WAVES : 1;
@@ -352,7 +366,7 @@ static int launch_spconv_w(const SpConvHArgs &a, hipStream_t stream) {
     if (grid > need) grid = need;
     grid = (grid + 7) & ~7;
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((k_spconv_w<CIN, COUT, G, M, WAVES, OCC>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
+    hipLaunchKernelGGL((k_spconv_w<CIN, COUT, G, M, WAVES, OCC, PK>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -440,7 +440,7 @@ __device__ __forceinline__ void nbr_row3(nbr_u3 w, nbr_u3 p, int ci, uint32_t bc
     vr = rbit && rv ? rrank : -1;
 }
 
-template <int K0, int K1, int KW, bool XCD>
+template <int K0, int K1, int KW, bool XCD, bool PACK = false>
 __global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restrict__ coords_out, const int *__restrict__ d_m_out,
                                                               int cap_out, const uint32_t *__restrict__ bitmap_in,
                                                               const uint32_t *__restrict__ prefix_in, LevelGeom li, ConvGeom g,
@@ -525,7 +525,15 @@ __global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restr
 #if DZ_NBR_DIAG & 2
                 bits ^= (uint32_t)(vl + vc + vr) & 0x8000000u;
 #else
-                if (o < m) {
+                if (PACK) {
+                    // packed row entry (DZ_NBR_PACKED, include/detzero_hip.h): the three x taps are consecutive ranks, so one word
+                    // holds r = active cells below the centre (bits 0..28) and the presence of left / centre / right (bits 29..31):
+                    // left = r - 1, centre = r, right = r + centre.  r from whichever neighbour exists (a prefix word is only
+                    // valid where its bitmap word holds a bit)
+                    const uint32_t rr = vl >= 0 ? (uint32_t)vl + 1u : (vc >= 0 ? (uint32_t)vc : (vr >= 0 ? (uint32_t)vr : 0u));
+                    const uint32_t e = rr | (vl >= 0 ? 1u << 29 : 0u) | (vc >= 0 ? 1u << 30 : 0u) | (vr >= 0 ? 1u << 31 : 0u);
+                    if (o < m) __builtin_amdgcn_raw_buffer_store_b32((int)e, tab, voff, (uint32_t)r * row_bytes, 0);
+                } else if (o < m) {
                     __builtin_amdgcn_raw_buffer_store_b32(vl, tab, voff, (uint32_t)tap * row_bytes, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(vc, tab, voff, (uint32_t)(tap + 1) * row_bytes, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(vr, tab, voff, (uint32_t)(tap + 2) * row_bytes, 0);
@@ -765,6 +773,31 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
     const long work = (long)cap_out * g.k[0] * g.k[1];
     hipLaunchKernelGGL(k_build_neighbors, dim3(stream_grid(work, 256)), dim3(256), 0, stream, coords_out, d_m_out,
                        cap_out, bitmap_in, prefix_in, li, g, nbr, tile_masks);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_build_neighbors_packed(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
+                              const uint32_t *prefix_in, int b, int d, int h, int w, int layout, const int *h_k3, const int *h_s3,
+                              const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(coords_out && d_m_out && bitmap_in && prefix_in && nbr && tile_masks, "dz_build_neighbors_packed: null argument");
+    ConvGeom g;
+    DZ_CHECK_ARG(geom_from(h_k3, h_s3, h_p3, d, h, w, g), "dz_build_neighbors_packed: bad kernel/stride/padding");
+    const bool kw3 = g.k[2] == 3 && g.p[2] == 1 && (long)(g.ow - 1) * g.s[2] <= w - 1;
+    const size_t table_bytes = (size_t)9 * cap_out * sizeof(int);
+    if (layout != DZ_LAYOUT_LINEAR || g.k[0] != 3 || g.k[1] != 3 || !kw3 || table_bytes >= 0xFFFFFFFFull || cap_out >= (1 << 29)) {
+        set_error("dz_build_neighbors_packed: needs linear keys, a 3 x 3 x 3 window with x padding 1 and fewer than 2^29 rows");
+        return DZ_ERR_UNSUPPORTED;
+    }
+    if (cap_out == 0) return DZ_OK;
+    const LevelGeom li = make_level(b, d, h, w, layout);
+    const int mask_rows = tile_masks_words(cap_out) * 32;
+    const size_t index_words = dz_index_words(b, d, h, w, layout);
+    const dim3 grid((stream_grid(mask_rows, 256) + 7) & ~7);
+    hipLaunchKernelGGL((k_build_neighbors_rows<3, 3, 3, true, true>), grid, dim3(256), 0, stream, coords_out, d_m_out, cap_out, bitmap_in,
+                       prefix_in, li, g, nbr, tile_masks, mask_rows, (uint32_t)(index_words - 3), (uint32_t)(index_words * 4),
+                       (uint32_t)table_bytes);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

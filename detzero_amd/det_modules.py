@@ -23,6 +23,8 @@ import torch.nn as nn
 from . import ops
 from .lib import DetZeroHipError
 
+PACKED_TABLES = bool(os.environ.get('DZ_TUNE_PACKED_TABLES'))     # opt-in: packed 27-tap tables for the small-channel levels (measured equal)
+
 K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
 
 
@@ -334,8 +336,12 @@ class VoxelResBackBone8x(_Cached):
         steps = []          # (down neighbour table or None, same-level table or None, level, ready event or None)
         tiled = self.engine == 'tiles' and self.math != 0
 
+        # opt-in (PACKED_TABLES): tables read only by the small-channel split-math kernels (<= 32 output channels: conv_input, conv1,
+        # conv2) built packed - a third of the words; the index chain gains what the decode costs the convolutions
+        pack = PACKED_TABLES and self.math != 0 and not tiled and self.layout == 0 and os.environ.get('DZ_TUNE_SPCONV_W', '1') != '0'
+
         def table(src, dst, k, s, p, cout):
-            nbr = src.neighbors_to(dst, k, s, p)
+            nbr = src.neighbors_to(dst, k, s, p, packed=pack and cout <= 32)
             return ops.build_tiles(nbr, dst) if tiled and cout in self.tile_couts and k[0] * k[1] * k[2] >= 3 else nbr
         ch = self.channels
         with torch.cuda.stream(side):

@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdetzero_hip.so')
 
 
+ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4        # include/detzero_hip.h
+
+
 class DetZeroHipError(RuntimeError):
     pass
 
@@ -87,6 +90,8 @@ _SIGS = {
     'dz_tile_masks_words': (c_int, [c_int]),
     'dz_build_neighbors': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dz_build_neighbors_packed': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_spconv_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p, c_int, c_void_p]),
@@ -100,6 +105,8 @@ _SIGS = {
     'dz_scatter_rows_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_forward_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'dz_spconv_forward_split_packed': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_tile_rows': (c_int, []),
     'dz_spconv_tile_info_words': (c_int, []),
     'dz_spconv_tile_table_entries': (c_int, []),

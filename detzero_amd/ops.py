@@ -224,18 +224,51 @@ class SparseLevel:
         L.check(rc, 'dz_index_downsample')
         return out
 
-    def neighbors_to(self, out_level, k, s, p):
-        """(kvol, out_level.cap) i32 neighbour table: rows of THIS level feeding each output row."""
+    def neighbors_to(self, out_level, k, s, p, packed=False):
+        """(kvol, out_level.cap) i32 neighbour table: rows of THIS level feeding each output row.
+        packed=True asks for the packed form of a 27-tap table (dz_build_neighbors_packed: (9, cap) words, `.packed` = True,
+        `.kvol` = 27) - what the small-channel split-math convolutions read; windows / layouts it does not cover come back
+        unpacked."""
         lib = L.load()
         kvol = k[0] * k[1] * k[2]
-        nbr = torch.empty((kvol, max(out_level.cap, 1)), dtype=torch.int32, device=self.coords.device)
-        masks = torch.empty((lib.dz_tile_masks_words(max(out_level.cap, 1)),), dtype=torch.int32, device=self.coords.device)
-        rc = lib.dz_build_neighbors(L.ptr(out_level.coords), L.ptr(out_level.d_m), out_level.cap,
-                                    L.ptr(self.bitmap), L.ptr(self.prefix), self.batch, *self.shape, self.layout, L.i3(k),
-                                    L.i3(s), L.i3(p), L.ptr(nbr), L.ptr(masks), L.stream())
+        cap = max(out_level.cap, 1)
+        masks = torch.empty((lib.dz_tile_masks_words(cap),), dtype=torch.int32, device=self.coords.device)
+        args = (L.ptr(out_level.coords), L.ptr(out_level.d_m), out_level.cap, L.ptr(self.bitmap), L.ptr(self.prefix), self.batch,
+                *self.shape, self.layout, L.i3(k), L.i3(s), L.i3(p))
+        if packed and kvol == 27 and self.layout == LAYOUT_LINEAR and p[2] == 1 and cap < (1 << 29):
+            nbr = torch.empty((9, cap), dtype=torch.int32, device=self.coords.device)
+            rc = lib.dz_build_neighbors_packed(*args, L.ptr(nbr), L.ptr(masks), L.stream())
+            if rc == 0:
+                nbr.tile_masks = masks
+                nbr.packed, nbr.kvol = True, 27
+                return nbr
+            if rc != L.ERR_UNSUPPORTED:
+                L.check(rc, 'dz_build_neighbors_packed')
+        nbr = torch.empty((kvol, cap), dtype=torch.int32, device=self.coords.device)
+        rc = lib.dz_build_neighbors(*args, L.ptr(nbr), L.ptr(masks), L.stream())
         L.check(rc, 'dz_build_neighbors')
         nbr.tile_masks = masks        # per-32-row tap masks ride along with the table (consumed by spconv_forward)
         return nbr
+
+
+def unpack_table(nbr):
+    """The (27, cap) form of a packed neighbour table (tests, statistics); other tables are returned as they are."""
+    if not getattr(nbr, 'packed', False):
+        return nbr
+    e = nbr.to(torch.int64) & 0xFFFFFFFF
+    r = e & 0x1FFFFFFF
+    left, cen, right = (e >> 29) & 1, (e >> 30) & 1, (e >> 31) & 1
+    minus = torch.full_like(r, -1)
+    taps = torch.stack([torch.where(left == 1, r - 1, minus), torch.where(cen == 1, r, minus), torch.where(right == 1, r + cen, minus)], dim=1)
+    return taps.reshape(27, nbr.shape[1]).to(torch.int32)
+
+
+def table_pairs(nbr, m):
+    """Number of (input, output) pairs of the first m output rows of a neighbour table (host sync)."""
+    if getattr(nbr, 'packed', False):
+        e = nbr[:, :m].to(torch.int64) & 0xFFFFFFFF
+        return int((((e >> 29) & 1) + ((e >> 30) & 1) + ((e >> 31) & 1)).sum().item())
+    return int((nbr[:, :m] >= 0).sum().item())
 
 
 def build_tiles(nbr, out_level):
@@ -289,6 +322,11 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     lib = L.load()
     L.require_cuda(feats, nbr, w_taps, scale, shift, residual)
     kvol, cap = nbr.shape
+    packed = getattr(nbr, 'packed', False)
+    if packed:
+        kvol = nbr.kvol
+        if not math:
+            raise L.DetZeroHipError('spconv_forward: a packed neighbour table feeds the split-math kernels only')
     if math:
         # (split weights are padded to 32 output channels: the true count comes from the BatchNorm vector, or `cout=`)
         cin, cout = w_taps.shape[2], (int(cout) if cout is not None else scale.shape[0] if scale is not None else w_taps.shape[1])
@@ -305,6 +343,10 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
             rc = lib.dz_spconv_tiles_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(tiles[0]), L.ptr(tiles[1]), L.ptr(tiles[2]),
                                              L.ptr(tiles[3]), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale),
                                              L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
+        elif packed:
+            rc = lib.dz_spconv_forward_split_packed(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(nbr.tile_masks), cap,
+                                                    L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual),
+                                                    1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
         elif math:
             rc = lib.dz_spconv_forward_split(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(getattr(nbr, 'tile_masks', None)),
                                              kvol, cap, L.ptr(out_level.d_m),
@@ -320,7 +362,7 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     else:
         # algorithmic work of this launch: 2*pairs*cin*cout FLOP; bytes per BASELINE.md section 3
         m = out_level.num_active()
-        pairs = int((nbr[:, :m] >= 0).sum().item())
+        pairs = table_pairs(nbr, m)
         flops = 2.0 * pairs * cin * cout
         n_in = in_level.num_active() if in_level is not None else m
         nbytes = 4.0 * (n_in * cin + m * cout + kvol * cin * cout + (m * cout if residual is not None else 0)) + 8.0 * pairs

@@ -139,6 +139,15 @@ int dz_build_neighbors(const int *coords_out, const int *d_m_out, int cap_out, c
 /* tile_masks (dz_tile_masks_words(cap_out) words, 16-byte aligned, or NULL): bit t of word o/32 = some row of the 32-row
  * group o/32 has a neighbour at tap t (what the conv kernels need to skip empty taps without scanning the table). */
 int dz_tile_masks_words(int cap_out);
+/* The same rulebook PACKED (DZ_NBR_PACKED) for 3 x 3 x 3 windows with x padding 1 on linear keys (every 27-tap table of
+ * VoxelResBackBone8x, backbone3d.py:243-280): rows are in key order, so the three x taps of a (tz, ty) row are consecutive input
+ * rows - one word per (tz, ty) and output row holds them: nbr[(tz*3+ty)*cap_out + o] = r | left << 29 | centre << 30 | right << 31
+ * with r = active input cells below the centre cell of the window; left neighbour = r - 1, centre = r, right = r + centre (each
+ * only when its bit is set).  9 words per output row instead of 27: a third of the table bytes written here and read by every
+ * convolution of the level.  tile_masks as dz_build_neighbors (required).  DZ_ERR_UNSUPPORTED for other windows / layouts. */
+int dz_build_neighbors_packed(const int *coords_out, const int *d_m_out, int cap_out, const uint32_t *bitmap_in,
+                              const uint32_t *prefix_in, int b, int d, int h, int w, int layout, const int *h_k3,
+                              const int *h_s3, const int *h_p3, int *nbr, uint32_t *tile_masks, void *stream);
 
 /* dst[rank[i]][0:c_src] = src[i][0:c_src]; dst[rank[i]][c_src:c_dst] = 0 (rows with rank<0 skipped) */
 int dz_scatter_rows(const float *src, const int *rank, const int *d_n, int n_cap, int c_src, float *dst,
@@ -242,6 +251,11 @@ int dz_spconv_tiles_forward(const float *in, int in_rows, int cin, const int *ha
                             const float *scale, const float *shift, const float *residual, int relu, float *out, int cout,
                             int math, void *stream);
 const char *dz_spconv_tiles_variant(int cin, int cout);
+/* dz_spconv_forward_split over a PACKED 27-tap table (dz_build_neighbors_packed): the small-channel levels (16 -> 16, 16 -> 32,
+ * 32 -> 32), whose HBM bytes are one third table in the unpacked form.  Same arithmetic, bit-identical results. */
+int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const int *nbr_packed, const uint32_t *tile_masks,
+                                   int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
+                                   const float *residual, int relu, float *out, int cout, int math, void *stream);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);

@@ -87,6 +87,57 @@ def test_spconv_split_vs_oracle(device, cin, cout, kvol, name, mid):
     torch.testing.assert_close(got, ref, rtol=TOL[mid], atol=TOL[mid])
 
 
+@pytest.mark.parametrize('name,mid', MODES)
+def test_packed_neighbour_tables(device, name, mid):
+    """The packed 27-tap rulebook (one word per (tz, ty) row of the window: rank below the centre + three presence bits) holds the
+    same triples as the plain table - on a dense grid whose rows straddle bitmap words, for submanifold and strided windows, and on
+    a level whose prefix words are only valid where the bitmap has bits (dz_voxelize_to_level) - and the small-channel
+    convolutions give the same bits from either form, with and without a residual."""
+    from detzero_amd import ops
+    from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_02, synth_waymo_frame
+    rng = np.random.default_rng(5 + mid)
+    shape, batch = [5, 9, 70], 2
+    cells = shape[0] * shape[1] * shape[2]
+    lin = np.nonzero(rng.random(batch * cells) < 0.5)[0]
+    lin = np.unique(np.concatenate([lin, [0, 31, 32, batch * cells - 1]]))
+    coords = np.stack([lin // cells, (lin % cells) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    lvl = ops.SparseLevel(batch, shape, coords.shape[0] + 3, device)
+    lvl.build_from_coords(_t(coords, device), want_rank=False)
+    K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    cases = [(lvl, lvl, K3, S1, P1)]
+    for s, p in (((2, 2, 2), (1, 1, 1)), ((2, 2, 2), (0, 1, 1))):
+        cases.append((lvl, lvl.downsample(K3, s, p), K3, s, p))
+    grid = [int(round((POINT_CLOUD_RANGE[3 + i] - POINT_CLOUD_RANGE[i]) / VOXEL_SIZE_02[i])) for i in range(3)]
+    lvl1, _ = ops.voxelize_to_level(_t(np.concatenate([synth_waymo_frame(3, 20000), synth_waymo_frame(4, 20000)], 0), device), 2,
+                                    POINT_CLOUD_RANGE, VOXEL_SIZE_02, 5, 200000, [grid[2] + 1, grid[1], grid[0]], 16, math=mid, xy_range_mask=True)
+    assert lvl1.prefix_partial
+    cases.append((lvl1, lvl1, K3, S1, P1))
+    cases.append((lvl1, lvl1.downsample(K3, (2, 2, 2), (1, 1, 1)), K3, (2, 2, 2), (1, 1, 1)))
+    for src, dst, k, s, p in cases:
+        plain = src.neighbors_to(dst, k, s, p)
+        packed = src.neighbors_to(dst, k, s, p, packed=True)
+        assert getattr(packed, 'packed', False) and tuple(packed.shape) == (9, plain.shape[1]) and packed.kvol == 27
+        m = dst.num_active()
+        assert torch.equal(ops.unpack_table(packed)[:, :m], plain[:, :m])
+        assert torch.equal(packed.tile_masks, plain.tile_masks)
+        assert ops.table_pairs(packed, m) == ops.table_pairs(plain, m) == int((plain[:, :m] >= 0).sum().item())
+        for cin, cout in ((16, 16), (16, 32), (32, 32)):
+            w = ops.pack_weight_split(_t((rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32), device), mid)
+            scale, shift = _t(rng.uniform(0.5, 1.5, cout).astype(np.float32), device), _t(rng.standard_normal(cout).astype(np.float32) * 0.1, device)
+            x = ops.pair16_from_f32(_t(rng.standard_normal((src.cap, cin)).astype(np.float32), device), cin, mid)
+            res = ops.pair16_from_f32(_t(rng.standard_normal((dst.cap, cout)).astype(np.float32), device), cout, mid)
+            for r in (None, res):
+                a = ops.spconv_forward(x, plain, dst, w, scale, shift, r, relu=True, in_level=src, math=mid)
+                b = ops.spconv_forward(x, packed, dst, w, scale, shift, r, relu=True, in_level=src, math=mid)
+                assert torch.equal(a[:m].view(torch.int32), b[:m].view(torch.int32)), (cin, cout, s, r is not None)
+    # windows the packed form does not cover come back plain
+    odd = lvl.neighbors_to(lvl.downsample((3, 1, 1), (2, 1, 1), (0, 0, 0)), (3, 1, 1), (2, 1, 1), (0, 0, 0), packed=True)
+    assert not getattr(odd, 'packed', False) and odd.shape[0] == 3
+    with pytest.raises(Exception):
+        ops.spconv_forward(ops.pair16_to_f32(x, mid)[:, :16].contiguous(), packed, dst, torch.zeros((27, 16, 16), device=x.device),
+                           None, None, math=0)
+
+
 def test_sparse_to_bev_split(device):
     from detzero_amd import ops
     from oracle import sparse as osp

@@ -24,6 +24,7 @@ def main():
     dev = torch.device('cuda:0')
     case = bench.Case(args, dev, 0, 'f16x2', a.batch)
     pipe = case.pipe
+    from detzero_amd import ops
     from detzero_amd.centerpoint import _StackedFrames
     frames = _StackedFrames(case.static_in.contiguous())
 
@@ -63,7 +64,7 @@ def main():
     pairs = []
     for nbr_d, nbr_s, lvl, _ in pyr['steps']:
         m = lvl.num_active()
-        pairs.append([None if t is None else int((t[:, :m] >= 0).sum().item()) for t in (nbr_d, nbr_s)])
+        pairs.append([None if t is None else ops.table_pairs(t, m) for t in (nbr_d, nbr_s)])
     print(json.dumps({'batch': a.batch, 'points': a.points, 'eager_voxelize_ms': round(tv, 4), 'eager_pyramid_ms': round(tp, 4),
                       'graph_chain_ms': round(e0.elapsed_time(e1) / a.reps, 4), 'rows': rows, 'pairs': pairs,
                       'caps': [st[2].cap for st in pyr['steps']]}))
