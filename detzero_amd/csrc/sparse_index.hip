@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void k_mark_outputs_w(const int *__restrict__ 
 // neighbour (when its bit is set) is row r - 1, the centre r, the right one r + centre_bit; when the centre sits at bit 0 / 31
 // the outer cell is bit 31 / 0 of the adjacent word (rank from that word's own prefix - a prefix entry is only valid where the
 // word holds a bit, common.h).  A thread fetches the THREE words around the centre with one 12-byte load each from the bitmap
-// and the prefix array: 2 * K0 * K1 independent, unconditional loads in flight together, no divergent second lookups (with 64
-// lanes nearly every wavefront has a lane at bit 0 or 31, and 18 serialised two-load lookups were most of the kernel's time).
+// and the prefix array: 2 * K0 * K1 independent, unconditional loads, the next z slab's issued before the current slab's taps are
+// computed, no divergent second lookups (with 64 lanes nearly every wavefront has a lane at bit 0 or 31).
 // A lane's tap mask is OR-reduced over its 32-row group in registers and stored - no atomics, no zero-fill of the mask words
 // (rows past the count store 0).
 #ifndef DZ_NBR_DIAG
