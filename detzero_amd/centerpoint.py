@@ -10,6 +10,8 @@ voxelize -> VFE -> sparse backbone -> BEV -> head -> decode -> NMS, every size-d
 in device counters, so one frame is ~110 kernel launches with no host synchronisation; results are
 padded (500, 9) boxes + a count, which is also the payload of the RCCL gather.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -233,6 +235,9 @@ def set_sparse_engine(model, engine):
     return model
 
 
+# development switch: DZ_TUNE_EAGER_PYRAMID=1 builds the whole index pyramid before the first convolution (the r01c-r03f schedule)
+STAGGERED_PYRAMID = not os.environ.get('DZ_TUNE_EAGER_PYRAMID')
+
 F16_PAIR_SAFE_MAX = 3.0e4      # |activation| up to which fp16 pairs are used (fp16 saturates at 65504; interior layers get 2x headroom)
 
 
@@ -363,21 +368,23 @@ class FramePipeline:
         return ('voxels',) + tuple(self._voxelize(frames))
 
     @torch.no_grad()
-    def pyramid_stage(self, vox, nb, overlap=True):
-        """Voxels -> the sparse index pyramid of the backbone (output sets, bitmaps, neighbour tables of every stage)."""
+    def pyramid_stage(self, vox, nb, overlap=True, staggered=False):
+        """Voxels -> the sparse index pyramid of the backbone (output sets, bitmaps, neighbour tables of every stage).
+        staggered (with overlap): the deeper stages are indexed from inside `backbone_stage`, each under the convolutions of the
+        stage before it (VoxelResBackBone8x.build_pyramid)."""
         caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
         bb = self.model.backbone3d
         if vox[0] == 'level':
-            pyr = bb.build_pyramid(vox[2], None, nb, None, overlap=overlap, caps=caps, level1=vox[1])
+            pyr = bb.build_pyramid(vox[2], None, nb, None, overlap=overlap, caps=caps, level1=vox[1], staggered=staggered)
         else:
-            pyr = bb.build_pyramid(vox[1], vox[2], nb, vox[3], overlap=overlap, caps=caps)
+            pyr = bb.build_pyramid(vox[1], vox[2], nb, vox[3], overlap=overlap, caps=caps, staggered=staggered)
         pyr['nb'] = nb
         return pyr
 
-    def prepare(self, frames, overlap=True):
+    def prepare(self, frames, overlap=True, staggered=False):
         """Stage A: everything that depends only on the points - voxelization, voxel features, the sparse index
         pyramid of the backbone.  Returns an opaque dict for ``infer``."""
-        return self.pyramid_stage(self.voxelize_stage(frames), len(frames), overlap)
+        return self.pyramid_stage(self.voxelize_stage(frames), len(frames), overlap, staggered)
 
     @torch.no_grad()
     def calibrate(self, frames, margin=1.5):
@@ -417,8 +424,8 @@ class FramePipeline:
     @torch.no_grad()
     def backbone_stage(self, prep):
         """The 21 sparse convolutions -> {name: (rows, SparseLevel)}."""
+        res = self.model.backbone3d.run_pyramid(prep)            # (a staggered pyramid finishes its index, and the flag, in here)
         self.last_overflow = prep.get('overflow', None)          # flag of THIS pass (device bool); the counter below is sticky
-        res = self.model.backbone3d.run_pyramid(prep)
         if self.last_overflow is not None:
             # (after run_pyramid: the flag is written on the index-pyramid side stream, and the main stream has by now waited for
             # the last stage's event, which covers it)
@@ -457,7 +464,7 @@ class FramePipeline:
             frames = _StackedFrames(points.contiguous())
         else:
             frames = points if isinstance(points, _StackedFrames) else list(points)
-        out, d_nk = self.infer(self.prepare(frames))
+        out, d_nk = self.infer(self.prepare(frames, staggered=STAGGERED_PYRAMID))
         return (out[0], d_nk) if single else (out, d_nk)
 
 

@@ -307,7 +307,8 @@ class VoxelResBackBone8x(_Cached):
         y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
         return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
-    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None, level1=None):
+    def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None, level1=None,
+                      staggered=False):
         """Everything of the backbone that depends only on voxel COORDINATES: the level-1 index + feature scatter and
         the output sets / bitmaps / neighbour tables of every stage.  Returns {'x': level-1 rows, 'steps': [...]}.
 
@@ -315,6 +316,11 @@ class VoxelResBackBone8x(_Cached):
         branch) so that they run under the convolutions of the earlier stages; events order each stage's tables
         before their first use.  overlap=False keeps everything on the current stream (used when the whole
         preparation stage is itself overlapped with the previous batch, see StreamingDetector).
+
+        staggered=True (with overlap): only level 1 is built here; `run_pyramid` asks for the index of stage i + 1 when it
+        starts the convolutions of stage i (pyr['build_stage']), gated on the main stream's progress - each stage's ~0.1-0.3 ms
+        of index kernels then runs under the convolutions of the stage before it instead of all of them crowding under the
+        memory-bound level-1 convolutions.
 
         caps: optional row capacities of the 4 strided stages (conv2, conv3, conv4, conv_out).  The default is the
         worst case (min(cells, 8 x inputs)), which is safe but grows with the batch; calibrated capacities
@@ -343,13 +349,32 @@ class VoxelResBackBone8x(_Cached):
         def table(src, dst, k, s, p, cout):
             nbr = src.neighbors_to(dst, k, s, p, packed=pack and cout <= 32)
             return ops.build_tiles(nbr, dst) if tiled and cout in self.tile_couts and k[0] * k[1] * k[2] >= 3 else nbr
+
+        def hand_over(step):                        # tensors born on the side stream are consumed on the main stream
+            nbr_d, nbr_s, lvl, _ = step
+            for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
+                if t is not None:
+                    t.record_stream(main)
+                    if getattr(t, 'tile_masks', None) is not None:
+                        t.tile_masks.record_stream(main)
+                    for tt in getattr(t, 'tiles', None) or ():
+                        tt.record_stream(main)
         ch = self.channels
         with torch.cuda.stream(side):
             nbr1 = table(lvl1, lvl1, K3, S1, P1, ch[0])
             steps.append((None, nbr1, lvl1, side.record_event() if overlap else None))
-            level = lvl1
-            overflow = None
-            for li, name in enumerate(('conv2', 'conv3', 'conv4', 'conv_out')):
+        x = voxel_features if level1 is not None else ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
+        pyr = {'x': x, 'steps': steps}
+        names = ('conv2', 'conv3', 'conv4', 'conv_out')
+
+        def build_stage(li, gate=None):
+            """Index of stage names[li] (output set, strided table, its submanifold table) on the side stream; gate = an event of the
+            main stream the work waits for."""
+            name = names[li]
+            level = steps[li][2]
+            with torch.cuda.stream(side):
+                if gate is not None:
+                    side.wait_event(gate)
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
                 nxt = level.downsample(dp['k'], dp['s'], dp['p'], cap=None if caps is None else int(caps[li]))
                 co = ch[min(li + 1, 3)]
@@ -363,24 +388,19 @@ class VoxelResBackBone8x(_Cached):
                     cache = self.__dict__.setdefault('_cap_limits', {})
                     if key not in cache:    # created on the first (eager, warm-up) call: no H2D copy inside a graph capture
                         cache[key] = torch.tensor(key[0], dtype=torch.int32, device=dev)
-                    overflow = (torch.cat([l.d_m for l in lv]) > cache[key]).any()
+                    pyr['overflow'] = (torch.cat([l.d_m for l in lv]) > cache[key]).any()
                 steps.append((nbr_d, nbr_s, nxt, side.record_event() if overlap else None))
-                level = nxt
+            if overlap:
+                hand_over(steps[-1])
+                if 'overflow' in pyr and name == 'conv_out':
+                    pyr['overflow'].record_stream(main)
         if overlap:
-            for nbr_d, nbr_s, lvl, _ in steps:      # tensors born on the side stream are consumed on the main stream
-                for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
-                    if t is not None:
-                        t.record_stream(main)
-                        if getattr(t, 'tile_masks', None) is not None:
-                            t.tile_masks.record_stream(main)
-                        for tt in getattr(t, 'tiles', None) or ():
-                            tt.record_stream(main)
-            if overflow is not None:
-                overflow.record_stream(main)
-        x = voxel_features if level1 is not None else ops.scatter_rows(voxel_features, rank, self.CIN_PAD, lvl1.cap, d_n, math=self.math)
-        pyr = {'x': x, 'steps': steps}
-        if overflow is not None:
-            pyr['overflow'] = overflow
+            hand_over(steps[0])
+        if staggered and overlap:
+            pyr['build_stage'] = build_stage
+        else:
+            for li in range(4):
+                build_stage(li)
         return pyr
 
     def run_pyramid(self, pyr):
@@ -390,10 +410,13 @@ class VoxelResBackBone8x(_Cached):
         steps = pyr['steps']
         x = pyr['x']
         main = torch.cuda.current_stream(x.device)
+        build_stage = pyr.pop('build_stage', None)          # staggered pyramid: stage i + 1's index is requested when stage i's convs start
 
         def ready(ev):
             if ev is not None:
                 main.wait_event(ev)
+        if build_stage is not None:
+            build_stage(0)                                  # conv2's index under the level-1 convolutions
         _, nbr, lvl1, ev = steps[0]
         ready(ev)
         ci = p['conv_input']
@@ -403,6 +426,8 @@ class VoxelResBackBone8x(_Cached):
         out = {'x_conv1': (x, lvl1)}
         level = lvl1
         for i, name in enumerate(('conv2', 'conv3', 'conv4')):
+            if build_stage is not None:
+                build_stage(i + 1, gate=main.record_event())       # the next stage's index under this stage's convolutions
             dp = p[name]['down']
             nbr_d, nbr, nxt, ev = steps[i + 1]
             ready(ev)
