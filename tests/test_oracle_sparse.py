@@ -153,3 +153,32 @@ def test_all_nine_rulebooks_of_the_backbone_against_a_dense_lookup():
         checked += 1
         coords, shape = oc, list(oshape)
     assert checked == 9 and shape == [2, 94, 94]
+
+
+def test_packed_table_format_against_the_rulebook():
+    """The packed form of a 27-tap table (include/detzero_hip.h: dz_build_neighbors_packed) rests on one property of rows kept in
+    key order: the three x taps of a window row are CONSECUTIVE input rows.  Checked on the oracle's own tables (submanifold and
+    both strided paddings of the backbone), then packed here as the header states and unpacked by the host helper."""
+    from detzero_amd import ops
+    shape, batch = (7, 12, 37), 2
+    coords, _ = _random_sparse(3, shape, 2500, 1, batch)
+    coords = coords[osp.canonical_order(coords, shape)]
+    for k, s, p in (((3, 3, 3), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1))):
+        oc = coords if s == (1, 1, 1) else osp.conv_out_coords(coords, shape, k, s, p)[0]
+        tab = osp.neighbor_table(coords, shape, oc, k, s, p).astype(np.int64)            # (27, M)
+        t3 = tab.reshape(9, 3, -1)
+        left, cen, right = t3[:, 0], t3[:, 1], t3[:, 2]
+        both = (left >= 0) & (cen >= 0)
+        assert np.array_equal(left[both] + 1, cen[both])
+        both = (cen >= 0) & (right >= 0)
+        assert np.array_equal(cen[both] + 1, right[both])
+        both = (left >= 0) & (cen < 0) & (right >= 0)
+        assert np.array_equal(left[both] + 1, right[both])                               # centre empty: right follows left
+        r = np.where(left >= 0, left + 1, np.where(cen >= 0, cen, np.where(right >= 0, right, 0)))
+        word = r | ((left >= 0).astype(np.int64) << 29) | ((cen >= 0).astype(np.int64) << 30) | ((right >= 0).astype(np.int64) << 31)
+        packed = torch.from_numpy(word.astype(np.uint32).view(np.int32))
+        packed.packed, packed.kvol = True, 27
+        assert torch.equal(ops.unpack_table(packed), torch.from_numpy(tab.astype(np.int32)))
+        assert ops.table_pairs(packed, oc.shape[0]) == int((tab >= 0).sum())
+        plain = torch.from_numpy(tab.astype(np.int32))
+        assert ops.unpack_table(plain) is plain and ops.table_pairs(plain, oc.shape[0]) == int((tab >= 0).sum())
