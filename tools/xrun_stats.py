@@ -3,7 +3,7 @@
 Rows are kept in key order, so the three x taps of a window row are consecutive input rows and the neighbours a tile of 32 consecutive
 output rows needs at one (tz, ty) offset lie in ONE short range of input rows.  For every level: the rows gathered today (one per
 (tap, row) pair), the distinct rows per (tile, tz, ty) group, and the rows a contiguous load of each group's range would fetch
-(groups whose range exceeds 64 rows counted as gathered per tap).  DESIGN.md section 8, "next".
+(groups whose range exceeds the tile's rows + 64 counted as gathered per tap).  DESIGN.md section 8, "next".
 usage: python tools/xrun_stats.py"""
 import numpy as np, sys
 sys.path.insert(0,'/root/repo')
@@ -32,14 +32,20 @@ def stats(name, cin_coords, in_shape, out_coords, k, s, p, tile=32):
             u = np.unique(v).size
             tot_unique += u
             hist.append(rng)
-            if rng > 2*tile: big += 1; tot_range += v.size   # fallback: per-tap gathers
+            if rng > tile + 64: big += 1; tot_range += v.size   # fallback: per-tap gathers
             else: tot_range += rng
     hist=np.array(hist)
-    print('%s: rows %d pairs/row %.2f | gathers now %d rows | unique per group sum %d (%.2fx fewer) | range-load rows %d (%.2fx fewer), groups>64: %.1f%%, median range %d, p90 %d' % (
+    print('%s: rows %d pairs/row %.2f | gathers now %d rows | unique per group sum %d (%.2fx fewer) | range-load rows %d (%.2fx fewer), groups over tile+64 rows: %.1f%%, median range %d, p90 %d' % (
         name, m, pairs/m, pairs, tot_unique, pairs/tot_unique, tot_range, pairs/tot_range, 100.0*big/max(groups,1), np.median(hist), np.percentile(hist,90)))
-stats('L1 subm', coords, shape, coords, K3, (1,1,1), (1,1,1))
+stats('L1 subm (32-row tiles)', coords, shape, coords, K3, (1,1,1), (1,1,1))
 oc, osh = osp.conv_out_coords(coords, shape, K3, (2,2,2), (1,1,1))
-stats('L1->L2 down', coords, shape, oc, K3, (2,2,2), (1,1,1))
-stats('L2 subm', oc, list(osh), oc, K3, (1,1,1), (1,1,1))
+stats('L1->L2 down (32)', coords, shape, oc, K3, (2,2,2), (1,1,1))
+stats('L2 subm (32)', oc, list(osh), oc, K3, (1,1,1), (1,1,1))
 oc3, osh3 = osp.conv_out_coords(oc, list(osh), K3, (2,2,2), (1,1,1))
-stats('L3 subm', oc3, list(osh3), oc3, K3, (1,1,1), (1,1,1), tile=32)
+stats('L2->L3 down (256)', oc, list(osh), oc3, K3, (2,2,2), (1,1,1), tile=256)
+for t in (128, 256):
+    stats('L3 subm (%d)' % t, oc3, list(osh3), oc3, K3, (1,1,1), (1,1,1), tile=t)
+oc4, osh4 = osp.conv_out_coords(oc3, list(osh3), K3, (2,2,2), (0,1,1))
+stats('L3->L4 down (128)', oc3, list(osh3), oc4, K3, (2,2,2), (0,1,1), tile=128)
+for t in (128, 256):
+    stats('L4 subm (%d)' % t, oc4, list(osh4), oc4, K3, (1,1,1), (1,1,1), tile=t)
