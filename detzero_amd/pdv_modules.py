@@ -455,12 +455,12 @@ class PDVHead(_Cached):
         r, l, e = point_features.shape
         feats = point_features.reshape(r * l, e).contiguous()
         pos_in = positional_input.reshape(r * l, -1).float()
-        pos_rows = pos_in.new_zeros((r * l, 16))
-        pos_rows[:, :pos_in.shape[1]] = pos_in
+        pos_rows = torch.nn.functional.pad(pos_in, (0, 16 - pos_in.shape[1]))      # (one launch: zero-padded to the stack's input width)
         pos, _ = _run_stack(pos_rows, p['pos'], math=self.stack_math())
         empty = key_padding_mask.all(-1)                                   # RoIs without any point: left untouched (:31-44)
         add_pos = (~key_padding_mask) & (~empty)[:, None]
-        src = torch.where(add_pos.reshape(r * l, 1), feats + pos, feats)
+        # feats + pos where add_pos, feats elsewhere, in one pass: pos * 1.0 and feats + 0.0 are exact (the encodings are finite)
+        src = torch.addcmul(feats, pos, add_pos.reshape(r * l, 1).to(feats.dtype))
         m = p['mha']
         q = ops.linear(src, m['wq'], m['one'], m['bq'], False, e)
         k = ops.linear(src, m['wk'], m['one'], m['bk'], False, e)
