@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU test suite, then the headline with / without one environment knob, two alternating rounds on ONE box: tools/gpu_ab_knob.sh NAME=VALUE [notests]
+# GPU test suite, then the headline with / without environment knobs, two alternating rounds on ONE box:
+#   tools/gpu_ab_knob.sh "NAME=VALUE [NAME2=VALUE2 ...]" [notests]
+# e.g. DZ_TUNE_EAGER_PYRAMID=1, DZ_BEV_SCATTER=1, DZ_TUNE_PACKED_TABLES=1, "DZ_TUNE_NBR_GENERIC=1 DZ_TUNE_MARK_PLAIN=1 DZ_TUNE_LINE_FLAGS=0"
 cd $GRAFT_REPO_ROOT
 if [ -z "$2" ]; then timeout 1200 python -m pytest tests -m gpu -q -x --timeout=600 -p no:cacheprovider 2>&1 | tail -4; fi
 B="python bench.py --steps 150 --warmup 10 --no-cpu-baseline --no-aux --no-refine --no-pdv --profile-frames 0"
