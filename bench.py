@@ -121,7 +121,7 @@ def parse():
     ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
-    ap.add_argument('--sparse-engine', default='gather', choices=['gather', 'tiles'], help='sparse-backbone engine of the headline run')
+    ap.add_argument('--sparse-engine', default='gather', choices=['gather', 'xrun', 'tiles'], help='sparse-backbone engine of the headline run')
     ap.add_argument('--sweeps', type=int, default=1, choices=[1, 2],
                     help='2: run the multisweep shape (BASELINE configs[4]) as the main workload - for profiling that leg on its own; the '
                          'metric of the printed line is then NOT the headline one (config.workload says so)')

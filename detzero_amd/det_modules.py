@@ -264,6 +264,8 @@ class VoxelResBackBone8x(_Cached):
         #   engine 'gather' + LAYOUT_LINEAR (default): one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h);
         #   engine 'tiles'  + LAYOUT_BRICK: tile-resident inputs (sparse_conv_t.hip) - built and parity-tested in round 3, measured
         #   SLOWER inside the detector on MI355X (743 vs 865 frames/s), so it is opt-in: set_sparse_engine(model, 'tiles').
+        #   engine 'xrun' + LAYOUT_LINEAR: the submanifold convolutions of the 32 / 64 / 128-channel levels stage each z slab's window
+        #   of input rows once per tile (sparse_conv_x.hip, packed tables + ops.build_windows); every other convolution as 'gather'.
         self.layout = int(os.environ.get('DZ_TUNE_LAYOUT', ops.LAYOUT_LINEAR))          # (environment: A/B runs on one box)
         self.engine = os.environ.get('DZ_TUNE_SPCONV_ENGINE', 'gather')
         # output widths whose convolutions run on the tile engine when it is selected (the others keep the gather kernels)
@@ -273,9 +275,10 @@ class VoxelResBackBone8x(_Cached):
         self.channels = channels
 
     def set_engine(self, engine):
-        """'gather' (default; rows in the canonical linear-key order) or 'tiles' (tile-resident convolution; rows in brick order)."""
-        if engine not in ('gather', 'tiles'):
-            raise DetZeroHipError('unknown sparse engine %r (gather | tiles)' % (engine,))
+        """'gather' (rows in the canonical linear-key order), 'xrun' (gather + the z-slab window kernel for the submanifold
+        convolutions of the 32 / 64 / 128-channel levels; same row order) or 'tiles' (tile-resident convolution; rows in brick order)."""
+        if engine not in ('gather', 'tiles', 'xrun'):
+            raise DetZeroHipError('unknown sparse engine %r (gather | xrun | tiles)' % (engine,))
         self.engine = engine
         self.layout = ops.LAYOUT_BRICK if engine == 'tiles' else ops.LAYOUT_LINEAR
 
@@ -346,7 +349,15 @@ class VoxelResBackBone8x(_Cached):
         # conv2) built packed - a third of the words; the index chain gains what the decode costs the convolutions
         pack = PACKED_TABLES and self.math != 0 and not tiled and self.layout == 0 and os.environ.get('DZ_TUNE_SPCONV_W', '1') != '0'
 
+        xrun = self.engine == 'xrun' and self.math != 0 and self.layout == 0
+        xrun_couts = tuple(int(c) for c in os.environ.get('DZ_TUNE_XRUN_COUTS', '32,64,128').split(',') if c)
+
         def table(src, dst, k, s, p, cout):
+            if xrun and src is dst and cout in xrun_couts and tuple(k) == (3, 3, 3):
+                # submanifold table of a level the x-run kernel covers: packed words + the tiles' windows
+                nbr = ops.build_windows(src.neighbors_to(dst, k, s, p, packed=True), dst, cout)
+                if getattr(nbr, 'xwin', None) is not None:
+                    return nbr
             nbr = src.neighbors_to(dst, k, s, p, packed=pack and cout <= 32)
             return ops.build_tiles(nbr, dst) if tiled and cout in self.tile_couts and k[0] * k[1] * k[2] >= 3 else nbr
 
@@ -359,6 +370,8 @@ class VoxelResBackBone8x(_Cached):
                         t.tile_masks.record_stream(main)
                     for tt in getattr(t, 'tiles', None) or ():
                         tt.record_stream(main)
+                    if getattr(t, 'xwin', None) is not None:
+                        t.xwin[0].record_stream(main)
         ch = self.channels
         with torch.cuda.stream(side):
             nbr1 = table(lvl1, lvl1, K3, S1, P1, ch[0])

@@ -292,6 +292,23 @@ def build_tiles(nbr, out_level):
     return nbr
 
 
+def build_windows(nbr, out_level, channels):
+    """Windows of the x-run convolution (dz_spconv_forward_split_x) for a PACKED submanifold table and the level's channel width:
+    per tile of dz_spconv_x_tile_rows(channels, channels) output rows and z offset the contiguous range of input rows its nine taps
+    read.  Attached as ``nbr.xwin`` = (windows, tile_rows); spconv_forward picks the x-run kernel whenever it is there and the
+    layer is channels -> channels.  Tables / widths the engine does not cover are returned unchanged."""
+    lib = L.load()
+    tr = lib.dz_spconv_x_tile_rows(int(channels), int(channels))
+    if not getattr(nbr, 'packed', False) or tr == 0:
+        return nbr
+    cap = nbr.shape[1]
+    win = torch.empty(((cap + tr - 1) // tr, 3, 2), dtype=torch.int32, device=nbr.device)
+    rc = lib.dz_spconv_x_windows(L.ptr(nbr), cap, L.ptr(out_level.d_m), tr, L.ptr(win), L.stream())
+    L.check(rc, 'dz_spconv_x_windows')
+    nbr.xwin = (win, tr)
+    return nbr
+
+
 def scatter_rows(src, rank, c_dst, cap, d_n=None, math=0):
     """dst[rank[i]] = src[i] (zero padded to c_dst channels); with math != 0 the rows are written as pair16."""
     lib = L.load()
@@ -337,9 +354,16 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
         out = torch.empty((cap, cout), dtype=torch.float32, device=feats.device)
 
     tiles = getattr(nbr, 'tiles', None) if (math and kvol >= 3) else None
+    xwin = getattr(nbr, 'xwin', None) if (math and packed and cin == cout) else None
+    if xwin is not None and lib.dz_spconv_x_tile_rows(cin, cout) != xwin[1]:
+        xwin = None
 
     def launch():
-        if tiles is not None:
+        if xwin is not None:
+            rc = lib.dz_spconv_forward_split_x(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(xwin[0]), xwin[1], cap,
+                                               L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual),
+                                               1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
+        elif tiles is not None:
             rc = lib.dz_spconv_tiles_forward(L.ptr(feats), feats.shape[0], cin, L.ptr(tiles[0]), L.ptr(tiles[1]), L.ptr(tiles[2]),
                                              L.ptr(tiles[3]), kvol, cap, L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale),
                                              L.ptr(shift), L.ptr(residual), 1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
@@ -366,7 +390,7 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
         flops = 2.0 * pairs * cin * cout
         n_in = in_level.num_active() if in_level is not None else m
         nbytes = 4.0 * (n_in * cin + m * cout + kvol * cin * cout + (m * cout if residual is not None else 0)) + 8.0 * pairs
-        name = (lib.dz_spconv_tiles_variant(cin, cout) if tiles is not None else
+        name = (lib.dz_spconv_x_variant(cin, cout) if xwin is not None else lib.dz_spconv_tiles_variant(cin, cout) if tiles is not None else
                 lib.dz_spconv_variant_split(cin, cout) if math else lib.dz_spconv_variant(cin, cout))
         PROFILER.wrap(name.decode(), flops, nbytes, launch)
     return out

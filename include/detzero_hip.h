@@ -256,6 +256,23 @@ const char *dz_spconv_tiles_variant(int cin, int cout);
 int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const int *nbr_packed, const uint32_t *tile_masks,
                                    int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
                                    const float *residual, int relu, float *out, int cout, int math, void *stream);
+/* Submanifold 3 x 3 x 3 convolutions with the inputs of a z slab staged once per tile (csrc/sparse_conv_x.hip, the "x-run" engine;
+ * the SubMConv3d pairs of SparseBasicBlock, backbone3d.py:93-121, at 32 / 64 / 128 channels: conv2, conv3, conv4 of
+ * VoxelResBackBone8x, backbone3d.py:261-280).  Rows of a level are in ascending linear key, so the nine taps of one z offset of a tile
+ * of T consecutive output rows read ONE contiguous range of input rows (a "window").
+ *   dz_spconv_x_tile_rows(cin, cout): T of the kernel for this layer, 0 = layer not covered (cin != cout, other widths).
+ *   dz_spconv_x_windows: from the PACKED table of the level (dz_build_neighbors_packed, input level == output level) the windows of
+ *     every tile: windows[(tile*3 + tz)*2 + {0, 1}] = first input row, number of rows (0 = slab has no neighbour; the centre slab of a
+ *     live tile always has one).  ceil(cap_out / tile_rows) * 6 int32.  Once per indice_key, shared by the level's convolutions.
+ *   dz_spconv_forward_split_x: operands, result convention and arithmetic of dz_spconv_forward_split (pair16 in / residual / out,
+ *     w (27, cout, cin) pair16, BatchNorm scale / shift, ReLU); per output element the products are accumulated in the order
+ *     (tz, 16-channel chunk, tap), so results agree with dz_spconv_forward_split to fp32 summation-order noise, not bit for bit. */
+int dz_spconv_x_tile_rows(int cin, int cout);
+int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, void *stream);
+int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, const int *windows, int tile_rows,
+                              int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
+                              const float *residual, int relu, float *out, int cout, int math, void *stream);
+const char *dz_spconv_x_variant(int cin, int cout);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);

@@ -54,11 +54,12 @@ def main():
     total = 0.0
     for (f, nbr, lvl, w, scale, shift, residual, relu, in_level) in calls:
         kvol = w.shape[0]
+        variant = 'x' if getattr(nbr, 'xwin', None) is not None and w.shape[1] == w.shape[2] else 'g'
         cin, cout = (w.shape[2], scale.shape[0]) if mm else (w.shape[1], w.shape[2])
         key = (kvol, cin, cout, lvl.cap, residual is not None, id(nbr))
         m = lvl.num_active()
         if key not in seen:
-            valid = nbr[:, :m] >= 0
+            valid = ops.unpack_table(nbr)[:, :m] >= 0
             pairs = int(valid.sum().item())
 
             def tile_taps(bm):
@@ -84,7 +85,7 @@ def main():
             halo = '  tiles: halo/rows %.2f max %d' % (float(nh.sum().item()) / max(m, 1), int(nh.max().item()))
         total += us
         flop = 2.0 * pairs * cin * cout
-        print('k%-2d %3d->%-3d rows %8d pairs/row %5.2f taps/tile[16|32|64|128] %5.2f %5.2f %5.2f %5.2f  %8.1f us  alg %6.2f TF/s  '
+        print(variant + ' k%-2d %3d->%-3d rows %8d pairs/row %5.2f taps/tile[16|32|64|128] %5.2f %5.2f %5.2f %5.2f  %8.1f us  alg %6.2f TF/s  '
               'dense64 %6.2f TF/s%s' % (kvol, cin, cout, m, pairs / max(m, 1), t16, t32, t64, t128, us, flop / us / 1e6,
                                         2.0 * m * t64 * cin * cout / us / 1e6, ('  +res' if residual is not None else '') + halo))
     print('sum over the %d sparse convs: %.1f us per step (%.1f us per frame)' % (len(calls), total, total / args.batch))
