@@ -47,21 +47,26 @@ struct SpConvXArgs {
     unsigned int in_bytes, w_bytes, nbr_bytes;
 };
 
-template <int COUT_, int WP_, int WC_, int PT_, int G_, int RCAP_>
+template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
 struct XCfg {
-    static constexpr int COUT = COUT_, WP = WP_, WC = WC_, PT = PT_, G = G_, RCAP = RCAP_;
+    static constexpr int COUT = COUT_, WP = WP_, WC = WC_, PT = PT_, TAPS = TAPS_, D = D_, RCAP = RCAP_;
     static constexpr int NW = WP * WC, THREADS = 64 * NW;
     static constexpr int CT = COUT / (32 * WC);
     static constexpr int BP = WP * PT * 32;                  // output rows per tile
-    static constexpr int NGQ = 9 / G;                        // steps per stage
-    static constexpr int WIN_BYTES = RCAP * 64, WSLOT_BYTES = G * COUT * 64;
-    static constexpr int OFF_WIN = 0, OFF_W = 2 * WIN_BYTES, OFF_ZERO = OFF_W + 2 * WSLOT_BYTES, OFF_SS = OFF_ZERO + 64;
+    static constexpr int SPS = 9 / TAPS;                     // steps per stage: a step = TAPS taps = 1 or 3 window rows ty
+    static constexpr int NSLOT = D + 1;                      // weight slots: a step's slices are issued D steps ahead of their use
+    static constexpr int WIN_BYTES = (RCAP + 1) * 64;        // + the zero row missing neighbours read
+    static constexpr int WSLOT_BYTES = TAPS * COUT * 64;
+    static constexpr int OFF_WIN = 0, OFF_W = 2 * WIN_BYTES, OFF_TRASH = OFF_W + NSLOT * WSLOT_BYTES, OFF_SS = OFF_TRASH + 1024;
     static constexpr int LDS_BYTES = OFF_SS + 2 * COUT * 4;
-    static constexpr int WJ = G * COUT / 16;                 // 1 KB direct loads of a weight slot
-    static constexpr int WIN_J = RCAP / 16;                  // ... of a full window buffer
-    static_assert(G == 9 || G == 3, "taps per step: a z slab or one of its window rows");
-    static_assert(COUT % (32 * WC) == 0 && RCAP % 16 == 0, "shape");
-    static_assert(WIN_BYTES >= NW * STG_WAVE_BYTES, "the epilogue staging windows live in a window buffer");
+    static constexpr int R = COUT / 16;                      // 1 KB runs (16 output channels x 64 bytes) per tap slice
+    static constexpr int WJ = TAPS * R, WPW = (WJ + NW - 1) / NW;               // 1 KB direct loads of a weight slot: in all, per wave
+    static constexpr int WIN_J = RCAP / 16, WPWIN = WIN_J / NW;                 // ... of a full window buffer
+    static constexpr int WINPW = WPWIN + 3 * PT;             // loads a wave issues at a stage's first step besides the weights
+    static_assert(TAPS == 3 || TAPS == 9, "a step is one window row or a whole z slab");
+    static_assert(D >= 1 && D <= SPS && D <= 3, "weight slices are issued 1..3 steps ahead, never before the stage's window");
+    static_assert(COUT % (32 * WC) == 0 && NW % R == 0 && RCAP % (16 * NW) == 0, "shape");
+    static_assert(RCAP * 64 >= NW * STG_WAVE_BYTES, "the epilogue staging windows live in a window buffer (below its zero row)");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -70,19 +75,19 @@ __device__ __forceinline__ void x_load16_lds(unsigned int lds_base, unsigned int
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(b), "v"(voff), "s"(rsrc), "s"(so) : "memory", "m0");
 }
 
-// position of a workgroup in its stream of steps (wave-uniform: lives in SGPRs)
-struct XPos {
-    int seq, tile;              // index in this workgroup's tile sequence, tile number
-    int lo0, n0, lo1, n1, lo2, n2;      // windows of the tile's three z slabs (scalars, never indexed: the struct must stay in SGPRs)
-    int wlo, wn;                // window of the current slab
-    int tz, kc, pass, gq;
-    int wb, ws;                 // window buffer / weight slot the step reads
-    bool live, stage_first, tz_first, tile_first;
+// one stage of a workgroup's stream (wave-uniform: SGPRs; never indexed dynamically)
+struct XStage {
+    int tile, tz, kc;
+    int wlo, wcnt;              // the window pass: first input row, rows (0: past the end of the stream - its loads fetch nothing)
+    int wb;                     // window buffer
+    bool live, fresh, tz_first, tile_first;     // fresh: row addresses differ from the previous stage's (new slab or pass)
 };
 
-template <class C, class M>
+// DIAG (development, DZ_TUNE_X_DIAG; timing experiments, results are garbage): bit 0 no MFMAs, 1 no fragment LDS reads, 2 no weight
+// loads, 3 no window loads, 4 no barriers, 5 no epilogue
+template <class C, class M, int DIAG = 0>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_spconv_x(SpConvXArgs a) {
-    constexpr int PT = C::PT, CT = C::CT, G = C::G, COUT = C::COUT, RCAP = C::RCAP, NW = C::NW;
+    constexpr int PT = C::PT, CT = C::CT, COUT = C::COUT, RCAP = C::RCAP, NW = C::NW, D = C::D, TAPS = C::TAPS, SPS = C::SPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const sc_s = reinterpret_cast<float *>(smem + C::OFF_SS), *const sh_s = sc_s + COUT;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,99 +102,121 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         sc_s[c] = a.scale ? a.scale[c] : 1.f;
         sh_s[c] = a.shift ? a.shift[c] : 0.f;
     }
-    if (tid < 16) reinterpret_cast<unsigned int *>(smem + C::OFF_ZERO)[tid] = 0u;
+    if (tid < 32) reinterpret_cast<unsigned int *>(smem + C::OFF_WIN + (tid >> 4) * C::WIN_BYTES + RCAP * 64)[tid & 15] = 0u;    // the zero rows
 
     // ---- direct loads: lane L of a 1 KB load writes LDS bytes [16 L, 16 L + 16) of its run = row L >> 2, slot L & 3 of 16 rows; the
-    // slot holds source piece slot ^ ((row >> 2) & 3), and (row >> 2) & 3 == (L >> 4) & 3 because runs start at multiples of 16 rows
+    // slot holds source piece slot ^ ((row >> 2) & 3), and (row >> 2) & 3 == (L >> 4) & 3 because runs start at multiples of 16 rows.
+    // Run j = i * NW + wid of a buffer belongs to wave wid: everything that depends on the wave only is computed here, once.
     const int lrow = lane >> 2;
     const unsigned int lpiece = (unsigned int)((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    const unsigned int w_voff = (unsigned int)lrow * row_bytes + lpiece;          // + (run's first cout) * row_bytes
+    const unsigned int w_voff = (unsigned int)lrow * row_bytes + lpiece;
+    const unsigned int wid_lds = (unsigned int)wid * 1024u;                                           // run wid of a buffer
+    const unsigned int wid_rows = (unsigned int)(wid * 16) * row_bytes;                               // window run wid: 16 * wid rows in
+    const unsigned int nw_rows = (unsigned int)(NW * 16) * row_bytes;
+    const unsigned int w_soff_w = (unsigned int)(wid / C::R) * tap_bytes + (unsigned int)((wid % C::R) * 16) * row_bytes;   // weight run wid: tap wid / R, cout 16 (wid % R)
+    const bool w_last_ok = C::WJ % NW == 0 || wid < C::WJ % NW;                                       // my run of the last, partial round of a weight slot exists
 
     // ---- fragment read addresses
     const unsigned int khsw = (unsigned int)(((2 * kh) ^ ((l31 >> 2) & 3)) << 4);   // swizzled slot of my hi piece in a row whose (row >> 2) & 3 is l31's
     const unsigned int wrow = (unsigned int)((wc * CT * 32 + l31) * 64);            // weight rows: cout index = wc*CT*32 + ct*32 + l31
 
-    // ---- this workgroup's tile sequence (XCD-aware: workgroup b runs on XCD b % 8; runs of XRUN consecutive tiles per XCD share
-    // their overlapping windows in that XCD's L2)
+    // ---- this workgroup's stream of stages.  Tiles: XCD-aware (workgroup b runs on XCD b % 8; runs of XRUN consecutive tiles per
+    // XCD share their overlapping windows in that XCD's L2).  Inside a tile: tz, 16-channel chunk, window pass.
     constexpr int XRUN = 8;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = gridDim.x >> 3;
-    XPos it;
-    auto enter_tile = [&]() {       // it.seq -> first live tile at or after it; loads its windows
-        for (;; ++it.seq) {
-            const int q = it.seq * nx + jx;
-            if ((q / XRUN) * 8 * XRUN >= ntiles) { it.live = false; return; }
-            it.tile = ((q / XRUN) * 8 + xcd) * XRUN + q % XRUN;
-            if (it.tile < ntiles) break;
+    struct Gen { int seq, tile, lo0, n0, lo1, n1, lo2, n2, tz, kc, pass, wlo, wn, wb; bool live, started; } g;
+    g.seq = -1; g.live = true; g.started = false; g.wb = 1; g.tile = 0; g.tz = g.kc = g.pass = 0; g.wlo = g.wn = 0;
+    g.lo0 = g.n0 = g.lo1 = g.n1 = g.lo2 = g.n2 = 0;
+    auto gen = [&]() {          // the next stage of the stream (live = false: past its end)
+        XStage s;
+        s.tile_first = s.tz_first = false;
+        bool next_tile = !g.started;
+        if (g.started) {
+            if ((g.pass + 1) * RCAP < g.wn) {
+                ++g.pass;
+            } else {
+                g.pass = 0;
+                if (++g.kc == nk) {
+                    g.kc = 0;
+                    s.tz_first = true;
+                    ++g.tz;
+                    if (g.tz == 1) { g.wlo = g.lo1; g.wn = g.n1; }                        // (n1 > 0 always)
+                    else if (g.tz == 2 && g.n2 > 0) { g.wlo = g.lo2; g.wn = g.n2; }
+                    else next_tile = true;
+                }
+            }
         }
-        const int *wq = a.win + (size_t)it.tile * 6;
-        it.lo0 = __builtin_amdgcn_readfirstlane(wq[0]); it.n0 = __builtin_amdgcn_readfirstlane(wq[1]);
-        it.lo1 = __builtin_amdgcn_readfirstlane(wq[2]); it.n1 = __builtin_amdgcn_readfirstlane(wq[3]);
-        it.lo2 = __builtin_amdgcn_readfirstlane(wq[4]); it.n2 = __builtin_amdgcn_readfirstlane(wq[5]);
-        it.tz = it.n0 > 0 ? 0 : 1;              // (the centre slab of a live tile is never empty: dz_spconv_x_windows)
-        it.wlo = it.n0 > 0 ? it.lo0 : it.lo1;
-        it.wn = it.n0 > 0 ? it.n0 : it.n1;
-        it.kc = it.pass = it.gq = 0;
-        it.stage_first = it.tz_first = it.tile_first = true;
+        if (next_tile && g.live) {
+            g.started = true;
+            for (++g.seq;; ++g.seq) {
+                const int q = g.seq * nx + jx;
+                if ((q / XRUN) * 8 * XRUN >= ntiles) { g.live = false; break; }
+                g.tile = ((q / XRUN) * 8 + xcd) * XRUN + q % XRUN;
+                if (g.tile < ntiles) break;
+            }
+            if (g.live) {
+                const int *wq = a.win + (size_t)g.tile * 6;
+                g.lo0 = __builtin_amdgcn_readfirstlane(wq[0]); g.n0 = __builtin_amdgcn_readfirstlane(wq[1]);
+                g.lo1 = __builtin_amdgcn_readfirstlane(wq[2]); g.n1 = __builtin_amdgcn_readfirstlane(wq[3]);
+                g.lo2 = __builtin_amdgcn_readfirstlane(wq[4]); g.n2 = __builtin_amdgcn_readfirstlane(wq[5]);
+                g.tz = g.n0 > 0 ? 0 : 1;          // (the centre slab of a live tile is never empty: dz_spconv_x_windows)
+                g.wlo = g.n0 > 0 ? g.lo0 : g.lo1;
+                g.wn = g.n0 > 0 ? g.n0 : g.n1;
+                g.kc = g.pass = 0;
+                s.tile_first = s.tz_first = true;
+            }
+        }
+        g.wb ^= 1;
+        s.live = g.live;
+        s.tile = g.tile; s.tz = g.tz; s.kc = g.kc; s.wb = g.wb;
+        s.wlo = g.wlo + g.pass * RCAP;
+        s.wcnt = g.live ? min(RCAP, g.wn - g.pass * RCAP) : 0;
+        s.fresh = s.tz_first || g.wn > RCAP;
+        return s;
     };
-    auto advance = [&]() {
-        it.ws ^= 1;
-        it.stage_first = it.tz_first = it.tile_first = false;
-        if (++it.gq < C::NGQ) return;
-        it.gq = 0;
-        it.stage_first = true;
-        it.wb ^= 1;
-        if ((it.pass + 1) * RCAP < it.wn) { ++it.pass; return; }
-        it.pass = 0;
-        if (++it.kc < nk) return;
-        it.kc = 0;
-        it.tz_first = true;
-        ++it.tz;
-        if (it.tz == 1) { it.wlo = it.lo1; it.wn = it.n1; return; }        // (n1 > 0 always)
-        if (it.tz == 2 && it.n2 > 0) { it.wlo = it.lo2; it.wn = it.n2; return; }
-        ++it.seq;
-        enter_tile();
-    };
-    it.seq = 0; it.wb = 0; it.ws = 0; it.live = true;
-    enter_tile();
-    if (!it.live) return;
-    __syncthreads();
 
     // packed table words of my rows, one array per window row ty (separate arrays, statically indexed: a [3][PT] array picked with a
-    // run-time ty is turned into a scratch array by the compiler): current z slab, next
+    // run-time index is turned into a scratch array by the compiler): current z slab, next
     unsigned int pw0[PT], pw1[PT], pw2[PT], pn0[PT], pn1[PT], pn2[PT];
-    auto issue = [&](const XPos &s) {
-        // weights of the step's G taps -> slot s.ws
-        {
-            const unsigned int soff0 = (unsigned int)(s.tz * 9 + s.gq * G) * tap_bytes + (unsigned int)(s.kc * 64);
-            const unsigned int lds0 = (unsigned int)(C::OFF_W + s.ws * C::WSLOT_BYTES);
+    // ---- issue: runs [I0, I1) of my share of stage s's window pass (WPWIN per wave and stage, always: a run past the window's end -
+    // every run of a stage past the end of the stream - fetches nothing, so the per-wave load counts stay static)
+    auto issue_win = [&](const XStage &s, auto i0_t, auto i1_t) {
+        if constexpr (DIAG & 8) return;
+        constexpr int I0 = decltype(i0_t)::value, I1 = decltype(i1_t)::value;
+        const unsigned int lds0 = (unsigned int)(C::OFF_WIN + s.wb * C::WIN_BYTES) + wid_lds;
+        const unsigned int soff0 = (unsigned int)s.wlo * row_bytes + (unsigned int)(s.kc * 64) + wid_rows;
+        const int left0 = s.wcnt - 1 - wid * 16;                  // rows of the window after the first row of my run 0
 #pragma unroll
-            for (int i = 0; i < (C::WJ + NW - 1) / NW; ++i) {
-                const int j = i * NW + wid;                         // run j: rows 16 j .. 16 j + 15 of the slot = tap j / (COUT/16), cout (16 j) % COUT ..
-                if (C::WJ % NW == 0 || j < C::WJ)
-                    x_load16_lds(lds0 + (unsigned int)(j * 1024), w_voff, crsrc,
-                                 soff0 + (unsigned int)(j / (COUT / 16)) * tap_bytes + (unsigned int)((j % (COUT / 16)) * 16) * row_bytes);
-            }
+        for (int i = I0; i < I1; ++i) {
+            const int left = left0 - i * NW * 16;
+            // (rows past the window's end re-read its last row: always inside the buffer, never referenced)
+            const unsigned int voff = left >= 0 ? (unsigned int)min(lrow, left) * row_bytes + lpiece : OOB_OFFSET;
+            x_load16_lds(lds0 + (unsigned int)(i * NW * 1024), voff, prsrc, soff0 + (unsigned int)i * nw_rows);
         }
-        // the stage's window pass -> buffer s.wb
-        if (s.stage_first) {
-            const int wlo = s.wlo + s.pass * RCAP, wcnt = min(RCAP, s.wn - s.pass * RCAP);
-            const unsigned int lds0 = (unsigned int)(C::OFF_WIN + s.wb * C::WIN_BYTES);
-            for (int j = wid; j * 16 < wcnt; j += NW) {
-                // (rows past the window's end re-read its last row: always inside the buffer, never referenced)
-                const unsigned int voff = (unsigned int)min(lrow, wcnt - 1 - j * 16) * row_bytes + lpiece;
-                x_load16_lds(lds0 + (unsigned int)(j * 1024), voff, prsrc, (unsigned int)(wlo + j * 16) * row_bytes + (unsigned int)(s.kc * 64));
-            }
-        }
-        // packed table words of the slab
-        if (s.tz_first) {
+    };
+    auto issue_pw = [&](const XStage &s) {
+        const bool want = s.live && s.tz_first;
+        const unsigned int so = (unsigned int)(s.tz * 3) * nbr_row_bytes;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const int row = s.tile * C::BP + (wp * PT + pt) * 32 + l31;
-                const unsigned int voff = row < m ? (unsigned int)row * 4u : OOB_OFFSET;
-                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn0[pt]) : "v"(voff), "s"(nrsrc), "s"((unsigned int)(s.tz * 3 + 0) * nbr_row_bytes) : "memory");
-                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn1[pt]) : "v"(voff), "s"(nrsrc), "s"((unsigned int)(s.tz * 3 + 1) * nbr_row_bytes) : "memory");
-                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn2[pt]) : "v"(voff), "s"(nrsrc), "s"((unsigned int)(s.tz * 3 + 2) * nbr_row_bytes) : "memory");
-            }
+        for (int pt = 0; pt < PT; ++pt) {
+            const int row = s.tile * C::BP + (wp * PT + pt) * 32 + l31;
+            const unsigned int voff = want && row < m ? (unsigned int)row * 4u : OOB_OFFSET;
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn0[pt]) : "v"(voff), "s"(nrsrc), "s"(so) : "memory");
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn1[pt]) : "v"(voff), "s"(nrsrc), "s"(so + nbr_row_bytes) : "memory");
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn2[pt]) : "v"(voff), "s"(nrsrc), "s"(so + 2u * nbr_row_bytes) : "memory");
+        }
+    };
+    // ---- issue: the weight slices of step q (= window row q when a step is one row) of stage s -> slot `slot` (WPW per wave, always)
+    auto issue_w = [&](const XStage &s, int q, int slot) {
+        if constexpr (DIAG & 4) return;
+        const unsigned int soff0 = (unsigned int)(s.tz * 9 + q * TAPS) * tap_bytes + (unsigned int)(s.kc * 64) + w_soff_w;
+        const unsigned int lds0 = (unsigned int)(C::OFF_W + slot * C::WSLOT_BYTES) + wid_lds;
+        const unsigned int vlive = s.live ? w_voff : OOB_OFFSET;
+#pragma unroll
+        for (int i = 0; i < C::WPW; ++i) {
+            const bool part = C::WJ % NW != 0 && i == C::WPW - 1;             // the last, partial round
+            x_load16_lds(part && !w_last_ok ? (unsigned int)C::OFF_TRASH : lds0 + (unsigned int)(i * NW * 1024), part && !w_last_ok ? OOB_OFFSET : vlive, crsrc,
+                         soff0 + (unsigned int)(i * (NW / C::R)) * tap_bytes);
         }
     };
 
@@ -201,92 +228,176 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    struct Frag { v4u c_hi[CT], c_lo[CT], p_hi[PT], p_lo[PT]; bool any[PT]; };
-    // the G taps of step `s`.  G == 9: all taps of the slab (ty static); G == 3: the taps of window row ty = s.gq, whose packed
-    // words are picked with two selects (ONE copy of the code: a switch over s.gq triples it and its accumulator live ranges)
-    auto compute = [&](const XPos &s) {
-        const int wlo = s.wlo + s.pass * RCAP;
-        const unsigned int wcnt = (unsigned int)min(RCAP, s.wn - s.pass * RCAP);
-        const unsigned int win_o = (unsigned int)(C::OFF_WIN + s.wb * C::WIN_BYTES);
-        const unsigned int w_hi_o = (unsigned int)(C::OFF_W + s.ws * C::WSLOT_BYTES) + wrow + khsw, w_lo_o = w_hi_o ^ 16u;
-        unsigned int ew[PT];
-        if constexpr (G != 9) {
-            static_assert(G == 3, "G = 1 would need the tap's x position at run time");
+    // row addresses of the current window pass: byte offset (inside a window buffer) of the hi piece of the row the tap reads, or of
+    // the zero row; per window row ty x tap tx x fragment.  anym: bit ty*3 + tx = some lane of my fragments has the tap
+    // (16 bits each - a window buffer is < 64 KB -, fragments 2 p and 2 p + 1 share a register: registers are what limits this kernel)
+    static_assert(C::WIN_BYTES < 65536 && PT % 2 == 0, "packed row addresses");
+    unsigned int radr[3][3][PT / 2];
+    unsigned int anym = 0u;
+    struct Frag { v4u c_hi[CT], c_lo[CT], p_hi[PT], p_lo[PT]; bool any; };
+    Frag fa, fb, fp;
+    fp.any = false;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) ew[pt] = s.gq == 0 ? pw0[pt] : (s.gq == 1 ? pw1[pt] : pw2[pt]);
+    for (int i = 0; i < CT; ++i) fp.c_hi[i] = fp.c_lo[i] = v4u{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < PT; ++i) fp.p_hi[i] = fp.p_lo[i] = v4u{0u, 0u, 0u, 0u};
+
+    // the MFMAs of fragment pt of a tap (term-major: consecutive MFMAs go to different accumulators; each still receives lo.hi,
+    // hi.lo, hi.hi in that order)
+    auto mma_pt = [&](const Frag &f, int pt) {
+        if constexpr (DIAG & 1) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(f.c_hi[ct]), "v"(f.c_lo[ct]), "v"(f.p_hi[pt]), "v"(f.p_lo[pt]));
+            return;
         }
-        auto load_frag = [&](Frag &f, auto g_t) {
-            constexpr int g = decltype(g_t)::value, ty = g / 3, tx = g % 3;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                f.c_hi[ct] = *reinterpret_cast<const v4u *>(smem + w_hi_o + (g * COUT + ct * 32) * 64);
-                f.c_lo[ct] = *reinterpret_cast<const v4u *>(smem + w_lo_o + (g * COUT + ct * 32) * 64);
-            }
+        for (int term = 3 - M::TERMS; term < 3; ++term)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const unsigned int e = G != 9 ? ew[pt] : (ty == 0 ? pw0[pt] : ty == 1 ? pw1[pt] : pw2[pt]);
-                const int off = (int)(e & 0x1FFFFFFFu) - wlo + (tx == 0 ? -1 : tx == 1 ? 0 : (int)((e >> 30) & 1u));
-                const bool valid = ((e >> (29 + tx)) & 1u) != 0u && (unsigned int)off < wcnt;
-                f.any[pt] = __ballot(valid) != 0ull;
-                const unsigned int ra = (unsigned int)off * 64u + (unsigned int)(((2 * kh) ^ ((off >> 2) & 3)) << 4);
-                const unsigned int po = valid ? win_o + ra : (unsigned int)C::OFF_ZERO;
-                f.p_hi[pt] = *reinterpret_cast<const v4u *>(smem + po);
-                f.p_lo[pt] = *reinterpret_cast<const v4u *>(smem + (po ^ 16u));
-            }
-        };
-        auto mma = [&](const Frag &f) {
+            for (int ct = 0; ct < CT; ++ct)
+                acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
+    };
+    // one tap: its MFMAs (skipped when no lane of the wave's fragments has the tap: wave-uniform) with the fillers - work of LATER
+    // taps that has to happen anyway - in between, so that it is issued in the shadow of the MFMAs instead of in front of them
+    auto block = [&](const Frag &f, auto &&fill_a, auto &&fill_b) {
+        if (f.any) {
+            mma_pt(f, 0);
+            fill_a();
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                if (!f.any[pt]) continue;                           // wave-uniform
-                // term-major: consecutive MFMAs go to different accumulators; each still receives lo.hi, hi.lo, hi.hi in that order
-#pragma unroll
-                for (int term = 3 - M::TERMS; term < 3; ++term)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
-            }
-        };
-        Frag f0, f1;
-        load_frag(f0, std::integral_constant<int, 0>{});
-        if constexpr (G == 3) {
-            load_frag(f1, std::integral_constant<int, 1>{});
-            mma(f0);
-            load_frag(f0, std::integral_constant<int, 2>{});
-            mma(f1);
-            mma(f0);
+            for (int pt = 1; pt < PT; ++pt) mma_pt(f, pt);
+            fill_b();
         } else {
-            load_frag(f1, std::integral_constant<int, 1>{}); mma(f0);
-            load_frag(f0, std::integral_constant<int, 2>{}); mma(f1);
-            load_frag(f1, std::integral_constant<int, 3>{}); mma(f0);
-            load_frag(f0, std::integral_constant<int, 4>{}); mma(f1);
-            load_frag(f1, std::integral_constant<int, 5>{}); mma(f0);
-            load_frag(f0, std::integral_constant<int, 6>{}); mma(f1);
-            load_frag(f1, std::integral_constant<int, 7>{}); mma(f0);
-            load_frag(f0, std::integral_constant<int, 8>{}); mma(f1);
-            mma(f0);
+            fill_a();
+            fill_b();
         }
     };
 
-    issue(it);
-    for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const XPos cur = it;
-        if (cur.tz_first) {
+    XStage cur = gen();
+    if (!cur.live) return;
+    XStage nxt = gen();
+    __syncthreads();
+    int ws = 0;                 // weight slot of the current step
+    auto slot_of = [&](int ahead) { const int v = ws + ahead; return v >= C::NSLOT ? v - C::NSLOT : v; };
+    // prologue: stage 0's window + words, the weights of its first D steps
+    issue_win(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, C::WPWIN>{});
+    issue_pw(cur);
+    issue_w(cur, 0, 0);
+    if constexpr (D >= 2) issue_w(cur, 1, 1);
+    if constexpr (D >= 3) issue_w(cur, 2, 2);
+
+    // one step = TAPS taps of the stage (window row Q, or the whole slab): wait for its data, (re)build its row addresses, run the
+    // taps.  The MFMAs of a step's last tap are issued AFTER the next step's barrier (fp carries its operands across), so no barrier
+    // is followed by a cold start.
+    auto step = [&](auto q_t) {
+        constexpr int Q = decltype(q_t)::value;
+        constexpr int NV = (D - 1) * C::WPW + ((Q >= 1 && Q <= D - 1) ? C::WINPW : 0);     // younger loads that may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+        if constexpr (!(DIAG & 16)) __syncthreads();
+        if (Q == 0 && cur.tz_first) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 asm volatile("" : "+v"(pn0[pt]), "+v"(pn1[pt]), "+v"(pn2[pt]));
                 pw0[pt] = pn0[pt]; pw1[pt] = pn1[pt]; pw2[pt] = pn2[pt];
             }
         }
-        advance();
-        if (it.live) issue(it);
-        compute(cur);
-        if (!it.live || it.tile_first) {
-            // last step of the tile: its window buffer (every wave is done with it after the barrier) stages the epilogue; the loads
-            // in flight go to the other window buffer and the other weight slot
+        // row addresses of window row ty (all three taps, all fragments)
+        auto addr_row = [&](auto ty_t) {
+            constexpr int ty = decltype(ty_t)::value;
+            unsigned int am = 0u;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const unsigned int e = ty == 0 ? pw0[pt] : (ty == 1 ? pw1[pt] : pw2[pt]);
+                const int base = (int)(e & 0x1FFFFFFFu) - cur.wlo;
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int off = base + (tx == 0 ? -1 : tx == 1 ? 0 : (int)((e >> 30) & 1u));
+                    const bool valid = ((e >> (29 + tx)) & 1u) != 0u && (unsigned int)off < (unsigned int)cur.wcnt;
+                    if (__ballot(valid) != 0ull) am |= 1u << tx;
+                    const unsigned int ra = valid ? (unsigned int)off * 64u + (unsigned int)(((2 * kh) ^ ((off >> 2) & 3)) << 4) : (unsigned int)(RCAP * 64);
+                    if (pt & 1) radr[ty][tx][pt / 2] |= ra << 16;
+                    else radr[ty][tx][pt / 2] = ra;
+                }
+            }
+            anym = (anym & ~(7u << (ty * 3))) | (am << (ty * 3));
+        };
+        const unsigned int win_o = (unsigned int)(C::OFF_WIN + cur.wb * C::WIN_BYTES);
+        const unsigned int w_hi_o = (unsigned int)(C::OFF_W + ws * C::WSLOT_BYTES) + wrow + khsw, w_lo_o = w_hi_o ^ 16u;
+        auto load_frag = [&](Frag &f, auto t_t) {           // tap t of the step
+            constexpr int t = decltype(t_t)::value, ty = TAPS == 3 ? Q : t / 3, tx = t % 3;
+            f.any = ((anym >> (ty * 3 + tx)) & 1u) != 0u;
+            if constexpr (DIAG & 2) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(f.c_hi[ct]), "+v"(f.c_lo[ct]));
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(f.p_hi[pt]), "+v"(f.p_lo[pt]));
+                return;
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f.c_hi[ct] = *reinterpret_cast<const v4u *>(smem + w_hi_o + (t * COUT + ct * 32) * 64);
+                f.c_lo[ct] = *reinterpret_cast<const v4u *>(smem + w_lo_o + (t * COUT + ct * 32) * 64);
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const unsigned int po = win_o + ((pt & 1) ? radr[ty][tx][pt / 2] >> 16 : radr[ty][tx][pt / 2] & 0xFFFFu);
+                f.p_hi[pt] = *reinterpret_cast<const v4u *>(smem + po);
+                f.p_lo[pt] = *reinterpret_cast<const v4u *>(smem + (po ^ 16u));
+            }
+        };
+        auto nothing = [] {};
+        auto issue_next_w = [&] {                           // weights D steps ahead: step Q + D of this stage, or Q + D - SPS of the next
+            if constexpr (Q + D < SPS) issue_w(cur, Q + D, slot_of(D));
+            else issue_w(nxt, Q + D - SPS, slot_of(D));
+        };
+        constexpr int H = C::WPWIN / 2;
+        using I0 = std::integral_constant<int, 0>;
+        using IH = std::integral_constant<int, H>;
+        using IE = std::integral_constant<int, C::WPWIN>;
+        if (cur.fresh) addr_row(std::integral_constant<int, TAPS == 3 ? Q : 0>{});
+        load_frag(fa, std::integral_constant<int, 0>{});
+        // (the previous step's last tap; a stage's first step also starts the next stage's window and table words behind it)
+        block(fp, [&] { if (Q == 0) issue_win(nxt, I0{}, IH{}); },
+              [&] {
+                  if (Q == 0) { issue_win(nxt, IH{}, IE{}); issue_pw(nxt); }
+                  if (TAPS == 9 && cur.fresh) addr_row(std::integral_constant<int, 1>{});
+              });
+        block(fa, [&] { load_frag(fb, std::integral_constant<int, 1>{}); }, [&] { issue_next_w(); });
+        block(fb, [&] { load_frag(fp, std::integral_constant<int, 2>{}); },
+              [&] { if (TAPS == 9 && cur.fresh) addr_row(std::integral_constant<int, 2>{}); });
+        if constexpr (TAPS == 9) {
+            block(fp, [&] { load_frag(fa, std::integral_constant<int, 3>{}); }, nothing);
+            block(fa, [&] { load_frag(fb, std::integral_constant<int, 4>{}); }, nothing);
+            block(fb, [&] { load_frag(fp, std::integral_constant<int, 5>{}); }, nothing);
+            block(fp, [&] { load_frag(fa, std::integral_constant<int, 6>{}); }, nothing);
+            block(fa, [&] { load_frag(fb, std::integral_constant<int, 7>{}); }, nothing);
+            block(fb, [&] { load_frag(fp, std::integral_constant<int, 8>{}); }, nothing);
+        }
+        ws = slot_of(1);
+    };
+
+    for (;;) {
+        step(std::integral_constant<int, 0>{});
+        if constexpr (SPS == 3) {
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+        }
+        if (!nxt.live || nxt.tile_first) {
+            // last stage of the tile: finish its last tap, then its window buffer (every wave is done with it after the barrier)
+            // stages the epilogue; the loads in flight go to the other window buffer and to other weight slots
+            if (fp.any) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) mma_pt(fp, pt);
+            }
+            fp.any = false;
             __syncthreads();
             const int row0 = cur.tile * C::BP;
+            if constexpr (DIAG & 32) {
+#pragma unroll
+                for (int i = 0; i < CT; ++i)
+#pragma unroll
+                    for (int j = 0; j < PT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+            } else
             store_tile_pair16<C, M>(acc, smem + C::OFF_WIN + cur.wb * C::WIN_BYTES, sc_s, sh_s, 0, a.cout, a.relu != 0,
                                     reinterpret_cast<const unsigned char *>(a.residual), reinterpret_cast<unsigned char *>(a.out), wp, wc, lane, wid,
                                     [&](int lr) {
@@ -299,8 +410,10 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int j = 0; j < PT; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            if (!it.live) break;
+            if (!nxt.live) break;
         }
+        cur = nxt;
+        nxt = gen();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -343,26 +456,50 @@ __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int c
     }
 }
 
-using X32 = XCfg<32, 8, 1, 2, 9, 832>;
-using X64 = XCfg<64, 8, 1, 2, 3, 832>;
-using X128 = XCfg<128, 4, 2, 2, 3, 576>;
+using X32 = XCfg<32, 8, 1, 2, 9, 1, 896>;
+using X64 = XCfg<64, 8, 1, 2, 3, 2, 896>;
+using X128 = XCfg<128, 4, 2, 2, 3, 2, 640>;
 
-template <class C, class M>
+template <class C, class M, int DIAG = 0>
 static int launch_x(const SpConvXArgs &a, hipStream_t stream) {
     static PerDeviceFlags done;
-    if (int rc = reserve_lds(reinterpret_cast<const void *>(&k_spconv_x<C, M>), C::LDS_BYTES, done, "dz_spconv_forward_split_x")) return rc;
+    if (int rc = reserve_lds(reinterpret_cast<const void *>(&k_spconv_x<C, M, DIAG>), C::LDS_BYTES, done, "dz_spconv_forward_split_x")) return rc;
     int grid = ceil_div(a.cap, C::BP);
     const int cus = device_cus();
     if (grid > cus) grid = cus;
     grid = (grid + 7) & ~7;
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((k_spconv_x<C, M>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_spconv_x<C, M, DIAG>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, a);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
+template <class C>
+static int x_diag(const SpConvXArgs &a, hipStream_t stream, int d) {
+    switch (d) {
+        case 1: return launch_x<C, MathF16, 1>(a, stream);
+        case 2: return launch_x<C, MathF16, 2>(a, stream);
+        case 3: return launch_x<C, MathF16, 3>(a, stream);
+        case 4: return launch_x<C, MathF16, 4>(a, stream);
+        case 8: return launch_x<C, MathF16, 8>(a, stream);
+        case 12: return launch_x<C, MathF16, 12>(a, stream);
+        case 16: return launch_x<C, MathF16, 16>(a, stream);
+        case 32: return launch_x<C, MathF16, 32>(a, stream);
+        case 15: return launch_x<C, MathF16, 15>(a, stream);
+        default: return launch_x<C, MathF16>(a, stream);
+    }
+}
+
 template <class M>
 static int x_dispatch(const SpConvXArgs &a, hipStream_t stream) {
+#ifdef DZ_SPCONV_DIAG
+    static const int diag = getenv("DZ_TUNE_X_DIAG") ? atoi(getenv("DZ_TUNE_X_DIAG")) : 0;
+    if (diag && M::ID == 1 && M::TERMS == 3) {
+        if (a.cout == 32) return x_diag<X32>(a, stream, diag);
+        if (a.cout == 64) return x_diag<X64>(a, stream, diag);
+        return x_diag<X128>(a, stream, diag);
+    }
+#endif
     if (a.cout == 32) return launch_x<X32, M>(a, stream);
     if (a.cout == 64) return launch_x<X64, M>(a, stream);
     return launch_x<X128, M>(a, stream);

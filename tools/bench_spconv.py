@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--points', type=int, default=160000)
     ap.add_argument('--math', default='f32')
+    ap.add_argument('--zero', action='store_true', help='time the layers on all-zero activations and weights (matrix-pipe power test)')
+    ap.add_argument('--only', default='', help='comma list of cin-cout pairs to time (default: every layer)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     from detzero_amd import ops
@@ -57,6 +59,8 @@ def main():
         variant = 'x' if getattr(nbr, 'xwin', None) is not None and w.shape[1] == w.shape[2] else 'g'
         cin, cout = (w.shape[2], scale.shape[0]) if mm else (w.shape[1], w.shape[2])
         key = (kvol, cin, cout, lvl.cap, residual is not None, id(nbr))
+        if args.only and '%d-%d' % (cin, cout) not in args.only.split(','):
+            continue
         m = lvl.num_active()
         if key not in seen:
             valid = ops.unpack_table(nbr)[:, :m] >= 0
@@ -68,6 +72,9 @@ def main():
                 return float(v.sum().item()) / v.shape[1]
             stats = (pairs, tile_taps(16), tile_taps(32), tile_taps(64), tile_taps(128))
             out = torch.empty((lvl.cap, cout), dtype=torch.float32, device=dev)
+            if args.zero:
+                f, w = torch.zeros_like(f), torch.zeros_like(w)
+                residual = torch.zeros_like(residual) if residual is not None else None
             for _ in range(3):
                 real(f, nbr, lvl, w, scale, shift, residual, relu, out, in_level, mm)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
