@@ -14,8 +14,11 @@
 //             deal of runs of consecutive tiles, as k_spconv_h); wave (wp, wc) owns PT 32-row fragments x CT 32-channel fragments.
 //   stage     (tz, 16-channel chunk kc, window pass): RCAP window rows x 64 bytes (one MFMA k-step of pair16: hi | lo of two 8-channel
 //             groups) -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, 1 KB per wave instruction), double buffered.
-//             A window longer than RCAP rows is walked in passes of RCAP rows (rows outside the pass read the zero row; ranks grow
-//             with the tap index, so a row's taps are still accumulated in ascending order whatever the pass boundaries are).
+//             A window longer than RCAP rows (2-3 % of the slabs: a tile in a sparse region next to a dense slab; up to 30 000 rows)
+//             is not staged at all: the stage runs in GATHER mode - each lane fetches its neighbour row's 2 x 16 bytes of the chunk
+//             straight from global memory into the MFMA operand registers (as k_spconv_w does), same taps, same order.  (Walking
+//             such a window in passes of RCAP rows costs up to 39 stages for one slab: measured, the slowest workgroup then took
+//             1.8-2x the average one.)
 //   step      G taps of a stage: their weight slices (COUT rows x 64 bytes each) -> LDS the same way, double buffered.  ONE barrier
 //             per step: s_waitcnt vmcnt(0) (this wave's pieces of the next step's data, issued a whole step ago, have landed),
 //             s_barrier (everyone's have, and everyone is done with the buffers the loads issued next will overwrite).
@@ -24,7 +27,7 @@
 //             which source piece a lane fetches.
 //   table     the PACKED neighbour table (dz_build_neighbors_packed: one word per (tz, ty) and output row = rank below the centre
 //             cell + three presence bits): 3 * PT words per lane and z slab instead of 27 * PT indices.
-//   skipping  a (tap, 32-row fragment) whose lanes all miss (no neighbour, or outside the pass) issues no MFMAs (wave-uniform
+//   skipping  a tap none of the wave's lanes has a neighbour at issues no MFMAs (wave-uniform
 //             branch on a ballot) - tap skipping at 32-row granularity without any mask table.
 // Accumulation order per output element: tz, kc, tap, k - fixed, independent of the tile the row falls into.
 // Epilogue = store_tile_pair16 (hgemm.h): BatchNorm scale / shift, residual, ReLU, split, 32-byte stores, staged through the
@@ -45,6 +48,7 @@ struct SpConvXArgs {
     float *out;
     int cin, cout, cap, relu;
     unsigned int in_bytes, w_bytes, nbr_bytes;
+    unsigned long long *dbg;    // DIAG bit 9 builds: per-wave cycle sums (8 words per wave) or null
 };
 
 template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
@@ -78,13 +82,13 @@ __device__ __forceinline__ void x_load16_lds(unsigned int lds_base, unsigned int
 // one stage of a workgroup's stream (wave-uniform: SGPRs; never indexed dynamically)
 struct XStage {
     int tile, tz, kc;
-    int wlo, wcnt;              // the window pass: first input row, rows (0: past the end of the stream - its loads fetch nothing)
+    int wlo, wcnt;              // the window: first input row, rows (0: gather mode, or past the end of the stream - its loads fetch nothing)
     int wb;                     // window buffer
-    bool live, fresh, tz_first, tile_first;     // fresh: row addresses differ from the previous stage's (new slab or pass)
+    bool live, gather, tz_first, tile_first;    // gather: the slab's window does not fit the buffer, operands come from global memory
 };
 
 // DIAG (development, DZ_TUNE_X_DIAG; timing experiments, results are garbage): bit 0 no MFMAs, 1 no fragment LDS reads, 2 no weight
-// loads, 3 no window loads, 4 no barriers, 5 no epilogue
+// loads, 3 no window loads, 4 no barriers, 5 no epilogue, 7 no tap skipping
 template <class C, class M, int DIAG = 0>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_spconv_x(SpConvXArgs a) {
     constexpr int PT = C::PT, CT = C::CT, COUT = C::COUT, RCAP = C::RCAP, NW = C::NW, D = C::D, TAPS = C::TAPS, SPS = C::SPS;
@@ -124,27 +128,20 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // XCD share their overlapping windows in that XCD's L2).  Inside a tile: tz, 16-channel chunk, window pass.
     constexpr int XRUN = 8;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = gridDim.x >> 3;
-    struct Gen { int seq, tile, lo0, n0, lo1, n1, lo2, n2, tz, kc, pass, wlo, wn, wb; bool live, started; } g;
-    g.seq = -1; g.live = true; g.started = false; g.wb = 1; g.tile = 0; g.tz = g.kc = g.pass = 0; g.wlo = g.wn = 0;
+    struct Gen { int seq, tile, lo0, n0, lo1, n1, lo2, n2, tz, kc, wlo, wn, wb; bool live, started; } g;
+    g.seq = -1; g.live = true; g.started = false; g.wb = 1; g.tile = 0; g.tz = g.kc = 0; g.wlo = g.wn = 0;
     g.lo0 = g.n0 = g.lo1 = g.n1 = g.lo2 = g.n2 = 0;
     auto gen = [&]() {          // the next stage of the stream (live = false: past its end)
         XStage s;
         s.tile_first = s.tz_first = false;
         bool next_tile = !g.started;
-        if (g.started) {
-            if ((g.pass + 1) * RCAP < g.wn) {
-                ++g.pass;
-            } else {
-                g.pass = 0;
-                if (++g.kc == nk) {
-                    g.kc = 0;
-                    s.tz_first = true;
-                    ++g.tz;
-                    if (g.tz == 1) { g.wlo = g.lo1; g.wn = g.n1; }                        // (n1 > 0 always)
-                    else if (g.tz == 2 && g.n2 > 0) { g.wlo = g.lo2; g.wn = g.n2; }
-                    else next_tile = true;
-                }
-            }
+        if (g.started && ++g.kc == nk) {
+            g.kc = 0;
+            s.tz_first = true;
+            ++g.tz;
+            if (g.tz == 1) { g.wlo = g.lo1; g.wn = g.n1; }                        // (n1 > 0 always)
+            else if (g.tz == 2 && g.n2 > 0) { g.wlo = g.lo2; g.wn = g.n2; }
+            else next_tile = true;
         }
         if (next_tile && g.live) {
             g.started = true;
@@ -162,62 +159,53 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 g.tz = g.n0 > 0 ? 0 : 1;          // (the centre slab of a live tile is never empty: dz_spconv_x_windows)
                 g.wlo = g.n0 > 0 ? g.lo0 : g.lo1;
                 g.wn = g.n0 > 0 ? g.n0 : g.n1;
-                g.kc = g.pass = 0;
+                g.kc = 0;
                 s.tile_first = s.tz_first = true;
             }
         }
         g.wb ^= 1;
         s.live = g.live;
         s.tile = g.tile; s.tz = g.tz; s.kc = g.kc; s.wb = g.wb;
-        s.wlo = g.wlo + g.pass * RCAP;
-        s.wcnt = g.live ? min(RCAP, g.wn - g.pass * RCAP) : 0;
-        s.fresh = s.tz_first || g.wn > RCAP;
+        s.gather = g.live && g.wn > RCAP;
+        s.wlo = g.wlo;
+        s.wcnt = g.live && g.wn <= RCAP ? g.wn : 0;
         return s;
     };
 
     // packed table words of my rows, one array per window row ty (separate arrays, statically indexed: a [3][PT] array picked with a
     // run-time index is turned into a scratch array by the compiler): current z slab, next
     unsigned int pw0[PT], pw1[PT], pw2[PT], pn0[PT], pn1[PT], pn2[PT];
-    // ---- issue: runs [I0, I1) of my share of stage s's window pass (WPWIN per wave and stage, always: a run past the window's end -
-    // every run of a stage past the end of the stream - fetches nothing, so the per-wave load counts stay static)
-    auto issue_win = [&](const XStage &s, auto i0_t, auto i1_t) {
+    // ---- issue, one load at a time (every load is a filler behind an MFMA, never a block of its own):
+    // run I of my share of stage s's window pass (WPWIN per wave and stage, always: a run past the window's end - every run of a
+    // stage past the end of the stream - fetches nothing, so the per-wave load counts stay static)
+    auto issue_win = [&](const XStage &s, auto i_t) {
         if constexpr (DIAG & 8) return;
-        constexpr int I0 = decltype(i0_t)::value, I1 = decltype(i1_t)::value;
-        const unsigned int lds0 = (unsigned int)(C::OFF_WIN + s.wb * C::WIN_BYTES) + wid_lds;
-        const unsigned int soff0 = (unsigned int)s.wlo * row_bytes + (unsigned int)(s.kc * 64) + wid_rows;
-        const int left0 = s.wcnt - 1 - wid * 16;                  // rows of the window after the first row of my run 0
-#pragma unroll
-        for (int i = I0; i < I1; ++i) {
-            const int left = left0 - i * NW * 16;
-            // (rows past the window's end re-read its last row: always inside the buffer, never referenced)
-            const unsigned int voff = left >= 0 ? (unsigned int)min(lrow, left) * row_bytes + lpiece : OOB_OFFSET;
-            x_load16_lds(lds0 + (unsigned int)(i * NW * 1024), voff, prsrc, soff0 + (unsigned int)i * nw_rows);
-        }
+        constexpr int I = decltype(i_t)::value;
+        const int left = s.wcnt - 1 - wid * 16 - I * NW * 16;     // rows of the window after the first row of my run
+        // (rows past the window's end re-read its last row: always inside the buffer, never referenced)
+        const unsigned int voff = left >= 0 ? (unsigned int)min(lrow, left) * row_bytes + lpiece : OOB_OFFSET;
+        x_load16_lds((unsigned int)(C::OFF_WIN + s.wb * C::WIN_BYTES) + wid_lds + (unsigned int)(I * NW * 1024), voff, prsrc,
+                     (unsigned int)s.wlo * row_bytes + (unsigned int)(s.kc * 64) + wid_rows + (unsigned int)I * nw_rows);
     };
-    auto issue_pw = [&](const XStage &s) {
-        const bool want = s.live && s.tz_first;
-        const unsigned int so = (unsigned int)(s.tz * 3) * nbr_row_bytes;
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int row = s.tile * C::BP + (wp * PT + pt) * 32 + l31;
-            const unsigned int voff = want && row < m ? (unsigned int)row * 4u : OOB_OFFSET;
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn0[pt]) : "v"(voff), "s"(nrsrc), "s"(so) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn1[pt]) : "v"(voff), "s"(nrsrc), "s"(so + nbr_row_bytes) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pn2[pt]) : "v"(voff), "s"(nrsrc), "s"(so + 2u * nbr_row_bytes) : "memory");
-        }
+    // table word (fragment PTI, window row TY) of stage s's slab
+    auto issue_pw = [&](const XStage &s, auto pt_t, auto ty_t) {
+        constexpr int PTI = decltype(pt_t)::value, TY = decltype(ty_t)::value;
+        const int row = s.tile * C::BP + (wp * PT + PTI) * 32 + l31;
+        const unsigned int voff = s.live && s.tz_first && row < m ? (unsigned int)row * 4u : OOB_OFFSET;
+        const unsigned int so = (unsigned int)(s.tz * 3 + TY) * nbr_row_bytes;
+        const srsrc_t rs = nrsrc;            // (named here: an asm operand alone does not capture a variable in a generic lambda)
+        unsigned int &dst = TY == 0 ? pn0[PTI] : (TY == 1 ? pn1[PTI] : pn2[PTI]);
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(so) : "memory");
     };
-    // ---- issue: the weight slices of step q (= window row q when a step is one row) of stage s -> slot `slot` (WPW per wave, always)
-    auto issue_w = [&](const XStage &s, int q, int slot) {
+    // run I of my share of the weight slices of step q of stage s -> slot `slot` (WPW per wave, always)
+    auto issue_w = [&](const XStage &s, int q, int slot, auto i_t) {
         if constexpr (DIAG & 4) return;
-        const unsigned int soff0 = (unsigned int)(s.tz * 9 + q * TAPS) * tap_bytes + (unsigned int)(s.kc * 64) + w_soff_w;
-        const unsigned int lds0 = (unsigned int)(C::OFF_W + slot * C::WSLOT_BYTES) + wid_lds;
-        const unsigned int vlive = s.live ? w_voff : OOB_OFFSET;
-#pragma unroll
-        for (int i = 0; i < C::WPW; ++i) {
-            const bool part = C::WJ % NW != 0 && i == C::WPW - 1;             // the last, partial round
-            x_load16_lds(part && !w_last_ok ? (unsigned int)C::OFF_TRASH : lds0 + (unsigned int)(i * NW * 1024), part && !w_last_ok ? OOB_OFFSET : vlive, crsrc,
-                         soff0 + (unsigned int)(i * (NW / C::R)) * tap_bytes);
-        }
+        constexpr int I = decltype(i_t)::value;
+        constexpr bool part = C::WJ % NW != 0 && I == C::WPW - 1;             // the last, partial round
+        const bool ok = !part || w_last_ok;
+        x_load16_lds(ok ? (unsigned int)(C::OFF_W + slot * C::WSLOT_BYTES) + wid_lds + (unsigned int)(I * NW * 1024) : (unsigned int)C::OFF_TRASH,
+                     ok && s.live ? w_voff : OOB_OFFSET, crsrc,
+                     (unsigned int)(s.tz * 9 + q * TAPS + I * (NW / C::R)) * tap_bytes + (unsigned int)(s.kc * 64) + w_soff_w);
     };
 
     f32x16 acc[CT][PT];
@@ -242,56 +230,88 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int i = 0; i < PT; ++i) fp.p_hi[i] = fp.p_lo[i] = v4u{0u, 0u, 0u, 0u};
 
-    // the MFMAs of fragment pt of a tap (term-major: consecutive MFMAs go to different accumulators; each still receives lo.hi,
-    // hi.lo, hi.hi in that order)
-    auto mma_pt = [&](const Frag &f, int pt) {
-        if constexpr (DIAG & 1) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(f.c_hi[ct]), "v"(f.c_lo[ct]), "v"(f.p_hi[pt]), "v"(f.p_lo[pt]));
-            return;
-        }
-#pragma unroll
-        for (int term = 3 - M::TERMS; term < 3; ++term)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
+    // A tap = FS slots.  Slot i issues MFMA i of the tap - term i / (CT*PT) (lo.hi, hi.lo, hi.hi), then fragment, then channel
+    // fragment: consecutive MFMAs go to different accumulators, each accumulator still receives its three terms in order - and then
+    // ONE filler: an LDS read of the next tap's operands, a direct load, a table word.  The vector-memory and LDS instructions are
+    // thus issued in the shadow of an MFMA instead of as blocks that stall both waves of a SIMD at once (measured: with the loads of a
+    // step issued back to back behind a tap, 20-30 % of the kernel was load issue).
+    constexpr int FS = 3 * CT * PT;
+    // loads a step issues: (first step of a stage) the next stage's window runs and table words, then the weight runs D steps ahead;
+    // op j is issued by tap block j / OPB, behind its MFMAs
+    auto nops_of = [](int q) constexpr { return (q == 0 ? C::WPWIN + 3 * PT : 0) + C::WPW; };
+    auto opb_of = [nops_of](int q) constexpr { return (nops_of(q) + TAPS - 1) / TAPS; };
+    // ... and how many of them block t of step q issues (gather mode: the loads younger than the block's last B-operand load)
+    auto younger_of = [nops_of, opb_of](int q, int t) constexpr {
+        const int left = nops_of(q) - t * opb_of(q);
+        return left < 0 ? 0 : (left < opb_of(q) ? left : opb_of(q));        // (all of a block's loads are issued behind its operand reads)
     };
-    // one tap: its MFMAs (skipped when no lane of the wave's fragments has the tap: wave-uniform) with the fillers - work of LATER
-    // taps that has to happen anyway - in between, so that it is issued in the shadow of the MFMAs instead of in front of them
-    auto block = [&](const Frag &f, auto &&fill_a, auto &&fill_b) {
-        if (f.any) {
-            mma_pt(f, 0);
-            fill_a();
-#pragma unroll
-            for (int pt = 1; pt < PT; ++pt) mma_pt(f, pt);
-            fill_b();
-        } else {
-            fill_a();
-            fill_b();
+    auto mfma_slot = [&](const Frag &f, auto i_t) {
+        constexpr int i = decltype(i_t)::value, term = i / (CT * PT), pt = (i % (CT * PT)) / CT, ct = i % CT;
+        if constexpr (term < 3 - M::TERMS) return;
+        if constexpr (DIAG & 1) { asm volatile("" ::"v"(f.c_hi[ct]), "v"(f.c_lo[ct]), "v"(f.p_hi[pt]), "v"(f.p_lo[pt])); return; }
+        acc[ct][pt] = M::mma(term == 0 ? f.c_lo[ct] : f.c_hi[ct], term == 1 ? f.p_lo[pt] : f.p_hi[pt], acc[ct][pt]);
+    };
+    auto tap_block = [&](const Frag &f, auto &&fill) {        // fill(slot): the filler behind slot's MFMA
+        // (a tap none of my lanes has issues no MFMAs - wave-uniform; one small branch per slot rather than two copies of the block:
+        // the copies' register allocation does not fit the 256 registers of a wave)
+        auto one = [&](auto i_t) {
+            if (f.any) mfma_slot(f, i_t);
+            fill(i_t);
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+        if constexpr (FS > 6) {
+            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
+            one(std::integral_constant<int, 9>{}); one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 11>{});
         }
     };
+    static_assert(FS == 6 || FS == 12, "slots per tap");
 
+    unsigned long long tm_vm = 0ull, tm_bar = 0ull, tm_step = 0ull, tm_epi = 0ull, tm_gen = 0ull, tm_n = 0ull;
+    const unsigned long long tm_start = (DIAG & 512) ? __builtin_readcyclecounter() : 0ull;
     XStage cur = gen();
     if (!cur.live) return;
     XStage nxt = gen();
     __syncthreads();
     int ws = 0;                 // weight slot of the current step
+    bool prev_gather = false;   // the stage before `cur` ran in gather mode
     auto slot_of = [&](int ahead) { const int v = ws + ahead; return v >= C::NSLOT ? v - C::NSLOT : v; };
-    // prologue: stage 0's window + words, the weights of its first D steps
-    issue_win(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, C::WPWIN>{});
-    issue_pw(cur);
-    issue_w(cur, 0, 0);
-    if constexpr (D >= 2) issue_w(cur, 1, 1);
-    if constexpr (D >= 3) issue_w(cur, 2, 2);
+    // prologue: stage 0's window + words, the weights of its first D steps (same order as in the loop: window, words, weights)
+    {
+        auto all_win = [&](auto self, auto i_t) -> void {
+            constexpr int i = decltype(i_t)::value;
+            if constexpr (i < C::WPWIN) { issue_win(cur, i_t); self(self, std::integral_constant<int, i + 1>{}); }
+        };
+        all_win(all_win, std::integral_constant<int, 0>{});
+        auto all_pw = [&](auto self, auto j_t) -> void {
+            constexpr int j = decltype(j_t)::value;
+            if constexpr (j < 3 * PT) { issue_pw(cur, std::integral_constant<int, j / 3>{}, std::integral_constant<int, j % 3>{}); self(self, std::integral_constant<int, j + 1>{}); }
+        };
+        all_pw(all_pw, std::integral_constant<int, 0>{});
+        auto all_w = [&](auto self, int q, auto i_t) -> void {
+            constexpr int i = decltype(i_t)::value;
+            if constexpr (i < C::WPW) { issue_w(cur, q, q, i_t); self(self, q, std::integral_constant<int, i + 1>{}); }
+        };
+        all_w(all_w, 0, std::integral_constant<int, 0>{});
+        if constexpr (D >= 2) all_w(all_w, 1, std::integral_constant<int, 0>{});
+        if constexpr (D >= 3) all_w(all_w, 2, std::integral_constant<int, 0>{});
+    }
 
     // one step = TAPS taps of the stage (window row Q, or the whole slab): wait for its data, (re)build its row addresses, run the
     // taps.  The MFMAs of a step's last tap are issued AFTER the next step's barrier (fp carries its operands across), so no barrier
     // is followed by a cold start.
     auto step = [&](auto q_t) {
         constexpr int Q = decltype(q_t)::value;
+        const bool gm_prev = Q == 0 ? prev_gather : cur.gather;          // mode of the step before this one
+        const bool GM = cur.gather;          // gather mode: the B operands come from global memory, not from the window (one small branch
+                                             // per operand read: two copies of the step do not fit the register file)
         constexpr int NV = (D - 1) * C::WPW + ((Q >= 1 && Q <= D - 1) ? C::WINPW : 0);     // younger loads that may stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+        unsigned long long t_top = 0ull;
+        if constexpr (DIAG & 512) t_top = __builtin_readcyclecounter();
+        if constexpr (!(DIAG & 256)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+        if constexpr (DIAG & 512) { const unsigned long long t = __builtin_readcyclecounter(); tm_vm += t - t_top; t_top = t; }
         if constexpr (!(DIAG & 16)) __syncthreads();
+        if constexpr (DIAG & 512) { const unsigned long long t = __builtin_readcyclecounter(); tm_bar += t - t_top; t_top = t; }
         if (Q == 0 && cur.tz_first) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
@@ -310,10 +330,10 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) {
                     const int off = base + (tx == 0 ? -1 : tx == 1 ? 0 : (int)((e >> 30) & 1u));
-                    const bool valid = ((e >> (29 + tx)) & 1u) != 0u && (unsigned int)off < (unsigned int)cur.wcnt;
+                    const bool valid = ((e >> (29 + tx)) & 1u) != 0u && (GM || (unsigned int)off < (unsigned int)cur.wcnt);
                     if (__ballot(valid) != 0ull) am |= 1u << tx;
                     const unsigned int ra = valid ? (unsigned int)off * 64u + (unsigned int)(((2 * kh) ^ ((off >> 2) & 3)) << 4) : (unsigned int)(RCAP * 64);
-                    if (pt & 1) radr[ty][tx][pt / 2] |= ra << 16;
+                    if (pt & 1) radr[ty][tx][pt / 2] |= ra << 16;       // (not read in gather mode)
                     else radr[ty][tx][pt / 2] = ra;
                 }
             }
@@ -321,9 +341,11 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         };
         const unsigned int win_o = (unsigned int)(C::OFF_WIN + cur.wb * C::WIN_BYTES);
         const unsigned int w_hi_o = (unsigned int)(C::OFF_W + ws * C::WSLOT_BYTES) + wrow + khsw, w_lo_o = w_hi_o ^ 16u;
-        auto load_frag = [&](Frag &f, auto t_t) {           // tap t of the step
+        // operand reads of tap t of the step into f: weights from the slot, neighbour rows from the window (LDS) or - gather mode -
+        // straight from global memory
+        auto frag_reads = [&](Frag &f, auto t_t) {
             constexpr int t = decltype(t_t)::value, ty = TAPS == 3 ? Q : t / 3, tx = t % 3;
-            f.any = ((anym >> (ty * 3 + tx)) & 1u) != 0u;
+            f.any = (DIAG & 128) ? true : ((anym >> (ty * 3 + tx)) & 1u) != 0u;       // (DIAG 128: no tap skipping)
             if constexpr (DIAG & 2) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(f.c_hi[ct]), "+v"(f.c_lo[ct]));
@@ -336,42 +358,87 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 f.c_hi[ct] = *reinterpret_cast<const v4u *>(smem + w_hi_o + (t * COUT + ct * 32) * 64);
                 f.c_lo[ct] = *reinterpret_cast<const v4u *>(smem + w_lo_o + (t * COUT + ct * 32) * 64);
             }
+            if (GM) {
+                // my lane's neighbour row itself: hi / lo half of 8-channel group 2 kc + kh (missing: out of range, zeros).  From inline
+                // asm: a load the compiler tracks makes its waitcnt pass drain the whole queue - vmcnt(0) - at the join of the two
+                // operand paths, and with it the direct loads in flight; the wait is in tap()
+                const srsrc_t rs = prsrc;
+                const unsigned int kso = __builtin_amdgcn_readfirstlane((unsigned int)(cur.kc * 64));
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const unsigned int po = win_o + ((pt & 1) ? radr[ty][tx][pt / 2] >> 16 : radr[ty][tx][pt / 2] & 0xFFFFu);
-                f.p_hi[pt] = *reinterpret_cast<const v4u *>(smem + po);
-                f.p_lo[pt] = *reinterpret_cast<const v4u *>(smem + (po ^ 16u));
+                for (int pt = 0; pt < PT; ++pt) {
+                    const unsigned int e = ty == 0 ? pw0[pt] : (ty == 1 ? pw1[pt] : pw2[pt]);
+                    const unsigned int idx = (e & 0x1FFFFFFFu) + (tx == 0 ? 0xFFFFFFFFu : tx == 1 ? 0u : ((e >> 30) & 1u));
+                    const unsigned int vo = ((e >> (29 + tx)) & 1u) ? idx * row_bytes + (unsigned int)(kh * 32) : OOB_OFFSET;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(f.p_hi[pt]) : "v"(vo), "s"(rs), "s"(kso) : "memory");
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(f.p_lo[pt]) : "v"(vo), "s"(rs), "s"(kso) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const unsigned int po = win_o + ((pt & 1) ? radr[ty][tx][pt / 2] >> 16 : radr[ty][tx][pt / 2] & 0xFFFFu);
+                    f.p_hi[pt] = *reinterpret_cast<const v4u *>(smem + po);
+                    f.p_lo[pt] = *reinterpret_cast<const v4u *>(smem + (po ^ 16u));
+                }
             }
         };
-        auto nothing = [] {};
-        auto issue_next_w = [&] {                           // weights D steps ahead: step Q + D of this stage, or Q + D - SPS of the next
-            if constexpr (Q + D < SPS) issue_w(cur, Q + D, slot_of(D));
-            else issue_w(nxt, Q + D - SPS, slot_of(D));
+        // loads of the step, in issue order: (first step of a stage) the next stage's window runs and table words, then the weight
+        // runs D steps ahead; op j goes behind MFMA slot (j % OPB) of tap block j / OPB, from the block's last slots backwards
+        constexpr int NWIN = Q == 0 ? C::WPWIN : 0, NPW = Q == 0 ? 3 * PT : 0, NOPS = nops_of(Q), OPB = opb_of(Q);
+        static_assert(OPB <= FS, "more loads per tap than MFMA slots");
+        auto load_op = [&](auto j_t) {
+            constexpr int j = decltype(j_t)::value;
+            if constexpr (j < NWIN) issue_win(nxt, j_t);
+            else if constexpr (j < NWIN + NPW) issue_pw(nxt, std::integral_constant<int, (j - NWIN) / 3>{}, std::integral_constant<int, (j - NWIN) % 3>{});
+            else if constexpr (j < NOPS) {
+                using I = std::integral_constant<int, j - NWIN - NPW>;
+                if constexpr (Q + D < SPS) issue_w(cur, Q + D, slot_of(D), I{});        // step Q + D of this stage
+                else issue_w(nxt, Q + D - SPS, slot_of(D), I{});                      // or Q + D - SPS of the next
+            }
         };
-        constexpr int H = C::WPWIN / 2;
-        using I0 = std::integral_constant<int, 0>;
-        using IH = std::integral_constant<int, H>;
-        using IE = std::integral_constant<int, C::WPWIN>;
-        if (cur.fresh) addr_row(std::integral_constant<int, TAPS == 3 ? Q : 0>{});
-        load_frag(fa, std::integral_constant<int, 0>{});
-        // (the previous step's last tap; a stage's first step also starts the next stage's window and table words behind it)
-        block(fp, [&] { if (Q == 0) issue_win(nxt, I0{}, IH{}); },
-              [&] {
-                  if (Q == 0) { issue_win(nxt, IH{}, IE{}); issue_pw(nxt); }
-                  if (TAPS == 9 && cur.fresh) addr_row(std::integral_constant<int, 1>{});
-              });
-        block(fa, [&] { load_frag(fb, std::integral_constant<int, 1>{}); }, [&] { issue_next_w(); });
-        block(fb, [&] { load_frag(fp, std::integral_constant<int, 2>{}); },
-              [&] { if (TAPS == 9 && cur.fresh) addr_row(std::integral_constant<int, 2>{}); });
+        // tap block T of the step: the operand reads of tap T (fnew), then the MFMAs of the tap before it (fprev; the reads' latency
+        // runs under them), then the block's share of the loads.  One branch for the MFMAs (a tap none of my lanes has issues none).
+        // Measured alternatives: one branch per MFMA slot with one filler each, or the MFMAs in two halves around the reads (+15-25 %
+        // per step: in this loop every branch costs ~20 cycles), two copies of the block (256 registers + spills at 64 / 128 channels).
+        auto tap = [&](Frag &fprev, Frag &fnew, auto t_t) {
+            constexpr int T = decltype(t_t)::value;
+            if (cur.tz_first && (TAPS == 3 ? T == 0 : T % 3 == 0)) addr_row(std::integral_constant<int, TAPS == 3 ? Q : T / 3>{});
+            // gather mode: fprev's B operands are global loads of the previous block (of this step, or the last block of the step
+            // before it); younger than the last of them are only the loads that block issued behind its operand reads
+            constexpr int QP = T > 0 ? Q : (Q + SPS - 1) % SPS, TP = T > 0 ? T - 1 : TAPS - 1;
+            if (T > 0 ? GM : gm_prev) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger_of(QP, TP)) : "memory");
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(fprev.p_hi[pt]), "+v"(fprev.p_lo[pt]));
+            }
+            frag_reads(fnew, t_t);
+            if (fprev.any) {
+                auto all = [&](auto self, auto i_t) -> void {
+                    constexpr int i = decltype(i_t)::value;
+                    if constexpr (i < FS) { mfma_slot(fprev, i_t); self(self, std::integral_constant<int, i + 1>{}); }
+                };
+                all(all, std::integral_constant<int, 0>{});
+            }
+            {
+                auto ops = [&](auto self, auto o_t) -> void {
+                    constexpr int o = decltype(o_t)::value;
+                    if constexpr (o < OPB && T * OPB + o < NOPS) { load_op(std::integral_constant<int, T * OPB + o>{}); self(self, std::integral_constant<int, o + 1>{}); }
+                };
+                ops(ops, std::integral_constant<int, 0>{});
+            }
+        };
+        tap(fp, fa, std::integral_constant<int, 0>{});
+        tap(fa, fb, std::integral_constant<int, 1>{});
+        tap(fb, fp, std::integral_constant<int, 2>{});
         if constexpr (TAPS == 9) {
-            block(fp, [&] { load_frag(fa, std::integral_constant<int, 3>{}); }, nothing);
-            block(fa, [&] { load_frag(fb, std::integral_constant<int, 4>{}); }, nothing);
-            block(fb, [&] { load_frag(fp, std::integral_constant<int, 5>{}); }, nothing);
-            block(fp, [&] { load_frag(fa, std::integral_constant<int, 6>{}); }, nothing);
-            block(fa, [&] { load_frag(fb, std::integral_constant<int, 7>{}); }, nothing);
-            block(fb, [&] { load_frag(fp, std::integral_constant<int, 8>{}); }, nothing);
+            tap(fp, fa, std::integral_constant<int, 3>{});
+            tap(fa, fb, std::integral_constant<int, 4>{});
+            tap(fb, fp, std::integral_constant<int, 5>{});
+            tap(fp, fa, std::integral_constant<int, 6>{});
+            tap(fa, fb, std::integral_constant<int, 7>{});
+            tap(fb, fp, std::integral_constant<int, 8>{});
         }
         ws = slot_of(1);
+        if constexpr (DIAG & 512) { tm_step += __builtin_readcyclecounter() - t_top; ++tm_n; }
     };
 
     for (;;) {
@@ -383,10 +450,14 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (!nxt.live || nxt.tile_first) {
             // last stage of the tile: finish its last tap, then its window buffer (every wave is done with it after the barrier)
             // stages the epilogue; the loads in flight go to the other window buffer and to other weight slots
-            if (fp.any) {
+            unsigned long long t_e = 0ull;
+            if constexpr (DIAG & 512) t_e = __builtin_readcyclecounter();
+            if (cur.gather) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger_of(SPS - 1, TAPS - 1)) : "memory");
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) mma_pt(fp, pt);
+                for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(fp.p_hi[pt]), "+v"(fp.p_lo[pt]));
             }
+            tap_block(fp, [](auto) {});
             fp.any = false;
             __syncthreads();
             const int row0 = cur.tile * C::BP;
@@ -410,10 +481,22 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int j = 0; j < PT; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            if constexpr (DIAG & 512) tm_epi += __builtin_readcyclecounter() - t_e;
             if (!nxt.live) break;
         }
+        prev_gather = cur.gather;
         cur = nxt;
-        nxt = gen();
+        if constexpr (DIAG & 512) {
+            const unsigned long long t_g = __builtin_readcyclecounter();
+            nxt = gen();
+            tm_gen += __builtin_readcyclecounter() - t_g;
+        } else nxt = gen();
+    }
+    if constexpr (DIAG & 512) {
+        if (a.dbg && lane == 0) {
+            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wid) * 8;
+            d[0] = tm_vm; d[1] = tm_bar; d[2] = tm_step; d[3] = tm_epi; d[4] = tm_gen; d[5] = tm_n; d[6] = __builtin_readcyclecounter() - tm_start; d[7] = 1ull;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -474,11 +557,12 @@ static int launch_x(const SpConvXArgs &a, hipStream_t stream) {
     return DZ_OK;
 }
 
+[[maybe_unused]] static unsigned long long *x_dbg_buf = nullptr;      // (diag builds) cycle sums of the last timed launch
+
 template <class C>
 static int x_diag(const SpConvXArgs &a, hipStream_t stream, int d) {
     switch (d) {
         case 1: return launch_x<C, MathF16, 1>(a, stream);
-        case 2: return launch_x<C, MathF16, 2>(a, stream);
         case 3: return launch_x<C, MathF16, 3>(a, stream);
         case 4: return launch_x<C, MathF16, 4>(a, stream);
         case 8: return launch_x<C, MathF16, 8>(a, stream);
@@ -486,6 +570,17 @@ static int x_diag(const SpConvXArgs &a, hipStream_t stream, int d) {
         case 16: return launch_x<C, MathF16, 16>(a, stream);
         case 32: return launch_x<C, MathF16, 32>(a, stream);
         case 15: return launch_x<C, MathF16, 15>(a, stream);
+        case 128: return launch_x<C, MathF16, 128>(a, stream);
+        case 144: return launch_x<C, MathF16, 144>(a, stream);
+        case 256: return launch_x<C, MathF16, 256>(a, stream);
+        case 2: return launch_x<C, MathF16, 2>(a, stream);
+        case 258: return launch_x<C, MathF16, 258>(a, stream);
+        case 259: return launch_x<C, MathF16, 259>(a, stream);
+        case 271: return launch_x<C, MathF16, 271>(a, stream);
+        case 287: return launch_x<C, MathF16, 287>(a, stream);
+        case 319: return launch_x<C, MathF16, 319>(a, stream);
+        case 447: return launch_x<C, MathF16, 447>(a, stream);
+        case 512: return launch_x<C, MathF16, 512>(a, stream);
         default: return launch_x<C, MathF16>(a, stream);
     }
 }
@@ -495,9 +590,17 @@ static int x_dispatch(const SpConvXArgs &a, hipStream_t stream) {
 #ifdef DZ_SPCONV_DIAG
     static const int diag = getenv("DZ_TUNE_X_DIAG") ? atoi(getenv("DZ_TUNE_X_DIAG")) : 0;
     if (diag && M::ID == 1 && M::TERMS == 3) {
-        if (a.cout == 32) return x_diag<X32>(a, stream, diag);
-        if (a.cout == 64) return x_diag<X64>(a, stream, diag);
-        return x_diag<X128>(a, stream, diag);
+        SpConvXArgs b = a;
+        if (diag & 512) {
+            static unsigned long long *dbg = nullptr;
+            if (!dbg && hipMalloc(&dbg, 256 * 8 * 8 * sizeof(unsigned long long)) != hipSuccess) dbg = nullptr;
+            if (dbg) (void)hipMemsetAsync(dbg, 0, 256 * 8 * 8 * sizeof(unsigned long long), stream);
+            b.dbg = dbg;
+            x_dbg_buf = dbg;
+        }
+        if (a.cout == 32) return x_diag<X32>(b, stream, diag);
+        if (a.cout == 64) return x_diag<X64>(b, stream, diag);
+        return x_diag<X128>(b, stream, diag);
     }
 #endif
     if (a.cout == 32) return launch_x<X32, M>(a, stream);
@@ -549,10 +652,32 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
         return DZ_ERR_UNSUPPORTED;
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
-                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes};
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);
 }
+
+#ifdef DZ_SPCONV_DIAG
+/* (diag builds only, not in the header) cycle sums of the last DZ_TUNE_X_DIAG=512 launch, averaged over the waves that ran */
+int dz_spconv_x_debug_dump(void) {
+    if (!x_dbg_buf) return -1;
+    static unsigned long long h[256 * 8 * 8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, x_dbg_buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    double s[7] = {0, 0, 0, 0, 0, 0, 0}, mx = 0;
+    int n = 0;
+    for (int w = 0; w < 256 * 8; ++w) {
+        if (!h[w * 8 + 7]) continue;
+        ++n;
+        for (int k = 0; k < 7; ++k) s[k] += (double)h[w * 8 + k];
+        if ((double)h[w * 8 + 6] > mx) mx = (double)h[w * 8 + 6];
+    }
+    if (!n) return -3;
+    printf("x-dbg: waves %d  steps/wave %.0f | per step (cycles): vmcnt wait %.0f  barrier %.0f  body %.0f | per wave total: epilogue %.0f  gen %.0f  kernel %.0f (max %.0f)\n", n, s[5] / n,
+           s[0] / s[5], s[1] / s[5], s[2] / s[5], s[3] / n, s[4] / n, s[6] / n, mx);
+    fflush(stdout);
+    return 0;
+}
+#endif
 
 const char *dz_spconv_x_variant(int cin, int cout) {
     if (cin == 32 && cout == 32) return "k_spconv_x<32>";

@@ -84,6 +84,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = 1000.0 * e0.elapsed_time(e1) / args.reps
+            if os.environ.get('DZ_TUNE_X_DIAG') and variant == 'x':
+                import ctypes
+                from detzero_amd import lib as L
+                try:
+                    L.load().dz_spconv_x_debug_dump()
+                except AttributeError:
+                    pass
             seen[key] = (us, stats)
         us, (pairs, t16, t32, t64, t128) = seen[key]
         halo = ''

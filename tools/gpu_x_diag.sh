@@ -10,6 +10,6 @@ objs=$(ls detzero_amd/csrc/build/*.o | grep -v sparse_conv_x.o)
 LIST=${1:-0 1 2 3 4 8 12 15 16 32 64}
 for d in $LIST; do
   echo "== DZ_TUNE_X_DIAG=$d"
-  DZ_TUNE_SPCONV_ENGINE=xrun DZ_TUNE_X_DIAG=$d timeout 200 python tools/bench_spconv.py --batch 16 --math f16x2 --reps 5 --only 32-32,64-64,128-128 2>&1 | grep -E "^x" | grep -v "+res" | sort -u | cut -c1-30,95-125
+  DZ_TUNE_SPCONV_ENGINE=xrun DZ_TUNE_X_DIAG=$d timeout 200 python tools/bench_spconv.py --batch 16 --math f16x2 --reps 5 --only 32-32,64-64,128-128 > /tmp/xd.txt 2>&1; grep -E "^x" /tmp/xd.txt | grep -v "+res" | sort -u | cut -c1-30,95-125; grep x-dbg /tmp/xd.txt | sort -u
 done
 cp /tmp/libdz_orig.so detzero_amd/libdetzero_hip.so
