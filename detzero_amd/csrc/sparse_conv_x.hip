@@ -49,6 +49,7 @@ struct SpConvXArgs {
     int cin, cout, cap, relu;
     unsigned int in_bytes, w_bytes, nbr_bytes;
     unsigned long long *dbg;    // DIAG bit 9 builds: per-wave cycle sums (8 words per wave) or null
+    int *queue;                 // 10 words behind the windows: next ticket of each XCD's tile queue, workgroups done, single-unit queue
 };
 
 template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
@@ -57,17 +58,21 @@ struct XCfg {
     static constexpr int NW = WP * WC, THREADS = 64 * NW;
     static constexpr int CT = COUT / (32 * WC);
     static constexpr int BP = WP * PT * 32;                  // output rows per tile
+    static constexpr int UR = BP / 2;                        // ... per unit: a tile is two consecutive units (fragment pt of every wave = unit pt), the
+                                                             // last tiles of a launch are single units (half the fragments idle): finer load balance
     static constexpr int SPS = 9 / TAPS;                     // steps per stage: a step = TAPS taps = 1 or 3 window rows ty
     static constexpr int NSLOT = D + 1;                      // weight slots: a step's slices are issued D steps ahead of their use
     static constexpr int WIN_BYTES = (RCAP + 1) * 64;        // + the zero row missing neighbours read
     static constexpr int WSLOT_BYTES = TAPS * COUT * 64;
     static constexpr int OFF_WIN = 0, OFF_W = 2 * WIN_BYTES, OFF_TRASH = OFF_W + NSLOT * WSLOT_BYTES, OFF_SS = OFF_TRASH + 1024;
-    static constexpr int LDS_BYTES = OFF_SS + 2 * COUT * 4;
+    static constexpr int OFF_TK = OFF_SS + 2 * COUT * 4;     // tickets of the workgroup's next two tiles
+    static constexpr int LDS_BYTES = OFF_TK + 16;
     static constexpr int R = COUT / 16;                      // 1 KB runs (16 output channels x 64 bytes) per tap slice
     static constexpr int WJ = TAPS * R, WPW = (WJ + NW - 1) / NW;               // 1 KB direct loads of a weight slot: in all, per wave
     static constexpr int WIN_J = RCAP / 16, WPWIN = WIN_J / NW;                 // ... of a full window buffer
     static constexpr int WINPW = WPWIN + 3 * PT;             // loads a wave issues at a stage's first step besides the weights
     static_assert(TAPS == 3 || TAPS == 9, "a step is one window row or a whole z slab");
+    static_assert(PT == 2, "a unit is one fragment per wave");
     static_assert(D >= 1 && D <= SPS && D <= 3, "weight slices are issued 1..3 steps ahead, never before the stage's window");
     static_assert(COUT % (32 * WC) == 0 && NW % R == 0 && RCAP % (16 * NW) == 0, "shape");
     static_assert(RCAP * 64 >= NW * STG_WAVE_BYTES, "the epilogue staging windows live in a window buffer (below its zero row)");
@@ -81,9 +86,10 @@ __device__ __forceinline__ void x_load16_lds(unsigned int lds_base, unsigned int
 
 // one stage of a workgroup's stream (wave-uniform: SGPRs; never indexed dynamically)
 struct XStage {
-    int tile, tz, kc;
+    int u0, seq, tz, kc;        // first unit of the tile, the tile's number in the workgroup's sequence
     int wlo, wcnt;              // the window: first input row, rows (0: gather mode, or past the end of the stream - its loads fetch nothing)
     int wb;                     // window buffer
+    bool half;                  // the tile is ONE unit (fragment 1 of every wave idle)
     bool live, gather, tz_first, tile_first;    // gather: the slab's window does not fit the buffer, operands come from global memory
 };
 
@@ -97,7 +103,10 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wid / C::WC, wc = wid % C::WC, l31 = lane & 31, kh = lane >> 5;
     const int m = min(*a.d_m_out, a.cap);
-    const int ntiles = (m + C::BP - 1) / C::BP;
+    const int nunits = (m + C::UR - 1) / C::UR;
+    // tiles of two units while at least a unit per workgroup remains beyond them (a multiple of 64 = whole runs for all 8 queues), then
+    // single units
+    const int nfull = (max(nunits - (int)gridDim.x, 0) / 2) / 64 * 64;
     const int nk = a.cin / 16;
     const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes), crsrc = make_srsrc(a.w, a.w_bytes), nrsrc = make_srsrc(a.nbr, a.nbr_bytes);
     const unsigned int row_bytes = (unsigned int)a.cin * 4u, tap_bytes = (unsigned int)(COUT * a.cin * 4);
@@ -124,12 +133,31 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const unsigned int khsw = (unsigned int)(((2 * kh) ^ ((l31 >> 2) & 3)) << 4);   // swizzled slot of my hi piece in a row whose (row >> 2) & 3 is l31's
     const unsigned int wrow = (unsigned int)((wc * CT * 32 + l31) * 64);            // weight rows: cout index = wc*CT*32 + ct*32 + l31
 
-    // ---- this workgroup's stream of stages.  Tiles: XCD-aware (workgroup b runs on XCD b % 8; runs of XRUN consecutive tiles per
-    // XCD share their overlapping windows in that XCD's L2).  Inside a tile: tz, 16-channel chunk, window pass.
+    // ---- this workgroup's stream of stages.  Tiles come from one queue per XCD (workgroup b runs on XCD b % 8): XCD x owns the runs
+    // x, x + 8, .. of XRUN consecutive tiles - neighbouring tiles share most of their windows in that XCD's L2 - and its workgroups
+    // take them in order, one ticket (atomic add on the queue's counter) per tile: tiles differ in cost (gather-mode slabs, empty
+    // slabs, skipped taps), a static deal left the slowest workgroup 20-25 % behind the average.  Thread 0 takes the tickets two tiles
+    // ahead - the atomic is issued at the start of a tile's epilogue and read at its end, among the epilogue's own loads and stores -
+    // and hands them to the other waves through LDS (tk_s[k & 1] = ticket of the workgroup's k-th tile); the last workgroup to finish
+    // resets the counters for the next launch.  Inside a tile: tz, 16-channel chunk.
+    // (The returning atomic is a plain, compiler-tracked one: an asynchronous one from inline asm does not survive the register copies
+    // the compiler inserts at loop edges - they read the destination before the value has landed.)
     constexpr int XRUN = 8;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = gridDim.x >> 3;
-    struct Gen { int seq, tile, lo0, n0, lo1, n1, lo2, n2, tz, kc, wlo, wn, wb; bool live, started; } g;
-    g.seq = -1; g.live = true; g.started = false; g.wb = 1; g.tile = 0; g.tz = g.kc = 0; g.wlo = g.wn = 0;
+    const int xcd = blockIdx.x & 7;
+    int *const tk_s = reinterpret_cast<int *>(smem + C::OFF_TK);
+    // a ticket: q < nfull / 8 = the q-th full tile of my XCD's queue; past those, 2^30 + s = the s-th single unit of the common queue
+    auto take_ticket = [&]() {
+        int t = atomicAdd(a.queue + xcd, 1);
+        if (t >= nfull / 8) t = 0x40000000 | atomicAdd(a.queue + 9, 1);
+        return t;
+    };
+    if (tid == 0) {
+        tk_s[0] = take_ticket();
+        tk_s[1] = take_ticket();
+    }
+    __syncthreads();
+    struct Gen { int seq, u0, lo0, n0, lo1, n1, lo2, n2, tz, kc, wlo, wn, wb; bool live, started, half; } g;
+    g.seq = -1; g.live = true; g.started = false; g.half = false; g.wb = 1; g.u0 = 0; g.tz = g.kc = 0; g.wlo = g.wn = 0;
     g.lo0 = g.n0 = g.lo1 = g.n1 = g.lo2 = g.n2 = 0;
     auto gen = [&]() {          // the next stage of the stream (live = false: past its end)
         XStage s;
@@ -145,18 +173,32 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         if (next_tile && g.live) {
             g.started = true;
-            for (++g.seq;; ++g.seq) {
-                const int q = g.seq * nx + jx;
-                if ((q / XRUN) * 8 * XRUN >= ntiles) { g.live = false; break; }
-                g.tile = ((q / XRUN) * 8 + xcd) * XRUN + q % XRUN;
-                if (g.tile < ntiles) break;
+            ++g.seq;                        // my g.seq-th tile: its ticket is in tk_s[g.seq & 1]
+            const int q = __builtin_amdgcn_readfirstlane(tk_s[g.seq & 1]);
+            if (q & 0x40000000) {
+                g.u0 = 2 * nfull + (q & 0x3FFFFFFF);
+                g.half = true;
+                g.live = g.u0 < nunits;
+            } else {
+                g.u0 = 2 * (((q / XRUN) * 8 + xcd) * XRUN + q % XRUN);
+                g.half = false;
             }
             if (g.live) {
-                const int *wq = a.win + (size_t)g.tile * 6;
-                g.lo0 = __builtin_amdgcn_readfirstlane(wq[0]); g.n0 = __builtin_amdgcn_readfirstlane(wq[1]);
-                g.lo1 = __builtin_amdgcn_readfirstlane(wq[2]); g.n1 = __builtin_amdgcn_readfirstlane(wq[3]);
-                g.lo2 = __builtin_amdgcn_readfirstlane(wq[4]); g.n2 = __builtin_amdgcn_readfirstlane(wq[5]);
-                g.tz = g.n0 > 0 ? 0 : 1;          // (the centre slab of a live tile is never empty: dz_spconv_x_windows)
+                // windows of the tile's unit(s): per z slab the union of the two units' ranges
+                const int *wq = a.win + (size_t)g.u0 * 6;
+                int lo[3], n[3];
+#pragma unroll
+                for (int z = 0; z < 3; ++z) {
+                    lo[z] = __builtin_amdgcn_readfirstlane(wq[2 * z]);
+                    n[z] = __builtin_amdgcn_readfirstlane(wq[2 * z + 1]);
+                    if (!g.half) {
+                        const int lb = __builtin_amdgcn_readfirstlane(wq[6 + 2 * z]), nb = __builtin_amdgcn_readfirstlane(wq[6 + 2 * z + 1]);
+                        if (n[z] == 0) { lo[z] = lb; n[z] = nb; }
+                        else if (nb > 0) { const int hi = max(lo[z] + n[z], lb + nb); lo[z] = min(lo[z], lb); n[z] = hi - lo[z]; }
+                    }
+                }
+                g.lo0 = lo[0]; g.n0 = n[0]; g.lo1 = lo[1]; g.n1 = n[1]; g.lo2 = lo[2]; g.n2 = n[2];
+                g.tz = g.n0 > 0 ? 0 : 1;          // (the centre slab of a live unit is never empty: dz_spconv_x_windows)
                 g.wlo = g.n0 > 0 ? g.lo0 : g.lo1;
                 g.wn = g.n0 > 0 ? g.n0 : g.n1;
                 g.kc = 0;
@@ -165,7 +207,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         g.wb ^= 1;
         s.live = g.live;
-        s.tile = g.tile; s.tz = g.tz; s.kc = g.kc; s.wb = g.wb;
+        s.u0 = g.u0; s.half = g.half; s.seq = g.seq; s.tz = g.tz; s.kc = g.kc; s.wb = g.wb;
         s.gather = g.live && g.wn > RCAP;
         s.wlo = g.wlo;
         s.wcnt = g.live && g.wn <= RCAP ? g.wn : 0;
@@ -190,8 +232,8 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // table word (fragment PTI, window row TY) of stage s's slab
     auto issue_pw = [&](const XStage &s, auto pt_t, auto ty_t) {
         constexpr int PTI = decltype(pt_t)::value, TY = decltype(ty_t)::value;
-        const int row = s.tile * C::BP + (wp * PT + PTI) * 32 + l31;
-        const unsigned int voff = s.live && s.tz_first && row < m ? (unsigned int)row * 4u : OOB_OFFSET;
+        const int row = (s.u0 + PTI) * C::UR + wp * 32 + l31;          // fragment PTI = unit PTI of the tile
+        const unsigned int voff = s.live && s.tz_first && row < m && !(PTI == 1 && s.half) ? (unsigned int)row * 4u : OOB_OFFSET;
         const unsigned int so = (unsigned int)(s.tz * 3 + TY) * nbr_row_bytes;
         const srsrc_t rs = nrsrc;            // (named here: an asm operand alone does not capture a variable in a generic lambda)
         unsigned int &dst = TY == 0 ? pn0[PTI] : (TY == 1 ? pn1[PTI] : pn2[PTI]);
@@ -217,14 +259,14 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // row addresses of the current window pass: byte offset (inside a window buffer) of the hi piece of the row the tap reads, or of
-    // the zero row; per window row ty x tap tx x fragment.  anym: bit ty*3 + tx = some lane of my fragments has the tap
+    // the zero row; per window row ty x tap tx x fragment.  anym: bit (ty*3 + tx)*2 + pt = some lane of my fragment pt has the tap
     // (16 bits each - a window buffer is < 64 KB -, fragments 2 p and 2 p + 1 share a register: registers are what limits this kernel)
     static_assert(C::WIN_BYTES < 65536 && PT % 2 == 0, "packed row addresses");
     unsigned int radr[3][3][PT / 2];
     unsigned int anym = 0u;
-    struct Frag { v4u c_hi[CT], c_lo[CT], p_hi[PT], p_lo[PT]; bool any; };
+    struct Frag { v4u c_hi[CT], c_lo[CT], p_hi[PT], p_lo[PT]; unsigned int any; };       // any: bit pt = some lane of fragment pt has the tap
     Frag fa, fb, fp;
-    fp.any = false;
+    fp.any = 0u;
 #pragma unroll
     for (int i = 0; i < CT; ++i) fp.c_hi[i] = fp.c_lo[i] = v4u{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -255,7 +297,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // (a tap none of my lanes has issues no MFMAs - wave-uniform; one small branch per slot rather than two copies of the block:
         // the copies' register allocation does not fit the 256 registers of a wave)
         auto one = [&](auto i_t) {
-            if (f.any) mfma_slot(f, i_t);
+            if ((f.any >> ((decltype(i_t)::value % (CT * PT)) / CT)) & 1u) mfma_slot(f, i_t);
             fill(i_t);
         };
         one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
@@ -270,14 +312,13 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     unsigned long long tm_vm = 0ull, tm_bar = 0ull, tm_step = 0ull, tm_epi = 0ull, tm_gen = 0ull, tm_n = 0ull;
     const unsigned long long tm_start = (DIAG & 512) ? __builtin_readcyclecounter() : 0ull;
     XStage cur = gen();
-    if (!cur.live) return;
     XStage nxt = gen();
     __syncthreads();
     int ws = 0;                 // weight slot of the current step
     bool prev_gather = false;   // the stage before `cur` ran in gather mode
     auto slot_of = [&](int ahead) { const int v = ws + ahead; return v >= C::NSLOT ? v - C::NSLOT : v; };
     // prologue: stage 0's window + words, the weights of its first D steps (same order as in the loop: window, words, weights)
-    {
+    if (cur.live) {
         auto all_win = [&](auto self, auto i_t) -> void {
             constexpr int i = decltype(i_t)::value;
             if constexpr (i < C::WPWIN) { issue_win(cur, i_t); self(self, std::integral_constant<int, i + 1>{}); }
@@ -331,13 +372,13 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int tx = 0; tx < 3; ++tx) {
                     const int off = base + (tx == 0 ? -1 : tx == 1 ? 0 : (int)((e >> 30) & 1u));
                     const bool valid = ((e >> (29 + tx)) & 1u) != 0u && (GM || (unsigned int)off < (unsigned int)cur.wcnt);
-                    if (__ballot(valid) != 0ull) am |= 1u << tx;
+                    if (__ballot(valid) != 0ull) am |= 1u << (tx * 2 + pt);
                     const unsigned int ra = valid ? (unsigned int)off * 64u + (unsigned int)(((2 * kh) ^ ((off >> 2) & 3)) << 4) : (unsigned int)(RCAP * 64);
                     if (pt & 1) radr[ty][tx][pt / 2] |= ra << 16;       // (not read in gather mode)
                     else radr[ty][tx][pt / 2] = ra;
                 }
             }
-            anym = (anym & ~(7u << (ty * 3))) | (am << (ty * 3));
+            anym = (anym & ~(63u << (ty * 6))) | (am << (ty * 6));
         };
         const unsigned int win_o = (unsigned int)(C::OFF_WIN + cur.wb * C::WIN_BYTES);
         const unsigned int w_hi_o = (unsigned int)(C::OFF_W + ws * C::WSLOT_BYTES) + wrow + khsw, w_lo_o = w_hi_o ^ 16u;
@@ -345,7 +386,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // straight from global memory
         auto frag_reads = [&](Frag &f, auto t_t) {
             constexpr int t = decltype(t_t)::value, ty = TAPS == 3 ? Q : t / 3, tx = t % 3;
-            f.any = (DIAG & 128) ? true : ((anym >> (ty * 3 + tx)) & 1u) != 0u;       // (DIAG 128: no tap skipping)
+            f.any = (DIAG & 128) ? 3u : (anym >> ((ty * 3 + tx) * 2)) & 3u;       // (DIAG 128: no tap skipping)
             if constexpr (DIAG & 2) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(f.c_hi[ct]), "+v"(f.c_lo[ct]));
@@ -411,13 +452,17 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(fprev.p_hi[pt]), "+v"(fprev.p_lo[pt]));
             }
             frag_reads(fnew, t_t);
-            if (fprev.any) {
-                auto all = [&](auto self, auto i_t) -> void {
-                    constexpr int i = decltype(i_t)::value;
-                    if constexpr (i < FS) { mfma_slot(fprev, i_t); self(self, std::integral_constant<int, i + 1>{}); }
-                };
-                all(all, std::integral_constant<int, 0>{});
-            }
+            // (one branch per fragment: a fragment none of whose lanes has the tap - every fragment 1 of a single-unit tile - issues
+            // no MFMAs; each MFMA appears once in the code: two copies for the two tile kinds do not fit the register file)
+            auto frag_mfmas = [&](auto self, auto i_t, auto pt_t) -> void {
+                constexpr int i = decltype(i_t)::value;
+                if constexpr (i < FS) {
+                    if constexpr ((i % (CT * PT)) / CT == decltype(pt_t)::value) mfma_slot(fprev, i_t);
+                    self(self, std::integral_constant<int, i + 1>{}, pt_t);
+                }
+            };
+            if (fprev.any & 1u) frag_mfmas(frag_mfmas, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (fprev.any & 2u) frag_mfmas(frag_mfmas, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             {
                 auto ops = [&](auto self, auto o_t) -> void {
                     constexpr int o = decltype(o_t)::value;
@@ -438,10 +483,16 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             tap(fb, fp, std::integral_constant<int, 8>{});
         }
         ws = slot_of(1);
+        if (Q == SPS - 1 && GM) {
+            // the stage's last operands cross the loop edge in fp: make sure they have landed before the compiler may copy registers
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger_of(SPS - 1, TAPS - 1)) : "memory");
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(fp.p_hi[pt]), "+v"(fp.p_lo[pt]));
+        }
         if constexpr (DIAG & 512) { tm_step += __builtin_readcyclecounter() - t_top; ++tm_n; }
     };
 
-    for (;;) {
+    while (cur.live) {
         step(std::integral_constant<int, 0>{});
         if constexpr (SPS == 3) {
             step(std::integral_constant<int, 1>{});
@@ -458,9 +509,11 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(fp.p_hi[pt]), "+v"(fp.p_lo[pt]));
             }
             tap_block(fp, [](auto) {});
-            fp.any = false;
+            fp.any = 0u;
             __syncthreads();
-            const int row0 = cur.tile * C::BP;
+            int next_ticket = 0;            // the ticket of the tile after next (thread 0; read at the end of the epilogue)
+            if (tid == 0) next_ticket = take_ticket();
+            const int u0 = cur.u0, nu = cur.half ? 1 : 2;
             if constexpr (DIAG & 32) {
 #pragma unroll
                 for (int i = 0; i < CT; ++i)
@@ -471,9 +524,9 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             } else
             store_tile_pair16<C, M>(acc, smem + C::OFF_WIN + cur.wb * C::WIN_BYTES, sc_s, sh_s, 0, a.cout, a.relu != 0,
                                     reinterpret_cast<const unsigned char *>(a.residual), reinterpret_cast<unsigned char *>(a.out), wp, wc, lane, wid,
-                                    [&](int lr) {
-                                        const int row = row0 + lr;
-                                        return row < m ? (size_t)row * a.cout * 4 : ~size_t(0);
+                                    [&](int lr) {           // lr = (wave row group * PT + fragment) * 32 + r: fragment = unit of the tile
+                                        const int pt = (lr >> 5) % PT, row = (u0 + pt) * C::UR + (lr / (32 * PT)) * 32 + (lr & 31);
+                                        return pt < nu && row < m ? (size_t)row * a.cout * 4 : ~size_t(0);
                                     });
 #pragma unroll
             for (int i = 0; i < CT; ++i)
@@ -481,6 +534,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int j = 0; j < PT; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            if (tid == 0) tk_s[cur.seq & 1] = next_ticket;
             if constexpr (DIAG & 512) tm_epi += __builtin_readcyclecounter() - t_e;
             if (!nxt.live) break;
         }
@@ -499,12 +553,20 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the last workgroup to get here resets the queues (every other one has taken its last ticket: its atomics have returned)
+    if (tid == 0) {
+        if (atomicAdd(a.queue + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) a.queue[i] = 0;
+        }
+    }
 }
 
 // windows of the tiles: one workgroup per tile; exact first / last referenced input row of every z slab
 __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int cap, const int *__restrict__ d_m_out, int tile_rows,
                                               int *__restrict__ win) {
     __shared__ int lo_s[3], hi_s[3];
+    if (blockIdx.x == 0 && threadIdx.x < 16) win[(size_t)gridDim.x * 6 + threadIdx.x] = 0;       // the tile queues of dz_spconv_forward_split_x
     const int m = min(*d_m_out, cap);
     const int tile = blockIdx.x, row0 = tile * tile_rows;
     if (threadIdx.x < 3) { lo_s[threadIdx.x] = 0x7FFFFFFF; hi_s[threadIdx.x] = -1; }
@@ -547,7 +609,7 @@ template <class C, class M, int DIAG = 0>
 static int launch_x(const SpConvXArgs &a, hipStream_t stream) {
     static PerDeviceFlags done;
     if (int rc = reserve_lds(reinterpret_cast<const void *>(&k_spconv_x<C, M, DIAG>), C::LDS_BYTES, done, "dz_spconv_forward_split_x")) return rc;
-    int grid = ceil_div(a.cap, C::BP);
+    int grid = ceil_div(a.cap, C::UR);
     const int cus = device_cus();
     if (grid > cus) grid = cus;
     grid = (grid + 7) & ~7;
@@ -616,10 +678,14 @@ extern "C" {
 
 int dz_spconv_x_tile_rows(int cin, int cout) {
     if (cin != cout) return 0;
-    if (cout == 32) return X32::BP;
-    if (cout == 64) return X64::BP;
-    if (cout == 128) return X128::BP;
+    if (cout == 32) return X32::UR;
+    if (cout == 64) return X64::UR;
+    if (cout == 128) return X128::UR;
     return 0;
+}
+
+size_t dz_spconv_x_windows_words(int cap_out, int tile_rows) {
+    return tile_rows > 0 && cap_out >= 0 ? (size_t)ceil_div(cap_out, tile_rows) * 6 + 16 : 0;
 }
 
 int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, void *stream_) {
@@ -632,7 +698,7 @@ int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, 
     return DZ_OK;
 }
 
-int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, const int *windows, int tile_rows, int cap_out,
+int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, int *windows, int tile_rows, int cap_out,
                               const int *d_m_out, const float *w, const float *scale, const float *shift, const float *residual, int relu,
                               float *out, int cout, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -652,7 +718,8 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
         return DZ_ERR_UNSUPPORTED;
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
-                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr};
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr,
+                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);
 }

@@ -302,7 +302,8 @@ def build_windows(nbr, out_level, channels):
     if not getattr(nbr, 'packed', False) or tr == 0:
         return nbr
     cap = nbr.shape[1]
-    win = torch.empty(((cap + tr - 1) // tr, 3, 2), dtype=torch.int32, device=nbr.device)
+    # (tiles x 3 x 2 window words + the tile-queue words of the convolution kernels)
+    win = torch.empty((lib.dz_spconv_x_windows_words(cap, tr),), dtype=torch.int32, device=nbr.device)
     rc = lib.dz_spconv_x_windows(L.ptr(nbr), cap, L.ptr(out_level.d_m), tr, L.ptr(win), L.stream())
     L.check(rc, 'dz_spconv_x_windows')
     nbr.xwin = (win, tr)

@@ -260,16 +260,20 @@ int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const 
  * the SubMConv3d pairs of SparseBasicBlock, backbone3d.py:93-121, at 32 / 64 / 128 channels: conv2, conv3, conv4 of
  * VoxelResBackBone8x, backbone3d.py:261-280).  Rows of a level are in ascending linear key, so the nine taps of one z offset of a tile
  * of T consecutive output rows read ONE contiguous range of input rows (a "window").
- *   dz_spconv_x_tile_rows(cin, cout): T of the kernel for this layer, 0 = layer not covered (cin != cout, other widths).
+ *   dz_spconv_x_tile_rows(cin, cout): rows per UNIT of the kernel for this layer (a tile is two consecutive units; the last tiles of
+ *     a launch are single units, for load balance), 0 = layer not covered (cin != cout, other widths).
  *   dz_spconv_x_windows: from the PACKED table of the level (dz_build_neighbors_packed, input level == output level) the windows of
- *     every tile: windows[(tile*3 + tz)*2 + {0, 1}] = first input row, number of rows (0 = slab has no neighbour; the centre slab of a
- *     live tile always has one).  ceil(cap_out / tile_rows) * 6 int32.  Once per indice_key, shared by the level's convolutions.
+ *     every unit: windows[(unit*3 + tz)*2 + {0, 1}] = first input row, number of rows (0 = slab has no neighbour; the centre slab of a
+ *     live unit always has one), followed by 16 words of tile-queue state the convolution kernels use (zeroed here, left zero by
+ *     every launch).  dz_spconv_x_windows_words(cap_out, tile_rows) int32 in all.  Once per indice_key, shared by the level's
+ *     convolutions (which therefore must not run concurrently on the same windows buffer).
  *   dz_spconv_forward_split_x: operands, result convention and arithmetic of dz_spconv_forward_split (pair16 in / residual / out,
  *     w (27, cout, cin) pair16, BatchNorm scale / shift, ReLU); per output element the products are accumulated in the order
  *     (tz, 16-channel chunk, tap), so results agree with dz_spconv_forward_split to fp32 summation-order noise, not bit for bit. */
 int dz_spconv_x_tile_rows(int cin, int cout);
+size_t dz_spconv_x_windows_words(int cap_out, int tile_rows);
 int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, void *stream);
-int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, const int *windows, int tile_rows,
+int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, int *windows, int tile_rows,
                               int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
                               const float *residual, int relu, float *out, int cout, int math, void *stream);
 const char *dz_spconv_x_variant(int cin, int cout);

@@ -35,19 +35,21 @@ def _level(rng, batch, shape, density, device, cap_extra=7):
 
 @pytest.mark.parametrize('channels', [32, 64, 128])
 def test_windows_cover_the_rulebook_exactly(device, channels):
-    """windows[tile][tz] = [first, first + count) is exactly the range of input rows the nine taps of slab tz reference in the tile
-    (so every row map entry lies inside, and nothing wider is staged); empty slabs give count 0, except the centre slab."""
+    """windows[unit][tz] = [first, first + count) is exactly the range of input rows the nine taps of slab tz reference in the unit
+    (half a kernel tile; so every row map entry lies inside, and nothing wider is staged); empty slabs give count 0, except the
+    centre slab."""
     from detzero_amd import ops
     from detzero_amd import lib as L
     rng = np.random.default_rng(channels)
     lvl, coords = _level(rng, 2, [5, 40, 60], (0.02, 0.6, 0.1), device)
     nbr = ops.build_windows(lvl.neighbors_to(lvl, K3, S1, P1, packed=True), lvl, channels)
     win, tr = nbr.xwin
-    assert tr == L.load().dz_spconv_x_tile_rows(channels, channels) and tr in (256, 512)
+    assert tr == L.load().dz_spconv_x_tile_rows(channels, channels) and tr in (128, 256)
     m = lvl.num_active()
     tab = ops.unpack_table(nbr)[:, :m].cpu().numpy().astype(np.int64)
-    win = win.cpu().numpy()
-    assert win.shape[0] == (lvl.cap + tr - 1) // tr
+    nt = (lvl.cap + tr - 1) // tr
+    assert win.numel() == nt * 6 + 16 and not win[nt * 6:].any()          # window words + the (idle) tile queues
+    win = win[:nt * 6].view(nt, 3, 2).cpu().numpy()
     for t in range((m + tr - 1) // tr):
         for tz in range(3):
             blk = tab[9 * tz:9 * tz + 9, t * tr:(t + 1) * tr]
@@ -138,7 +140,7 @@ def test_xrun_refuses_what_it_does_not_cover(device):
     assert getattr(ops.build_windows(packed, lvl, 16), 'xwin', None) is None
     plain = lvl.neighbors_to(lvl, K3, S1, P1)
     assert getattr(ops.build_windows(plain, lvl, 64), 'xwin', None) is None        # unpacked table: left alone
-    win = torch.zeros((1, 3, 2), dtype=torch.int32, device=device)
+    win = torch.zeros((6 + 16,), dtype=torch.int32, device=device)
     x = torch.zeros((lvl.cap, 32), device=device)
     rc = lib.dz_spconv_forward_split_x(L.ptr(x), lvl.cap, 32, L.ptr(packed), L.ptr(win), 128, lvl.cap, L.ptr(lvl.d_m), L.ptr(x), None, None,
                                        None, 0, L.ptr(x), 32, 1, L.stream())
