@@ -25,7 +25,8 @@ Besides the headline the default single-GPU run measures, into the same JSON lin
   with_h2d   frames start in pinned host memory; the H2D copy of step i+1 runs on a copy stream under step i
   stages     voxelize / index pyramid / sparse backbone / dense / post-processing: time per step (each stage replayed as its
              own hipGraph, serially), algorithmic bytes and HBM GB/s as a fraction of the 8 TB/s peak
-  tiles      the opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip, rows in brick order) on the headline workload
+  gather     the gather sparse engine (default of rounds 1-3) on the headline workload: A/B against the x-run engine on this box
+  tiles      (--tiles-leg) the opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip, rows in brick order)
   refine     BASELINE configs[3], the secondary kernel set: GRM objects/s and PRM tracks/s (fp32 and f16x2 stacks) and the
              attention core (k_mha_block) with its roofline against the fp32-MFMA peak
   pdv        the two-stage detector (PDVHead second stage) on a merged 2-sweep frame: ms per stage, RoIs/s
@@ -121,7 +122,8 @@ def parse():
     ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
     ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
-    ap.add_argument('--sparse-engine', default='gather', choices=['gather', 'xrun', 'tiles'], help='sparse-backbone engine of the headline run')
+    ap.add_argument('--tiles-leg', action='store_true', help='also time the opt-in tile-resident engine of round 3 (slower)')
+    ap.add_argument('--sparse-engine', default='xrun', choices=['gather', 'xrun', 'tiles'], help='sparse-backbone engine of the headline run')
     ap.add_argument('--sweeps', type=int, default=1, choices=[1, 2],
                     help='2: run the multisweep shape (BASELINE configs[4]) as the main workload - for profiling that leg on its own; the '
                          'metric of the printed line is then NOT the headline one (config.workload says so)')
@@ -158,7 +160,8 @@ class Case:
     lengths = (lo, hi), mode 'padded': frames of lo..hi points padded with out-of-range rows to slots of hi rows (same route).
     lengths = (lo, hi), mode 'list': slot j holds a frame of its own length L_j in lo..hi (ragged list route)."""
 
-    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1, engine='gather'):
+    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1, engine=None):
+        engine = engine or args.sparse_engine
         from detzero_amd.centerpoint import FramePipeline, set_sparse_engine, synth_detector
         from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
         self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
@@ -317,13 +320,19 @@ class Case:
             peak = PEAK_F16_MFMA_TFLOPS / terms if split else PEAK_F32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': top['kernel'], 'achieved': round(achieved, 2),
                     'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                    'traffic': pmc_traffic(top['kernel'], self.math),
                     'flop_per_launch': round(a['flops'] / a['launches'], 1),
                     'avg_launch_us': round(1000.0 * a['ms'] / a['launches'], 2),
                     'note': (('one v_mfma_f32_32x32x16_f16 per product (f16 mode), peak = 2516.6 TF/s; ' if self.math == 'f16' else
                               'split-precision pairs: 3 x v_mfma_f32_32x32x16_f16 per product, peak = 2516.6/3 TF/s algorithmic; ') if split else 'fp32-input MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TF/s dense; ')
                             + 'algorithmic FLOP = 2*pixels*taps*Cin*Cout (dense) / 2*pairs*Cin*Cout (sparse); '
                               'fraction of the fp32-MFMA peak: %.3f' % (achieved / PEAK_F32_MFMA_TFLOPS)}
+        if roof is not None:
+            # HBM bytes of the same launch from the committed PMC passes: `traffic` is the scalar the contract names, the parts and
+            # the file they come from next to it (flat: nested objects do not survive every consumer of this line)
+            tr = pmc_traffic(roof['kernel'], self.math)
+            roof['traffic'] = tr['bytes'] if tr else None
+            if tr:
+                roof.update({'traffic_read_bytes': tr['read_bytes'], 'traffic_write_bytes': tr['write_bytes'], 'traffic_source': tr['source']})
         return kern, roof, agg
 
     def stage_profile(self, replays=10):
@@ -527,6 +536,25 @@ def main():
         try:
             out['stages'] = case.stage_profile()
             log('stages:', [(s['stage'], s['ms_per_step']) for s in out['stages']])
+            # the north star's own fractions ("voxelize + sparse backbone at >= 60 % of the HBM roofline") inside `roofline`, so that
+            # whoever keeps only that object can recompute them: algorithmic bytes (from the live counts), milliseconds
+            # per step (each stage replayed as its own graph, HIP events on the launch stream), fraction of the 8 TB/s peak
+            if isinstance(out.get('roofline'), dict):
+                st = {r['stage']: r for r in out['stages']}
+                hbm = {}
+                for nme in ('voxelize', 'index', 'sparse_backbone'):
+                    hbm[nme] = {'bytes': st[nme]['algorithmic_bytes'], 'ms': st[nme]['ms_per_step'], 'gbs': st[nme]['hbm_gbs'], 'frac': st[nme]['frac_of_hbm_peak']}
+                vb_bytes = hbm['voxelize']['bytes'] + hbm['sparse_backbone']['bytes']
+                vb_ms = hbm['voxelize']['ms'] + hbm['sparse_backbone']['ms']
+                hbm['voxelize_plus_backbone'] = {'bytes': vb_bytes, 'ms': round(vb_ms, 4), 'gbs': round(vb_bytes / (vb_ms * 1e-3) / 1e9, 1),
+                                                 'frac': round(vb_bytes / (vb_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                out['roofline']['hbm'] = hbm
+                for nme, rec in hbm.items():
+                    for k, v in rec.items():
+                        out['roofline']['hbm_%s_%s' % (nme, k)] = v
+                out['roofline']['hbm_peak_gbs'] = PEAK_HBM_GBS
+                out['roofline']['dense_ms'] = st['dense']['ms_per_step']
+                out['roofline']['post_ms'] = st['post']['ms_per_step']
         except Exception as e:
             out['stages'] = {'error': str(e).split('\n')[0][:200]}
         # frames in pinned host memory: H2D of step i+1 on a copy stream under step i (double-buffered staging in HBM)
@@ -608,7 +636,24 @@ def main():
                                         'offset), DynamicMeanVFE + centerpoint_3sweeps backbone and head' % args.points)
         del c
         torch.cuda.empty_cache()
-        if args.math != 'f32':
+        if args.math != 'f32' and args.sparse_engine != 'gather':
+            try:        # the previous default engine on the same frames (A/B on this box)
+                c = Case(args, dev, rank, args.math, B, seed_base=500, engine='gather')
+                fps, ms, k = c.aux_leg(sec)
+                rec = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(ms, 4), 'steps': k, 'frames_per_step': B, 'math': args.math,
+                       'note': 'gather engine (one gathered row per (output row, tap) pair for every sparse convolution: sparse_conv_h.hip, '
+                               'sparse_conv_w.h) - the default of rounds 1-3; the headline runs the submanifold convolutions of the 32 / 64 / '
+                               '128-channel levels on the x-run engine (sparse_conv_x.hip)'}
+                if args.profile_frames > 0:
+                    kern, _, _ = c.kernel_profile(args.profile_frames)
+                    rec['kernels'] = [r for r in kern if 'spconv' in r['kernel']]
+                out['gather'] = rec
+                log('gather engine %.1f frames/s' % fps)
+                del c
+            except Exception as e:
+                out['gather'] = {'error': str(e).split('\n')[0][:200]}
+            torch.cuda.empty_cache()
+        if args.math != 'f32' and args.tiles_leg:
             try:
                 c = Case(args, dev, rank, args.math, B, seed_base=500, engine='tiles')
                 fps, ms, k = c.aux_leg(sec)
@@ -644,6 +689,17 @@ def main():
                                  'avg_launch_us': r32['mha_core_prm_us'],
                                  'note': 'PRM cross-attention core: 96 tracks x 8 heads, 200 queries x 9600 keys x 32, exact fp32 on v_mfma_f32_16x16x4_f32; '
                                          'algorithmic FLOP = 4 * Lq * Lk * d per track'},
+                    # the dominant kernels of the f16x2 refiner (PRM pass): algorithmic FLOP = 2 * rows * sum(cin * cout) of the layers a
+                    # launch fuses, against the split-pair peak (three 16-bit MFMAs per product)
+                    'roofline_f16x2': None if 'k_mlp_chain_prm_tflops' not in r16 else {
+                        'bound': 'mfma', 'kernel': 'k_mlp_chain', 'achieved': r16['k_mlp_chain_prm_tflops'], 'peak': round(PEAK_F16_MFMA_TFLOPS / 3.0, 1),
+                        'unit': 'TFLOP/s', 'frac': round(r16['k_mlp_chain_prm_tflops'] / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
+                        'avg_launch_us': r16['k_mlp_chain_prm_us'], 'share_of_prm_pass': r16['k_mlp_chain_prm_share'],
+                        'second': {'kernel': 'k_pointnet3', 'achieved': r16.get('k_pointnet3_prm_tflops'), 'avg_launch_us': r16.get('k_pointnet3_prm_us'),
+                                   'frac': None if 'k_pointnet3_prm_tflops' not in r16 else round(r16['k_pointnet3_prm_tflops'] / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
+                                   'share_of_prm_pass': r16.get('k_pointnet3_prm_share')},
+                        'note': 'memory MLP 128 -> 512 -> 256 + K / V projections as one kernel (k_mlp_chain), PointNet 32 -> 128 -> 128 -> 512 + max as one '
+                                'kernel (k_pointnet3); HIP events on the launch stream inside the PRM pass'},
                     'roofline_grm': None if 'xattn_folded_grm_gbs' not in r32 else {
                         'bound': 'hbm', 'kernel': 'k_xattn_fold', 'achieved': r32['xattn_folded_grm_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(r32['xattn_folded_grm_gbs'] / PEAK_HBM_GBS, 4), 'avg_launch_us': r32['xattn_folded_grm_us'],

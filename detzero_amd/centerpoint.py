@@ -229,8 +229,9 @@ def set_math(model, mode):
 
 
 def set_sparse_engine(model, engine):
-    """Convolution engine of the sparse backbone in the split math modes: 'gather' (default: sparse_conv_h.hip / sparse_conv_w.h on
-    rows in the canonical linear-key order) or 'tiles' (sparse_conv_t.hip: tile-resident inputs on rows in the brick order)."""
+    """Convolution engine of the sparse backbone in the split math modes: 'xrun' (default: the gather kernels plus sparse_conv_x.hip
+    for the submanifold convolutions of the 32 / 64 / 128-channel levels), 'gather' (sparse_conv_h.hip / sparse_conv_w.h only; both
+    on rows in the canonical linear-key order) or 'tiles' (sparse_conv_t.hip: tile-resident inputs on rows in the brick order)."""
     model.backbone3d.set_engine(engine)
     return model
 
@@ -239,6 +240,10 @@ def set_sparse_engine(model, engine):
 STAGGERED_PYRAMID = not os.environ.get('DZ_TUNE_EAGER_PYRAMID')
 
 F16_PAIR_SAFE_MAX = 3.0e4      # |activation| up to which fp16 pairs are used (fp16 saturates at 65504; interior layers get 2x headroom)
+# ... and the stage PEAK below which they are not: the lo half of an fp16 pair is subnormal below |x| ~ 0.06 (absolute quantum 2^-24), so a
+# value x carries max(2^-22, 2^-25 / |x|) relative error - worse than a bf16 pair's 2^-16 once |x| < 2^-9.  A stage whose largest
+# activation is under 2^-6 has its bulk (peak / 10 and below) in that regime
+F16_PAIR_SAFE_MIN = 2.0 ** -6
 
 
 @torch.no_grad()
@@ -257,12 +262,14 @@ def activation_range(model, dataset_info, frames):
     return out
 
 
-def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX):
+def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX, low_limit=F16_PAIR_SAFE_MIN):
     """Pick the split-precision mode for a checkpoint from a calibration pass: fp16 pairs (22-bit significands) while every
-    stage stays below `limit`, else bf16 pairs (16 bits, the full fp32 exponent range) - fp16 pairs SATURATE at +-65504 + lo,
-    so a network whose activations reach 1e5 must not run on them.  Returns (mode, per-stage maxima) and sets the mode."""
+    stage's largest activation stays inside [`low_limit`, `limit`], else bf16 pairs (16 bits, the full fp32 exponent range) -
+    fp16 pairs SATURATE at +-65504 + lo, so a network whose activations reach 1e5 must not run on them, and their lo half goes
+    subnormal for small values, so a network whose stages peak at 1e-3 is better served by bf16 pairs too.  Returns (mode,
+    per-stage maxima) and sets the mode."""
     rng = activation_range(model, dataset_info, frames)
-    mode = prefer if max(rng.values()) <= limit else 'bf16x2'
+    mode = prefer if (max(rng.values()) <= limit and min(rng.values()) >= low_limit) else 'bf16x2'
     set_math(model, mode)
     return mode, rng
 
@@ -390,8 +397,10 @@ class FramePipeline:
     def calibrate(self, frames, margin=1.5):
         """Measure the active-site counts of the strided backbone stages on sample frames (one host sync) and size
         the per-frame row capacities to `margin` x the largest count seen; afterwards buffers grow with B x that
-        instead of the worst case.  Frames that later exceed a capacity lose rows; `prepare(...)['overflow']` /
-        `self.last_overflow` (device bool) tells.  Call before graph capture."""
+        instead of the worst case.  Frames that later exceed a capacity lose rows; `self.last_overflow` (device bool, set by
+        `backbone_stage` - with a staggered pyramid the flag exists only once the convolutions have requested the last stage's index)
+        and the sticky counter behind `overflow_seen()` / `check_overflow()` tell.  Call before graph capture: the counter is
+        allocated here, so a capture that follows immediately records no allocation / memset node for it."""
         self.level_caps = None
         best = [0, 0, 0, 0]
         for f in frames:
@@ -399,6 +408,8 @@ class FramePipeline:
             for i, st in enumerate(pyr['steps'][1:]):
                 best[i] = max(best[i], st[2].num_active())
         self.level_caps = [int(margin * b) + 4096 for b in best]
+        if self._overflow_acc is None and frames:
+            self._overflow_acc = torch.zeros((), dtype=torch.int32, device=frames[0].device)
         return self.level_caps
 
     def overflow_seen(self, clear=True):
@@ -429,7 +440,10 @@ class FramePipeline:
         if self.last_overflow is not None:
             # (after run_pyramid: the flag is written on the index-pyramid side stream, and the main stream has by now waited for
             # the last stage's event, which covers it)
-            if self._overflow_acc is None:                       # (first pass is an eager warm-up: never allocated inside a capture)
+            if self._overflow_acc is None:                       # (capacities set by hand instead of calibrate())
+                if torch.cuda.is_current_stream_capturing():
+                    raise DetZeroHipError('FramePipeline: the overflow counter must exist before graph capture - run calibrate() or '
+                                          'one eager pass first (a counter allocated inside a capture is re-zeroed by every replay)')
                 self._overflow_acc = torch.zeros((), dtype=torch.int32, device=self.last_overflow.device)
             self._overflow_acc |= self.last_overflow.to(torch.int32)
         return res

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
                         for (int e = 0; e < 4; ++e) {
                             if (col + e >= gcout || v[e] == -INFINITY) continue;
                             // float max through integer atomics: non-negative values order like ints, negative ones inversely like uints
-                            if (v[e] >= 0.f) atomicMax(reinterpret_cast<int *>(orow + col + e), __float_as_int(v[e]));
+                            // (by the SIGN BIT, not by value: -0.0 compares >= 0 but its pattern is INT_MIN as an int and would
+                            // never beat the -inf prefill; as an unsigned it is the smallest "negative" pattern - the right maximum)
+                            if (__float_as_int(v[e]) >= 0) atomicMax(reinterpret_cast<int *>(orow + col + e), __float_as_int(v[e]));
                             else atomicMin(reinterpret_cast<unsigned int *>(orow + col + e), __float_as_uint(v[e]));
                         }
                     }

@@ -94,7 +94,7 @@ __global__ void k_sparse_to_bev_split(const unsigned short *__restrict__ feats, 
 // the image is written once with 16-byte stores: no zero-fill pass over the 591 MB canvas and no 2-byte scatter stores.
 __global__ __launch_bounds__(256) void k_sparse_to_bev_split_dense2(const uint2 *__restrict__ feats, const uint32_t *__restrict__ bitmap,
                                                                      const uint32_t *__restrict__ prefix, LevelGeom lg, int c, int pad,
-                                                                     uint4 *__restrict__ bev) {
+                                                                     uint4 *__restrict__ bev, int feat_rows) {
     const int hp = lg.h + 2 * pad, wp = lg.w + 2 * pad;
     const int groups = c * 2 / 8, in_groups = c / 8;
     const long total = (long)lg.b * hp * wp * groups;
@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void k_sparse_to_bev_split_dense2(const uint2 
         const int x = xp - pad, y = yp - pad;
         uint2 h0 = make_uint2(0u, 0u), l0 = h0, h1 = h0, l1 = h0;
         if ((unsigned)x < (unsigned)lg.w && (unsigned)y < (unsigned)lg.h) {
-            const int r0 = bitmap_find(bitmap, prefix, lg.key(b, 0, y, x)), r1 = bitmap_find(bitmap, prefix, lg.key(b, 1, y, x));
+            int r0 = bitmap_find(bitmap, prefix, lg.key(b, 0, y, x)), r1 = bitmap_find(bitmap, prefix, lg.key(b, 1, y, x));
+            // a level that overflowed its row capacity still has every site in its bitmap: ranks past the feature rows read as empty
+            // cells (the pipeline's overflow flag reports the frame; nothing is read past the buffer)
+            if (r0 >= feat_rows) r0 = -1;
+            if (r1 >= feat_rows) r1 = -1;
             // input group og / 2 (16 B hi | 16 B lo = four uint2), its channels (og & 1) * 4 .. + 3
             if (r0 >= 0) { const uint2 *s = feats + ((size_t)r0 * in_groups + (og >> 1)) * 4 + (og & 1); h0 = s[0]; l0 = s[2]; }
             if (r1 >= 0) { const uint2 *s = feats + ((size_t)r1 * in_groups + (og >> 1)) * 4 + (og & 1); h1 = s[0]; l1 = s[2]; }
@@ -186,17 +190,17 @@ int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m
     return DZ_OK;
 }
 
-int dz_sparse_to_bev_split_dense(const float *feats, const uint32_t *bitmap, const uint32_t *prefix, int batch, int c, int d, int h,
-                                 int w, int layout, int pad, float *bev, void *stream_) {
+int dz_sparse_to_bev_split_dense(const float *feats, int feat_rows, const uint32_t *bitmap, const uint32_t *prefix, int batch, int c, int d,
+                                 int h, int w, int layout, int pad, float *bev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(feats && bitmap && prefix && bev && batch > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0 && pad >= 0,
+    DZ_CHECK_ARG(feats && bitmap && prefix && bev && batch > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0 && pad >= 0 && feat_rows >= 0,
                  "dz_sparse_to_bev_split_dense: bad argument");
     if (d != 2) { set_error("dz_sparse_to_bev_split_dense: %d z slabs (the dense form interleaves exactly 2)", d); return DZ_ERR_UNSUPPORTED; }
     DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_sparse_to_bev_split_dense: bad layout %d", layout);
     const LevelGeom lg = make_level(batch, d, h, w, layout);
     const long total = (long)batch * (h + 2 * pad) * (w + 2 * pad) * (c * 2 / 8);
     hipLaunchKernelGGL(k_sparse_to_bev_split_dense2, dim3(stream_grid(total, 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const uint2 *>(feats), bitmap, prefix, lg, c, pad, reinterpret_cast<uint4 *>(bev));
+                       reinterpret_cast<const uint2 *>(feats), bitmap, prefix, lg, c, pad, reinterpret_cast<uint4 *>(bev), feat_rows);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

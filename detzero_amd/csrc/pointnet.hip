@@ -136,7 +136,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 run[cb * 32] = -INFINITY;
                 if (cur_group < 0 || v == -INFINITY) continue;
                 float *o = a.out + (size_t)cur_group * a.c3 + cb * 32 + l31;
-                if (v >= 0.f) atomicMax(reinterpret_cast<int *>(o), __float_as_int(v));
+                if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int *>(o), __float_as_int(v));      // (sign bit, not value: -0.0)
                 else atomicMin(reinterpret_cast<unsigned int *>(o), __float_as_uint(v));
             }
         }

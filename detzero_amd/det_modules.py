@@ -261,13 +261,14 @@ class VoxelResBackBone8x(_Cached):
             norm_fn(channels[3]), nn.ReLU())
         self.num_point_features = channels[3]
         # Row order of the sparse levels (ops.LAYOUT_*) and convolution engine of the split math modes.
-        #   engine 'gather' + LAYOUT_LINEAR (default): one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h);
+        #   engine 'gather' + LAYOUT_LINEAR (default of rounds 1-3): one gather per (row, tap) pair (sparse_conv_h.hip, sparse_conv_w.h);
         #   engine 'tiles'  + LAYOUT_BRICK: tile-resident inputs (sparse_conv_t.hip) - built and parity-tested in round 3, measured
         #   SLOWER inside the detector on MI355X (743 vs 865 frames/s), so it is opt-in: set_sparse_engine(model, 'tiles').
-        #   engine 'xrun' + LAYOUT_LINEAR: the submanifold convolutions of the 32 / 64 / 128-channel levels stage each z slab's window
-        #   of input rows once per tile (sparse_conv_x.hip, packed tables + ops.build_windows); every other convolution as 'gather'.
+        #   engine 'xrun' + LAYOUT_LINEAR (default since round 4: +7 % frames/s, A/B on one box): the submanifold convolutions of the
+        #   32 / 64 / 128-channel levels stage each z slab's window of input rows once per tile (sparse_conv_x.hip, packed tables +
+        #   ops.build_windows); every other convolution as 'gather'.
         self.layout = int(os.environ.get('DZ_TUNE_LAYOUT', ops.LAYOUT_LINEAR))          # (environment: A/B runs on one box)
-        self.engine = os.environ.get('DZ_TUNE_SPCONV_ENGINE', 'gather')
+        self.engine = os.environ.get('DZ_TUNE_SPCONV_ENGINE', 'xrun')
         # output widths whose convolutions run on the tile engine when it is selected (the others keep the gather kernels)
         self.tile_couts = tuple(int(c) for c in os.environ.get('DZ_TUNE_SPCONV_TILE_COUTS', '16,32,64,128').split(',') if c)
         self.backbone_channels = {'x_conv1': channels[0], 'x_conv2': channels[1], 'x_conv3': channels[2],
@@ -363,7 +364,8 @@ class VoxelResBackBone8x(_Cached):
 
         def hand_over(step):                        # tensors born on the side stream are consumed on the main stream
             nbr_d, nbr_s, lvl, _ = step
-            for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m):
+            # (the level's bitmap / prefix / workspace too: the dense BEV hand-over and the PDV lookups read them on the main stream)
+            for t in (nbr_d, nbr_s, lvl.coords, lvl.d_m, lvl.bitmap, lvl.prefix, lvl.ws):
                 if t is not None:
                     t.record_stream(main)
                     if getattr(t, 'tile_masks', None) is not None:

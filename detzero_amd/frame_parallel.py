@@ -17,6 +17,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .lib import DetZeroHipError
+
 
 def shard_indices(num_frames, rank, world_size):
     """Indices rank ``rank`` processes: pad by wrap-around to a multiple of the world size, then
@@ -95,8 +97,19 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
             cnts.append(c.reshape(-1))
     boxes = torch.cat(outs, dim=0)
     counts = torch.cat(cnts, dim=0).to(torch.int32)
-    if hasattr(pipeline, 'check_overflow'):            # calibrated level capacities: a dropped site must not go unnoticed (one sync per chunk)
-        pipeline.check_overflow()
+    if hasattr(pipeline, 'overflow_seen'):
+        # calibrated level capacities: a dropped site must not go unnoticed (one sync per chunk).  With several ranks the flag is
+        # all-reduced BEFORE anyone raises: a rank that raised on its own would leave the others waiting in the box gather below
+        # until the collective times out
+        over = bool(pipeline.overflow_seen())
+        if world > 1:
+            flag = torch.tensor([1 if over else 0], dtype=torch.int32, device=boxes.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            over = bool(flag.item())
+        if over:
+            raise DetZeroHipError('run_frame_parallel: a sparse level overflowed its calibrated row capacity on some rank (per-frame '
+                                  'capacities %s): re-run calibrate() on denser samples / with a larger margin, or drop the calibration'
+                                  % (getattr(pipeline, 'level_caps', None),))
     if world == 1:
         all_b, all_c = boxes[None], counts[None]
     else:

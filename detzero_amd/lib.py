@@ -123,7 +123,7 @@ _SIGS = {
     'dz_spconv_x_variant': (ctypes.c_char_p, [c_int, c_int]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
-    'dz_sparse_to_bev_split_dense': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+    'dz_sparse_to_bev_split_dense': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                              c_void_p]),
     'dz_conv2d_forward_split': (c_int, [ctypes.POINTER(Conv2dDesc), c_int, c_int, c_void_p]),
     'dz_conv2d_variant_split': (ctypes.c_char_p, [ctypes.POINTER(Conv2dDesc)]),

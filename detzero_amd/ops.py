@@ -408,7 +408,7 @@ def sparse_to_bev(feats, level, c, pad=1, out=None, math=0):
         out = torch.empty((level.batch, h + 2 * pad, w + 2 * pad, c * d), dtype=torch.float32, device=feats.device)
     if math and d == 2 and c % 8 == 0 and BEV_DENSE:
         # two z slabs (the backbone's encoded tensor): the whole image, zeros included, written once from the level's own index
-        rc = lib.dz_sparse_to_bev_split_dense(L.ptr(feats), L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, c, d, h, w, level.layout,
+        rc = lib.dz_sparse_to_bev_split_dense(L.ptr(feats), feats.shape[0], L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, c, d, h, w, level.layout,
                                               pad, L.ptr(out), L.stream())
         L.check(rc, 'dz_sparse_to_bev_split_dense')
         return out

@@ -283,9 +283,11 @@ int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m
 /* the same image written whole (zeros included) from the level's own index instead of scattered into a zero-filled canvas:
  * for d == 2 z slabs (VoxelResBackBone8x's encoded tensor; DZ_ERR_UNSUPPORTED otherwise).  bitmap / prefix = the level's index
  * (dz_index_downsample), batch / d / h / w / layout its grid.  Same bytes as fill + dz_sparse_to_bev_split
- * (height_compression.py:20-24: channel = ch * D + z). */
-int dz_sparse_to_bev_split_dense(const float *feats, const uint32_t *bitmap, const uint32_t *prefix, int batch, int c, int d,
-                                 int h, int w, int layout, int pad, float *bev, void *stream);
+ * (height_compression.py:20-24: channel = ch * D + z).  feat_rows = rows of the `feats` buffer (the level's row capacity): a cell
+ * whose rank is not below it - a level that overflowed a calibrated capacity keeps every site in its bitmap - is written as empty,
+ * exactly what the scatter form does with the rows it drops; nothing is read past the buffer. */
+int dz_sparse_to_bev_split_dense(const float *feats, int feat_rows, const uint32_t *bitmap, const uint32_t *prefix, int batch, int c,
+                                 int d, int h, int w, int layout, int pad, float *bev, void *stream);
 /* dz_conv2d_forward on pair16 images: desc->in pair16, desc->w (groups, kh*kw, cout_pad, cin) pair16
  * (cout_pad % 32 == 0, cin % 32 == 0), desc->out pair16 or, with out_f32 != 0, plain fp32 (last head conv). */
 int dz_conv2d_forward_split(const dz_conv2d_desc *h_desc, int math, int out_f32, void *stream);

@@ -170,7 +170,7 @@ def test_tile_engine_brick_order_160k(full, device, math):
             worst = _check_boxes(ref['final'], boxes9[i], int(counts[i].item()), 'tiles/%s/frame%d' % (math, i))
             print('tile engine %s frame %d: worst matched box error %.2e' % (math, i, worst))
     finally:
-        set_sparse_engine(model, 'gather')
+        set_sparse_engine(model, 'xrun')          # (the default engine)
         set_math(model, 'f32')
 
 

@@ -172,6 +172,23 @@ def test_sparse_to_bev_split(device):
     fp_b = torch.empty_like(fp)
     fp_b[rank_b.long()] = fp                                                    # rows in the brick order
     assert torch.equal(ops.sparse_to_bev(fp_b, lvl_b, 128, pad=1, math=1).view(torch.int32), bev.view(torch.int32))
+    # a level that overflowed its row capacity (calibrated capacities): the bitmap holds all n sites, the feature buffer only the first
+    # `cap` rows - the dense writer treats the dropped ranks as empty cells, like the scatter form, and reads nothing past the buffer
+    # (the rows behind the capacity are a poisoned guard region here)
+    cap = 300
+    lvl_o = ops.SparseLevel(2, shape, cap, device)
+    lvl_o.build_from_coords(_t(coords, device), want_rank=False)
+    assert int(lvl_o.d_m.item()) == n > cap
+    guard = torch.full((cap + 64, 128), float('nan'), device=device)
+    guard[:cap] = fp[:cap]
+    over = ops.sparse_to_bev(guard[:cap], lvl_o, 128, pad=1, math=1)
+    assert not torch.isnan(ops.pair16_to_f32(over, 1)).any()
+    ops.BEV_DENSE = False
+    try:
+        over_s = ops.sparse_to_bev(guard[:cap], lvl_o, 128, pad=1, math=1)
+    finally:
+        ops.BEV_DENSE = True
+    assert torch.equal(over.view(torch.int32), over_s.view(torch.int32))
 
 
 @pytest.mark.parametrize('name,mid', MODES)
@@ -362,6 +379,33 @@ def test_math_mode_selection_by_activation_range(device, gain, expect):
         bad = _stage_features(model, info, pts, 'f16x2')
         worst = max(float((bad[n] - ref[n]).abs().max()) / float(ref[n].abs().max()) for n in ref)
         assert worst > 1e-2, worst
+
+
+def test_math_mode_selection_guards_small_activations(device):
+    """A detector whose activations are scaled DOWN until its stages peak far below 2^-6: the lo halves of fp16 pairs are
+    subnormal there (absolute quantum 2^-24, i.e. fewer than 22 significant bits), so select_math must fall over to bf16 pairs -
+    which keep their 16 bits at any magnitude and track the fp32 engine to 2e-3 relative."""
+    from detzero_amd.centerpoint import F16_PAIR_SAFE_MIN, select_math
+    model, info = _scaled_model(device, 1.0e-5)
+    with torch.no_grad():           # (no shifts: the later layers then scale with the first one - a uniformly small network)
+        for mod in model.backbone3d.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.bias.zero_()
+                mod.running_mean.zero_()
+    pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
+    mode, rng = select_math(model, info, [pts])
+    assert min(rng.values()) < F16_PAIR_SAFE_MIN and mode == 'bf16x2', (mode, rng)
+    ref = _stage_features(model, info, pts, 'f32')
+    got = _stage_features(model, info, pts, 'bf16x2')
+    pairs = _stage_features(model, info, pts, 'f16x2')
+    for name in ref:
+        scale = float(ref[name].abs().max())
+        if scale == 0.0:
+            continue
+        err = float((got[name] - ref[name]).abs().max()) / scale
+        err16 = float((pairs[name] - ref[name]).abs().max()) / scale
+        print('%s: peak %.3g  bf16x2 %.2e  f16x2 %.2e (relative to the peak)' % (name, scale, err, err16))
+        assert err < 2e-3, (name, err, scale)
 
 
 @pytest.mark.parametrize('name,mid', MODES)

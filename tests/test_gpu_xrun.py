@@ -170,4 +170,4 @@ def test_detector_on_the_xrun_engine_160k(device, name, mid):
         nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), out[:k, :7].cpu().numpy(), out[:k, 7].cpu().numpy(), tol=1e-3)
         assert n_ref > 50 and abs(k - n_ref) <= 2 and nm >= n_ref - 2, (eng, k, n_ref, nm, worst)
         print('%s [%s]: %d boxes, %d/%d within 1e-3 of the oracle (worst %.2e)' % (eng, name, k, nm, n_ref, worst))
-    set_sparse_engine(model, 'gather')
+    set_sparse_engine(model, 'xrun')

@@ -55,6 +55,24 @@ def measure(dev, objects=1024, chunk=128, steps=3, math='f32', with_crop=True):
     out['grm_tflops'] = round(nchunks * b * 5.5e9 / t / 1e12, 2)
     del grm, gd
 
+    # the fused kernels that carry the split-math refiner (csrc/pointnet.hip, csrc/mlp_chain.hip), timed inside the PRM pass with events
+    # on the launch stream: algorithmic FLOP = 2 * rows * sum(cin * cout) of the layers each fuses
+    fused = {}
+
+    def spy(name, fn, flop_of):
+        def wrapped(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args, **kw)
+            e1.record()
+            fused.setdefault(name, []).append((e0, e1, flop_of(*args, **kw)))
+            return r
+        return wrapped
+    real_pn, real_mc = ops.pointnet3, ops.mlp_chain
+    if math != 'f32':
+        ops.pointnet3 = spy('k_pointnet3', real_pn, lambda x, layers, *a, **k: 2.0 * x.shape[0] * (32 * 128 + 128 * 128 + 128 * layers[2][0].shape[0]))
+        ops.mlp_chain = spy('k_mlp_chain', real_mc, lambda x, la, lb, gs, gr, m, kv=None: 2.0 * x.shape[0] * (128 * 512 + 512 * 256 + (2 * 256 * 256 if kv is not None else 0)))
+
     prm = PositionTransformer(PCFG, 32, 32).eval()
     prm.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in prm.state_dict().items()}, 2))
     prm = prm.to(dev).set_math(math)
@@ -68,6 +86,15 @@ def measure(dev, objects=1024, chunk=128, steps=3, math='f32', with_crop=True):
     t = timed(lambda: [prm(dict(pd)) for _ in range(pchunks)], steps)
     out['prm_objects_per_s'] = round(pchunks * bp / t, 1)
     out['prm_tflops'] = round(pchunks * bp * (12.8e9 + 2.5e9 + 2 * 0.98e9) / t / 1e12, 2)
+    ops.pointnet3, ops.mlp_chain = real_pn, real_mc
+    if fused:
+        torch.cuda.synchronize()
+        for name, recs in fused.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out['%s_prm_us' % name] = round(1000.0 * ms / len(recs), 1)
+            out['%s_prm_tflops' % name] = round(fl / (ms * 1e-3) / 1e12, 2)
+            out['%s_prm_share' % name] = round(ms * 1e-3 / ((1 + steps) * t), 3)         # of the PRM pass's wall time (warm-up call included in both)
     del prm, pd
 
     # attention core alone, PRM cross-attention shape (200 queries x 9600 keys, 8 heads x 32): exact fp32 on the fp32 matrix cores
