@@ -716,6 +716,9 @@ def main():
                 out['pdv'] = bench_pdv.measure(dev, args.points, 8, 'f32')
                 p16 = bench_pdv.measure(dev, args.points, 8, 'f16x2')
                 out['pdv']['f16x2'] = {k: p16[k] for k in ('first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
+                # the same modules over 8 frames per pass (one batch_dict: every kernel of both stages launched once for all frames / RoIs)
+                p16b = bench_pdv.measure(dev, args.points, 4, 'f16x2', batch=8)
+                out['pdv']['f16x2_batch8'] = {k: p16b[k] for k in ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
                 log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs); f16x2: %.2f + %.2f ms' % (
                     out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois'], p16['first_stage_ms'], p16['second_stage_ms']))
             except Exception as e:

@@ -312,7 +312,7 @@ class VoxelResBackBone8x(_Cached):
         return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
 
     def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None, level1=None,
-                      staggered=False):
+                      staggered=False, exact=False):
         """Everything of the backbone that depends only on voxel COORDINATES: the level-1 index + feature scatter and
         the output sets / bitmaps / neighbour tables of every stage.  Returns {'x': level-1 rows, 'steps': [...]}.
 
@@ -329,7 +329,11 @@ class VoxelResBackBone8x(_Cached):
         caps: optional row capacities of the 4 strided stages (conv2, conv3, conv4, conv_out).  The default is the
         worst case (min(cells, 8 x inputs)), which is safe but grows with the batch; calibrated capacities
         (FramePipeline.calibrate) keep large batches inside the 2 GiB buffer-addressing window.  Rows beyond a
-        capacity are DROPPED by the kernels; pyr['overflow'] (device bool) reports it."""
+        capacity are DROPPED by the kernels; pyr['overflow'] (device bool) reports it.
+
+        exact=True (the plugin path, `run`): every strided stage's row count is read back (one host sync per stage) and the level
+        shrunk to it before its tables and feature rows are sized - the worst case grows 8x per stage and passes the 2 GiB
+        buffer-addressing window at ~4 frames of 160k points; exact sizes take dozens."""
         p = self.plan()
         dev = voxel_features.device
         if level1 is None:
@@ -392,6 +396,10 @@ class VoxelResBackBone8x(_Cached):
                     side.wait_event(gate)
                 dp = p[name]['down'] if name != 'conv_out' else p[name]
                 nxt = level.downsample(dp['k'], dp['s'], dp['p'], cap=None if caps is None else int(caps[li]))
+                if exact and caps is None:
+                    m = nxt.num_active()                    # (host sync) rows of the level: its buffers need no more
+                    nxt.cap = max(int(m), 1)
+                    nxt.coords = nxt.coords[:nxt.cap]
                 co = ch[min(li + 1, 3)]
                 nbr_d = table(level, nxt, dp['k'], dp['s'], dp['p'], co)
                 nbr_s = table(nxt, nxt, K3, S1, P1, co) if name != 'conv_out' else None
@@ -458,9 +466,10 @@ class VoxelResBackBone8x(_Cached):
         out['encoded'] = (x, nxt)
         return out
 
-    def run(self, voxel_features, voxel_coords, batch_size, d_n=None, side_key=0):
-        """Capacity-sized execution without host syncs.  Returns dict of (features, SparseLevel)."""
-        return self.run_pyramid(self.build_pyramid(voxel_features, voxel_coords, batch_size, d_n, True, side_key))
+    def run(self, voxel_features, voxel_coords, batch_size, d_n=None, side_key=0, exact=False):
+        """Capacity-sized execution without host syncs (exact=True: exact-sized levels, one sync per strided stage).  Returns dict of
+        (features, SparseLevel)."""
+        return self.run_pyramid(self.build_pyramid(voxel_features, voxel_coords, batch_size, d_n, True, side_key, exact=exact))
 
     def _side_stream(self, dev, key=0):
         pool = self.__dict__.setdefault('_side_streams', {})
@@ -475,7 +484,7 @@ class VoxelResBackBone8x(_Cached):
         vc = batch_dict['voxel_coords'].int().contiguous()
         batch_size = batch_dict['batch_size']
         with torch.no_grad():
-            res = self.run(vf, vc, batch_size)
+            res = self.run(vf, vc, batch_size, exact=True)        # (the plugin path reads the row counts back anyway: as_tensor below)
 
         def as_tensor(item):
             feats, level = item

@@ -16,8 +16,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def measure(dev, points=160000, reps=10, math='f32', phases=False):
-    """Two-stage detector on one merged 2-sweep frame -> dict (also the `pdv` leg of bench.py)."""
+def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1):
+    """Two-stage detector on `batch` merged 2-sweep frames per pass -> dict (also the `pdv` leg of bench.py).  batch > 1: the frames go
+    through the plugin modules as ONE batch_dict (batch-index column, as collate_batch builds it): every kernel of both stages is
+    launched once per pass over all frames / all RoIs."""
     from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
     from detzero_amd.config import centerpoint_pdv_cfg
     from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
@@ -31,13 +33,16 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False):
         hl.iou[1].bias.fill_(0.6)
     model = model.to(dev)
     set_math(model, math)
-    frame = merge_two_sweeps(synth_waymo_frame(60, points), synth_waymo_frame(70, points))
-    pts = np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)
+    rows = []
+    for b in range(batch):
+        frame = merge_two_sweeps(synth_waymo_frame(60 + b, points), synth_waymo_frame(70 + b, points))
+        rows.append(np.concatenate([np.full((frame.shape[0], 1), b, np.float32), frame], 1))
+    pts = np.concatenate(rows, 0)
     points_t = torch.from_numpy(pts).to(dev)
     first = [model.vfe, model.backbone3d, model.map_to_bev, model.backbone2d, model.dense_head]
 
     def run(timed):
-        bd = {'batch_size': 1, 'points': points_t}
+        bd = {'batch_size': batch, 'points': points_t}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         with torch.no_grad():
             ev[0].record()
@@ -47,7 +52,7 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False):
             bd = model.roi_head(bd)
             ev[2].record()
         torch.cuda.synchronize()
-        return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[1])) if timed else None
+        return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[0] * bd['rois'].shape[1])) if timed else None
     for _ in range(3):
         run(False)
     if phases:                   # per-method device time of the second stage (events around the head's own methods)
@@ -89,10 +94,10 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False):
         a, b, n_roi = run(True)
         t1 += a / reps
         t2 += b / reps
-    return {'metric': 'two-stage detector, ms per frame (plugin modules, eager, one frame)', 'math': math,
-            'points_per_frame': int(frame.shape[0]), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
+    return {'metric': 'two-stage detector, ms per pass of %d frame(s) (plugin modules, eager)' % batch, 'math': math, 'frames_per_pass': batch,
+            'points_per_frame': int(pts.shape[0] // batch), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
             'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
-            'frames_per_s': round(1000.0 / (t1 + t2), 2), 'data': 'synthetic'}
+            'frames_per_s': round(1000.0 * batch / (t1 + t2), 2), 'data': 'synthetic'}
 
 
 def main():
@@ -100,9 +105,10 @@ def main():
     ap.add_argument('--points', type=int, default=160000, help='points per sweep (two sweeps are merged per frame)')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--math', default='f32')
+    ap.add_argument('--batch', type=int, default=1, help='frames per pass (one batch_dict)')
     ap.add_argument('--phases', action='store_true', help='also print the device time of the second stage per method (stderr)')
     args = ap.parse_args()
-    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math, args.phases)))
+    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math, args.phases, args.batch)))
 
 
 if __name__ == '__main__':
