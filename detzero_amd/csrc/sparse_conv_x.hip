@@ -49,6 +49,7 @@ struct SpConvXArgs {
     int cin, cout, cap, relu;
     unsigned int in_bytes, w_bytes, nbr_bytes;
     unsigned long long *dbg;    // DIAG bit 9 builds: per-wave cycle sums (8 words per wave) or null
+    const int *perm;            // output row of each (unit, position) when the table is in tap-set order, or null
     int *queue;                 // 10 words behind the windows: next ticket of each XCD's tile queue, workgroups done, single-unit queue
 };
 
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     auto issue_pw = [&](const XStage &s, auto pt_t, auto ty_t) {
         constexpr int PTI = decltype(pt_t)::value, TY = decltype(ty_t)::value;
         const int row = (s.u0 + PTI) * C::UR + wp * 32 + l31;          // fragment PTI = unit PTI of the tile
+        // (with a table in tap-set order `row` is a POSITION; live rows keep the positions below m: k_xwin)
         const unsigned int voff = s.live && s.tz_first && row < m && !(PTI == 1 && s.half) ? (unsigned int)row * 4u : OOB_OFFSET;
         const unsigned int so = (unsigned int)(s.tz * 3 + TY) * nbr_row_bytes;
         const srsrc_t rs = nrsrc;            // (named here: an asm operand alone does not capture a variable in a generic lambda)
@@ -525,8 +527,10 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             store_tile_pair16<C, M>(acc, smem + C::OFF_WIN + cur.wb * C::WIN_BYTES, sc_s, sh_s, 0, a.cout, a.relu != 0,
                                     reinterpret_cast<const unsigned char *>(a.residual), reinterpret_cast<unsigned char *>(a.out), wp, wc, lane, wid,
                                     [&](int lr) {           // lr = (wave row group * PT + fragment) * 32 + r: fragment = unit of the tile
-                                        const int pt = (lr >> 5) % PT, row = (u0 + pt) * C::UR + (lr / (32 * PT)) * 32 + (lr & 31);
-                                        return pt < nu && row < m ? (size_t)row * a.cout * 4 : ~size_t(0);
+                                        const int pt = (lr >> 5) % PT, pos = (u0 + pt) * C::UR + (lr / (32 * PT)) * 32 + (lr & 31);
+                                        if (pt >= nu || pos >= m) return ~size_t(0);
+                                        const int row = a.perm ? a.perm[pos] : pos;         // (tap-set order: position -> output row)
+                                        return (size_t)row * a.cout * 4;
                                     });
 #pragma unroll
             for (int i = 0; i < CT; ++i)
@@ -562,10 +566,17 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// windows of the tiles: one workgroup per tile; exact first / last referenced input row of every z slab
+// windows of the units: one workgroup per unit; exact first / last referenced input row of every z slab.
+// With nbr_sorted / perm (optional): the rows of the unit in the order of their TAP SETS (the 27-bit presence mask as an integer;
+// ascending in even units, descending in odd ones - the two units of a tile give every wave one light and one heavy fragment):
+// perm[unit * rows + i] = output row at sorted position i, nbr_sorted = the packed table re-ordered the same way (zero words for
+// positions past the level's last row).  The convolution's window is LDS-resident and its row map is per lane, so the order of a
+// tile's rows is free - and with rows of similar tap sets in one 32-row fragment, 11-13 % fewer (fragment, tap) pairs have any lane
+// to multiply for (tools/xrun_stats: 22.6 -> 19.9-20.4 taps per row at levels 3 / 4).
 __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int cap, const int *__restrict__ d_m_out, int tile_rows,
-                                              int *__restrict__ win) {
+                                              int *__restrict__ win, int *__restrict__ nbr_sorted, int *__restrict__ perm) {
     __shared__ int lo_s[3], hi_s[3];
+    __shared__ unsigned long long key_s[256];
     if (blockIdx.x == 0 && threadIdx.x < 16) win[(size_t)gridDim.x * 6 + threadIdx.x] = 0;       // the tile queues of dz_spconv_forward_split_x
     const int m = min(*d_m_out, cap);
     const int tile = blockIdx.x, row0 = tile * tile_rows;
@@ -595,9 +606,52 @@ __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int c
         const int tz = threadIdx.x;
         int lo = lo_s[tz], n = hi_s[tz] >= 0 ? hi_s[tz] - lo + 1 : 0;
         if (n == 0) lo = 0;
-        if (tz == 1 && n == 0 && row0 < m) n = 1;        // a live tile always runs its centre slab (the kernel's step stream needs one stage per tile)
+        if (tz == 1 && n == 0 && row0 < m) n = 1;        // a live unit always runs its centre slab (the kernel's step stream needs one stage per tile)
         win[(size_t)tile * 6 + 2 * tz] = lo;
         win[(size_t)tile * 6 + 2 * tz + 1] = n;
+    }
+    if (!perm) return;
+    // ---- tap-set order: one row per thread (tile_rows <= 256), bitonic sort of (mask, row) keys in LDS.  Rows past the level's end
+    // sort LAST in either direction: the live rows of the last unit keep the positions row0 .. m - 1, so "position < m" stays the
+    // test for a live position and nothing is written past the table's `cap` columns
+    const int i = threadIdx.x, row = row0 + i;
+    unsigned int words[9];
+    unsigned long long key = ~0ull;                                       // padding threads: behind everything
+    if (i < tile_rows) {
+        unsigned int mask = 0u;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            words[g] = row < row1 ? (unsigned int)nbr[(size_t)g * cap + row] : 0u;
+            mask |= (words[g] >> 29) << (3 * g);
+        }
+        const unsigned int k27 = (tile & 1) ? (0x7FFFFFFu - mask) : mask;    // odd units descending
+        key = ((unsigned long long)(row < row1 ? k27 : 0x8000000u) << 16) | (unsigned int)i;
+    }
+    key_s[i] = key;
+    __syncthreads();
+    for (int k = 2; k <= 256; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = i ^ j;
+            if (p > i) {
+                const unsigned long long ka = key_s[i], kb = key_s[p];
+                const bool up = (i & k) == 0;
+                if ((ka > kb) == up) { key_s[i] = kb; key_s[p] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+    const int src = i < tile_rows ? (int)(key_s[i] & 0xFFFFu) : 0;        // the row (of this unit) at sorted position i
+    if (i < tile_rows && row0 + i < cap) perm[row0 + i] = row0 + src;
+    __syncthreads();
+    int *const pos_s = reinterpret_cast<int *>(key_s);                  // (every key has been read) position of row r of the unit
+    if (i < tile_rows) pos_s[src] = i;
+    __syncthreads();
+    if (i < tile_rows) {
+        const int pos = row0 + pos_s[i];                                 // my row's table words go to its position
+        if (pos < cap) {
+#pragma unroll
+            for (int g = 0; g < 9; ++g) nbr_sorted[(size_t)g * cap + pos] = (int)words[g];
+        }
     }
 }
 
@@ -688,18 +742,20 @@ size_t dz_spconv_x_windows_words(int cap_out, int tile_rows) {
     return tile_rows > 0 && cap_out >= 0 ? (size_t)ceil_div(cap_out, tile_rows) * 6 + 16 : 0;
 }
 
-int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, void *stream_) {
+int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, int *nbr_sorted, int *perm,
+                        void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(nbr_packed && d_m_out && windows, "dz_spconv_x_windows: null pointer");
-    DZ_CHECK_ARG(tile_rows > 0 && tile_rows % 32 == 0 && cap_out >= 0, "dz_spconv_x_windows: bad tile_rows %d / cap %d", tile_rows, cap_out);
+    DZ_CHECK_ARG(tile_rows > 0 && tile_rows % 32 == 0 && tile_rows <= 256 && cap_out >= 0, "dz_spconv_x_windows: bad tile_rows %d / cap %d", tile_rows, cap_out);
+    DZ_CHECK_ARG((nbr_sorted == nullptr) == (perm == nullptr), "dz_spconv_x_windows: nbr_sorted and perm come together");
     if (cap_out == 0) return DZ_OK;
-    hipLaunchKernelGGL(k_xwin, dim3(ceil_div(cap_out, tile_rows)), dim3(256), 0, stream, nbr_packed, cap_out, d_m_out, tile_rows, windows);
+    hipLaunchKernelGGL(k_xwin, dim3(ceil_div(cap_out, tile_rows)), dim3(256), 0, stream, nbr_packed, cap_out, d_m_out, tile_rows, windows, nbr_sorted, perm);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
-int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, int *windows, int tile_rows, int cap_out,
-                              const int *d_m_out, const float *w, const float *scale, const float *shift, const float *residual, int relu,
+int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, const int *perm, int *windows, int tile_rows,
+                              int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift, const float *residual, int relu,
                               float *out, int cout, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(in && nbr_packed && windows && d_m_out && w && out, "dz_spconv_forward_split_x: null pointer");
@@ -718,7 +774,7 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
         return DZ_ERR_UNSUPPORTED;
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
-                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr,
+                  (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr, perm,
                   windows + (size_t)ceil_div(cap_out, tile_rows) * 6};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);

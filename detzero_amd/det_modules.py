@@ -377,7 +377,9 @@ class VoxelResBackBone8x(_Cached):
                     for tt in getattr(t, 'tiles', None) or ():
                         tt.record_stream(main)
                     if getattr(t, 'xwin', None) is not None:
-                        t.xwin[0].record_stream(main)
+                        for tt in t.xwin:
+                            if torch.is_tensor(tt):
+                                tt.record_stream(main)
         ch = self.channels
         with torch.cuda.stream(side):
             nbr1 = table(lvl1, lvl1, K3, S1, P1, ch[0])

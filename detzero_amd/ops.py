@@ -292,6 +292,9 @@ def build_tiles(nbr, out_level):
     return nbr
 
 
+XRUN_SORT = os.environ.get('DZ_TUNE_XRUN_SORT', '1') != '0'       # development switch: rows of a unit in tap-set order
+
+
 def build_windows(nbr, out_level, channels):
     """Windows of the x-run convolution (dz_spconv_forward_split_x) for a PACKED submanifold table and the level's channel width:
     per tile of dz_spconv_x_tile_rows(channels, channels) output rows and z offset the contiguous range of input rows its nine taps
@@ -304,9 +307,12 @@ def build_windows(nbr, out_level, channels):
     cap = nbr.shape[1]
     # (tiles x 3 x 2 window words + the tile-queue words of the convolution kernels)
     win = torch.empty((lib.dz_spconv_x_windows_words(cap, tr),), dtype=torch.int32, device=nbr.device)
-    rc = lib.dz_spconv_x_windows(L.ptr(nbr), cap, L.ptr(out_level.d_m), tr, L.ptr(win), L.stream())
+    # the table and the row map in tap-set order (rows of a unit sorted by their neighbour pattern: fewer (fragment, tap) pairs to multiply)
+    nbr_sorted = torch.empty_like(nbr) if XRUN_SORT else None
+    perm = torch.empty((cap,), dtype=torch.int32, device=nbr.device) if XRUN_SORT else None
+    rc = lib.dz_spconv_x_windows(L.ptr(nbr), cap, L.ptr(out_level.d_m), tr, L.ptr(win), L.ptr(nbr_sorted), L.ptr(perm), L.stream())
     L.check(rc, 'dz_spconv_x_windows')
-    nbr.xwin = (win, tr)
+    nbr.xwin = (win, tr, nbr_sorted, perm)
     return nbr
 
 
@@ -361,7 +367,8 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
 
     def launch():
         if xwin is not None:
-            rc = lib.dz_spconv_forward_split_x(L.ptr(feats), feats.shape[0], cin, L.ptr(nbr), L.ptr(xwin[0]), xwin[1], cap,
+            rc = lib.dz_spconv_forward_split_x(L.ptr(feats), feats.shape[0], cin, L.ptr(xwin[2] if xwin[3] is not None else nbr), L.ptr(xwin[3]),
+                                               L.ptr(xwin[0]), xwin[1], cap,
                                                L.ptr(out_level.d_m), L.ptr(w_taps), L.ptr(scale), L.ptr(shift), L.ptr(residual),
                                                1 if relu else 0, L.ptr(out), cout, int(math), L.stream())
         elif tiles is not None:

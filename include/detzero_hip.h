@@ -272,10 +272,15 @@ int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const 
  *     (tz, 16-channel chunk, tap), so results agree with dz_spconv_forward_split to fp32 summation-order noise, not bit for bit. */
 int dz_spconv_x_tile_rows(int cin, int cout);
 size_t dz_spconv_x_windows_words(int cap_out, int tile_rows);
-int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, void *stream);
-int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, int *windows, int tile_rows,
+int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, int *nbr_sorted, int *perm,
+                        void *stream);
+/* nbr_sorted (9 x cap_out) / perm (cap_out), both or neither: the rows of every unit re-ordered by their tap set (ascending in even
+ * units, descending in odd ones): perm[position] = output row, nbr_sorted = the packed table in that order.  Fragments of 32 rows
+ * with similar tap sets let the kernel skip 11-13 % more (fragment, tap) pairs; pass both to dz_spconv_forward_split_x. */
+int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *nbr_packed, const int *perm, int *windows, int tile_rows,
                               int cap_out, const int *d_m_out, const float *w, const float *scale, const float *shift,
                               const float *residual, int relu, float *out, int cout, int math, void *stream);
+/* (nbr_packed = the level's packed table and perm = NULL, or nbr_sorted and its perm) */
 const char *dz_spconv_x_variant(int cin, int cout);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,

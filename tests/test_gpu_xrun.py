@@ -43,7 +43,7 @@ def test_windows_cover_the_rulebook_exactly(device, channels):
     rng = np.random.default_rng(channels)
     lvl, coords = _level(rng, 2, [5, 40, 60], (0.02, 0.6, 0.1), device)
     nbr = ops.build_windows(lvl.neighbors_to(lvl, K3, S1, P1, packed=True), lvl, channels)
-    win, tr = nbr.xwin
+    win, tr, nbr_sorted, perm = nbr.xwin
     assert tr == L.load().dz_spconv_x_tile_rows(channels, channels) and tr in (128, 256)
     m = lvl.num_active()
     tab = ops.unpack_table(nbr)[:, :m].cpu().numpy().astype(np.int64)
@@ -60,6 +60,19 @@ def test_windows_cover_the_rulebook_exactly(device, channels):
             else:
                 assert n == (1 if tz == 1 else 0)
     assert (win[(m + tr - 1) // tr:, :, 1] == 0).all()
+    # the tap-set order: perm is a permutation of every unit's rows (live rows at the positions below m), the sorted table holds the
+    # words of row perm[position] at `position`, and masks ascend in even units / descend in odd ones
+    perm = perm[:m].cpu().numpy().astype(np.int64)
+    packed = nbr[:, :m].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    srt = nbr_sorted[:, :m].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(np.sort(perm), np.arange(m)) and np.array_equal(perm // tr, np.arange(m) // tr)
+    assert np.array_equal(srt, packed[:, perm])
+    mask = np.zeros(m, np.int64)
+    for g in range(9):
+        mask |= (srt[g] >> 29) << (3 * g)
+    for u in range((m + tr - 1) // tr):
+        d = np.diff(mask[u * tr:(u + 1) * tr])
+        assert (d <= 0).all() if u & 1 else (d >= 0).all(), u
 
 
 def _run_case(device, rng, lvl, coords, channels, mid, with_res, relu):
@@ -142,7 +155,7 @@ def test_xrun_refuses_what_it_does_not_cover(device):
     assert getattr(ops.build_windows(plain, lvl, 64), 'xwin', None) is None        # unpacked table: left alone
     win = torch.zeros((6 + 16,), dtype=torch.int32, device=device)
     x = torch.zeros((lvl.cap, 32), device=device)
-    rc = lib.dz_spconv_forward_split_x(L.ptr(x), lvl.cap, 32, L.ptr(packed), L.ptr(win), 128, lvl.cap, L.ptr(lvl.d_m), L.ptr(x), None, None,
+    rc = lib.dz_spconv_forward_split_x(L.ptr(x), lvl.cap, 32, L.ptr(packed), None, L.ptr(win), 128, lvl.cap, L.ptr(lvl.d_m), L.ptr(x), None, None,
                                        None, 0, L.ptr(x), 32, 1, L.stream())
     assert rc != 0 and b'tiles' in lib.dz_last_error()
 

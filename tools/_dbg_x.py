@@ -9,7 +9,7 @@ for shape, dens, batch in (([3, 20, 33], (0.08,), 1), ([6, 36, 50], (0.3, 0.35, 
     m = coords.shape[0]
     for c in (32, 64, 128):
         xt = ops.build_windows(lvl.neighbors_to(lvl, K3, S1, P1, packed=True), lvl, c)
-        win, tr = xt.xwin
+        win, tr = xt.xwin[:2]
         nt = (lvl.cap + tr - 1) // tr
         x = ops.pair16_from_f32(torch.randn((lvl.cap, c), device=dev), c, 1)
         w = ops.pack_weight_split(torch.randn((27, c, c), device=dev) * 0.05, 1)
