@@ -219,6 +219,33 @@ def sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack):
     return out
 
 
+def sa_pool_split_supported(c, stack, nsample, math):
+    return (FUSED_SA[0] and SPLIT_SA[0] and math in (1, 2) and len(stack) == 2 and
+            bool(L.load().dz_pdv_sa_pool_split_supported(int(c), stack[0]['w'].shape[0], stack[0]['cout'], stack[1]['cout'], int(nsample),
+                                                         int(stack[0]['relu']), int(stack[1]['relu']))))
+
+
+SPLIT_SA = [True]            # development switch: the pair16 instance of the fused branch in the split math modes
+
+
+def sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, math):
+    """dz_pdv_sa_pool_split: sa_pool on pair16 operands (the head's split math modes)."""
+    from .refine_modules import _split_w
+    _full_prefix(level, 'dz_pdv_sa_pool_split')
+    mq, nsample = idx.shape
+    l1, l2 = stack
+    w1, w2 = _split_w(l1, math), _split_w(l2, math)
+    out = torch.empty((mq, l2['cout']), dtype=torch.float32, device=new_xyz.device)
+    cells = level.shape[0] * level.shape[1] * level.shape[2]
+    with torch.cuda.device(new_xyz.device):
+        rc = L.load().dz_pdv_sa_pool_split(L.ptr(new_xyz), mq, per_batch, L.ptr(xyz), L.ptr(feats), feats.shape[0], feats.shape[1], L.ptr(level.bitmap),
+                                           L.ptr(level.prefix), cells, L.ptr(idx), L.ptr(cnt), nsample, L.ptr(w1), w1.shape[1], L.ptr(l1['scale32']),
+                                           L.ptr(l1['shift32']), l1['cout'], L.ptr(w2), w2.shape[1], L.ptr(l2['scale32']), L.ptr(l2['shift32']),
+                                           l2['cout'], l1['w'].shape[0], int(math), L.ptr(out), L.stream())
+    L.check(rc, 'dz_pdv_sa_pool_split')
+    return out
+
+
 def part_counts(points_b, rois, grid_size, max_num_boxes):
     """density_utils.find_num_points_per_part_multi -> (B, O, G, G, G) int32."""
     b, o = rois.shape[0], rois.shape[1]
@@ -238,6 +265,19 @@ def attention_single_head(q, k, v, key_padding_mask, scale):
         rc = L.load().dz_attention_single_head(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(m8), r, l, e, float(scale), L.ptr(out), L.stream())
     L.check(rc, 'dz_attention_single_head')
     return out
+
+
+def self_attention_split(qp, xp, key_padding_mask, r, l, math):
+    """dz_self_attention_split: softmax(q' x^T + mask) x per group of l rows; q', x and the result (r * l, 192) pair16."""
+    out = torch.empty_like(xp)
+    m8 = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(xp.device):
+        rc = L.load().dz_self_attention_split(L.ptr(qp), L.ptr(xp), L.ptr(m8), r, l, xp.shape[1], L.ptr(out), int(math), L.stream())
+    L.check(rc, 'dz_self_attention_split')
+    return out
+
+
+FOLDED_ATTENTION = [True]    # development switch: the encoder layer on split operands with folded key / value projections
 
 
 def _seq_plan(seq, cin_pad=None):
@@ -323,6 +363,16 @@ class PDVHead(_Cached):
                     'ln': [(n.weight.detach().float().contiguous(), n.bias.detach().float().contiguous(), n.eps) for n in (enc.norm1, enc.norm2)]}
         if getattr(enc, 'norm_first', False):
             raise DetZeroHipError('PDVHead: post-norm encoder layers only')
+        # one head: the key / value projections fold into the query and output GEMMs (csrc/pdv_attn.hip), in float64 on the host:
+        #   scores (x_i wq + bq) . (x_j wk + bk) = (x_i (wq wk^T) + wk bq) . x_j + terms constant in j;  output (P x) (wv wo) + (bv wo + bo)
+        m = p['mha']
+        d = lambda t: t.detach().double()       # noqa: E731
+        c2 = m['scale'] * 1.4426950408889634   # scores in log2 units (the kernel exponentiates with v_exp_f32)
+        lyr = lambda w, b: {'w': w.float().contiguous(), 'cout': w.shape[1], 'scale32': torch.ones(w.shape[1], device=w.device),      # noqa: E731
+                            'shift32': b.float().contiguous()}
+        p['fold'] = {'q': lyr(d(m['wq']) @ d(m['wk']).t() * c2, (d(m['wk']) @ d(m['bq'])) * c2),
+                     'o': lyr(d(m['wv']) @ d(m['wo']), d(m['bv']) @ d(m['wo']) + d(m['bo'])),
+                     'f1': lyr(p['enc']['w1'], p['enc']['b1']), 'f2': lyr(p['enc']['w2'], p['enc']['b2'])}
         # shared FC: the reference flattens (RoI, C, 216) channel-major; the pooled rows here are (RoI, 216, C) -> permute the columns once
         shared = [m for m in self.shared_fc_layer if not isinstance(m, nn.Dropout)]
         w0 = shared[0].weight.detach()
@@ -427,8 +477,10 @@ class PDVHead(_Cached):
                     continue
                 idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
                 stack = p['pool'][k][s]['stack']
-                if sa_pool_supported(feats.shape[1], stack, nsample):     # (exact fp32 in every math mode)
-                    pooled.append(sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack))    # group + MLP + max in one kernel
+                if sa_pool_split_supported(feats.shape[1], stack, nsample, self.stack_math()):       # group + MLP + max in one kernel
+                    pooled.append(sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, self.stack_math()))
+                elif sa_pool_supported(feats.shape[1], stack, nsample):   # (exact fp32)
+                    pooled.append(sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack))
                 else:
                     rows = group_features(new_xyz, per_batch, xyz, feats, level, idx, cnt, p['pool'][k][s]['stride'])
                     out, _ = _run_stack(rows, stack, math=self.stack_math())
@@ -462,6 +514,9 @@ class PDVHead(_Cached):
         # feats + pos where add_pos, feats elsewhere, in one pass: pos * 1.0 and feats + 0.0 are exact (the encodings are finite)
         src = torch.addcmul(feats, pos, add_pos.reshape(r * l, 1).to(feats.dtype))
         m = p['mha']
+        sm = self.stack_math()
+        if FOLDED_ATTENTION[0] and sm in (1, 2) and m['heads'] == 1 and L.load().dz_self_attention_split_supported(l, e) and e % 32 == 0:
+            return self._attention_split(p, sm, point_features, src, key_padding_mask, empty, r, l, e)
         q = ops.linear(src, m['wq'], m['one'], m['bq'], False, e)
         k = ops.linear(src, m['wk'], m['one'], m['bk'], False, e)
         v = ops.linear(src, m['wv'], m['one'], m['bv'], False, e)
@@ -473,6 +528,21 @@ class PDVHead(_Cached):
         h = ops.linear(x, enc['w1'], enc['one1'], enc['b1'], True, enc['w1'].shape[1])
         y = ops.linear(h, enc['w2'], enc['one2'], enc['b2'], False, enc['w2'].shape[1])
         y = ops.add_layernorm(x, y, *enc['ln'][1])
+        return torch.where(empty[:, None, None], point_features, y.view(r, l, e))
+
+    def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e):
+        """The encoder layer on pair16 operands: q' GEMM, dz_self_attention_split over the input rows themselves, output GEMM, and the
+        feed-forward block; LayerNorms and residuals in fp32 (dz_add_layernorm)."""
+        from .refine_modules import _split_w
+        f, enc = p['fold'], p['enc']
+        lin = lambda xp, k, relu, f32: ops.linear_split(xp, _split_w(f[k], sm), f[k]['scale32'], f[k]['shift32'], relu, f[k]['cout'], sm, out_f32=f32)   # noqa: E731
+        srcp = ops.pair16_from_f32(src, math=sm)
+        qp = lin(srcp, 'q', False, False)
+        mask = key_padding_mask & (~empty)[:, None]                        # (an all-masked group's result is discarded below)
+        op = self_attention_split(qp, srcp, mask, r, l, sm)
+        x = ops.add_layernorm(src, lin(op, 'o', False, True), *enc['ln'][0])
+        hp = lin(ops.pair16_from_f32(x, math=sm), 'f1', True, False)
+        y = ops.add_layernorm(x, lin(hp, 'f2', False, True), *enc['ln'][1])
         return torch.where(empty[:, None, None], point_features, y.view(r, l, e))
 
     def generate_predicted_boxes(self, batch_size, rois, cls_preds, box_preds):

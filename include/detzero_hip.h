@@ -560,6 +560,15 @@ int dz_pdv_sa_pool(const float *new_xyz, int mq, int per_batch, const float *xyz
                    const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt, int nsample, const float *w1, int ldw1,
                    const float *s1, const float *b1, int h1, const float *w2, int ldw2, const float *s2, const float *b2, int h2, int cin_pad,
                    float *out, void *stream);
+/* The same branch on pair16 operands (math = DZ_MATH_F16X2 / DZ_MATH_BF16X2; the PDV head's split modes): w1 (h1, ldw1) / w2 (h2, ldw2) are
+ * pair16 rows per OUTPUT channel (ld in channels, dz_pair16 packing), features stay fp32 rows (feat_rows x c) and are split in the
+ * kernel.  Instances: (c, cin_pad, h1, h2) = (64, 80, 32, 32) and (128, 144, 64, 64), nsample 16.  Same outputs as dz_pdv_sa_pool up
+ * to the pair16 product error (~2^-21 relative per product, fp32 accumulation). */
+int dz_pdv_sa_pool_split_supported(int c, int cin_pad, int h1, int h2, int nsample, int relu1, int relu2);
+int dz_pdv_sa_pool_split(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, long feat_rows, int c,
+                         const uint32_t *bitmap, const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt, int nsample,
+                         const float *w1, int ldw1, const float *s1, const float *b1, int h1, const float *w2, int ldw2, const float *s2,
+                         const float *b2, int h2, int cin_pad, int math, float *out, void *stream);
 /* density_utils.find_num_points_per_part_multi (:52-109) on points_in_multi_boxes (roiaware_pool3d_kernel.cu:377-404): counts
  * (batch, o, grid, grid, grid) int32 of the points (n, stride) [b, x, y, z, ...] per cell of every RoI (batch, o, 7), a point
  * counting for the first max_boxes RoIs (in RoI order) that contain it. */
@@ -569,6 +578,13 @@ int dz_pdv_part_counts(const float *points_b, int n, int stride, const float *ro
  * (nn.MultiheadAttention core of attention_utils.TransformerEncoder; q, k, v, out (r, l, e) f32; mask (r, l) bytes or NULL). */
 int dz_attention_single_head(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask, int r, int l,
                              int e, float scale, float *out, void *stream);
+/* The same layer with the key / value projections folded into its two GEMMs (one head): o' = softmax(q' x^T + mask) x over every group
+ * of l consecutive rows, where x (r * l, e) pair16 are the layer's input rows (keys = values) and q' = x (Wq Wk^T) + Wk bq, scaled by
+ * log2(e) / sqrt(E), (r * l, e) pair16; the caller applies (Wv Wo, bv Wo + bo) to o' (pdv_modules.py: PDVHead.attention).  e = 192,
+ * l <= 224, math = DZ_MATH_F16X2 / DZ_MATH_BF16X2; out (r * l, e) pair16.  A fully masked group gives zero rows. */
+int dz_self_attention_split_supported(int l, int e);
+int dz_self_attention_split(const float *q, const float *x, const unsigned char *key_padding_mask, int r, int l, int e, float *out,
+                            int math, void *stream);
 
 #ifdef __cplusplus
 }

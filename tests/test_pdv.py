@@ -246,3 +246,87 @@ def test_fused_grid_pooling_equals_the_layered_path(device, g):
     err = float((outs[0] - outs[1]).abs().max())
     print('fused grid pooling vs layered: max |diff| %.2e (max |value| %.2f)' % (err, float(outs[1].abs().max())))
     assert tuple(outs[0].shape) == tuple(outs[1].shape) and err <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,mid,tol', [('f16x2', 1, 2e-5), ('bf16x2', 2, 2e-4)])
+def test_grid_pooling_on_split_operands(device, g, mode, mid, tol):
+    """dz_pdv_sa_pool_split (the same branch with (hi, lo) 16-bit operands, two grid points per wave, rows gathered straight into the
+    MFMA operands) against the exact-fp32 kernel on the golden scene and against the golden itself at the fp32 path's tolerance."""
+    from detzero_amd import pdv_modules as pm
+    head = _head().to(device)
+    outs = []
+    for m in (0, mid):
+        head.set_math(m)
+        bd = _batch(g, device)
+        bd['point_features'], bd['point_coords'] = head.get_point_voxel_features(bd)
+        outs.append(head.roi_grid_pool(bd)[0])
+    for k, layer in enumerate(head.roi_grid_pool_layers):      # every branch of this config has a split instance too
+        for s, ns in enumerate(layer.nsamples):
+            st = head.plan()['pool'][k][s]['stack']
+            assert pm.sa_pool_split_supported(st[0]['w'].shape[0] - 16, st, ns, mid)
+    err = float((outs[0] - outs[1]).abs().max())
+    print('grid pooling [%s] vs fp32: max |diff| %.2e (max |value| %.2f)' % (mode, err, float(outs[0].abs().max())))
+    assert tuple(outs[0].shape) == tuple(outs[1].shape) and err <= tol * max(1.0, float(outs[0].abs().max()))
+    torch.testing.assert_close(outs[1][g['roi_subset']].cpu(), torch.from_numpy(g['pooled']), rtol=1e-4 if mid == 1 else 2e-3, atol=1e-4 if mid == 1 else 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,mid,tol', [('f16x2', 1, 2e-5), ('bf16x2', 2, 3e-4)])
+@pytest.mark.parametrize('r,l', [(5, 216), (3, 50), (2, 224), (1, 1)])
+def test_self_attention_on_split_operands(device, mode, mid, tol, r, l):
+    """dz_self_attention_split: o' = softmax(q' x^T + mask) x per group of l rows (keys = values = x, scores in log2 units) against
+    torch in float64 on the values the pair16 operands actually hold."""
+    from detzero_amd import ops
+    from detzero_amd import pdv_modules as pm
+    gen_ = torch.Generator().manual_seed(100 * r + l + mid)
+    e = 192
+    x = torch.randn(r * l, e, generator=gen_)
+    q = torch.randn(r * l, e, generator=gen_) * 0.3
+    mask = torch.rand(r, l, generator=gen_) < 0.3
+    mask[:, 0] = False                                          # (every group keeps a key)
+    if r > 1:
+        mask[1] = False
+    xp, qp = ops.pair16_from_f32(x.to(device), math=mid), ops.pair16_from_f32(q.to(device), math=mid)
+    out = ops.pair16_to_f32(pm.self_attention_split(qp, xp, mask.to(device), r, l, mid), mid).cpu().view(r, l, e)
+    xv, qv = ops.pair16_to_f32(xp, mid).cpu().double().view(r, l, e), ops.pair16_to_f32(qp, mid).cpu().double().view(r, l, e)
+    s = torch.einsum('rqe,rke->rqk', qv, xv) * float(np.log(2.0))
+    s = s.masked_fill(mask[:, None, :], float('-inf'))
+    ref = torch.einsum('rqk,rke->rqe', torch.softmax(s, dim=-1), xv)
+    err = float((out.double() - ref).abs().max())
+    print('self attention [%s] r %d l %d: max |err| %.2e' % (mode, r, l, err))
+    assert err <= tol * max(1.0, float(ref.abs().max()))
+    # without a mask; and a fully masked group gives zeros
+    out2 = ops.pair16_to_f32(pm.self_attention_split(qp, xp, None, r, l, mid), mid).cpu().view(r, l, e)
+    ref2 = torch.einsum('rqk,rke->rqe', torch.softmax(torch.einsum('rqe,rke->rqk', qv, xv) * float(np.log(2.0)), dim=-1), xv)
+    assert float((out2.double() - ref2).abs().max()) <= tol * max(1.0, float(ref2.abs().max()))
+    full = torch.ones(r, l, dtype=torch.bool)
+    assert not ops.pair16_to_f32(pm.self_attention_split(qp, xp, full.to(device), r, l, mid), mid).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,mid', [('f16x2', 1), ('bf16x2', 2)])
+def test_head_on_split_operands(device, g, mode, mid):
+    """PDVHead in the split math modes (pooling on pair16 operands, the encoder layer with folded key / value projections, pair16 FC
+    stacks) against the golden of the reference's classes, at the fp32 path's tolerances; and the folded encoder against the unfolded
+    fp32 one on the same pooled features."""
+    from detzero_amd import pdv_modules as pm
+    head = _head().to(device)
+    head.set_math(mid)
+    out = head(_batch(g, device))
+    r = head.forward_ret_dict
+    sub = g['roi_subset']
+    tol = 2e-3 if mid == 1 else 5e-3
+    torch.testing.assert_close(r['attention_output'][sub].cpu(), torch.from_numpy(g['pooled'] + g['attention']), rtol=tol, atol=tol)
+    assert torch.equal(r['attention_output'][27], 2 * r['pooled_features'][27]) or bool(g['key_padding_mask'][27].all())
+    torch.testing.assert_close(out['batch_box_preds'].cpu(), torch.from_numpy(g['batch_box_preds']), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(out['batch_cls_preds'].cpu(), torch.from_numpy(g['batch_cls_preds']), rtol=2e-3, atol=2e-3)
+    att_fold = r['attention_output'].clone()
+    pm.FOLDED_ATTENTION[0] = False
+    try:
+        head(_batch(g, device))
+    finally:
+        pm.FOLDED_ATTENTION[0] = True
+    err = float((head.forward_ret_dict['attention_output'] - att_fold).abs().max())
+    print('encoder layer [%s]: folded split path vs unfolded fp32 path, max |diff| %.2e' % (mode, err))
+    assert err <= tol

@@ -1,0 +1,7 @@
+#!/bin/bash
+# PDV second stage: its tests, then the 8-frame profile (tools/gpu_pdv_prof.sh).
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/pdv
+timeout 900 python -m pytest tests/test_pdv.py -q -x --timeout=300 -p no:cacheprovider -m gpu -s 2>&1 | grep -v "^$" | tail -40 | tee gpurun_out/pdv/tests.txt
+if [ "$1" != "noprof" ]; then bash tools/gpu_pdv_prof.sh 8; fi
