@@ -85,6 +85,85 @@ __device__ __forceinline__ void x_load16_lds(unsigned int lds_base, unsigned int
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(b), "v"(voff), "s"(rsrc), "s"(so) : "memory", "m0");
 }
 
+// store_tile_pair16 (hgemm.h) for this kernel: the output rows of the lane's items come in `orow` (fetched through the row map a
+// whole stage earlier: -1 = no row), and ALL residual groups of the tile are requested before the first fragment is staged - one
+// round trip to memory per tile instead of one per 32 x 32 fragment (measured: the residual cost of the per-fragment form was as much
+// as the rest of the epilogue).
+template <class T, class M>
+__device__ __forceinline__ void x_store_tile(const f32x16 (&acc)[T::CT][T::PT], unsigned char *smem_bytes, const float *sc_s, const float *sh_s,
+                                             int cout, bool relu, const unsigned char *residual, unsigned char *out, int wc, int lane, int wid,
+                                             const int (&orow)[T::PT][2]) {
+    unsigned char *const stg = smem_bytes + wid * STG_WAVE_BYTES;
+    const int h = lane >> 5, g = lane & 3;
+    const size_t row_bytes = (size_t)cout * 4;
+    uint4 rh[T::PT][T::CT][2], rl[T::PT][T::CT][2];
+    if (residual) {
+#pragma unroll
+        for (int pt = 0; pt < T::PT; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < T::CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    rh[pt][ct][i] = rl[pt][ct][i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (orow[pt][i] >= 0) {
+                        const unsigned char *rp = residual + (size_t)orow[pt][i] * row_bytes + (size_t)(wc * T::CT * 32 + ct * 32 + g * 8) * 4;
+                        rh[pt][ct][i] = *reinterpret_cast<const uint4 *>(rp);
+                        rl[pt][ct][i] = *reinterpret_cast<const uint4 *>(rp + 16);
+                    }
+                }
+    }
+#pragma unroll
+    for (int pt = 0; pt < T::PT; ++pt) {
+#pragma unroll
+        for (int ct = 0; ct < T::CT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = make_float4(acc[ct][pt][4 * j], acc[ct][pt][4 * j + 1], acc[ct][pt][4 * j + 2], acc[ct][pt][4 * j + 3]);
+                *reinterpret_cast<float4 *>(stg + (lane & 31) * STG_ROW_BYTES + j * 32 + h * 16) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int lc = wc * T::CT * 32 + ct * 32 + g * 8;                 // my 8-channel group
+            const float4 sc0 = *reinterpret_cast<const float4 *>(sc_s + lc), sc1 = *reinterpret_cast<const float4 *>(sc_s + lc + 4);
+            const float4 sh0 = *reinterpret_cast<const float4 *>(sh_s + lc), sh1 = *reinterpret_cast<const float4 *>(sh_s + lc + 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (lane >> 2) + 16 * i;
+                const float4 va = *reinterpret_cast<const float4 *>(stg + r * STG_ROW_BYTES + g * 32);
+                const float4 vb = *reinterpret_cast<const float4 *>(stg + r * STG_ROW_BYTES + g * 32 + 16);
+                float v[8] = {fmaf(va.x, sc0.x, sh0.x), fmaf(va.y, sc0.y, sh0.y), fmaf(va.z, sc0.z, sh0.z), fmaf(va.w, sc0.w, sh0.w),
+                              fmaf(vb.x, sc1.x, sh1.x), fmaf(vb.y, sc1.y, sh1.y), fmaf(vb.z, sc1.z, sh1.z), fmaf(vb.w, sc1.w, sh1.w)};
+                if (residual) {
+                    const uint4 a4 = rh[pt][ct][i], b4 = rl[pt][ct][i];
+                    const unsigned int hw[4] = {a4.x, a4.y, a4.z, a4.w}, lw[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] += M::join(hw[k] & 0xFFFFu, lw[k] & 0xFFFFu);
+                        v[2 * k + 1] += M::join(hw[k] >> 16, lw[k] >> 16);
+                    }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                uint2 h0, l0, h1, l1;
+                split4<M>(v0, h0, l0);
+                split4<M>(v1, h1, l1);
+                if (orow[pt][i] >= 0) {
+                    unsigned char *gp = out + (size_t)orow[pt][i] * row_bytes + (size_t)lc * 4;
+                    *reinterpret_cast<uint4 *>(gp) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    *reinterpret_cast<uint4 *>(gp + 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // one stage of a workgroup's stream (wave-uniform: SGPRs; never indexed dynamically)
 struct XStage {
     int u0, seq, tz, kc;        // first unit of the tile, the tile's number in the workgroup's sequence
@@ -494,13 +573,27 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if constexpr (DIAG & 512) { tm_step += __builtin_readcyclecounter() - t_top; ++tm_n; }
     };
 
+    int orow[PT][2];            // output rows of my epilogue items (fragment pt, row (lane >> 2) + 16 i of it), -1 = none
     while (cur.live) {
+        const bool tile_last = !nxt.live || nxt.tile_first;
+        if (tile_last) {
+            // the tile's last stage: the rows of my epilogue items, through the row map when the table is in tap-set order - requested
+            // now, used after this stage's MFMAs.  (Extra loads in flight only make the counted waits below stricter.)
+            const int nu = cur.half ? 1 : 2;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pos = (cur.u0 + pt) * C::UR + wp * 32 + (lane >> 2) + 16 * i;
+                    orow[pt][i] = (pt < nu && pos < m) ? (a.perm ? a.perm[pos] : pos) : -1;
+                }
+        }
         step(std::integral_constant<int, 0>{});
         if constexpr (SPS == 3) {
             step(std::integral_constant<int, 1>{});
             step(std::integral_constant<int, 2>{});
         }
-        if (!nxt.live || nxt.tile_first) {
+        if (tile_last) {
             // last stage of the tile: finish its last tap, then its window buffer (every wave is done with it after the barrier)
             // stages the epilogue; the loads in flight go to the other window buffer and to other weight slots
             unsigned long long t_e = 0ull;
@@ -515,7 +608,6 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             __syncthreads();
             int next_ticket = 0;            // the ticket of the tile after next (thread 0; read at the end of the epilogue)
             if (tid == 0) next_ticket = take_ticket();
-            const int u0 = cur.u0, nu = cur.half ? 1 : 2;
             if constexpr (DIAG & 32) {
 #pragma unroll
                 for (int i = 0; i < CT; ++i)
@@ -524,14 +616,8 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                         for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
             } else
-            store_tile_pair16<C, M>(acc, smem + C::OFF_WIN + cur.wb * C::WIN_BYTES, sc_s, sh_s, 0, a.cout, a.relu != 0,
-                                    reinterpret_cast<const unsigned char *>(a.residual), reinterpret_cast<unsigned char *>(a.out), wp, wc, lane, wid,
-                                    [&](int lr) {           // lr = (wave row group * PT + fragment) * 32 + r: fragment = unit of the tile
-                                        const int pt = (lr >> 5) % PT, pos = (u0 + pt) * C::UR + (lr / (32 * PT)) * 32 + (lr & 31);
-                                        if (pt >= nu || pos >= m) return ~size_t(0);
-                                        const int row = a.perm ? a.perm[pos] : pos;         // (tap-set order: position -> output row)
-                                        return (size_t)row * a.cout * 4;
-                                    });
+            x_store_tile<C, M>(acc, smem + C::OFF_WIN + cur.wb * C::WIN_BYTES, sc_s, sh_s, a.cout, a.relu != 0,
+                               reinterpret_cast<const unsigned char *>(a.residual), reinterpret_cast<unsigned char *>(a.out), wc, lane, wid, orow);
 #pragma unroll
             for (int i = 0; i < CT; ++i)
 #pragma unroll
