@@ -179,7 +179,7 @@ struct SaHArgs {
     const int *idx, *cnt;
     const float *w1, *s1, *b1, *w2, *s2, *b2;        // w1 (H, ldw1) / w2 (H, ldw2) pair16 rows
     float *out;
-    int mq, per_batch, cells_per_batch, ldw1, ldw2;
+    int mq, per_batch, cells_per_batch, ldw1, ldw2, ldo;
     unsigned int feat_bytes;
 };
 
@@ -238,11 +238,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         lo = *reinterpret_cast<const v4u *>(p + 16);
     };
 
-    int t = blockIdx.x * 8 + wid;
-    Head hd = head(t), hd_next = head(t + stride);
+    // The first iteration is a VIRTUAL tile of two empty balls: its result (the layer stack on zero rows) is what every empty ball gets,
+    // and a tile whose two balls are both empty afterwards costs only its stores (RoIs over free space: most of their grid points).
+    const int t0 = blockIdx.x * 8 + wid;
+    Head hd{0, 0, 0.f, 0.f, 0.f}, hd_next = head(t0);
     Rows rows;
     gather(hd, rows);
-    for (; t < ntiles; t += stride) {
+    float res_empty[NF];
+#pragma unroll
+    for (int cb = 0; cb < NF; ++cb) res_empty[cb] = 0.f;
+    bool virt = true;
+    for (int t = t0 - stride; t < ntiles; t += stride) {
+        const int q_mine = 2 * t + h;
+        if (!virt && __builtin_amdgcn_ballot_w64(hd.cnt > 0) == 0ull) {      // (wave-uniform)
+#pragma unroll
+            for (int cb = 0; cb < NF; ++cb)
+                if (q_mine < a.mq) a.out[(size_t)q_mine * a.ldo + cb * 32 + l31] = res_empty[cb];
+            hd = hd_next;
+            gather(hd, rows);
+            hd_next = head(t + 2 * stride);
+            continue;
+        }
         // ---- offsets and the kernel density estimate of my sample (kde_utils.py:17-64: Gaussian, bandwidth 0.25, over the ball's cnt samples)
         const bool ok = hd.cnt > 0;
         const float gx = ok ? __fsub_rn(rows.px, hd.nx) : 0.f, gy = ok ? __fsub_rn(rows.py, hd.ny) : 0.f, gz = ok ? __fsub_rn(rows.pz, hd.nz) : 0.f;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- the next tile's rows go out now (they land under the rest of this tile and the other wave of the SIMD); the head of the one after
         hd = hd_next;
         gather(hd, rows);
-        hd_next = head(t + 2 * stride);
+        hd_next = virt ? head(t0 + stride) : head(t + 2 * stride);
         __builtin_amdgcn_sched_barrier(0);
         // BatchNorm + ReLU + split; lane (row, h) holds channels 32 ct + 8 q + 4 h + {0..3}: the groups with (q & 1) == h stay, the others
         // are swapped with lane ^ 32 (pointnet.hip)
@@ -335,7 +351,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         // ---- layer 2, transposed: lane = channel cb * 32 + l31, rows 8 (e >> 2) + 4 h + (e & 3); max over each ball's 16 rows
-        const int q_mine = 2 * t + h;
 #pragma unroll
         for (int cb = 0; cb < NF; ++cb) {
             f32x16 d;
@@ -355,8 +370,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 8; ++e) { ma = fmaxf(ma, fmaf(d[e], sc, sh)); mb = fmaxf(mb, fmaf(d[8 + e], sc, sh)); }
             ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
             mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-            if (q_mine < a.mq) a.out[(size_t)q_mine * H + cb * 32 + l31] = h ? mb : ma;
+            if (virt) res_empty[cb] = ma;
+            else if (q_mine < a.mq) a.out[(size_t)q_mine * a.ldo + cb * 32 + l31] = h ? mb : ma;
         }
+        virt = false;
     }
 }
 
@@ -423,19 +440,19 @@ int dz_pdv_sa_pool_split_supported(int c, int cin_pad, int h1, int h2, int nsamp
 int dz_pdv_sa_pool_split(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, long feat_rows, int c,
                          const uint32_t *bitmap, const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt, int nsample,
                          const float *w1, int ldw1, const float *s1, const float *b1, int h1, const float *w2, int ldw2, const float *s2,
-                         const float *b2, int h2, int cin_pad, int math, float *out, void *stream_) {
+                         const float *b2, int h2, int cin_pad, int math, float *out, int ldo, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!dz_pdv_sa_pool_split_supported(c, cin_pad, h1, h2, nsample, 1, 1)) {
         set_error("dz_pdv_sa_pool_split: no instance for c %d, cin_pad %d, widths %d / %d, nsample %d", c, cin_pad, h1, h2, nsample);
         return DZ_ERR_UNSUPPORTED;
     }
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_pdv_sa_pool_split: math %d is not a split mode", math);
-    DZ_CHECK_ARG(mq >= 0 && per_batch >= 1 && ldw1 >= cin_pad && ldw2 >= h1 && ldw1 % 4 == 0 && ldw2 % 4 == 0 && feat_rows >= 0, "dz_pdv_sa_pool_split: bad sizes");
+    DZ_CHECK_ARG(mq >= 0 && per_batch >= 1 && ldw1 >= cin_pad && ldw2 >= h1 && ldw1 % 4 == 0 && ldw2 % 4 == 0 && feat_rows >= 0 && ldo >= h2, "dz_pdv_sa_pool_split: bad sizes");
     if (mq == 0) return DZ_OK;
     DZ_CHECK_ARG(new_xyz && xyz && feats && bitmap && prefix && idx && cnt && w1 && s1 && b1 && w2 && s2 && b2 && out, "dz_pdv_sa_pool_split: null pointer");
     const size_t fb = (size_t)feat_rows * c * 4;
     if (fb >= 0x80000000ull) { set_error("dz_pdv_sa_pool_split: features of %zu bytes exceed the 2 GiB buffer-addressing limit", fb); return DZ_ERR_UNSUPPORTED; }
-    const SaHArgs a{new_xyz, xyz, feats, bitmap, prefix, idx, cnt, w1, s1, b1, w2, s2, b2, out, mq, per_batch, cells_per_batch, ldw1, ldw2, (unsigned int)fb};
+    const SaHArgs a{new_xyz, xyz, feats, bitmap, prefix, idx, cnt, w1, s1, b1, w2, s2, b2, out, mq, per_batch, cells_per_batch, ldw1, ldw2, ldo, (unsigned int)fb};
     int rc;
     if (cin_pad == 80) rc = math == DZ_MATH_F16X2 ? launch_sa_h<80, 32, MathF16>(a, stream) : launch_sa_h<80, 32, MathBF16>(a, stream);
     else rc = math == DZ_MATH_F16X2 ? launch_sa_h<144, 64, MathF16>(a, stream) : launch_sa_h<144, 64, MathBF16>(a, stream);

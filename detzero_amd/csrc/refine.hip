@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void k_group_max(const float *__restrict__ x, 
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void k_add_layernorm(const float *__restrict__ x, const float *__restrict__ y,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                       int rows, float eps, int do_norm, float *__restrict__ out) {
+                                                       int rows, float eps, int do_norm, float *__restrict__ out,
+                                                       const float *__restrict__ post = nullptr, const uint8_t *__restrict__ group_skip = nullptr,
+                                                       int group_rows = 1) {
     constexpr int C = PER_LANE * 64;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -60,7 +62,12 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const float *__restrict__
 #pragma unroll
     for (int j = 0; j < PER_LANE; ++j) {
         const int ch = j * 64 + lane;
-        out[(size_t)row * C + ch] = (v[j] - mean) * rstd * gamma[ch] + beta[ch];
+        float r = (v[j] - mean) * rstd * gamma[ch] + beta[ch];
+        if (post) {                        // out = post + (the row's group is skipped ? post : LN(x + y))
+            const float pv = post[(size_t)row * C + ch];
+            r = pv + ((group_skip && group_skip[row / group_rows]) ? pv : r);
+        }
+        out[(size_t)row * C + ch] = r;
     }
 }
 
@@ -95,6 +102,19 @@ int dz_add_layernorm(const float *x, const float *y, const float *gamma, const f
         case 512: hipLaunchKernelGGL(k_add_layernorm<8>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, eps, do_norm, out); break;
         default: set_error("dz_add_layernorm: c=%d not in {64,128,192,256,512}", c); return DZ_ERR_UNSUPPORTED;
     }
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+/* out = post + (group_skip[row / group_rows] ? post : LayerNorm(x + y)): the encoder layer's second normalisation with PDV's COMBINE
+ * (pooled + attended features) and its "RoIs without points stay untouched" rule in the same pass.  c = 192. */
+int dz_add_layernorm_combine(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c, float eps, const float *post,
+                             const unsigned char *group_skip, int group_rows, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(rows >= 0 && c == 192 && group_rows >= 1, "dz_add_layernorm_combine: c = 192, group_rows >= 1 (got %d, %d)", c, group_rows);
+    if (rows == 0) return DZ_OK;
+    DZ_CHECK_ARG(x && out && gamma && beta && post, "dz_add_layernorm_combine: null pointer");
+    hipLaunchKernelGGL(k_add_layernorm<3>, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, y, gamma, beta, rows, eps, 1, out, post, group_skip, group_rows);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

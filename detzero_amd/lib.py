@@ -143,7 +143,7 @@ _SIGS = {
     'dz_self_attention_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_pdv_sa_pool_split_supported': (c_int, [c_int] * 7),
     'dz_pdv_sa_pool_split': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_mlp_chain_forward': (c_int, [c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_int, c_void_p]),
     'dz_pointnet3_forward': (c_int, [c_void_p, ctypes.c_long] + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'dz_centerhead_decode_workspace_bytes': (c_size_t, [c_int] * 4),
@@ -179,6 +179,7 @@ _SIGS = {
     'dz_linear_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_group_max': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_add_layernorm_combine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_add_layernorm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
 }
 

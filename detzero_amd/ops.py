@@ -669,6 +669,18 @@ def add_layernorm(x, y, gamma, beta, eps=1e-5, norm=True):
     return out
 
 
+def add_layernorm_combine(x, y, gamma, beta, eps, post, group_skip, group_rows):
+    """post + (group_skip[row // group_rows] ? post : LayerNorm(x + y)) in one pass (c = 192)."""
+    lib = L.load()
+    L.require_cuda(x, y, gamma, beta, post, group_skip)
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    rc = lib.dz_add_layernorm_combine(L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(beta), x.numel() // c, c, float(eps), L.ptr(post), L.ptr(group_skip),
+                                      int(group_rows), L.ptr(out), L.stream())
+    L.check(rc, 'dz_add_layernorm_combine')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # head post-processing
 # ------------------------------------------------------------------------------------------------

@@ -228,20 +228,24 @@ def sa_pool_split_supported(c, stack, nsample, math):
 SPLIT_SA = [True]            # development switch: the pair16 instance of the fused branch in the split math modes
 
 
-def sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, math):
-    """dz_pdv_sa_pool_split: sa_pool on pair16 operands (the head's split math modes)."""
+def sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, math, out=None):
+    """dz_pdv_sa_pool_split: sa_pool on pair16 operands (the head's split math modes).  out: a (M, cout) column block of a wider
+    row-major tensor (the branches' results side by side: no concatenation pass)."""
     from .refine_modules import _split_w
     _full_prefix(level, 'dz_pdv_sa_pool_split')
     mq, nsample = idx.shape
     l1, l2 = stack
     w1, w2 = _split_w(l1, math), _split_w(l2, math)
-    out = torch.empty((mq, l2['cout']), dtype=torch.float32, device=new_xyz.device)
+    if out is None:
+        out = torch.empty((mq, l2['cout']), dtype=torch.float32, device=new_xyz.device)
+    if tuple(out.shape) != (mq, l2['cout']) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise DetZeroHipError('sa_pool_split: out must be a (M, cout) fp32 column block')
     cells = level.shape[0] * level.shape[1] * level.shape[2]
     with torch.cuda.device(new_xyz.device):
         rc = L.load().dz_pdv_sa_pool_split(L.ptr(new_xyz), mq, per_batch, L.ptr(xyz), L.ptr(feats), feats.shape[0], feats.shape[1], L.ptr(level.bitmap),
                                            L.ptr(level.prefix), cells, L.ptr(idx), L.ptr(cnt), nsample, L.ptr(w1), w1.shape[1], L.ptr(l1['scale32']),
                                            L.ptr(l1['shift32']), l1['cout'], L.ptr(w2), w2.shape[1], L.ptr(l2['scale32']), L.ptr(l2['shift32']),
-                                           l2['cout'], l1['w'].shape[0], int(math), L.ptr(out), L.stream())
+                                           l2['cout'], l1['w'].shape[0], int(math), L.ptr(out), out.stride(0), L.stream())
     L.check(rc, 'dz_pdv_sa_pool_split')
     return out
 
@@ -462,6 +466,7 @@ class PDVHead(_Cached):
         per_batch = new_xyz.shape[0] // batch_size
         lo = np.asarray(self.point_cloud_range[:3], dtype=np.float32)
         pooled, balls = [], []
+        wide, placed = None, []        # the branches' results side by side (written in place by the split kernels)
         for k, loc in enumerate(self.pool_cfg.FEATURE_LOCATIONS):
             coords, dims, vs = self._point_index[loc]
             xyz = batch_dict['point_coords'][loc][:, 1:4].contiguous()
@@ -478,7 +483,12 @@ class PDVHead(_Cached):
                 idx, cnt = ball_query(new_xyz, per_batch, xyz, level, lo, vs, radius, nsample)
                 stack = p['pool'][k][s]['stack']
                 if sa_pool_split_supported(feats.shape[1], stack, nsample, self.stack_math()):       # group + MLP + max in one kernel
-                    pooled.append(sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, self.stack_math()))
+                    if wide is None:
+                        wide = torch.empty((new_xyz.shape[0], self.c_out), dtype=torch.float32, device=new_xyz.device)
+                    c0 = sum(t.shape[1] for t in pooled)
+                    pooled.append(sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, self.stack_math(),
+                                                out=wide[:, c0:c0 + stack[-1]['cout']]))
+                    placed.append(True)
                 elif sa_pool_supported(feats.shape[1], stack, nsample):   # (exact fp32)
                     pooled.append(sa_pool(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack))
                 else:
@@ -486,7 +496,8 @@ class PDVHead(_Cached):
                     out, _ = _run_stack(rows, stack, math=self.stack_math())
                     pooled.append(ops.group_max(out, new_xyz.shape[0], nsample))
                 balls.append(idx)
-        all_pooled = torch.cat(pooled, dim=-1).view(-1, g ** 3, self.c_out)
+        in_place = wide is not None and len(placed) == len(pooled)          # every branch wrote its column block of `wide`
+        all_pooled = (wide if in_place else torch.cat(pooled, dim=-1)).view(-1, g ** 3, self.c_out)
         all_balls = torch.cat(balls, dim=-1).view(-1, g ** 3, sum(b.shape[1] for b in balls))
         return all_pooled, glob.view(batch_size, -1, 3), local, all_balls
 
@@ -502,7 +513,8 @@ class PDVHead(_Cached):
         return torch.cat((local_roi_grid_points, ppp), dim=-1)
 
     # ---- the encoder layer (attention_utils.py:17-52 around nn.TransformerEncoderLayer, post-norm, ReLU)
-    def attention(self, point_features, positional_input, key_padding_mask):
+    def attention(self, point_features, positional_input, key_padding_mask, combine=False):
+        """combine: return pooled + attended features (COMBINE) instead of the attended ones."""
         p = self.plan()
         r, l, e = point_features.shape
         feats = point_features.reshape(r * l, e).contiguous()
@@ -516,7 +528,7 @@ class PDVHead(_Cached):
         m = p['mha']
         sm = self.stack_math()
         if FOLDED_ATTENTION[0] and sm in (1, 2) and m['heads'] == 1 and L.load().dz_self_attention_split_supported(l, e) and e % 32 == 0:
-            return self._attention_split(p, sm, point_features, src, key_padding_mask, empty, r, l, e)
+            return self._attention_split(p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine)
         q = ops.linear(src, m['wq'], m['one'], m['bq'], False, e)
         k = ops.linear(src, m['wk'], m['one'], m['bk'], False, e)
         v = ops.linear(src, m['wv'], m['one'], m['bv'], False, e)
@@ -528,9 +540,10 @@ class PDVHead(_Cached):
         h = ops.linear(x, enc['w1'], enc['one1'], enc['b1'], True, enc['w1'].shape[1])
         y = ops.linear(h, enc['w2'], enc['one2'], enc['b2'], False, enc['w2'].shape[1])
         y = ops.add_layernorm(x, y, *enc['ln'][1])
-        return torch.where(empty[:, None, None], point_features, y.view(r, l, e))
+        out = torch.where(empty[:, None, None], point_features, y.view(r, l, e))
+        return point_features + out if combine else out
 
-    def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e):
+    def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine=False):
         """The encoder layer on pair16 operands: q' GEMM, dz_self_attention_split over the input rows themselves, output GEMM, and the
         feed-forward block; LayerNorms and residuals in fp32 (dz_add_layernorm)."""
         from .refine_modules import _split_w
@@ -542,6 +555,9 @@ class PDVHead(_Cached):
         op = self_attention_split(qp, srcp, mask, r, l, sm)
         x = ops.add_layernorm(src, lin(op, 'o', False, True), *enc['ln'][0])
         hp = lin(ops.pair16_from_f32(x, math=sm), 'f1', True, False)
+        if combine:     # pooled + (RoI without points ? pooled : LayerNorm(x + ffn)) in the normalisation's own pass
+            g2, b2, eps2 = enc['ln'][1]
+            return ops.add_layernorm_combine(x, lin(hp, 'f2', False, True), g2, b2, eps2, point_features.reshape(r * l, e), empty.to(torch.uint8), l).view(r, l, e)
         y = ops.add_layernorm(x, lin(hp, 'f2', False, True), *enc['ln'][1])
         return torch.where(empty[:, None, None], point_features, y.view(r, l, e))
 
@@ -568,9 +584,7 @@ class PDVHead(_Cached):
         pooled, _, local, ball_idxs = self.roi_grid_pool(batch_dict)
         mask = (ball_idxs == 0).all(-1) if self.pool_cfg.ATTENTION.get('MASK_EMPTY_POINTS') else torch.zeros(pooled.shape[:2], dtype=torch.bool, device=pooled.device)
         pos_in = self.get_positional_input(batch_dict['points'], batch_dict['rois'], local)
-        att = self.attention(pooled, pos_in, mask)
-        if self.pool_cfg.ATTENTION.get('COMBINE'):
-            att = pooled + att
+        att = self.attention(pooled, pos_in, mask, combine=bool(self.pool_cfg.ATTENTION.get('COMBINE')))
         rows = att.reshape(att.shape[0], -1).contiguous()                   # (RoI, 216 * C): the shared FC's columns were permuted to match
         shared, _ = _run_stack(rows, p['shared'], math=self.stack_math())
         rcnn_reg, _ = _run_stack(shared, p['reg'], math=self.stack_math())

@@ -438,6 +438,10 @@ int dz_group_max(const float *x, int groups, int len, int c, float *out, void *s
  * y may be NULL; do_norm == 0 gives the plain sum x + y (with_pos_embed, decoder.py:50-51). */
 int dz_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c,
                      float eps, int do_norm, float *out, void *stream);
+/* out = post + (group_skip[row / group_rows] ? post : LayerNorm(x + y)), c = 192: the PDV encoder layer's second normalisation together
+ * with COMBINE (pooled + attended features) and the untouched rows of RoIs without points (pdv_head.py:540-560, attention_utils.py:31-44). */
+int dz_add_layernorm_combine(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c, float eps, const float *post,
+                             const unsigned char *group_skip, int group_rows, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Object features: cropped object points -> inputs of the refining models.
@@ -568,7 +572,9 @@ int dz_pdv_sa_pool_split_supported(int c, int cin_pad, int h1, int h2, int nsamp
 int dz_pdv_sa_pool_split(const float *new_xyz, int mq, int per_batch, const float *xyz, const float *feats, long feat_rows, int c,
                          const uint32_t *bitmap, const uint32_t *prefix, int cells_per_batch, const int *idx, const int *cnt, int nsample,
                          const float *w1, int ldw1, const float *s1, const float *b1, int h1, const float *w2, int ldw2, const float *s2,
-                         const float *b2, int h2, int cin_pad, int math, float *out, void *stream);
+                         const float *b2, int h2, int cin_pad, int math, float *out, int ldo, void *stream);
+/* (ldo: row stride of out in floats, >= h2 - the branches of a head write side by side into one (mq, sum of widths) tensor.  Grid points
+ * whose ball is empty skip the arithmetic: their result is the layer stack applied to a zero row, computed once per wave.) */
 /* density_utils.find_num_points_per_part_multi (:52-109) on points_in_multi_boxes (roiaware_pool3d_kernel.cu:377-404): counts
  * (batch, o, grid, grid, grid) int32 of the points (n, stride) [b, x, y, z, ...] per cell of every RoI (batch, o, 7), a point
  * counting for the first max_boxes RoIs (in RoI order) that contain it. */
