@@ -469,6 +469,38 @@ class FramePipeline:
         return self.post_stage(*self.dense_stage(self.backbone_stage(prep), prep['nb']))
 
     @torch.no_grad()
+    def two_stage(self, points, before_second=None):
+        """A model with SECOND_STAGE (the PDV configs): first stage as `__call__` (batched, sync-free, its own streams), then the model's
+        roi_head ONCE over the whole batch - the RoIs of all frames pooled by one launch per branch (pdv_modules.PDVHead).  points: list of
+        (N_i, C) tensors or a (B, N, C) tensor.  Returns the batch_dict the plugin path's roi_head returns (rois, roi_scores, roi_labels,
+        batch_box_preds, batch_cls_preds; CenterPoint.post_processing reads exactly these).  The second stage sizes its work by the
+        largest RoI count of the batch (one host sync), as the plugin path's reorder_rois does (center_head.py:388-406)."""
+        from .det_modules import SparseConvTensor
+        m = self.model
+        if getattr(m, 'roi_head', None) is None:
+            raise DetZeroHipError('FramePipeline.two_stage: the model has no roi_head (MODEL.SECOND_STAGE)')
+        frames = _StackedFrames(points.contiguous()) if torch.is_tensor(points) else (points if isinstance(points, _StackedFrames) else list(points))
+        nb = len(frames)
+        prep = self.prepare(frames, staggered=STAGGERED_PYRAMID)
+        res = self.backbone_stage(prep)
+        out, d_nk = self.post_stage(*self.dense_stage(res, nb))
+        bb = m.backbone3d
+
+        def as_tensor(item):
+            feats, level = item
+            return SparseConvTensor(None, level.coords[:level.num_active()], level.shape, nb, level=level, padded=(feats, level), math=bb.math)
+        k = max(int(d_nk.max().item()), 1)
+        pts = [frames[i] for i in range(nb)]
+        points_b = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p], dim=1) for i, p in enumerate(pts)], dim=0)
+        bd = {'batch_size': nb, 'points': points_b, 'rois': out[:, :k, :7].contiguous(), 'roi_scores': out[:, :k, 7].contiguous(),
+              'roi_labels': out[:, :k, 8].long(), 'has_class_labels': True,
+              'multi_scale_3d_features': {n: as_tensor(res[n]) for n in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4')},
+              'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}}
+        if before_second is not None:
+            before_second()                 # (timing hook: called between the stages)
+        return m.roi_head(bd)
+
+    @torch.no_grad()
     def __call__(self, points):
         """points: (N,C) tensor = one frame; list of (N_i,C) tensors or a (B,N,C) tensor = a batch."""
         single = torch.is_tensor(points) and points.dim() == 2

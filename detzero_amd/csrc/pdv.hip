@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256) void k_part_counts(const float *__restrict__ p
         mine = (int)p[0] == b_blk;
         x = p[1]; y = p[2]; z = p[3];
     }
+    // (a batch's points are contiguous in a collated batch: most (block of points, batch item) pairs have nothing to do)
+    if (!__syncthreads_or(mine ? 1 : 0)) return;
     int found = 0;
     const float *bx = rois + (size_t)b_blk * o * 7;
     for (int base = 0; base < o; base += 64) {

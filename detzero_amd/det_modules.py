@@ -85,13 +85,24 @@ class SparseConvTensor:
     dense() (pdv_head.py:567-637, height_compression.py:21)."""
 
     def __init__(self, features, indices, spatial_shape, batch_size, level=None, padded=None, math=0):
-        self.features = features
+        self._features = features  # fp32 rows, or None: decoded from the padded matrix on first use (most consumers never ask)
         self.indices = indices
         self.spatial_shape = list(spatial_shape)
         self.batch_size = batch_size
         self._level = level
         self._padded = padded      # (capacity-sized feature matrix, SparseLevel) for the fast path
         self._math = math          # encoding of the padded matrix (0 = fp32, else pair16); .features is always fp32
+
+    @property
+    def features(self):
+        if self._features is None:
+            rows = self._padded[0][:self.indices.shape[0]]
+            self._features = ops.pair16_to_f32(rows, self._math) if self._math else rows
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._features = value
 
     def replace_feature(self, new_features):
         return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._level)
@@ -491,9 +502,7 @@ class VoxelResBackBone8x(_Cached):
         def as_tensor(item):
             feats, level = item
             m = level.num_active()
-            plain = ops.pair16_to_f32(feats[:m], self.math) if self.math else feats[:m]
-            return SparseConvTensor(plain, level.coords[:m], level.shape, batch_size, level=level,
-                                    padded=(feats, level), math=self.math)
+            return SparseConvTensor(None, level.coords[:m], level.shape, batch_size, level=level, padded=(feats, level), math=self.math)
         batch_dict.update({'encoded_spconv_tensor': as_tensor(res['encoded']), 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {k: as_tensor(res[k]) for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4')}})
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})

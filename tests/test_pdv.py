@@ -330,3 +330,40 @@ def test_head_on_split_operands(device, g, mode, mid):
     err = float((head.forward_ret_dict['attention_output'] - att_fold).abs().max())
     print('encoder layer [%s]: folded split path vs unfolded fp32 path, max |diff| %.2e' % (mode, err))
     assert err <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'f16x2'])
+def test_frame_pipeline_two_stage_equals_the_plugin_path(device, mode):
+    """FramePipeline.two_stage (first stage batched and sync-free, roi_head once over the batch) against the plugin modules run one after
+    the other on the same collated batch: same RoIs, same refined boxes and confidences."""
+    from detzero_amd.centerpoint import FramePipeline, SyntheticDatasetInfo, build_network, set_math
+    from detzero_amd.config import centerpoint_pdv_cfg
+    from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
+    cfg = centerpoint_pdv_cfg((0.2, 0.2, 0.15))
+    torch.manual_seed(0)
+    info = SyntheticDatasetInfo(cfg, num_point_features=6)
+    model = build_network(cfg.MODEL, 3, info).eval()
+    with torch.no_grad():
+        hl = model.dense_head.heads_list[0]
+        hl.hm[1].bias.fill_(-0.5); hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4])); hl.iou[1].bias.fill_(0.6)
+    model = model.to(device)
+    set_math(model, mode)
+    frames = [merge_two_sweeps(synth_waymo_frame(60 + i, 10000), synth_waymo_frame(70 + i, 10000)) for i in range(3)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), i, np.float32), f], 1) for i, f in enumerate(frames)])
+    bd = {'batch_size': 3, 'points': torch.from_numpy(pts).to(device)}
+    with torch.no_grad():
+        for mod in model.module_list:
+            bd = mod(bd)
+    pipe = FramePipeline(model, info, dynamic=True, math=mode)
+    out = pipe.two_stage([torch.from_numpy(f).to(device) for f in frames])
+    n = bd['rois'].shape[1]
+    assert out['rois'].shape == bd['rois'].shape and n > 3
+    tol = 1e-4 if mode == 'f32' else 2e-3
+    torch.testing.assert_close(out['rois'], bd['rois'], rtol=tol, atol=tol)
+    assert torch.equal(out['roi_labels'], bd['roi_labels'])
+    torch.testing.assert_close(out['roi_scores'], bd['roi_scores'], rtol=tol, atol=tol)
+    torch.testing.assert_close(out['batch_box_preds'], bd['batch_box_preds'], rtol=10 * tol, atol=10 * tol)
+    torch.testing.assert_close(out['batch_cls_preds'], bd['batch_cls_preds'], rtol=10 * tol, atol=10 * tol)
+    pred, _ = model.post_processing(out)
+    assert len(pred) == 3 and all(torch.isfinite(d['pred_boxes']).all() for d in pred)

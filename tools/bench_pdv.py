@@ -16,10 +16,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1):
+def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1, pipeline=False):
     """Two-stage detector on `batch` merged 2-sweep frames per pass -> dict (also the `pdv` leg of bench.py).  batch > 1: the frames go
     through the plugin modules as ONE batch_dict (batch-index column, as collate_batch builds it): every kernel of both stages is
-    launched once per pass over all frames / all RoIs."""
+    launched once per pass over all frames / all RoIs.  pipeline: the first stage through FramePipeline.two_stage (batched, sync-free,
+    its own streams) instead of the plugin modules."""
     from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
     from detzero_amd.config import centerpoint_pdv_cfg
     from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
@@ -40,16 +41,25 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1):
     pts = np.concatenate(rows, 0)
     points_t = torch.from_numpy(pts).to(dev)
     first = [model.vfe, model.backbone3d, model.map_to_bev, model.backbone2d, model.dense_head]
+    pipe = None
+    if pipeline:
+        from detzero_amd.centerpoint import FramePipeline
+        pipe = FramePipeline(model, SyntheticDatasetInfo(cfg, num_point_features=6), dynamic=True, math=math)
+        frames_t = [points_t[points_t[:, 0] == b][:, 1:].contiguous() for b in range(batch)]
+        pipe.calibrate(frames_t[:4])
 
     def run(timed):
         bd = {'batch_size': batch, 'points': points_t}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         with torch.no_grad():
             ev[0].record()
-            for m in first:
-                bd = m(bd)
-            ev[1].record()
-            bd = model.roi_head(bd)
+            if pipe is not None:
+                bd = pipe.two_stage(frames_t, before_second=ev[1].record)
+            else:
+                for m in first:
+                    bd = m(bd)
+                ev[1].record()
+                bd = model.roi_head(bd)
             ev[2].record()
         torch.cuda.synchronize()
         return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[0] * bd['rois'].shape[1])) if timed else None
@@ -94,7 +104,7 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1):
         a, b, n_roi = run(True)
         t1 += a / reps
         t2 += b / reps
-    return {'metric': 'two-stage detector, ms per pass of %d frame(s) (plugin modules, eager)' % batch, 'math': math, 'frames_per_pass': batch,
+    return {'metric': 'two-stage detector, ms per pass of %d frame(s) (%s, eager)' % (batch, 'FramePipeline.two_stage' if pipeline else 'plugin modules'), 'math': math, 'frames_per_pass': batch,
             'points_per_frame': int(pts.shape[0] // batch), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
             'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
             'frames_per_s': round(1000.0 * batch / (t1 + t2), 2), 'data': 'synthetic'}
@@ -106,9 +116,10 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--math', default='f32')
     ap.add_argument('--batch', type=int, default=1, help='frames per pass (one batch_dict)')
+    ap.add_argument('--pipeline', action='store_true', help='first stage through FramePipeline.two_stage instead of the plugin modules')
     ap.add_argument('--phases', action='store_true', help='also print the device time of the second stage per method (stderr)')
     args = ap.parse_args()
-    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math, args.phases, args.batch)))
+    print(json.dumps(measure(torch.device('cuda', 0), args.points, args.reps, args.math, args.phases, args.batch, args.pipeline)))
 
 
 if __name__ == '__main__':
