@@ -282,6 +282,29 @@ def self_attention_split(qp, xp, key_padding_mask, r, l, math):
 
 
 FOLDED_ATTENTION = [True]    # development switch: the encoder layer on split operands with folded key / value projections
+FUSED_ENCODER = [True]       # ... and its two halves around the attention as row-chain kernels (csrc/pdv_enc.hip)
+
+
+def encoder_front(pos_in, feats, row_add, f, math):
+    """dz_pdv_encoder_front -> (src, q') pair16 rows."""
+    rows = feats.shape[0]
+    src, q = torch.empty_like(feats), torch.empty_like(feats)
+    with torch.cuda.device(feats.device):
+        rc = L.load().dz_pdv_encoder_front(L.ptr(pos_in), pos_in.shape[1], L.ptr(feats), L.ptr(row_add), rows, L.ptr(f['w0']), L.ptr(f['s0']), L.ptr(f['b0']),
+                                           L.ptr(f['w1']), L.ptr(f['b1']), L.ptr(f['wq']), L.ptr(f['uq']), L.ptr(src), L.ptr(q), int(math), L.stream())
+    L.check(rc, 'dz_pdv_encoder_front')
+    return src, q
+
+
+def encoder_back(op, srcp, pooled, row_skip, f, math):
+    """dz_pdv_encoder_back -> pooled + (row_skip ? pooled : encoder output), fp32 rows."""
+    out = torch.empty_like(pooled)
+    with torch.cuda.device(pooled.device):
+        rc = L.load().dz_pdv_encoder_back(L.ptr(op), L.ptr(srcp), L.ptr(pooled), L.ptr(row_skip), pooled.shape[0], L.ptr(f['wo']), L.ptr(f['bo']),
+                                          L.ptr(f['g1']), L.ptr(f['be1']), float(f['eps1']), L.ptr(f['fw1']), L.ptr(f['fb1']), L.ptr(f['fw2']), L.ptr(f['fb2']),
+                                          L.ptr(f['g2']), L.ptr(f['be2']), float(f['eps2']), L.ptr(out), int(math), L.stream())
+    L.check(rc, 'dz_pdv_encoder_back')
+    return out
 
 
 def _seq_plan(seq, cin_pad=None):
@@ -519,14 +542,17 @@ class PDVHead(_Cached):
         r, l, e = point_features.shape
         feats = point_features.reshape(r * l, e).contiguous()
         pos_in = positional_input.reshape(r * l, -1).float()
-        pos_rows = torch.nn.functional.pad(pos_in, (0, 16 - pos_in.shape[1]))      # (one launch: zero-padded to the stack's input width)
-        pos, _ = _run_stack(pos_rows, p['pos'], math=self.stack_math())
         empty = key_padding_mask.all(-1)                                   # RoIs without any point: left untouched (:31-44)
         add_pos = (~key_padding_mask) & (~empty)[:, None]
-        # feats + pos where add_pos, feats elsewhere, in one pass: pos * 1.0 and feats + 0.0 are exact (the encodings are finite)
-        src = torch.addcmul(feats, pos, add_pos.reshape(r * l, 1).to(feats.dtype))
         m = p['mha']
         sm = self.stack_math()
+        if (FOLDED_ATTENTION[0] and FUSED_ENCODER[0] and combine and sm in (1, 2) and m['heads'] == 1 and e == 192 and
+                L.load().dz_self_attention_split_supported(l, e) and self._fused_encoder_ok(p, positional_input)):
+            return self._attention_fused(p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e)
+        pos_rows = torch.nn.functional.pad(pos_in, (0, 16 - pos_in.shape[1]))      # (one launch: zero-padded to the stack's input width)
+        pos, _ = _run_stack(pos_rows, p['pos'], math=self.stack_math())
+        # feats + pos where add_pos, feats elsewhere, in one pass: pos * 1.0 and feats + 0.0 are exact (the encodings are finite)
+        src = torch.addcmul(feats, pos, add_pos.reshape(r * l, 1).to(feats.dtype))
         if FOLDED_ATTENTION[0] and sm in (1, 2) and m['heads'] == 1 and L.load().dz_self_attention_split_supported(l, e) and e % 32 == 0:
             return self._attention_split(p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine)
         q = ops.linear(src, m['wq'], m['one'], m['bq'], False, e)
@@ -542,6 +568,34 @@ class PDVHead(_Cached):
         y = ops.add_layernorm(x, y, *enc['ln'][1])
         out = torch.where(empty[:, None, None], point_features, y.view(r, l, e))
         return point_features + out if combine else out
+
+    @staticmethod
+    def _fused_encoder_ok(p, positional_input):
+        pos, enc = p['pos'], p['enc']
+        return (positional_input.shape[-1] in (4, 8) and len(pos) == 2 and pos[0]['cout'] == 96 and pos[0]['relu'] and pos[1]['cout'] == 192 and
+                not pos[1]['relu'] and tuple(enc['w1'].shape) == (192, 128) and tuple(enc['w2'].shape) == (128, 192))
+
+    def _attention_fused(self, p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e):
+        """COMBINE'd encoder layer in three launches: front chain (positional encoder, src, folded query), attention over the input rows,
+        back chain (output projection, both LayerNorms, feed-forward block, pooled + result)."""
+        from .refine_modules import _split_w
+        key = 'fused%d' % sm
+        if key not in p:
+            f, enc, pos = p['fold'], p['enc'], p['pos']
+            w0 = pos[0]['w'][:16]                                  # (16, 96): the stack's inputs are zero-padded to 16
+            p[key] = {'w0': ops.pack_weight_split(w0, sm), 's0': pos[0]['scale'][:96].contiguous(), 'b0': pos[0]['shift'][:96].contiguous(),
+                      'w1': ops.pack_weight_split(pos[1]['w'][:96], sm), 'b1': pos[1]['shift'][:192].contiguous(),
+                      'wq': _split_w(f['q'], sm), 'uq': f['q']['shift32'], 'wo': _split_w(f['o'], sm), 'bo': f['o']['shift32'],
+                      'g1': enc['ln'][0][0], 'be1': enc['ln'][0][1], 'eps1': enc['ln'][0][2], 'g2': enc['ln'][1][0], 'be2': enc['ln'][1][1],
+                      'eps2': enc['ln'][1][2], 'fw1': _split_w(f['f1'], sm), 'fb1': f['f1']['shift32'], 'fw2': _split_w(f['f2'], sm), 'fb2': f['f2']['shift32']}
+        f = p[key]
+        pooled = point_features.reshape(r * l, e).contiguous()
+        pos_in = positional_input.reshape(r * l, -1).float().contiguous()
+        srcp, qp = encoder_front(pos_in, pooled, add_pos.reshape(r * l).to(torch.uint8), f, sm)
+        mask = key_padding_mask & (~empty)[:, None]
+        op = self_attention_split(qp, srcp, mask, r, l, sm)
+        skip = empty.to(torch.uint8)[:, None].expand(r, l).reshape(r * l).contiguous()
+        return encoder_back(op, srcp, pooled, skip, f, sm).view(r, l, e)
 
     def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine=False):
         """The encoder layer on pair16 operands: q' GEMM, dz_self_attention_split over the input rows themselves, output GEMM, and the

@@ -588,6 +588,17 @@ int dz_attention_single_head(const float *q, const float *k, const float *v, con
  * of l consecutive rows, where x (r * l, e) pair16 are the layer's input rows (keys = values) and q' = x (Wq Wk^T) + Wk bq, scaled by
  * log2(e) / sqrt(E), (r * l, e) pair16; the caller applies (Wv Wo, bv Wo + bo) to o' (pdv_modules.py: PDVHead.attention).  e = 192,
  * l <= 224, math = DZ_MATH_F16X2 / DZ_MATH_BF16X2; out (r * l, e) pair16.  A fully masked group gives zero rows. */
+/* The rest of the encoder layer around that attention, as two row-chain kernels (csrc/pdv_enc.hip; activations stay in registers):
+ *   front: src = feats + (row_add ? W_p2 . ReLU(s0 * (W_p1 . pos_in) + b0) + b1 : 0), q = src . wq + uq          -> (rows, 192) pair16 each
+ *   back:  x = LN1(src + op . wo + bo), y = LN2(x + w2 . ReLU(w1 . x + b1) + b2), out = pooled + (row_skip ? pooled : y) -> (rows, 192) fp32
+ * Weights are pair16 rows per OUTPUT channel: w0 (96, 16), w1 (192, 96), wq / wo (192, 192), back w1 (128, 192), w2 (192, 128); pos_in
+ * (rows, pin) fp32 with pin 4 or 8; feats / pooled (rows, 192) fp32; row_add / row_skip (rows) bytes; math = DZ_MATH_F16X2 / BF16X2. */
+int dz_pdv_encoder_front(const float *pos_in, int pin, const float *feats, const unsigned char *row_add, long rows, const float *w0, const float *s0,
+                         const float *b0, const float *w1, const float *b1, const float *wq, const float *uq, float *src, float *q, int math,
+                         void *stream);
+int dz_pdv_encoder_back(const float *op, const float *src, const float *pooled, const unsigned char *row_skip, long rows, const float *wo,
+                        const float *bo, const float *g1, const float *be1, float eps1, const float *w1, const float *b1, const float *w2,
+                        const float *b2, const float *g2, const float *be2, float eps2, float *out, int math, void *stream);
 int dz_self_attention_split_supported(int l, int e);
 int dz_self_attention_split(const float *q, const float *x, const unsigned char *key_padding_mask, int r, int l, int e, float *out,
                             int math, void *stream);

@@ -322,14 +322,15 @@ def test_head_on_split_operands(device, g, mode, mid):
     torch.testing.assert_close(out['batch_box_preds'].cpu(), torch.from_numpy(g['batch_box_preds']), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(out['batch_cls_preds'].cpu(), torch.from_numpy(g['batch_cls_preds']), rtol=2e-3, atol=2e-3)
     att_fold = r['attention_output'].clone()
-    pm.FOLDED_ATTENTION[0] = False
-    try:
-        head(_batch(g, device))
-    finally:
-        pm.FOLDED_ATTENTION[0] = True
-    err = float((head.forward_ret_dict['attention_output'] - att_fold).abs().max())
-    print('encoder layer [%s]: folded split path vs unfolded fp32 path, max |diff| %.2e' % (mode, err))
-    assert err <= tol
+    for switch, what in ((pm.FUSED_ENCODER, 'layer-by-layer split path'), (pm.FOLDED_ATTENTION, 'unfolded fp32 path')):
+        switch[0] = False
+        try:
+            head(_batch(g, device))
+        finally:
+            switch[0] = True
+        err = float((head.forward_ret_dict['attention_output'] - att_fold).abs().max())
+        print('encoder layer [%s]: fused row chains vs the %s, max |diff| %.2e' % (mode, what, err))
+        assert err <= tol
 
 
 @pytest.mark.gpu
@@ -367,3 +368,52 @@ def test_frame_pipeline_two_stage_equals_the_plugin_path(device, mode):
     torch.testing.assert_close(out['batch_cls_preds'], bd['batch_cls_preds'], rtol=10 * tol, atol=10 * tol)
     pred, _ = model.post_processing(out)
     assert len(pred) == 3 and all(torch.isfinite(d['pred_boxes']).all() for d in pred)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,mid,tol', [('f16x2', 1, 1e-4), ('bf16x2', 2, 2e-3)])
+@pytest.mark.parametrize('rows', [216 * 3, 1000, 256 * 9 + 17])
+def test_encoder_row_chains(device, mode, mid, tol, rows):
+    """dz_pdv_encoder_front / dz_pdv_encoder_back (the encoder layer around its attention as two row-chain kernels) against the same
+    arithmetic in float64: rows that are no multiple of the 256-row tile, random row flags."""
+    from detzero_amd import ops
+    from detzero_amd import pdv_modules as pm
+    gen_ = torch.Generator().manual_seed(rows + mid)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=gen_) * k)        # noqa: E731
+    e, f_, p_ = 192, 128, 96
+    dev = lambda t: t.to(device).contiguous()                           # noqa: E731
+    # ---- front
+    pos_in, feats = rnd(rows, 4), rnd(rows, e)
+    add = torch.rand(rows, generator=gen_) < 0.7
+    w0, s0, b0 = rnd(16, p_, k=0.3), torch.rand(p_, generator=gen_) + 0.5, rnd(p_, k=0.1)
+    w1, b1 = rnd(p_, e, k=0.1), rnd(e, k=0.1)
+    wq, uq = rnd(e, e, k=0.07), rnd(e, k=0.1)
+    fw = {'w0': ops.pack_weight_split(dev(w0), mid), 's0': dev(s0), 'b0': dev(b0), 'w1': ops.pack_weight_split(dev(w1), mid), 'b1': dev(b1),
+          'wq': ops.pack_weight_split(dev(wq), mid), 'uq': dev(uq)}
+    srcp, qp = pm.encoder_front(dev(pos_in), dev(feats), dev(add.to(torch.uint8)), fw, mid)
+    d = lambda t: t.double()                                              # noqa: E731
+    hid = torch.relu(d(s0) * (d(pos_in) @ d(w0[:4])) + d(b0))
+    src = d(feats) + d(add)[:, None] * (hid @ d(w1) + d(b1))
+    q = src @ d(wq) + d(uq)
+    got_src, got_q = ops.pair16_to_f32(srcp, mid).cpu().double(), ops.pair16_to_f32(qp, mid).cpu().double()
+    e1, e2 = float((got_src - src).abs().max()), float((got_q - q).abs().max())
+    print('encoder front [%s] %d rows: src %.2e, q %.2e' % (mode, rows, e1, e2))
+    assert e1 <= tol * max(1.0, float(src.abs().max())) and e2 <= tol * max(1.0, float(q.abs().max()))
+    # ---- back (on the front's own outputs as the layer input, a random attention output)
+    op_rows, pooled = rnd(rows, e), rnd(rows, e)
+    skip = torch.rand(rows, generator=gen_) < 0.2
+    wo, bo = rnd(e, e, k=0.07), rnd(e, k=0.1)
+    g1, be1, g2, be2 = torch.rand(e, generator=gen_) + 0.5, rnd(e, k=0.1), torch.rand(e, generator=gen_) + 0.5, rnd(e, k=0.1)
+    fw1, fb1, fw2, fb2 = rnd(e, f_, k=0.07), rnd(f_, k=0.1), rnd(f_, e, k=0.09), rnd(e, k=0.1)
+    opp = ops.pair16_from_f32(dev(op_rows), math=mid)
+    bw = {'wo': ops.pack_weight_split(dev(wo), mid), 'bo': dev(bo), 'g1': dev(g1), 'be1': dev(be1), 'eps1': 1e-5, 'g2': dev(g2), 'be2': dev(be2), 'eps2': 1e-5,
+          'fw1': ops.pack_weight_split(dev(fw1), mid), 'fb1': dev(fb1), 'fw2': ops.pack_weight_split(dev(fw2), mid), 'fb2': dev(fb2)}
+    out = pm.encoder_back(opp, srcp, dev(pooled), dev(skip.to(torch.uint8)), bw, mid).cpu().double()
+    ln = lambda t, g, b: (t - t.mean(-1, keepdim=True)) / torch.sqrt(t.var(-1, unbiased=False, keepdim=True) + 1e-5) * d(g) + d(b)     # noqa: E731
+    opv = ops.pair16_to_f32(opp, mid).cpu().double()
+    x = ln(got_src + opv @ d(wo) + d(bo), g1, be1)
+    y = ln(x + torch.relu(x @ d(fw1) + d(fb1)) @ d(fw2) + d(fb2), g2, be2)
+    ref = d(pooled) + torch.where(skip[:, None], d(pooled), y)
+    e3 = float((out - ref).abs().max())
+    print('encoder back [%s] %d rows: out %.2e' % (mode, rows, e3))
+    assert e3 <= 4 * tol * max(1.0, float(ref.abs().max()))
