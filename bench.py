@@ -719,8 +719,15 @@ def main():
                 # the same modules over 8 frames per pass (one batch_dict: every kernel of both stages launched once for all frames / RoIs)
                 p16b = bench_pdv.measure(dev, args.points, 4, 'f16x2', batch=8)
                 out['pdv']['f16x2_batch8'] = {k: p16b[k] for k in ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
-                log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs); f16x2: %.2f + %.2f ms' % (
-                    out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois'], p16['first_stage_ms'], p16['second_stage_ms']))
+                # FramePipeline.two_stage: first stage batched and sync-free, roi_head once over the batch
+                keys = ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')
+                for nb in (8, 16):
+                    pp = bench_pdv.measure(dev, args.points, 4, 'f16x2', batch=nb, pipeline=True)
+                    out['pdv']['f16x2_pipeline_batch%d' % nb] = {k: pp[k] for k in keys}
+                out['pdv']['frames_per_s_best'] = max(out['pdv'][k]['frames_per_s'] for k in ('f16x2_batch8', 'f16x2_pipeline_batch8', 'f16x2_pipeline_batch16'))
+                log('pdv first stage %.2f ms, second stage %.2f ms (%d RoIs); f16x2: %.2f + %.2f ms; pipeline x16: %.1f frames/s' % (
+                    out['pdv']['first_stage_ms'], out['pdv']['second_stage_ms'], out['pdv']['rois'], p16['first_stage_ms'], p16['second_stage_ms'],
+                    out['pdv']['f16x2_pipeline_batch16']['frames_per_s']))
             except Exception as e:
                 out['pdv'] = {'error': str(e).split('\n')[0][:200]}
             torch.cuda.empty_cache()

@@ -158,7 +158,8 @@ def test_final_boxes_and_confidences(device, g):
 
 
 @pytest.mark.gpu
-def test_pdv_head_at_bench_size(device, golden_dir):
+@pytest.mark.parametrize('mode', ['f32', 'f16x2'])
+def test_pdv_head_at_bench_size(device, golden_dir, mode):
     """PDVHead at the shape tools/bench_pdv.py and the `pdv` leg of bench.py time: a full-range 120k-point frame, 320 RoIs
     (69 120 grid points against ~40 k voxel centroids per location).  Golden = the reference's own PDVHead over the same seeded
     scene (gen_pdv_golden.py --big; 133 s on the CPU): the ball-query index sums of every RoI exactly, the key-padding mask, the
@@ -170,6 +171,7 @@ def test_pdv_head_at_bench_size(device, golden_dir):
     head = PDVHead(512, gen.roi_head_cfg(), gen.RANGE_BIG, gen.VOXEL, num_class=1).eval()
     head.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in head.state_dict().items()}, seed=gen.WEIGHT_SEED), strict=True)
     head = head.to(device)
+    head.set_math(mode)        # 'f16x2': pooling and the encoder layer on split operands (row-chain kernels, folded attention)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)        # noqa: E731
     bd = {'batch_size': 1, 'points': t(sc['points']), 'rois': t(sc['rois']), 'roi_scores': t(sc['roi_scores']), 'roi_labels': t(sc['roi_labels']),
           'has_class_labels': True, 'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8},
@@ -191,7 +193,7 @@ def test_pdv_head_at_bench_size(device, golden_dir):
     db = (out['batch_box_preds'].cpu() - torch.from_numpy(g['batch_box_preds'])).abs().amax(dim=-1)[0].numpy()
     dc = (out['batch_cls_preds'].cpu() - torch.from_numpy(g['batch_cls_preds'])).abs().amax(dim=-1)[0].numpy()
     eb, ec = float(db[~moved].max()), float(dc[~moved].max())
-    print('PDV at bench size: boxes max abs err %.2e, confidences %.2e (RoIs with a moved boundary centroid: %.2e / %.2e)' % (
+    print('PDV at bench size [' + mode + ']: boxes max abs err %.2e, confidences %.2e (RoIs with a moved boundary centroid: %.2e / %.2e)' % (
         eb, ec, float(db[moved].max()) if moved.any() else 0.0, float(dc[moved].max()) if moved.any() else 0.0))
     assert tuple(out['batch_box_preds'].shape) == (1, 320, 7) and eb <= 1e-3 and ec <= 1e-3
     assert float(db.max()) <= 5e-2 and float(dc.max()) <= 5e-2           # one sample of 16 in one of 216 x 4 balls: still the same box

@@ -55,5 +55,7 @@ echo "==== refiner"
 for m in f32 f16x2; do timeout 300 python tools/bench_refine.py --math $m 2>/dev/null | tail -1 > $O/${TAG}_bench_refine_$m.json; cut -c1-500 $O/${TAG}_bench_refine_$m.json; done
 echo "==== two-stage detector (PDV second stage)"
 for b in 1 8; do timeout 300 python tools/bench_pdv.py --math f16x2 --batch $b 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv_b$b.json; cat $O/${TAG}_bench_pdv_b$b.json; done
+for b in 8 16; do timeout 300 python tools/bench_pdv.py --math f16x2 --batch $b --pipeline 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv_pipeline_b$b.json; cat $O/${TAG}_bench_pdv_pipeline_b$b.json; done
+bash tools/gpu_pdv_prof.sh 8 > /dev/null 2>&1; cp gpurun_out/pdv/kernel_trace_pdv_b8.txt $O/${TAG}_kernel_trace_pdv_b8.txt; cp gpurun_out/pdv/phases_b8.txt $O/${TAG}_pdv_phases_b8.txt
 fi
 find $O -name "*.db" -delete
