@@ -10,8 +10,11 @@
 // The kernel keeps that window resident in LDS and runs all nine taps of the slab from it; the tap shift is a per-lane row offset
 // into the window (rank of the neighbour - first row of the window), a missing neighbour reads a zero row.
 //
-//   tile      T = WP * PT * 32 consecutive output rows x all COUT channels, one 512-thread workgroup per CU (persistent, XCD-aware
-//             deal of runs of consecutive tiles, as k_spconv_h); wave (wp, wc) owns PT 32-row fragments x CT 32-channel fragments.
+//   tile      two UNITS of UR = WP * 32 consecutive output rows x all COUT channels, one 512-thread workgroup per CU; wave (wp, wc) owns
+//             one 32-row fragment of each unit x CT 32-channel fragments.  Workgroups are persistent and take tiles from per-XCD queues
+//             (runs of 64 consecutive tiles per XCD: neighbouring tiles share window rows in that XCD's L2; one atomic ticket per tile,
+//             fetched during the epilogue of the tile before); the last units of a launch are dealt one by one (half the fragments
+//             idle) so that no workgroup is left with a whole tile while the others have finished.
 //   stage     (tz, 16-channel chunk kc, window pass): RCAP window rows x 64 bytes (one MFMA k-step of pair16: hi | lo of two 8-channel
 //             groups) -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, 1 KB per wave instruction), double buffered.
 //             A window longer than RCAP rows (2-3 % of the slabs: a tile in a sparse region next to a dense slab; up to 30 000 rows)
@@ -19,16 +22,20 @@
 //             straight from global memory into the MFMA operand registers (as k_spconv_w does), same taps, same order.  (Walking
 //             such a window in passes of RCAP rows costs up to 39 stages for one slab: measured, the slowest workgroup then took
 //             1.8-2x the average one.)
-//   step      G taps of a stage: their weight slices (COUT rows x 64 bytes each) -> LDS the same way, double buffered.  ONE barrier
-//             per step: s_waitcnt vmcnt(0) (this wave's pieces of the next step's data, issued a whole step ago, have landed),
-//             s_barrier (everyone's have, and everyone is done with the buffers the loads issued next will overwrite).
+//   step      TAPS taps of a stage (one window row ty, or the whole slab at 32 channels): their weight slices (COUT rows x 64 bytes
+//             each) -> LDS the same way, D steps ahead in a ring of D + 1 slots.  ONE barrier per step: s_waitcnt vmcnt(N) with N =
+//             the loads issued since for LATER steps (vector memory operations retire in order; every step issues the same number of
+//             loads, absent rows through an out-of-range offset), then s_barrier (everyone's pieces have landed, and everyone is done
+//             with the buffers the loads issued next will overwrite).  The MFMAs of a step's last tap are issued after the NEXT
+//             step's barrier, so no barrier is followed by a cold matrix pipe.
 //   rows      64-byte rows are unpadded; 16-byte piece p of row r sits at slot p ^ ((r >> 2) & 3) (conflict-free for the 16-lane
 //             groups ds_read_b128 is served in when the rows are consecutive); the direct loads realise the swizzle by permuting
 //             which source piece a lane fetches.
 //   table     the PACKED neighbour table (dz_build_neighbors_packed: one word per (tz, ty) and output row = rank below the centre
 //             cell + three presence bits): 3 * PT words per lane and z slab instead of 27 * PT indices.
-//   skipping  a tap none of the wave's lanes has a neighbour at issues no MFMAs (wave-uniform
-//             branch on a ballot) - tap skipping at 32-row granularity without any mask table.
+//   skipping  a (fragment, tap) none of the fragment's 32 rows has a neighbour at issues no MFMAs (wave-uniform branch on a ballot) -
+//             tap skipping at 32-row granularity without any mask table; the rows of a unit are processed in the order of their TAP SETS
+//             (k_xwin sorts them; the epilogue writes through the row map), which makes whole fragments agree on what they skip.
 // Accumulation order per output element: tz, kc, tap, k - fixed, independent of the tile the row falls into.
 // Epilogue = store_tile_pair16 (hgemm.h): BatchNorm scale / shift, residual, ReLU, split, 32-byte stores, staged through the
 // window buffer the tile has finished with.
