@@ -322,7 +322,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int row = (s.u0 + PTI) * C::UR + wp * 32 + l31;          // fragment PTI = unit PTI of the tile
         // (with a table in tap-set order `row` is a POSITION; live rows keep the positions below m: k_xwin)
         const unsigned int voff = s.live && s.tz_first && row < m && !(PTI == 1 && s.half) ? (unsigned int)row * 4u : OOB_OFFSET;
-        const unsigned int so = (unsigned int)(s.tz * 3 + TY) * nbr_row_bytes;
+        const unsigned int so = __builtin_amdgcn_readfirstlane((unsigned int)(s.tz * 3 + TY) * nbr_row_bytes);     // (scalar operand of the load)
         const srsrc_t rs = nrsrc;            // (named here: an asm operand alone does not capture a variable in a generic lambda)
         unsigned int &dst = TY == 0 ? pn0[PTI] : (TY == 1 ? pn1[PTI] : pn2[PTI]);
         asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(so) : "memory");
