@@ -29,7 +29,14 @@ def test_committed_bench_line_has_the_contract_keys():
     r = d['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1
-    assert r['traffic'] is None or r['traffic']['bytes'] > 0
+    # HBM bytes of the dominant kernel per launch from the PMC passes (r04: a number, its read / write split beside it; r01-r03 lines: a dict)
+    t = r['traffic']
+    assert t is None or (t['bytes'] > 0 if isinstance(t, dict) else (t > 0 and t == r['traffic_read_bytes'] + r['traffic_write_bytes']))
+    if 'hbm' in r:                                                        # the north star's stage fractions (r04)
+        for st in ('voxelize', 'index', 'sparse_backbone', 'voxelize_plus_backbone'):
+            h = r['hbm'][st]
+            assert h['bytes'] > 0 and h['ms'] > 0 and abs(h['gbs'] - h['bytes'] / h['ms'] / 1e6) / h['gbs'] < 1e-2
+            assert abs(h['frac'] - h['gbs'] / r['hbm_peak_gbs']) < 1e-3
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and isinstance(c['sample'], str)
     assert c['unit'] == d['unit']
