@@ -310,6 +310,7 @@ class FramePipeline:
         self._streams = {}
         self.level_caps = None        # per-frame row capacities of the strided stages (None = worst case)
         self._ws = {}                 # zero-bordered activation images of the dense stage, reused across steps
+        self.dense_group = int(os.environ.get('DZ_TUNE_DENSE_GROUP', '16'))     # frames per pass of the dense layers (2 GiB image window)
         self.last_overflow = None
         self._overflow_acc = None
 
@@ -450,13 +451,25 @@ class FramePipeline:
 
     @torch.no_grad()
     def dense_stage(self, res, nb):
-        """HeightCompression + BaseBEVBackbone + the CenterHead convolutions -> (head map (B,H*W,12), H, W)."""
+        """HeightCompression + BaseBEVBackbone + the CenterHead convolutions -> (head map (B,H*W,12), H, W).
+        More than `dense_group` frames go through the dense layers in groups: the kernels address an image through 32-bit buffer
+        offsets, and the 512-channel concatenation of the Waymo config passes 2 GiB at ~20 frames.  The BEV image (1.2 GB at 32
+        frames) is built once; a group is a contiguous slice of it."""
         m = self.model
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
-        with cp_modules.workspace(self._ws):
-            concat = m.backbone2d.run(bev, nb)
-            return self.head.run_convs(concat, nb)
+        if nb <= self.dense_group:
+            with cp_modules.workspace(self._ws):
+                concat = m.backbone2d.run(bev, nb)
+                return self.head.run_convs(concat, nb)
+        maps, h, w = [], 0, 0
+        for g0 in range(0, nb, self.dense_group):
+            ng = min(self.dense_group, nb - g0)
+            with cp_modules.workspace(self._ws):
+                concat = m.backbone2d.run(bev[g0:g0 + ng], ng)
+                hd, h, w = self.head.run_convs(concat, ng)
+            maps.append(hd.clone())            # (the activation images, the head map among them, are reused by the next group)
+        return torch.cat(maps, dim=0), h, w
 
     @torch.no_grad()
     def post_stage(self, head, h, w):

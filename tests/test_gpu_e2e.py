@@ -96,6 +96,23 @@ def test_frame_pipeline_equals_module_path(small, device):
     assert int(d_n2.item()) == n and torch.equal(out2[:n], out[:n])
 
 
+def test_dense_stage_in_frame_groups(small, device):
+    """More frames than `dense_group` pass the dense layers in groups (the 2 GiB image window at 32 frames of the Waymo config):
+    same detections, bit for bit, as the whole batch at once - with a ragged last group."""
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info, pts, ref = small
+    frames = [torch.from_numpy(masked_frame(20 + i, 9000 + 500 * i)).to(device) for i in range(5)]
+    pipe = FramePipeline(model, info)
+    out, cnt = pipe(frames)
+    pipe2 = FramePipeline(model, info)
+    pipe2.dense_group = 2
+    out2, cnt2 = pipe2(frames)
+    assert torch.equal(cnt, cnt2) and int(cnt.min()) > 0
+    for i in range(5):
+        n = int(cnt[i])
+        assert torch.equal(out[i, :n], out2[i, :n])
+
+
 @pytest.mark.parametrize('dynamic', [False, True])
 def test_batched_frames_equal_single_frames(small, device, dynamic):
     """B frames in one pass (batch-index column, reference collate_batch layout) give, per frame, bit-identical

@@ -1,17 +1,10 @@
 #!/bin/bash
-# Frames-per-step sweep of bench.py on one GPU (graph replay, default math)
-cd "$(dirname "$0")/.."
+# dense-stage grouping: its test, then the batch sweep of the headline (frames per pass 8 .. 32).
+cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/sweep
-for b in ${@:-1 2 4 8 16}; do
-  timeout 400 python bench.py --steps 30 --warmup 5 --batch $b --no-cpu-baseline --profile-frames 0 2> gpurun_out/sweep/b$b.err > gpurun_out/sweep/b$b.json || tail -5 gpurun_out/sweep/b$b.err
-  python - $b <<'PY'
-import json, sys
-b = sys.argv[1]
-try:
-    d = json.load(open('gpurun_out/sweep/b%s.json' % b))
-    print('batch', b, 'value', d['value'], 'ms/step', d['ms_per_step'], 'ms/frame', d['config']['ms_per_frame'], d['config']['launch'][:40])
-except Exception as e:
-    print('no bench json', e)
-PY
-done
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_e2e.py -q -x --timeout=300 -p no:cacheprovider -k "dense_stage_in_frame_groups or batched_frames" 2>&1 | tail -3 | tee gpurun_out/sweep_tests.txt
+P='import json,sys; d=json.loads(sys.stdin.read()); print(d["config"].get("frames_per_step_per_gpu"), d["value"], d["ms_per_step"])'
+for b in 8 16 24 32; do
+  timeout 400 python bench.py --batch $b --steps 60 --warmup 5 --no-cpu-baseline --no-aux --no-refine --no-pdv --profile-frames 0 2>gpurun_out/sweep_$b.err | tail -1 | python -c "$P" || tail -3 gpurun_out/sweep_$b.err
+done | tee gpurun_out/sweep.txt
