@@ -751,13 +751,22 @@ __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int c
 using X32 = XCfg<32, 8, 1, 2, 9, 1, 896>;
 using X64 = XCfg<64, 8, 1, 2, 3, 2, 896>;
 using X128 = XCfg<128, 4, 2, 2, 3, 2, 640>;
+// development variants of the 32-channel configuration (DZ_TUNE_X32 = 1 / 2): 256-thread workgroups whose LDS lets TWO of them share a
+// CU (one's epilogue / barrier waits under the other's steps): one window row per step with the full window, or whole slabs from a
+// short window
+using X32B = XCfg<32, 4, 1, 2, 3, 2, 448>;
+using X32C = XCfg<32, 4, 1, 2, 9, 1, 320>;
+static int x32_variant() {
+    static const int v = getenv("DZ_TUNE_X32") ? atoi(getenv("DZ_TUNE_X32")) : 0;
+    return v;
+}
 
 template <class C, class M, int DIAG = 0>
 static int launch_x(const SpConvXArgs &a, hipStream_t stream) {
     static PerDeviceFlags done;
     if (int rc = reserve_lds(reinterpret_cast<const void *>(&k_spconv_x<C, M, DIAG>), C::LDS_BYTES, done, "dz_spconv_forward_split_x")) return rc;
     int grid = ceil_div(a.cap, C::UR);
-    const int cus = device_cus();
+    const int cus = device_cus() * (C::THREADS <= 256 && 2 * C::LDS_BYTES <= 160 * 1024 ? 2 : 1);      // (workgroups that fit a CU in pairs)
     if (grid > cus) grid = cus;
     grid = (grid + 7) & ~7;
     if (grid < 8) grid = 8;
@@ -812,7 +821,11 @@ static int x_dispatch(const SpConvXArgs &a, hipStream_t stream) {
         return x_diag<X128>(b, stream, diag);
     }
 #endif
-    if (a.cout == 32) return launch_x<X32, M>(a, stream);
+    if (a.cout == 32) {
+        if (x32_variant() == 1) return launch_x<X32B, M>(a, stream);
+        if (x32_variant() == 2) return launch_x<X32C, M>(a, stream);
+        return launch_x<X32, M>(a, stream);
+    }
     if (a.cout == 64) return launch_x<X64, M>(a, stream);
     return launch_x<X128, M>(a, stream);
 }
@@ -825,7 +838,7 @@ extern "C" {
 
 int dz_spconv_x_tile_rows(int cin, int cout) {
     if (cin != cout) return 0;
-    if (cout == 32) return X32::UR;
+    if (cout == 32) return x32_variant() == 1 ? X32B::UR : (x32_variant() == 2 ? X32C::UR : X32::UR);
     if (cout == 64) return X64::UR;
     if (cout == 128) return X128::UR;
     return 0;

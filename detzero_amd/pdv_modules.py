@@ -591,11 +591,19 @@ class PDVHead(_Cached):
         f = p[key]
         pooled = point_features.reshape(r * l, e).contiguous()
         pos_in = positional_input.reshape(r * l, -1).float().contiguous()
-        srcp, qp = encoder_front(pos_in, pooled, add_pos.reshape(r * l).to(torch.uint8), f, sm)
+        add = add_pos.reshape(r * l).to(torch.uint8)
         mask = key_padding_mask & (~empty)[:, None]
-        op = self_attention_split(qp, srcp, mask, r, l, sm)
         skip = empty.to(torch.uint8)[:, None].expand(r, l).reshape(r * l).contiguous()
-        return encoder_back(op, srcp, pooled, skip, f, sm).view(r, l, e)
+        # the row tensors are addressed through 32-bit buffer offsets: RoIs in chunks of < 2 GiB of rows (11 k RoIs of 216 x 192)
+        step = max(1, ((1 << 31) - (1 << 20)) // (l * e * 4))
+        outs = []
+        for r0 in range(0, r, step):
+            r1 = min(r, r0 + step)
+            a, b = r0 * l, r1 * l
+            srcp, qp = encoder_front(pos_in[a:b], pooled[a:b], add[a:b], f, sm)
+            op = self_attention_split(qp, srcp, mask[r0:r1], r1 - r0, l, sm)
+            outs.append(encoder_back(op, srcp, pooled[a:b], skip[a:b], f, sm))
+        return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)).view(r, l, e)
 
     def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine=False):
         """The encoder layer on pair16 operands: q' GEMM, dz_self_attention_split over the input rows themselves, output GEMM, and the
