@@ -68,25 +68,48 @@ __global__ void k_cen_parent_keys(const int *__restrict__ coords, const int *__r
     }
 }
 
-// sums[v][1..] += w * row[1..], counts[v] += w   (w = 1 for points, the point count of a level-1 centroid for level 2)
+// sums[v][1..] += w * row[1..], counts[v] += w   (w = 1 for points, the point count of a level-1 centroid for level 2).
+// One thread per row.  Rows arrive in scan order (points) or key order (level-1 centroids), so the lanes of a wavefront hold runs of
+// rows of ONE cell: the run is summed in registers (segmented scan, a fixed tree per run) and its last lane issues one atomic per
+// column - a fraction of the memory-side atomics of a thread per (row, column); any order stays correct.
 __global__ void k_cen_accumulate(const float *__restrict__ rows, int n, const int *__restrict__ d_n, int stride, int cols,
                                  const int *__restrict__ weights, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ bitmap,
                                  const uint32_t *__restrict__ prefix, int cap, float *__restrict__ sums, int *__restrict__ counts) {
     const int nn = d_n ? min(*d_n, n) : n;
-    const long total = (long)nn * cols;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(idx / cols), ch = (int)(idx % cols);
-        const uint32_t key = keys[i];
-        if (key == KEY_INVALID) continue;
-        const int v = bitmap_rank(bitmap, prefix, key);
-        if (v >= cap) continue;
-        const int w = weights ? weights[i] : 1;
-        if (ch == 0) {
-            atomicAdd(&counts[v], w);
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (nn + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+        const uint32_t key = i < nn ? keys[i] : KEY_INVALID;
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64), next = (uint32_t)__shfl_down((int)key, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || prev != key);
+        const int first = 63 - __clzll(heads & (~0ull >> (63 - lane)));      // first lane of this lane's run
+        const bool live = key != KEY_INVALID;
+        const bool last = live && (lane == 63 || next != key);
+        int v = cap;
+        if (last) v = bitmap_rank(bitmap, prefix, key);
+        int w = live ? (weights ? weights[i] : 1) : 0;
+        int steps = 0;                                  // scan steps the longest run of this wavefront needs
+        while (steps < 6 && __ballot(lane - (1 << steps) >= first) != 0ull) ++steps;
+        int wsum = w;
+        for (int j = 0; j < steps; ++j) {
+            const int t = __shfl_up(wsum, 1 << j, 64);
+            if (lane - (1 << j) >= first) wsum += t;
+        }
+        if (v < cap) {
+            atomicAdd(&counts[v], wsum);
             sums[(size_t)v * cols] = rows[(size_t)i * stride];               // batch index column: identical for all members
-        } else {
-            const float x = rows[(size_t)i * stride + ch];
-            atomicAdd(&sums[(size_t)v * cols + ch], weights ? __fmul_rn(x, (float)w) : x);
+        }
+        for (int ch = 1; ch < cols; ++ch) {
+            float x = 0.f;
+            if (live) {
+                x = rows[(size_t)i * stride + ch];
+                if (weights) x = __fmul_rn(x, (float)w);
+            }
+            for (int j = 0; j < steps; ++j) {
+                const float t = __shfl_up(x, 1 << j, 64);
+                if (lane - (1 << j) >= first) x = __fadd_rn(x, t);
+            }
+            if (v < cap) atomicAdd(&sums[(size_t)v * cols + ch], x);
         }
     }
 }
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(256) void k_group_features(const float *__restrict_
 // cell of the point in each of those boxes' G x G x G grids; counts (B, O, G, G, G)
 __global__ __launch_bounds__(256) void k_part_counts(const float *__restrict__ pts, int n, int stride, const float *__restrict__ rois, int batch,
                                                      int o, int gsz, int max_boxes, int *__restrict__ counts) {
-    extern __shared__ float sb[];                                    // [chunk of 64 boxes][9]
+    extern __shared__ float sb[];                                    // [chunk of 64 boxes][10]
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int b_blk = blockIdx.y;                                    // one batch item per grid row: its boxes are staged in LDS
     float x = 0.f, y = 0.f, z = 0.f;
@@ -233,17 +256,20 @@ __global__ __launch_bounds__(256) void k_part_counts(const float *__restrict__ p
         __syncthreads();
         if ((int)threadIdx.x < nb) {
             const float *qb = bx + (size_t)(base + threadIdx.x) * 7;
-            float *d = sb + threadIdx.x * 9;
+            float *d = sb + threadIdx.x * 10;
             for (int j = 0; j < 7; ++j) d[j] = qb[j];
             d[7] = cosf(-qb[6]);
             d[8] = sinf(-qb[6]);
+            const float rr = 0.5f * (fabsf(qb[3]) + fabsf(qb[4])) + 1e-2f;      // a radius that certainly covers the box footprint (+ slack)
+            d[9] = rr * rr * 1.001f;
         }
         __syncthreads();
         if (!mine || found >= max_boxes) continue;
         for (int k = 0; k < nb && found < max_boxes; ++k) {
-            const float *qb = sb + k * 9;
-            if ((double)fabsf(z - qb[2]) > (double)qb[5] / 2.0) continue;           // check_pt_in_box3d
+            const float *qb = sb + k * 10;
             const float sx = x - qb[0], sy = y - qb[1];
+            if (sx * sx + sy * sy > qb[9]) continue;                                 // far outside the footprint: the exact test below would fail
+            if ((double)fabsf(z - qb[2]) > (double)qb[5] / 2.0) continue;           // check_pt_in_box3d
             const float lx = sx * qb[7] + sy * (-qb[8]);
             const float ly = sx * qb[8] + sy * qb[7];
             if (!(((double)fabsf(lx) < (double)qb[3] / 2.0 + (double)1e-5f) && ((double)fabsf(ly) < (double)qb[4] / 2.0 + (double)1e-5f))) continue;
@@ -403,7 +429,7 @@ int dz_pdv_voxel_centroids(const float *points_b, int n, int c, const float *h_r
     rc = bitmap_scan(bm1, words1, pf1, d_m1, 0, ScanDims{g.g[2], g.g[1], g.g[0]}, coords1, cap1, base + o_sw, sw_bytes, stream);
     if (rc) return rc;
     if (n > 0 && cap1 > 0) {
-        hipLaunchKernelGGL(k_cen_accumulate, dim3(stream_grid((long)n * cols, 256)), dim3(256), 0, stream, points_b, n, (const int *)nullptr, cols, cols,
+        hipLaunchKernelGGL(k_cen_accumulate, dim3(stream_grid((long)n, 256)), dim3(256), 0, stream, points_b, n, (const int *)nullptr, cols, cols,
                            (const int *)nullptr, keys, bm1, pf1, cap1, cen1, counts1);
         hipLaunchKernelGGL(k_cen_divide, dim3(stream_grid((long)cap1 * cols, 256)), dim3(256), 0, stream, cen1, counts1, d_m1, cap1, cols);
     }
@@ -419,7 +445,7 @@ int dz_pdv_voxel_centroids(const float *points_b, int n, int c, const float *h_r
         rc = bitmap_scan(bm2, words2, pf2, d_m2, 0, ScanDims{d2, h2, w2}, coords2, cap2, base + o_sw, sw_bytes, stream);
         if (rc) return rc;
         if (cap1 > 0 && cap2 > 0) {
-            hipLaunchKernelGGL(k_cen_accumulate, dim3(stream_grid((long)cap1 * cols, 256)), dim3(256), 0, stream, cen1, cap1, d_m1, cols, cols, counts1,
+            hipLaunchKernelGGL(k_cen_accumulate, dim3(stream_grid((long)cap1, 256)), dim3(256), 0, stream, cen1, cap1, d_m1, cols, cols, counts1,
                                keys2, bm2, pf2, cap2, cen2, counts2);
             hipLaunchKernelGGL(k_cen_divide, dim3(stream_grid((long)cap2 * cols, 256)), dim3(256), 0, stream, cen2, counts2, d_m2, cap2, cols);
         }
@@ -475,7 +501,7 @@ int dz_pdv_part_counts(const float *points_b, int n, int stride, const float *ro
     const int rc = fill_u32(counts, 0u, (size_t)batch * o * grid * grid * grid, stream);
     if (rc) return rc;
     if (n == 0) return DZ_OK;
-    hipLaunchKernelGGL(k_part_counts, dim3(ceil_div(n, 256), batch), dim3(256), 64 * 9 * sizeof(float), stream, points_b, n, stride, rois, batch, o, grid,
+    hipLaunchKernelGGL(k_part_counts, dim3(ceil_div(n, 256), batch), dim3(256), 64 * 10 * sizeof(float), stream, points_b, n, stride, rois, batch, o, grid,
                        max_boxes, counts);
     DZ_LAUNCH_CHECK();
     return DZ_OK;

@@ -323,10 +323,13 @@ __global__ void k_dyn_accumulate(const float *__restrict__ pts, int n, int c, co
         const bool last = key != KEY_INVALID && (lane == 63 || next != key);
         int v = cap;
         if (last) v = bitmap_rank(bitmap, prefix, key);
+        int steps = 0;                                  // scan steps the longest run of this wavefront needs (runs of lidar points are short)
+        while (steps < 6 && __ballot(lane - (1 << steps) >= first) != 0ull) ++steps;
         for (int ch = 0; ch < c; ++ch) {
             long long q = key != KEY_INVALID ? __float2ll_rn(pts[(size_t)i * (c + 1) + 1 + ch] * DYN_FIX) : 0ll;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
+                if (j >= steps) break;                  // (wave-uniform: no run of this wavefront reaches back 2^j lanes)
                 const int lo = __shfl_up((int)(unsigned int)q, 1 << j, 64), hi = __shfl_up((int)(q >> 32), 1 << j, 64);
                 if (lane - (1 << j) >= first) q += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
             }
