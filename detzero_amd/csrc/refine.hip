@@ -26,6 +26,21 @@ __global__ __launch_bounds__(256) void k_group_max(const float *__restrict__ x, 
                                                            fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
 
+// out[i] = every int of row i of up to four (rows, w[k]) tensors is zero (PDV's empty-grid-point mask over the ball indices of all
+// branches, pdv_head.py:521-523, without concatenating them first); one thread per (row, tensor) 16-byte piece is overkill: rows are
+// 16-64 ints - one thread per row, vector loads
+struct ZeroRowsArgs { const int *p[4]; int w[4]; int n; };
+__global__ void k_rows_all_zero(ZeroRowsArgs a, int rows, unsigned char *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        unsigned int acc = 0u;
+        for (int k = 0; k < a.n; ++k) {
+            const int4 *q = reinterpret_cast<const int4 *>(a.p[k] + (size_t)i * a.w[k]);
+            for (int j = 0; j < a.w[k] / 4; ++j) { const int4 v = q[j]; acc |= (unsigned int)(v.x | v.y | v.z | v.w); }
+        }
+        out[i] = acc == 0u;
+    }
+}
+
 // one wavefront per row; c <= 1024, c % 64 == 0
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void k_add_layernorm(const float *__restrict__ x, const float *__restrict__ y,
@@ -83,6 +98,23 @@ int dz_group_max(const float *x, int groups, int len, int c, float *out, void *s
     if (groups == 0) return DZ_OK;
     DZ_CHECK_ARG(x && out, "dz_group_max: null pointer");
     hipLaunchKernelGGL(k_group_max, dim3(groups, ceil_div(c, 64)), dim3(256), 0, stream, x, len, c, out);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+/* out[i] = 1 when every int of row i of all n (n <= 4) row-major int32 tensors t[k] (rows x w[k], w[k] % 4 == 0) is zero. */
+int dz_rows_all_zero(const int *const *t, const int *w, int n, int rows, unsigned char *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n >= 1 && n <= 4 && rows >= 0 && t && w, "dz_rows_all_zero: 1..4 tensors");
+    if (rows == 0) return DZ_OK;
+    ZeroRowsArgs a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) {
+        DZ_CHECK_ARG(t[k] && w[k] >= 4 && w[k] % 4 == 0, "dz_rows_all_zero: row widths are multiples of 4 ints");
+        a.p[k] = t[k]; a.w[k] = w[k];
+    }
+    DZ_CHECK_ARG(out, "dz_rows_all_zero: null pointer");
+    hipLaunchKernelGGL(k_rows_all_zero, dim3(stream_grid(rows, 256)), dim3(256), 0, stream, a, rows, out);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -182,6 +182,7 @@ _SIGS = {
     'dz_linear_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_group_max': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_rows_all_zero': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_add_layernorm_combine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'dz_add_layernorm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
 }

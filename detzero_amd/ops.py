@@ -669,6 +669,19 @@ def add_layernorm(x, y, gamma, beta, eps=1e-5, norm=True):
     return out
 
 
+def rows_all_zero(tensors):
+    """(rows,) bool: every int of the row is zero in all of up to four (rows, w) int32 tensors."""
+    lib = L.load()
+    L.require_cuda(*tensors)
+    ts = [t.contiguous() for t in tensors]
+    rows = ts[0].shape[0]
+    out = torch.empty((rows,), dtype=torch.uint8, device=ts[0].device)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    ws = (ctypes.c_int * len(ts))(*[int(t.shape[1]) for t in ts])
+    L.check(lib.dz_rows_all_zero(ptrs, ws, len(ts), rows, L.ptr(out), L.stream()), 'dz_rows_all_zero')
+    return out.bool()
+
+
 def add_layernorm_combine(x, y, gamma, beta, eps, post, group_skip, group_rows):
     """post + (group_skip[row // group_rows] ? post : LayerNorm(x + y)) in one pass (c = 192)."""
     lib = L.load()

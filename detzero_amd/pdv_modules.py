@@ -281,6 +281,17 @@ def self_attention_split(qp, xp, key_padding_mask, r, l, math):
     return out
 
 
+class _LazyDict(dict):
+    """dict whose callable values are evaluated on first read (diagnostic tensors nobody may ask for)."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if callable(v) and not torch.is_tensor(v):
+            v = v()
+            dict.__setitem__(self, k, v)
+        return v
+
+
 FOLDED_ATTENTION = [True]    # development switch: the encoder layer on split operands with folded key / value projections
 FUSED_ENCODER = [True]       # ... and its two halves around the attention as row-chain kernels (csrc/pdv_enc.hip)
 
@@ -480,7 +491,8 @@ class PDVHead(_Cached):
         m = int(getattr(self, 'math', 0) or 0)
         return 1 if m == 3 else m
 
-    def roi_grid_pool(self, batch_dict):
+    def roi_grid_pool(self, batch_dict, cat_balls=True):
+        """cat_balls=False: the fourth result is the list of per-branch ball-index tensors (M, nsample) instead of their concatenation."""
         p = self.plan()
         batch_size = batch_dict['batch_size']
         g = self.pool_cfg.GRID_SIZE
@@ -521,6 +533,8 @@ class PDVHead(_Cached):
                 balls.append(idx)
         in_place = wide is not None and len(placed) == len(pooled)          # every branch wrote its column block of `wide`
         all_pooled = (wide if in_place else torch.cat(pooled, dim=-1)).view(-1, g ** 3, self.c_out)
+        if not cat_balls:
+            return all_pooled, glob.view(batch_size, -1, 3), local, balls
         all_balls = torch.cat(balls, dim=-1).view(-1, g ** 3, sum(b.shape[1] for b in balls))
         return all_pooled, glob.view(batch_size, -1, 3), local, all_balls
 
@@ -643,8 +657,15 @@ class PDVHead(_Cached):
         p = self.plan()
         batch_dict['point_features'], batch_dict['point_coords'] = self.get_point_voxel_features(batch_dict)
         self.proposal_layer(batch_dict, nms_config=self.model_cfg.NMS_CONFIG['TEST'])
-        pooled, _, local, ball_idxs = self.roi_grid_pool(batch_dict)
-        mask = (ball_idxs == 0).all(-1) if self.pool_cfg.ATTENTION.get('MASK_EMPTY_POINTS') else torch.zeros(pooled.shape[:2], dtype=torch.bool, device=pooled.device)
+        pooled, _, local, balls = self.roi_grid_pool(batch_dict, cat_balls=False)
+        g3 = self.pool_cfg.GRID_SIZE ** 3
+        if not self.pool_cfg.ATTENTION.get('MASK_EMPTY_POINTS'):
+            mask = torch.zeros(pooled.shape[:2], dtype=torch.bool, device=pooled.device)
+        elif len(balls) <= 4 and all(b.shape[1] % 4 == 0 for b in balls):
+            mask = ops.rows_all_zero(balls).view(-1, g3)            # (ball_idxs == 0).all(-1) over the branches, no concatenation
+        else:
+            mask = (torch.cat(balls, dim=-1) == 0).all(-1).view(-1, g3)
+        ball_idxs = lambda: torch.cat(balls, dim=-1).view(-1, g3, sum(b.shape[1] for b in balls))     # noqa: E731  (built when somebody reads it)
         pos_in = self.get_positional_input(batch_dict['points'], batch_dict['rois'], local)
         att = self.attention(pooled, pos_in, mask, combine=bool(self.pool_cfg.ATTENTION.get('COMBINE')))
         rows = att.reshape(att.shape[0], -1).contiguous()                   # (RoI, 216 * C): the shared FC's columns were permuted to match
@@ -654,6 +675,6 @@ class PDVHead(_Cached):
         cls_preds, box_preds = self.generate_predicted_boxes(batch_dict['batch_size'], batch_dict['rois'], rcnn_cls.contiguous(), rcnn_reg.contiguous())
         batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = cls_preds, box_preds
         batch_dict['cls_preds_normalized'] = False
-        self.forward_ret_dict = {'pooled_features': pooled, 'ball_idxs': ball_idxs, 'positional_input': pos_in, 'key_padding_mask': mask,
-                                 'attention_output': att, 'rcnn_cls': rcnn_cls, 'rcnn_reg': rcnn_reg}
+        self.forward_ret_dict = _LazyDict({'pooled_features': pooled, 'ball_idxs': ball_idxs, 'positional_input': pos_in, 'key_padding_mask': mask,
+                                 'attention_output': att, 'rcnn_cls': rcnn_cls, 'rcnn_reg': rcnn_reg})
         return batch_dict

@@ -436,6 +436,9 @@ int dz_group_max(const float *x, int groups, int len, int c, float *out, void *s
 
 /* out = LayerNorm(x + y) * gamma + beta over rows of 256 channels (decoder.py:75-88: residual + post-LN);
  * y may be NULL; do_norm == 0 gives the plain sum x + y (with_pos_embed, decoder.py:50-51). */
+/* out[i] = 1 when every int of row i of all n (<= 4) row-major int32 tensors t[k] (rows x w[k], w[k] % 4 == 0) is zero: PDV's
+ * empty-grid-point mask `(ball_idxs == 0).all(-1)` (pdv_head.py:521-523) over the per-branch ball indices, without concatenating them. */
+int dz_rows_all_zero(const int *const *t, const int *w, int n, int rows, unsigned char *out, void *stream);
 int dz_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, int rows, int c,
                      float eps, int do_norm, float *out, void *stream);
 /* out = post + (group_skip[row / group_rows] ? post : LayerNorm(x + y)), c = 192: the PDV encoder layer's second normalisation together
