@@ -191,9 +191,10 @@ struct EncBackArgs {
     const unsigned char *row_skip;             // (rows): 1 = the row's RoI has no points: out = 2 * pooled
     const float *wo, *w1, *w2;                 // pair16 rows per output channel: (192, 192), (128, 192), (192, 128)
     const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
-    float *out;                                // (rows, 192) fp32
+    float *out;                                // (rows, 192) fp32, or pair16 (out_pair16: the operand of the FC stack that follows)
     long rows;
     float eps1, eps2;
+    int out_pair16;
 };
 constexpr int VB_BO = 0, VB_G1 = 192, VB_BE1 = 384, VB_B1 = 576, VB_B2 = 704, VB_G2 = 896, VB_BE2 = 1088;
 
@@ -399,10 +400,23 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 en_split8<M>((c & 1) ? pb[2 * sl] : pa[2 * sl], (c & 1) ? pb[2 * sl + 1] : pa[2 * sl + 1], pscale, ph, pl);
                 d = en_add_rows<M>(d, en_identity<M>(sl, l31, h), ph, pl);
             }
+            if (a.out_pair16) {                          // (wave-uniform; four stores either way: the counted waits hold)
+                float v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                en_st16(v4u{__float_as_uint(d[4 * q]), __float_as_uint(d[4 * q + 1]), __float_as_uint(d[4 * q + 2]), __float_as_uint(d[4 * q + 3])}, r_out,
-                        rowb + (unsigned int)((c * 32 + q * 8 + h * 4) * 4));
+                for (int e = 0; e < 16; ++e) v[e] = d[e];
+                v4u oh0, ol0, oh1, ol1;
+                en_to_ops<M>(v, h, oh0, ol0, oh1, ol1);
+                const unsigned int off = rowb + (unsigned int)((4 * c + h) * 32);
+                en_st16(oh0, r_out, off);
+                en_st16o(ol0, r_out, off);
+                en_st16(oh1, r_out, off + 64u);
+                en_st16o(ol1, r_out, off + 64u);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    en_st16(v4u{__float_as_uint(d[4 * q]), __float_as_uint(d[4 * q + 1]), __float_as_uint(d[4 * q + 2]), __float_as_uint(d[4 * q + 3])}, r_out,
+                            rowb + (unsigned int)((c * 32 + q * 8 + h * 4) * 4));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -630,17 +644,17 @@ int dz_pdv_encoder_front(const float *pos_in, int pin, const float *feats, const
 }
 
 // out = pooled + (row_skip ? pooled : LN2(x + W2 . ReLU(W1 . x + b1) + b2)) with x = LN1(src + op . Wo + bo); op, src (rows, 192) pair16,
-// pooled / out (rows, 192) fp32, wo (192, 192), w1 (128, 192), w2 (192, 128) pair16 rows per OUTPUT channel.
+// pooled (rows, 192) fp32, out (rows, 192) fp32 or - out_pair16 - pair16; wo (192, 192), w1 (128, 192), w2 (192, 128) pair16 rows per OUTPUT channel.
 int dz_pdv_encoder_back(const float *op, const float *src, const float *pooled, const unsigned char *row_skip, long rows, const float *wo,
                         const float *bo, const float *g1, const float *be1, float eps1, const float *w1, const float *b1, const float *w2,
-                        const float *b2, const float *g2, const float *be2, float eps2, float *out, int math, void *stream_) {
+                        const float *b2, const float *g2, const float *be2, float eps2, float *out, int out_pair16, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(rows >= 0, "dz_pdv_encoder_back: negative rows");
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2, "dz_pdv_encoder_back: math %d is not a split mode", math);
     if (rows == 0) return DZ_OK;
     DZ_CHECK_ARG(op && src && pooled && row_skip && wo && bo && g1 && be1 && w1 && b1 && w2 && b2 && g2 && be2 && out, "dz_pdv_encoder_back: null pointer");
     if ((size_t)rows * EN_ROWB >= 0x80000000ull) { set_error("dz_pdv_encoder_back: %ld rows exceed the 2 GiB buffer-addressing limit", rows); return DZ_ERR_UNSUPPORTED; }
-    const EncBackArgs a{op, src, pooled, row_skip, wo, w1, w2, bo, g1, be1, b1, b2, g2, be2, out, rows, eps1, eps2};
+    const EncBackArgs a{op, src, pooled, row_skip, wo, w1, w2, bo, g1, be1, b1, b2, g2, be2, out, rows, eps1, eps2, out_pair16 ? 1 : 0};
     int rc;
     if (math == DZ_MATH_F16X2) { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathF16>, a, rows, "dz_pdv_encoder_back", done, stream); }
     else { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathBF16>, a, rows, "dz_pdv_encoder_back", done, stream); }

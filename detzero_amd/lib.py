@@ -141,7 +141,7 @@ _SIGS = {
                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_pdv_encoder_front': (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_long] + [c_void_p] * 9 + [c_int, c_void_p]),
     'dz_pdv_encoder_back': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     'dz_self_attention_split_supported': (c_int, [c_int, c_int]),
     'dz_self_attention_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_pdv_sa_pool_split_supported': (c_int, [c_int] * 7),

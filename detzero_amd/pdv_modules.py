@@ -307,13 +307,13 @@ def encoder_front(pos_in, feats, row_add, f, math):
     return src, q
 
 
-def encoder_back(op, srcp, pooled, row_skip, f, math):
-    """dz_pdv_encoder_back -> pooled + (row_skip ? pooled : encoder output), fp32 rows."""
+def encoder_back(op, srcp, pooled, row_skip, f, math, out_pair16=False):
+    """dz_pdv_encoder_back -> pooled + (row_skip ? pooled : encoder output), fp32 rows (or pair16 rows: the FC stack's operand)."""
     out = torch.empty_like(pooled)
     with torch.cuda.device(pooled.device):
         rc = L.load().dz_pdv_encoder_back(L.ptr(op), L.ptr(srcp), L.ptr(pooled), L.ptr(row_skip), pooled.shape[0], L.ptr(f['wo']), L.ptr(f['bo']),
                                           L.ptr(f['g1']), L.ptr(f['be1']), float(f['eps1']), L.ptr(f['fw1']), L.ptr(f['fb1']), L.ptr(f['fw2']), L.ptr(f['fb2']),
-                                          L.ptr(f['g2']), L.ptr(f['be2']), float(f['eps2']), L.ptr(out), int(math), L.stream())
+                                          L.ptr(f['g2']), L.ptr(f['be2']), float(f['eps2']), L.ptr(out), 1 if out_pair16 else 0, int(math), L.stream())
     L.check(rc, 'dz_pdv_encoder_back')
     return out
 
@@ -550,8 +550,9 @@ class PDVHead(_Cached):
         return torch.cat((local_roi_grid_points, ppp), dim=-1)
 
     # ---- the encoder layer (attention_utils.py:17-52 around nn.TransformerEncoderLayer, post-norm, ReLU)
-    def attention(self, point_features, positional_input, key_padding_mask, combine=False):
-        """combine: return pooled + attended features (COMBINE) instead of the attended ones."""
+    def attention(self, point_features, positional_input, key_padding_mask, combine=False, pair16_ok=False):
+        """combine: return pooled + attended features (COMBINE) instead of the attended ones.  pair16_ok: the fused split path may return
+        ('pair16', rows (R * L, E) pair16, math) - the FC stack's operand - instead of an fp32 tensor."""
         p = self.plan()
         r, l, e = point_features.shape
         feats = point_features.reshape(r * l, e).contiguous()
@@ -562,7 +563,7 @@ class PDVHead(_Cached):
         sm = self.stack_math()
         if (FOLDED_ATTENTION[0] and FUSED_ENCODER[0] and combine and sm in (1, 2) and m['heads'] == 1 and e == 192 and
                 L.load().dz_self_attention_split_supported(l, e) and self._fused_encoder_ok(p, positional_input)):
-            return self._attention_fused(p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e)
+            return self._attention_fused(p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e, pair16_ok)
         pos_rows = torch.nn.functional.pad(pos_in, (0, 16 - pos_in.shape[1]))      # (one launch: zero-padded to the stack's input width)
         pos, _ = _run_stack(pos_rows, p['pos'], math=self.stack_math())
         # feats + pos where add_pos, feats elsewhere, in one pass: pos * 1.0 and feats + 0.0 are exact (the encodings are finite)
@@ -589,7 +590,7 @@ class PDVHead(_Cached):
         return (positional_input.shape[-1] in (4, 8) and len(pos) == 2 and pos[0]['cout'] == 96 and pos[0]['relu'] and pos[1]['cout'] == 192 and
                 not pos[1]['relu'] and tuple(enc['w1'].shape) == (192, 128) and tuple(enc['w2'].shape) == (128, 192))
 
-    def _attention_fused(self, p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e):
+    def _attention_fused(self, p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e, pair16_out=False):
         """COMBINE'd encoder layer in three launches: front chain (positional encoder, src, folded query), attention over the input rows,
         back chain (output projection, both LayerNorms, feed-forward block, pooled + result)."""
         from .refine_modules import _split_w
@@ -616,8 +617,9 @@ class PDVHead(_Cached):
             a, b = r0 * l, r1 * l
             srcp, qp = encoder_front(pos_in[a:b], pooled[a:b], add[a:b], f, sm)
             op = self_attention_split(qp, srcp, mask[r0:r1], r1 - r0, l, sm)
-            outs.append(encoder_back(op, srcp, pooled[a:b], skip[a:b], f, sm))
-        return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)).view(r, l, e)
+            outs.append(encoder_back(op, srcp, pooled[a:b], skip[a:b], f, sm, out_pair16=pair16_out))
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return ('pair16', out, sm) if pair16_out else out.view(r, l, e)
 
     def _attention_split(self, p, sm, point_features, src, key_padding_mask, empty, r, l, e, combine=False):
         """The encoder layer on pair16 operands: q' GEMM, dz_self_attention_split over the input rows themselves, output GEMM, and the
@@ -667,9 +669,17 @@ class PDVHead(_Cached):
             mask = (torch.cat(balls, dim=-1) == 0).all(-1).view(-1, g3)
         ball_idxs = lambda: torch.cat(balls, dim=-1).view(-1, g3, sum(b.shape[1] for b in balls))     # noqa: E731  (built when somebody reads it)
         pos_in = self.get_positional_input(batch_dict['points'], batch_dict['rois'], local)
-        att = self.attention(pooled, pos_in, mask, combine=bool(self.pool_cfg.ATTENTION.get('COMBINE')))
-        rows = att.reshape(att.shape[0], -1).contiguous()                   # (RoI, 216 * C): the shared FC's columns were permuted to match
-        shared, _ = _run_stack(rows, p['shared'], math=self.stack_math())
+        from .refine_modules import _run_stack_split, _splittable
+        nroi = pooled.shape[0]
+        att = self.attention(pooled, pos_in, mask, combine=bool(self.pool_cfg.ATTENTION.get('COMBINE')),
+                             pair16_ok=_splittable(p['shared'], nroi, self.stack_math()))
+        if isinstance(att, tuple):          # the fused encoder's result as pair16 rows = the first FC layer's operand: no conversion pass
+            _, attp, sm = att
+            shared, _ = _run_stack_split(attp.view(nroi, -1), p['shared'], math=sm)
+            att = lambda: ops.pair16_to_f32(attp, sm).view(pooled.shape)      # noqa: E731  (fp32 view for whoever reads forward_ret_dict)
+        else:
+            rows = att.reshape(att.shape[0], -1).contiguous()               # (RoI, 216 * C): the shared FC's columns were permuted to match
+            shared, _ = _run_stack(rows, p['shared'], math=self.stack_math())
         rcnn_reg, _ = _run_stack(shared, p['reg'], math=self.stack_math())
         rcnn_cls, _ = _run_stack(shared, p['cls'], math=self.stack_math())
         cls_preds, box_preds = self.generate_predicted_boxes(batch_dict['batch_size'], batch_dict['rois'], rcnn_cls.contiguous(), rcnn_reg.contiguous())

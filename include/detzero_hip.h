@@ -601,7 +601,8 @@ int dz_pdv_encoder_front(const float *pos_in, int pin, const float *feats, const
                          void *stream);
 int dz_pdv_encoder_back(const float *op, const float *src, const float *pooled, const unsigned char *row_skip, long rows, const float *wo,
                         const float *bo, const float *g1, const float *be1, float eps1, const float *w1, const float *b1, const float *w2,
-                        const float *b2, const float *g2, const float *be2, float eps2, float *out, int math, void *stream);
+                        const float *b2, const float *g2, const float *be2, float eps2, float *out, int out_pair16, int math, void *stream);
+/* (out_pair16: the result as pair16 rows - the operand of the head's FC stack - instead of fp32) */
 int dz_self_attention_split_supported(int l, int e);
 int dz_self_attention_split(const float *q, const float *x, const unsigned char *key_padding_mask, int r, int l, int e, float *out,
                             int math, void *stream);

@@ -324,6 +324,18 @@ def test_head_on_split_operands(device, g, mode, mid):
     torch.testing.assert_close(out['batch_box_preds'].cpu(), torch.from_numpy(g['batch_box_preds']), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(out['batch_cls_preds'].cpu(), torch.from_numpy(g['batch_cls_preds']), rtol=2e-3, atol=2e-3)
     att_fold = r['attention_output'].clone()
+    # the route of large batches (>= SPLIT_MIN_ROWS RoIs): the encoder hands pair16 rows straight to the pair16 FC stack
+    from detzero_amd import refine_modules as rm
+    keep = rm.SPLIT_MIN_ROWS
+    rm.SPLIT_MIN_ROWS = 16
+    try:
+        out2 = head(_batch(g, device))
+        att2 = head.forward_ret_dict['attention_output']
+    finally:
+        rm.SPLIT_MIN_ROWS = keep
+    assert float((att2 - att_fold).abs().max()) <= (1e-5 if mid == 1 else 1e-3)
+    torch.testing.assert_close(out2['batch_box_preds'].cpu(), torch.from_numpy(g['batch_box_preds']), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(out2['batch_cls_preds'].cpu(), torch.from_numpy(g['batch_cls_preds']), rtol=2e-3, atol=2e-3)
     for switch, what in ((pm.FUSED_ENCODER, 'layer-by-layer split path'), (pm.FOLDED_ATTENTION, 'unfolded fp32 path')):
         switch[0] = False
         try:
@@ -419,3 +431,6 @@ def test_encoder_row_chains(device, mode, mid, tol, rows):
     e3 = float((out - ref).abs().max())
     print('encoder back [%s] %d rows: out %.2e' % (mode, rows, e3))
     assert e3 <= 4 * tol * max(1.0, float(ref.abs().max()))
+    # the same result as pair16 rows (the operand of the FC stack that follows): the fp32 result rounded to the pair format
+    outp = ops.pair16_to_f32(pm.encoder_back(opp, srcp, dev(pooled), dev(skip.to(torch.uint8)), bw, mid, out_pair16=True), mid).cpu().double()
+    assert float((outp - out).abs().max()) <= (4e-6 if mid == 1 else 2e-4) * max(1.0, float(ref.abs().max()))
