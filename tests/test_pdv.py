@@ -76,6 +76,49 @@ def _batch(g, device):
             'multi_scale_3d_features': {'x_conv3': _Sparse(t(g['c3']), t(g['f3']), g['s3'], 2), 'x_conv4': _Sparse(t(g['c4']), t(g['f4']), g['s4'], 2)}}
 
 
+def test_folded_projections_equal_the_encoder_layer():
+    """The host-side fold of the one-head attention (PDVHead.plan()['fold']: q' = x (Wq Wk^T) + Wk bq in log2 units, output (P x)(Wv Wo) +
+    (bv Wo + bo)) against torch's own nn.MultiheadAttention in float64 - the algebra csrc/pdv_attn.hip and csrc/pdv_enc.hip rely on,
+    checked without a GPU."""
+    head = _head()
+    p = head.plan()
+    enc = head.attention_head.transformer_encoder.layers[0]
+    mha = enc.self_attn.double()
+    gen_ = torch.Generator().manual_seed(5)
+    r, l, e = 3, 216, 192
+    x = torch.randn(r, l, e, generator=gen_, dtype=torch.float64)
+    mask = torch.rand(r, l, generator=gen_) < 0.3
+    mask[:, 0] = False
+    ref, _ = mha(x.transpose(0, 1), x.transpose(0, 1), x.transpose(0, 1), key_padding_mask=mask, need_weights=False)
+    ref = ref.transpose(0, 1)
+    f = p['fold']
+    q = x @ f['q']['w'].double() + f['q']['shift32'].double()                      # scores in log2 units
+    s = torch.einsum('rqe,rke->rqk', q, x) * float(np.log(2.0))
+    s = s.masked_fill(mask[:, None, :], float('-inf'))
+    o = torch.einsum('rqk,rke->rqe', torch.softmax(s, dim=-1), x)
+    got = o @ f['o']['w'].double() + f['o']['shift32'].double()
+    err = float((got - ref).abs().max())
+    assert err <= 2e-6 * max(1.0, float(ref.abs().max())), err                   # (the fold is stored in fp32)
+    d = _LazyProbe()
+    assert d['x'] == 7 and d.calls == 1 and d['x'] == 7 and d.calls == 1        # forward_ret_dict's lazy entries evaluate once
+
+
+class _LazyProbe(dict):
+    """(helper of the test above: the same first-read evaluation as pdv_modules._LazyDict, counted)"""
+
+    def __init__(self):
+        from detzero_amd.pdv_modules import _LazyDict
+        self.calls = 0
+        self._d = _LazyDict({'x': self._make})
+
+    def _make(self):
+        self.calls += 1
+        return 7
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+
 @pytest.mark.gpu
 def test_centroids_and_feature_rows(device, g):
     """get_point_voxel_features: the centroid lists (order, count, coordinates) and the x_conv rows gathered under them.
