@@ -89,7 +89,8 @@ def test_folded_projections_equal_the_encoder_layer():
     x = torch.randn(r, l, e, generator=gen_, dtype=torch.float64)
     mask = torch.rand(r, l, generator=gen_) < 0.3
     mask[:, 0] = False
-    ref, _ = mha(x.transpose(0, 1), x.transpose(0, 1), x.transpose(0, 1), key_padding_mask=mask, need_weights=False)
+    with torch.no_grad():
+        ref, _ = mha(x.transpose(0, 1), x.transpose(0, 1), x.transpose(0, 1), key_padding_mask=mask, need_weights=False)
     ref = ref.transpose(0, 1)
     f = p['fold']
     q = x @ f['q']['w'].double() + f['q']['shift32'].double()                      # scores in log2 units
