@@ -104,10 +104,12 @@ _T0 = time.perf_counter()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=500, help='timed steps (default: ~10 s of GPU time at 16 frames per step)')
+    ap.add_argument('--steps', type=int, default=300, help='timed steps (default: ~10 s of GPU time at 32 frames per step)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
-    ap.add_argument('--batch', type=int, default=16, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU)')
+    ap.add_argument('--batch', type=int, default=32, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU = 8, leg ref_batch; 16 was the default of '
+                    'rounds 1-3, leg batch16; chosen by the sweep of DESIGN.md section 4: 8 / 16 / 24 / 32 -> 940 / 1031 / 1029 / 1051 frames/s; 48 does not fit '
+                    'the 32-bit voxel keys)')
     ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2', 'f16'],
                     help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores; '
                          'f16 = one fp16 MFMA per product on the same tensors (fast mode, not fp32-class)')
@@ -614,6 +616,9 @@ def main():
         del c
         c, out['ref_batch'] = leg('ref_batch', args.math, REF_BATCH, note='BATCH_SIZE_PER_GPU of centerpoint_1sweep.yaml:88')
         del c
+        if B != 16:
+            c, out['batch16'] = leg('batch16', args.math, 16, note='16 frames per pass: the headline configuration of rounds 1-3 (round-over-round comparison)')
+            del c
         c, padded = leg('ragged/padded', args.math, B, (150000, 180000), 'padded',
                         note='frames of 150k-180k points padded with out-of-range rows to 180k-row slots: stacked dz_voxelize_to_level route')
         del c
