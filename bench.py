@@ -18,6 +18,7 @@ value = frames/s over all GPUs.  Prints ONE JSON line on rank 0.
 Besides the headline the default single-GPU run measures, into the same JSON line (each a few seconds; --no-aux skips):
   fp32       the same workload with every convolution in exact fp32 (--fp32-batch frames per step), with its own roofline
   ref_batch  the headline arithmetic at the reference's BATCH_SIZE_PER_GPU = 8 (centerpoint_1sweep.yaml:88)
+  batch16    ... at 16 frames per pass, the default of rounds 1-3 (the default is 32 since round 4: DESIGN.md section 4, batch sweep)
   ragged     frames of 150k-180k points: padded to the slot capacity with out-of-range rows (the stacked route), and as a
              ragged list (per-frame voxelizers on parallel streams)
   f16        opt-in fast mode: one fp16 MFMA per product on the same fp16-pair tensors (not fp32-class; its own tolerance), with roofline
@@ -29,7 +30,8 @@ Besides the headline the default single-GPU run measures, into the same JSON lin
   tiles      (--tiles-leg) the opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip, rows in brick order)
   refine     BASELINE configs[3], the secondary kernel set: GRM objects/s and PRM tracks/s (fp32 and f16x2 stacks) and the
              attention core (k_mha_block) with its roofline against the fp32-MFMA peak
-  pdv        the two-stage detector (PDVHead second stage) on a merged 2-sweep frame: ms per stage, RoIs/s
+  pdv        the two-stage detector (PDVHead second stage) on merged 2-sweep frames: ms per stage, RoIs/s, frames/s at 1 / 8 frames per pass
+             through the plugin modules and at 8 / 16 through FramePipeline.two_stage
 The exact-fp32 leg is also promoted to the top-level keys value_fp32 / roofline_fp32 (the precision-equivalent number next to
 `value`, whose arithmetic carries 22 significant bits).
 
