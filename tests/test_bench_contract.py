@@ -31,7 +31,7 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1
     # HBM bytes of the dominant kernel per launch from the PMC passes (r04: a number, its read / write split beside it; r01-r03 lines: a dict)
     t = r['traffic']
-    assert t is None or (t['bytes'] > 0 if isinstance(t, dict) else (t > 0 and t == r['traffic_read_bytes'] + r['traffic_write_bytes']))
+    assert t is None or (t['bytes'] > 0 if isinstance(t, dict) else (t > 0 and abs(t - r['traffic_read_bytes'] - r['traffic_write_bytes']) <= 2))
     if 'hbm' in r:                                                        # the north star's stage fractions (r04)
         for st in ('voxelize', 'index', 'sparse_backbone', 'voxelize_plus_backbone'):
             h = r['hbm'][st]
