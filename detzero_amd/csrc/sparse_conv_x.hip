@@ -669,19 +669,29 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int cap, const int *__restrict__ d_m_out, int tile_rows,
                                               int *__restrict__ win, int *__restrict__ nbr_sorted, int *__restrict__ perm) {
     __shared__ int lo_s[3], hi_s[3];
-    __shared__ unsigned long long key_s[256];
+    __shared__ __attribute__((aligned(16))) unsigned int key_s[256];
     if (blockIdx.x == 0 && threadIdx.x < 16) win[(size_t)gridDim.x * 6 + threadIdx.x] = 0;       // the tile queues of dz_spconv_forward_split_x
     const int m = min(*d_m_out, cap);
     const int tile = blockIdx.x, row0 = tile * tile_rows;
     if (threadIdx.x < 3) { lo_s[threadIdx.x] = 0x7FFFFFFF; hi_s[threadIdx.x] = -1; }
     __syncthreads();
     const int row1 = min(m, row0 + tile_rows);
+    // one row per thread (tile_rows <= 256): its nine table words, read once
+    const int i = threadIdx.x, row = row0 + i;
+    const bool mine = i < tile_rows && row < row1;
+    unsigned int words[9];
+    unsigned int mask = 0u;
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        words[g] = mine ? (unsigned int)nbr[(size_t)g * cap + row] : 0u;
+        mask |= (words[g] >> 29) << (3 * g);
+    }
+#pragma unroll
     for (int tz = 0; tz < 3; ++tz) {
         int lo = 0x7FFFFFFF, hi = -1;
-        for (int i = threadIdx.x; i < 3 * tile_rows; i += blockDim.x) {
-            const int ty = i / tile_rows, row = row0 + i % tile_rows;
-            if (row >= row1) continue;
-            const unsigned int e = (unsigned int)nbr[(size_t)(tz * 3 + ty) * cap + row];
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const unsigned int e = words[tz * 3 + ty];
             if (!(e >> 29)) continue;
             const int r = (int)(e & 0x1FFFFFFFu), l = (int)((e >> 29) & 1u), c = (int)((e >> 30) & 1u), rt = (int)(e >> 31);
             lo = min(lo, r - l);
@@ -694,6 +704,13 @@ __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int c
         }
         if ((threadIdx.x & 63) == 0 && hi >= 0) { atomicMin(&lo_s[tz], lo); atomicMax(&hi_s[tz], hi); }
     }
+    // ---- tap-set order: rank of my (mask, row) key among the unit's keys by counting (every thread walks the 256 keys in LDS:
+    // broadcast reads, no exchange stages, no barriers in the loop).  Rows past the level's end sort LAST in either direction: the
+    // live rows of the last unit keep the positions row0 .. m - 1, so "position < m" stays the test for a live position and nothing is
+    // written past the table's `cap` columns
+    const unsigned int k27 = (tile & 1) ? (0x7FFFFFFu - mask) : mask;            // odd units descending
+    const unsigned int key = mine ? k27 : 0x8000000u;
+    key_s[i] = key;
     __syncthreads();
     if (threadIdx.x < 3) {
         const int tz = threadIdx.x;
@@ -703,48 +720,18 @@ __global__ __launch_bounds__(256) void k_xwin(const int *__restrict__ nbr, int c
         win[(size_t)tile * 6 + 2 * tz] = lo;
         win[(size_t)tile * 6 + 2 * tz + 1] = n;
     }
-    if (!perm) return;
-    // ---- tap-set order: one row per thread (tile_rows <= 256), bitonic sort of (mask, row) keys in LDS.  Rows past the level's end
-    // sort LAST in either direction: the live rows of the last unit keep the positions row0 .. m - 1, so "position < m" stays the
-    // test for a live position and nothing is written past the table's `cap` columns
-    const int i = threadIdx.x, row = row0 + i;
-    unsigned int words[9];
-    unsigned long long key = ~0ull;                                       // padding threads: behind everything
-    if (i < tile_rows) {
-        unsigned int mask = 0u;
-#pragma unroll
-        for (int g = 0; g < 9; ++g) {
-            words[g] = row < row1 ? (unsigned int)nbr[(size_t)g * cap + row] : 0u;
-            mask |= (words[g] >> 29) << (3 * g);
-        }
-        const unsigned int k27 = (tile & 1) ? (0x7FFFFFFu - mask) : mask;    // odd units descending
-        key = ((unsigned long long)(row < row1 ? k27 : 0x8000000u) << 16) | (unsigned int)i;
+    if (!perm || i >= tile_rows) return;
+    int rank = 0;
+    for (int j = 0; j < tile_rows; j += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&key_s[j]);
+        rank += (v.x < key || (v.x == key && j < i)) + (v.y < key || (v.y == key && j + 1 < i)) + (v.z < key || (v.z == key && j + 2 < i)) +
+                (v.w < key || (v.w == key && j + 3 < i));
     }
-    key_s[i] = key;
-    __syncthreads();
-    for (int k = 2; k <= 256; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int p = i ^ j;
-            if (p > i) {
-                const unsigned long long ka = key_s[i], kb = key_s[p];
-                const bool up = (i & k) == 0;
-                if ((ka > kb) == up) { key_s[i] = kb; key_s[p] = ka; }
-            }
-            __syncthreads();
-        }
-    }
-    const int src = i < tile_rows ? (int)(key_s[i] & 0xFFFFu) : 0;        // the row (of this unit) at sorted position i
-    if (i < tile_rows && row0 + i < cap) perm[row0 + i] = row0 + src;
-    __syncthreads();
-    int *const pos_s = reinterpret_cast<int *>(key_s);                  // (every key has been read) position of row r of the unit
-    if (i < tile_rows) pos_s[src] = i;
-    __syncthreads();
-    if (i < tile_rows) {
-        const int pos = row0 + pos_s[i];                                 // my row's table words go to its position
-        if (pos < cap) {
+    const int pos = row0 + rank;                                           // my row's position in the unit's tap-set order
+    if (pos < cap) {
+        perm[pos] = row;
 #pragma unroll
-            for (int g = 0; g < 9; ++g) nbr_sorted[(size_t)g * cap + pos] = (int)words[g];
-        }
+        for (int g = 0; g < 9; ++g) nbr_sorted[(size_t)g * cap + pos] = (int)words[g];
     }
 }
 

@@ -293,6 +293,7 @@ def build_tiles(nbr, out_level):
 
 
 XRUN_SORT = os.environ.get('DZ_TUNE_XRUN_SORT', '1') != '0'       # development switch: rows of a unit in tap-set order
+XRUN_SORT_MIN_CHANNELS = int(os.environ.get('DZ_TUNE_XRUN_SORT_MIN', '64'))
 
 
 def build_windows(nbr, out_level, channels):
@@ -308,8 +309,10 @@ def build_windows(nbr, out_level, channels):
     # (tiles x 3 x 2 window words + the tile-queue words of the convolution kernels)
     win = torch.empty((lib.dz_spconv_x_windows_words(cap, tr),), dtype=torch.int32, device=nbr.device)
     # the table and the row map in tap-set order (rows of a unit sorted by their neighbour pattern: fewer (fragment, tap) pairs to multiply)
-    nbr_sorted = torch.empty_like(nbr) if XRUN_SORT else None
-    perm = torch.empty((cap,), dtype=torch.int32, device=nbr.device) if XRUN_SORT else None
+    # (at 32 channels the order saves ~1 % of the kernel - less than sorting a level of 1.8 M rows and writing its table again costs)
+    sort = XRUN_SORT and channels >= XRUN_SORT_MIN_CHANNELS
+    nbr_sorted = torch.empty_like(nbr) if sort else None
+    perm = torch.empty((cap,), dtype=torch.int32, device=nbr.device) if sort else None
     rc = lib.dz_spconv_x_windows(L.ptr(nbr), cap, L.ptr(out_level.d_m), tr, L.ptr(win), L.ptr(nbr_sorted), L.ptr(perm), L.stream())
     L.check(rc, 'dz_spconv_x_windows')
     nbr.xwin = (win, tr, nbr_sorted, perm)

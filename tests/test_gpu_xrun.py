@@ -60,8 +60,12 @@ def test_windows_cover_the_rulebook_exactly(device, channels):
             else:
                 assert n == (1 if tz == 1 else 0)
     assert (win[(m + tr - 1) // tr:, :, 1] == 0).all()
-    # the tap-set order: perm is a permutation of every unit's rows (live rows at the positions below m), the sorted table holds the
-    # words of row perm[position] at `position`, and masks ascend in even units / descend in odd ones
+    # the tap-set order (64 / 128 channels; at 32 the order saves less than building it costs: ops.XRUN_SORT_MIN_CHANNELS): perm is a
+    # permutation of every unit's rows (live rows at the positions below m), the sorted table holds the words of row perm[position] at
+    # `position`, and masks ascend in even units / descend in odd ones
+    assert (perm is None) == (channels < ops.XRUN_SORT_MIN_CHANNELS) and (nbr_sorted is None) == (perm is None)
+    if perm is None:
+        return
     perm = perm[:m].cpu().numpy().astype(np.int64)
     packed = nbr[:, :m].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     srt = nbr_sorted[:, :m].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
