@@ -14,6 +14,11 @@ OBJDIR = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libdetzero_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+if os.environ.get('DZ_BUILD_EXPERIMENTAL', '0') not in ('', '0'):
+    # the engines that were built, parity-tested and measured SLOWER than the shipped ones: the tile-resident sparse
+    # convolution (sparse_conv_t.hip) and the direct-to-LDS gather variant (sparse_conv_d.h).  Not part of the default library; their
+    # tests carry the `experimental` marker (tests/conftest.py)
+    FLAGS.append('-DDZ_BUILD_EXPERIMENTAL')
 FLAGS += os.environ.get('DZ_HIPCC_FLAGS', '').split()      # development only (e.g. -DDZ_SPCONV_DIAG: tools/gpu_diag.sh)
 
 

@@ -269,7 +269,14 @@ def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE
     subnormal for small values, so a network whose stages peak at 1e-3 is better served by bf16 pairs too.  Returns (mode,
     per-stage maxima) and sets the mode."""
     rng = activation_range(model, dataset_info, frames)
-    mode = prefer if (max(rng.values()) <= limit and min(rng.values()) >= low_limit) else 'bf16x2'
+    # a stage with no active site on the calibration frames (maximum exactly 0) says nothing about the range of its activations
+    live = {k: v for k, v in rng.items() if v > 0.0}
+    too_big = [k for k, v in live.items() if v > limit]
+    too_small = [k for k, v in live.items() if v < low_limit]
+    mode = prefer if not (too_big or too_small) else 'bf16x2'
+    if mode != prefer:
+        import warnings
+        warnings.warn('select_math: %s -> bf16x2 (stages above %g: %s; stages peaking below %g: %s)' % (prefer, limit, too_big, low_limit, too_small))
     set_math(model, mode)
     return mode, rng
 
@@ -458,18 +465,24 @@ class FramePipeline:
         m = self.model
         x, lvl = res['encoded']
         bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
-        if nb <= self.dense_group:
+        # frames per group: the configured number, but never more than the largest activation image (the concatenation of the
+        # upsampled maps, channel-last fp32-sized words, zero border included) allows inside the 2 GiB buffer window
+        per_frame = bev.shape[1] * bev.shape[2] * max(int(m.backbone2d.num_bev_features), int(bev.shape[3])) * 4
+        group = max(1, min(self.dense_group if self.dense_group > 0 else nb, (2 ** 31 - 1) // per_frame))
+        if nb <= group:
             with cp_modules.workspace(self._ws):
                 concat = m.backbone2d.run(bev, nb)
                 return self.head.run_convs(concat, nb)
-        maps, h, w = [], 0, 0
-        for g0 in range(0, nb, self.dense_group):
-            ng = min(self.dense_group, nb - g0)
+        out, h, w = None, 0, 0
+        for g0 in range(0, nb, group):
+            ng = min(group, nb - g0)
             with cp_modules.workspace(self._ws):
                 concat = m.backbone2d.run(bev[g0:g0 + ng], ng)
                 hd, h, w = self.head.run_convs(concat, ng)
-            maps.append(hd.clone())            # (the activation images, the head map among them, are reused by the next group)
-        return torch.cat(maps, dim=0), h, w
+            if out is None:
+                out = hd.new_empty((nb,) + tuple(hd.shape[1:]))
+            out[g0:g0 + ng].copy_(hd)          # (the activation images, the head map among them, are reused by the next group)
+        return out, h, w
 
     @torch.no_grad()
     def post_stage(self, head, h, w):
@@ -499,10 +512,19 @@ class FramePipeline:
         out, d_nk = self.post_stage(*self.dense_stage(res, nb))
         bb = m.backbone3d
 
+        k = max(int(d_nk.max().item()), 1)
+        # a calibrated level that overflowed holds ranks beyond its row capacity in its bitmap / prefix: the second stage looks voxels
+        # up by rank (PDVHead.get_point_voxel_features), so it must not run on such a pass - the flag of THIS pass is read here (the
+        # host is synchronised by the line above anyway) and the pass is refused; the sticky counter still reports it to check_overflow
+        if self.last_overflow is not None and bool(self.last_overflow.item()):
+            raise DetZeroHipError('FramePipeline.two_stage: a sparse level overflowed its calibrated row capacity (%s per frame) - the second '
+                                  'stage would read rows past the feature tensors; re-run calibrate() on denser samples / with a larger '
+                                  'margin, or drop the calibration' % (self.level_caps,))
+
         def as_tensor(item):
             feats, level = item
-            return SparseConvTensor(None, level.coords[:level.num_active()], level.shape, nb, level=level, padded=(feats, level), math=bb.math)
-        k = max(int(d_nk.max().item()), 1)
+            m_act = min(level.num_active(), level.cap, feats.shape[0])          # (never more rows than the tensors hold)
+            return SparseConvTensor(None, level.coords[:m_act], level.shape, nb, level=level, padded=(feats, level), math=bb.math)
         pts = [frames[i] for i in range(nb)]
         points_b = torch.cat([torch.cat([p.new_full((p.shape[0], 1), float(i)), p], dim=1) for i, p in enumerate(pts)], dim=0)
         bd = {'batch_size': nb, 'points': points_b, 'rois': out[:, :k, :7].contiguous(), 'roi_scores': out[:, :k, 7].contiguous(),

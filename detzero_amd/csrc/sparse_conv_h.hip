@@ -6,7 +6,10 @@
 #include <stdlib.h>
 
 #include "hgemm.h"
-#include "sparse_conv_d.h"
+#include "sparse_conv_w.h"
+#ifdef DZ_BUILD_EXPERIMENTAL
+#include "sparse_conv_d.h"          // k_spconv_d: operand tiles by direct-to-LDS loads in the gather engine (measured slower)
+#endif
 
 namespace dz {
 
@@ -235,11 +238,13 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     }
     if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4, 3, 4, 5>(a, stream);
     if (a.cin == 32 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 32, 4, 1>, M, 3, 3, 1, 3>(a, stream);
+#ifdef DZ_BUILD_EXPERIMENTAL
     static const int td = tune("DZ_TUNE_SPCONV_D", 0);          // operand tiles by direct-to-LDS loads (sparse_conv_d.h)
     if (td && a.tile_masks && a.nbr_bytes && a.cin % 32 == 0) {
         if (a.cout_pad == 64 && (td & 1)) return launch_spconv_d<64, M>(a, stream);
         if (a.cout_pad == 128 && (td & 2)) return launch_spconv_d<128, M>(a, stream);
     }
+#endif
     if ((a.cin == 32 || a.cin == 64) && a.cout_pad == 64) {
         if (t64 == 1) return launch_spconv_h<HTile<64, 64, 32, 2, 2>, M, 4, 3, 3, 3>(a, stream);       // 4 waves of 32 x 32 (r01d)
         if (t64 == 2) return launch_spconv_h<HTile<128, 64, 32, 4, 2>, M, 3, 3, 4, 4>(a, stream);      // 8 waves of 32 x 32 (r01e-r03b)

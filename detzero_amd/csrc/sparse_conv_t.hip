@@ -32,6 +32,7 @@
 
 #include "hgemm.h"
 
+#ifdef DZ_BUILD_EXPERIMENTAL
 namespace dz {
 
 constexpr int T_THREADS = 512, T_WAVES = 8, T_TR = 512;
@@ -622,3 +623,24 @@ const char *dz_spconv_tiles_variant(int cin, int cout) {
 }
 
 }  // extern "C"
+#else   // default build: the tile engine (measured slower than the gather / x-run engines) is not compiled; its entry points stay
+        // exported so that include/detzero_hip.h == the library's symbols in every build, and say how to get the engine
+#include "common.h"
+using namespace dz;
+extern "C" {
+static int no_tiles(const char *fn) {
+    set_error("%s: the tile-resident sparse engine is an experimental build option - rebuild with DZ_BUILD_EXPERIMENTAL=1 (python -m detzero_amd.build --force)", fn);
+    return DZ_ERR_UNSUPPORTED;
+}
+int dz_spconv_tile_rows(void) { return 0; }
+int dz_spconv_tile_info_words(void) { return 0; }
+int dz_spconv_tile_table_entries(void) { return 0; }
+size_t dz_build_tiles_halo_stride(int) { return 0; }
+int dz_build_tiles(const int *, int, int, const int *, int *, int *, unsigned short *, unsigned short *, void *) { return no_tiles("dz_build_tiles"); }
+int dz_spconv_tiles_forward(const float *, int, int, const int *, const int *, const unsigned short *, const unsigned short *, int, int, const int *,
+                            const float *, const float *, const float *, const float *, int, float *, int, int, void *) {
+    return no_tiles("dz_spconv_tiles_forward");
+}
+const char *dz_spconv_tiles_variant(int, int) { return "none (built without DZ_BUILD_EXPERIMENTAL)"; }
+}  // extern "C"
+#endif

@@ -831,6 +831,14 @@ int dz_spconv_x_tile_rows(int cin, int cout) {
     return 0;
 }
 
+int dz_spconv_x_window_rows(int cin, int cout) {
+    if (cin != cout) return 0;
+    if (cout == 32) return x32_variant() == 1 ? X32B::RCAP : (x32_variant() == 2 ? X32C::RCAP : X32::RCAP);
+    if (cout == 64) return X64::RCAP;
+    if (cout == 128) return X128::RCAP;
+    return 0;
+}
+
 size_t dz_spconv_x_windows_words(int cap_out, int tile_rows) {
     return tile_rows > 0 && cap_out >= 0 ? (size_t)ceil_div(cap_out, tile_rows) * 6 + 16 : 0;
 }

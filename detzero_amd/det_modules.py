@@ -291,6 +291,9 @@ class VoxelResBackBone8x(_Cached):
         convolutions of the 32 / 64 / 128-channel levels; same row order) or 'tiles' (tile-resident convolution; rows in brick order)."""
         if engine not in ('gather', 'tiles', 'xrun'):
             raise DetZeroHipError('unknown sparse engine %r (gather | xrun | tiles)' % (engine,))
+        if engine == 'tiles' and ops.L.load().dz_spconv_tile_rows() == 0:
+            raise DetZeroHipError("sparse engine 'tiles' is an experimental build option (measured slower, DESIGN.md 2d): rebuild the library "
+                                  'with DZ_BUILD_EXPERIMENTAL=1 (python -m detzero_amd.build --force)')
         self.engine = engine
         self.layout = ops.LAYOUT_BRICK if engine == 'tiles' else ops.LAYOUT_LINEAR
 
@@ -369,7 +372,10 @@ class VoxelResBackBone8x(_Cached):
         xrun_couts = tuple(int(c) for c in os.environ.get('DZ_TUNE_XRUN_COUTS', '32,64,128').split(',') if c)
 
         def table(src, dst, k, s, p, cout):
-            if xrun and src is dst and cout in xrun_couts and tuple(k) == (3, 3, 3):
+            # (asked BEFORE the packed table is built: a width / capacity the x-run kernel does not cover would otherwise build the
+            # table twice - packed for nothing, then plain)
+            if (xrun and src is dst and cout in xrun_couts and tuple(k) == (3, 3, 3) and dst.cap < (1 << 29)
+                    and ops.L.load().dz_spconv_x_tile_rows(int(cout), int(cout)) != 0):
                 # submanifold table of a level the x-run kernel covers: packed words + the tiles' windows
                 nbr = ops.build_windows(src.neighbors_to(dst, k, s, p, packed=True), dst, cout)
                 if getattr(nbr, 'xwin', None) is not None:

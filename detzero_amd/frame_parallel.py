@@ -79,8 +79,10 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
     batch = frames per pipeline call (the reference's BATCH_SIZE_PER_GPU).  batch == 1: ``pipeline(points) -> ((K,9), (1,))``;
     batch > 1: ``pipeline([points, ...]) -> ((B,K,9), (B,))`` - the shard is walked in consecutive groups of ``batch`` frames
     (sampler order is kept: only the grouping changes), the last group may be shorter."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grouped = dist.is_initialized()     # an initialised process group always goes through the collectives, also with ONE rank (the
+                                        # single-GPU RCCL test runs exactly the code path of the 8-GPU job)
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
     n = len(frames) if not callable(frames) else frames.num_frames
     mine = shard_indices(n, rank, world)
     get = frames if callable(frames) else frames.__getitem__
@@ -102,7 +104,7 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
         # all-reduced BEFORE anyone raises: a rank that raised on its own would leave the others waiting in the box gather below
         # until the collective times out
         over = bool(pipeline.overflow_seen())
-        if world > 1:
+        if grouped:
             flag = torch.tensor([1 if over else 0], dtype=torch.int32, device=boxes.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
             over = bool(flag.item())
@@ -110,7 +112,7 @@ def run_frame_parallel(pipeline, frames, class_names, group=None, metas=None, ba
             raise DetZeroHipError('run_frame_parallel: a sparse level overflowed its calibrated row capacity on some rank (per-frame '
                                   'capacities %s): re-run calibrate() on denser samples / with a larger margin, or drop the calibration'
                                   % (getattr(pipeline, 'level_caps', None),))
-    if world == 1:
+    if not grouped:
         all_b, all_c = boxes[None], counts[None]
     else:
         all_b, all_c = gather_frame_boxes(boxes, counts, group)

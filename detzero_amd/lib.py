@@ -116,6 +116,7 @@ _SIGS = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_tiles_variant': (ctypes.c_char_p, [c_int, c_int]),
     'dz_spconv_x_tile_rows': (c_int, [c_int, c_int]),
+    'dz_spconv_x_window_rows': (c_int, [c_int, c_int]),
     'dz_spconv_x_windows_words': (c_size_t, [c_int, c_int]),
     'dz_spconv_x_windows': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_spconv_forward_split_x': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

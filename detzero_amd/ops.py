@@ -292,6 +292,7 @@ def build_tiles(nbr, out_level):
     return nbr
 
 
+_XWIN_MISMATCH_LOGGED = False
 XRUN_SORT = os.environ.get('DZ_TUNE_XRUN_SORT', '1') != '0'       # development switch: rows of a unit in tap-set order
 XRUN_SORT_MIN_CHANNELS = int(os.environ.get('DZ_TUNE_XRUN_SORT_MIN', '64'))
 
@@ -366,6 +367,13 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     tiles = getattr(nbr, 'tiles', None) if (math and kvol >= 3) else None
     xwin = getattr(nbr, 'xwin', None) if (math and packed and cin == cout) else None
     if xwin is not None and lib.dz_spconv_x_tile_rows(cin, cout) != xwin[1]:
+        # (windows built for another tile size - e.g. DZ_TUNE_X32 changed after the index was built: the packed gather kernel runs instead)
+        global _XWIN_MISMATCH_LOGGED
+        if not _XWIN_MISMATCH_LOGGED:
+            _XWIN_MISMATCH_LOGGED = True
+            import warnings
+            warnings.warn('spconv_forward: windows built for %d-row units, the %d-channel x-run kernel uses %d - falling back to the packed '
+                          'gather kernel for this table' % (xwin[1], cout, lib.dz_spconv_x_tile_rows(cin, cout)))
         xwin = None
 
     def launch():

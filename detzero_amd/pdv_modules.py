@@ -465,9 +465,12 @@ class PDVHead(_Cached):
                 level = ops.SparseLevel(x_conv.batch_size, x_conv.spatial_shape, max(x_conv.indices.shape[0], 1), points.device)
                 level.build_from_coords(x_conv.indices.int().contiguous(), want_rank=False)
             rows = index_lookup(coords, level)
-            sel = torch.nonzero(rows >= 0).flatten()
+            feats = x_conv.features
+            # (ranks at or beyond the feature rows exist only when a calibrated level overflowed its capacity - FramePipeline.two_stage
+            # refuses such a pass; the mask keeps the gather inside the tensor for any other caller)
+            sel = torch.nonzero((rows >= 0) & (rows < feats.shape[0])).flatten()
             point_coords[loc] = cen[sel][:, :4].contiguous()
-            point_features[loc] = x_conv.features[rows[sel].long()].contiguous()
+            point_features[loc] = feats[rows[sel].long()].contiguous()
             self._point_index[loc] = (coords[sel].contiguous(), dims, vs)
         return point_features, point_coords
 
@@ -587,7 +590,13 @@ class PDVHead(_Cached):
     @staticmethod
     def _fused_encoder_ok(p, positional_input):
         pos, enc = p['pos'], p['enc']
-        return (positional_input.shape[-1] in (4, 8) and len(pos) == 2 and pos[0]['cout'] == 96 and pos[0]['relu'] and pos[1]['cout'] == 192 and
+        if 'pos1_unit_scale' not in p:
+            # the fused front chain applies the second positional layer as w1 x + b1 (no per-channel scale): a BatchNorm behind that
+            # layer (any non-identity scale) takes the layered path instead.  Checked once per plan (one host sync; plans are rebuilt
+            # when the weights are reloaded)
+            sc = pos[1].get('scale') if len(pos) == 2 else None
+            p['pos1_unit_scale'] = sc is None or bool(torch.all(sc[:192] == 1).item())
+        return (p['pos1_unit_scale'] and positional_input.shape[-1] in (4, 8) and len(pos) == 2 and pos[0]['cout'] == 96 and pos[0]['relu'] and pos[1]['cout'] == 192 and
                 not pos[1]['relu'] and tuple(enc['w1'].shape) == (192, 128) and tuple(enc['w2'].shape) == (128, 192))
 
     def _attention_fused(self, p, sm, point_features, positional_input, key_padding_mask, empty, add_pos, r, l, e, pair16_out=False):

@@ -271,6 +271,9 @@ int dz_spconv_forward_split_packed(const float *in, int in_rows, int cin, const 
  *     w (27, cout, cin) pair16, BatchNorm scale / shift, ReLU); per output element the products are accumulated in the order
  *     (tz, 16-channel chunk, tap), so results agree with dz_spconv_forward_split to fp32 summation-order noise, not bit for bit. */
 int dz_spconv_x_tile_rows(int cin, int cout);
+/* rows of a z-slab window the kernel can stage in LDS for this layer (0 = layer not covered); a (tile, slab) whose window is longer
+ * runs in gather mode - same taps, same accumulation order, operands fetched per lane instead of from the staged window */
+int dz_spconv_x_window_rows(int cin, int cout);
 size_t dz_spconv_x_windows_words(int cap_out, int tile_rows);
 int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, int *nbr_sorted, int *perm,
                         void *stream);

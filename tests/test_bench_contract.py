@@ -37,6 +37,14 @@ def test_committed_bench_line_has_the_contract_keys():
             h = r['hbm'][st]
             assert h['bytes'] > 0 and h['ms'] > 0 and abs(h['gbs'] - h['bytes'] / h['ms'] / 1e6) / h['gbs'] < 1e-2
             assert abs(h['frac'] - h['gbs'] / r['hbm_peak_gbs']) < 1e-3
+    if 'hbm_sparse_backbone_frac' in r and 'hbm' not in r:              # r05: flat keys only, the four fractions right behind the contract keys
+        keys = list(r)
+        assert keys[:6] == ['bound', 'achieved', 'peak', 'unit', 'frac', 'traffic']
+        assert keys[6:10] == ['hbm_voxelize_plus_backbone_frac', 'hbm_sparse_backbone_frac', 'hbm_index_frac', 'hbm_voxelize_frac']
+        for st in ('voxelize', 'index', 'sparse_backbone', 'voxelize_plus_backbone'):
+            b, ms, gbs, fr = (r['hbm_%s_%s' % (st, k)] for k in ('bytes', 'ms', 'gbs', 'frac'))
+            assert b > 0 and ms > 0 and abs(gbs - b / ms / 1e6) / gbs < 1e-2 and abs(fr - gbs / r['hbm_peak_gbs']) < 1e-3
+        assert d['config']['latency_ms_per_pass'] == d['ms_per_step'] and 'ref_batch' in d['config']['like_for_like']
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and isinstance(c['sample'], str)
     assert c['unit'] == d['unit']

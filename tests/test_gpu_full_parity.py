@@ -148,6 +148,7 @@ def test_modules_stage_by_stage_160k(full, device, math):
     set_math(model, 'f32')
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize('math', ['f16x2', 'bf16x2'])
 def test_tile_engine_brick_order_160k(full, device, math):
     """The opt-in tile-resident sparse engine (csrc/sparse_conv_t.hip; rows of every level in the brick order) through the batched

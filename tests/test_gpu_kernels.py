@@ -268,6 +268,7 @@ def _random_level(rng, shape, n, batch, device, layout, dense_block=False):
     return lvl
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('kvol', [27, 3])
 def test_build_tiles_is_the_table(device, layout, kvol):
@@ -322,18 +323,21 @@ def test_build_tiles_is_the_table(device, layout, kvol):
     assert worst > 895                                                               # the dense block needs more than one LDS pass
 
 
-@pytest.mark.parametrize('layout', [0, 1])
-@pytest.mark.parametrize('math', ['f16x2', 'bf16x2', 'f16'])
-@pytest.mark.parametrize('cin,cout,kvol', [(16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 27),
-                                           (128, 128, 27), (128, 128, 3)])
+_TILE_SHAPES = [(16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 27), (128, 128, 27), (128, 128, 3)]
+# every shape in both row orders on the default arithmetic; the other math modes run a subset (brick order, three widths)
+_TILE_CASES = ([(ci, co, kv, 'f16x2', lay) for lay in (0, 1) for (ci, co, kv) in _TILE_SHAPES] +
+               [(ci, co, 27, mth, 1) for mth in ('bf16x2', 'f16') for (ci, co) in ((16, 16), (64, 64), (128, 128))] +
+               [(128, 128, 3, mth, 1) for mth in ('bf16x2', 'f16')])
+
+
+@pytest.mark.experimental
+@pytest.mark.parametrize('cin,cout,kvol,math,layout', _TILE_CASES)
 def test_spconv_tiles_vs_oracle_and_gather(device, cin, cout, kvol, math, layout):
     """The tile-resident convolution against the oracle (rulebook + fp32 torch) and against the gather kernels on the same
     pair16 operands, in both row orders; the level holds a fully occupied block, so some tiles run in two LDS passes, the last
     tile is ragged, and the epilogue (BatchNorm scale / shift, residual, ReLU) is exercised with and without its parts."""
     from detzero_amd import ops
     from oracle import sparse as osp
-    if math != 'f16x2' and (layout == 0 or (cin, cout) not in [(16, 16), (64, 64), (128, 128)]):
-        pytest.skip('the other math modes run a subset')
     mid = ops.math_id(math)
     rng = np.random.default_rng(cin * 1000 + cout + kvol)
     shape = [12, 48, 40]
@@ -377,6 +381,7 @@ def test_spconv_tiles_vs_oracle_and_gather(device, cin, cout, kvol, math, layout
         torch.testing.assert_close(a, b, rtol=tol, atol=tol)                          # same products, another summation order
 
 
+@pytest.mark.experimental
 def test_spconv_tiles_small_and_empty(device):
     """Fewer rows than a tile, a level with a single site (one tap: the step list is padded with empty taps), and no rows at all."""
     from detzero_amd import ops

@@ -79,7 +79,8 @@ def test_windows_cover_the_rulebook_exactly(device, channels):
         assert (d <= 0).all() if u & 1 else (d >= 0).all(), u
 
 
-def _run_case(device, rng, lvl, coords, channels, mid, with_res, relu):
+def _run_case(device, rng, lvl, coords, channels, mid, with_res, relu, expect_gather=None):
+    from detzero_amd import lib as L
     from detzero_amd import ops
     from oracle import sparse as osp
     m = coords.shape[0]
@@ -102,6 +103,12 @@ def _run_case(device, rng, lvl, coords, channels, mid, with_res, relu):
     plain = lvl.neighbors_to(lvl, K3, S1, P1)
     xt = ops.build_windows(lvl.neighbors_to(lvl, K3, S1, P1, packed=True), lvl, channels)
     assert getattr(xt, 'xwin', None) is not None
+    if expect_gather is not None:
+        # the windows of a tile are the union of its two units': the longest unit window is a lower bound.  Without this the
+        # gather-mode arm of the kernel (windows beyond the LDS staging capacity) could go untested silently if _level changed
+        rcap = L.load().dz_spconv_x_window_rows(channels, channels)
+        longest = int(xt.xwin[0][:-16].view(-1, 3, 2)[..., 1].max().item())
+        assert rcap > 0 and (longest > rcap) == expect_gather, (channels, longest, rcap)
     a = ops.spconv_forward(x, plain, lvl, ws, _t(scale, device), _t(shift, device), r, relu=relu, math=mid)
     b = ops.spconv_forward(x, xt, lvl, ws, _t(scale, device), _t(shift, device), r, relu=relu, math=mid)
     ga, gb = ops.pair16_to_f32(a, mid)[:m].cpu(), ops.pair16_to_f32(b, mid)[:m].cpu()
@@ -118,10 +125,12 @@ def test_xrun_vs_oracle_and_gather(device, channels, name, mid):
     batch of two, rows that are not a multiple of the tile, with / without residual and ReLU."""
     rng = np.random.default_rng(100 * channels + mid)
     # (shape, per-slab density): the second one puts a 90 %-full slab next to 1 %-full ones -> windows far beyond the LDS capacity
-    for shape, dens, batch in (([6, 36, 50], (0.3, 0.35, 0.25), 2), ([4, 48, 64], (0.01, 0.9, 0.02, 0.5), 1), ([3, 20, 33], (0.08,), 1)):
+    # (third column: the case must / must not contain a window beyond the kernel's staging capacity = a gather-mode stage)
+    for shape, dens, batch, gather in (([6, 36, 50], (0.3, 0.35, 0.25), 2, None), ([4, 48, 64], (0.01, 0.9, 0.02, 0.5), 1, True),
+                                       ([3, 20, 33], (0.08,), 1, False)):
         lvl, coords = _level(rng, batch, shape, dens, device)
         for with_res, relu in ((True, True), (False, False)):
-            _run_case(device, rng, lvl, coords, channels, mid, with_res, relu)
+            _run_case(device, rng, lvl, coords, channels, mid, with_res, relu, expect_gather=gather)
 
 
 def test_xrun_single_product_mode(device):
