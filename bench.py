@@ -122,6 +122,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
+    ap.add_argument('--dump-launches', default=None, help='file: every conv launch of one eager pass in launch order (us, GFLOP, MB)')
     ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
     ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
@@ -303,6 +304,15 @@ class Case:
                 self.load_inputs(i)
                 self.pipe(self.static_in)
             agg = prof.summary()
+            if getattr(self.args, 'dump_launches', None):
+                # every launch of the LAST eager pass, in launch order (the per-layer view the aggregated `kernels` list hides)
+                per_pass = len(prof.records) // max(passes, 1)
+                with open(self.args.dump_launches, 'w') as f:
+                    f.write('# launch order of one eager pass (%d frames): kernel, us, algorithmic GFLOP, algorithmic MB, TF/s, GB/s\n' % self.B)
+                    for name, flops, nbytes, e0, e1 in prof.records[-per_pass:]:
+                        ms = e0.elapsed_time(e1)
+                        f.write('%-34s %9.1f us %9.2f GF %9.1f MB %8.1f TF/s %8.1f GB/s\n' % (name, 1000.0 * ms, flops / 1e9, nbytes / 1e6,
+                                                                                           flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9))
         finally:
             ops.PROFILER = None
         kern = []

@@ -1,36 +1,93 @@
 #!/bin/bash
-# One GPU-box session: gpu test-suite (single process, as the driver runs it), smoke, bench, rocprofv3.
-# usage: tools/gpu_round.sh [quick|full]   (quick: no PMC passes, no eager bench)
-MODE=${1:-full}
+# The evidence set of a round on ONE GPU box (replaces gpu_round2/3/4.sh, gpu_profiles.sh, gpu_pmc*.sh, gpu_trace*.sh, gpu_x_diag.sh,
+# gpu_pdv_prof.sh of earlier rounds): gpu test-suite, smoke, the default bench line (all legs), rocprofv3 kernel trace of the headline
+# command, HBM-side PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes - never together with a trace domain) and the SQ matrix-pipe
+# counters of the same command, the per-layer sparse benchmark of both engines, the x-run kernel's in-kernel cycle accounting
+# (diag build), the refiner and two-stage (PDV) benches with their traces.
+# usage: tools/gpu_round.sh <tag> [sections]     tag = r05a ...; sections = any of: tests bench trace pmc sq layers xdiag refine pdv
+#        (default: all).  Outputs -> gpurun_out/<round>/<tag>_*  (copy what is to be judged into profiles/).
+TAG=${1:-r05a}
+SECT=${2:-tests bench trace pmc sq layers xdiag refine pdv}
 cd "$(dirname "$0")/.."
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof
-echo "==== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 2>&1 | tail -15
-echo "==== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-echo "==== bench (graph)"; timeout 600 python bench.py --steps 100 --warmup 10 2> gpurun_out/bench_graph.err | tee gpurun_out/bench_graph.json | cut -c1-700; tail -4 gpurun_out/bench_graph.err
-python - <<'PY'
+O=$ROOT/gpurun_out/${TAG:0:3}
+mkdir -p $O
+has() { case " $SECT " in *" $1 "*) return 0;; *) return 1;; esac; }
+COMMON="--steps 20 --warmup 5 --no-graph --no-cpu-baseline --profile-frames 0 --no-aux --no-refine --no-pdv"
+PARGS="--steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 --no-aux --no-refine --no-pdv"
+trace() {   # name, command...
+  local name=$1; shift
+  echo "==== rocprofv3 kernel-trace: $name ($*)"
+  rm -rf $O/trace_$name; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- "$@" > $O/trace_${name}_stdout.txt 2>&1 )
+  python tools/rocpd_summary.py $O/trace_$name/t_results.db > $O/${TAG}_kernel_trace_$name.txt; head -${TRACE_HEAD:-16} $O/${TAG}_kernel_trace_$name.txt
+}
+if has tests; then
+  echo "==== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider 2>&1 | tail -4 | tee $O/${TAG}_gputests.txt
+  echo "==== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $O/${TAG}_smoke.txt
+fi
+if has bench; then
+  echo "==== bench (default command)"; timeout 900 python bench.py 2> $O/${TAG}_bench.err > $O/${TAG}_bench_graph.json; tail -14 $O/${TAG}_bench.err
+fi
+if has trace; then trace bench_eager20 python $ROOT/bench.py $COMMON; fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "==== rocprofv3 pmc $c"
+    rm -rf $O/pmc_$c; ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o bench -- python $ROOT/bench.py $PARGS > $O/pmc_${c}_stdout.txt 2>&1 )
+    python tools/rocpd_summary.py $O/pmc_$c/bench_results.db --json $O/pmc_$c.json | sed -n '/PMC/,$p' > $O/${TAG}_pmc_${c}_bench_eager3.txt; head -8 $O/${TAG}_pmc_${c}_bench_eager3.txt
+  done
+  python - <<PY
 import json
-try:
-    d = json.load(open('gpurun_out/bench_graph.json'))
-    print('value', d['value'], 'ms', d['ms_per_step'], 'cpu', d.get('cpu_baseline', {}).get('value'))
-    for k in d['kernels']:
-        print('  %-32s x%-5.1f avg %8.2f us  %7.3f ms/step  %6.2f TF/s  %7.1f GB/s' % (k['kernel'], k['launches_per_step'], k['avg_us'], k['ms_per_step'], k['tflops'], k['algorithmic_gbs']))
-except Exception as e:
-    print('no bench json', e)
+out = {}
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    try:
+        for k, v in json.load(open('$O/pmc_%s.json' % c)).items():
+            out.setdefault(k, {}).update(v)
+    except Exception as e:
+        print('no', c, e)
+json.dump(out, open('$O/${TAG}_pmc_traffic.json', 'w'), indent=1, sort_keys=True)
+print('traffic entries', len(out))
+for k, v in sorted(out.items()):
+    if 'spconv' in k or 'conv3x3' in k or 'conv2d' in k:
+        rd = 2.0 * 1024.0 * v.get('FETCH_SIZE', {'per_call': 0})['per_call']; wr = 1024.0 * v.get('WRITE_SIZE', {'per_call': 0})['per_call']
+        print('%-60s read %7.1f MB  write %7.1f MB per launch' % (k[:60], rd / 1e6, wr / 1e6))
 PY
-if [ "$MODE" = "full" ]; then
-echo "==== bench (eager)"; timeout 300 python bench.py --steps 50 --warmup 5 --no-graph --no-cpu-baseline 2> gpurun_out/bench_eager.err | tee gpurun_out/bench_eager.json | cut -c1-300
 fi
-echo "==== rocprofv3 kernel-trace (eager, 20 steps)"
-rm -rf gpurun_out/prof/trace
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/trace_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-python tools/rocpd_summary.py gpurun_out/prof/trace/bench_results.db > gpurun_out/prof/trace_summary.txt; head -32 gpurun_out/prof/trace_summary.txt
-if [ "$MODE" = "full" ]; then
-for c in FETCH_SIZE WRITE_SIZE; do
-echo "==== rocprofv3 pmc $c"
-rm -rf gpurun_out/prof/pmc_$c
-cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$c -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --profile-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_${c}_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-python tools/rocpd_summary.py gpurun_out/prof/pmc_$c/bench_results.db --json gpurun_out/prof/pmc_$c.json | sed -n '/PMC/,$p' > gpurun_out/prof/pmc_${c}_summary.txt; head -12 gpurun_out/prof/pmc_${c}_summary.txt
-done
+if has sq; then
+  echo "==== rocprofv3 pmc SQ (matrix pipe)"
+  rm -rf $O/pmc_sq; ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/pmc_sq -o bench -- python $ROOT/bench.py $PARGS > $O/pmc_sq_stdout.txt 2>&1 )
+  python tools/rocpd_summary.py $O/pmc_sq/bench_results.db | sed -n '/PMC/,$p' > $O/${TAG}_pmc_SQ_bench_eager3.txt; grep -E "MFMA_BUSY" $O/${TAG}_pmc_SQ_bench_eager3.txt | head -10
 fi
-find gpurun_out/prof -name "*.db" -delete
+if has layers; then
+  echo "==== per-layer sparse benchmark, both engines"
+  for e in gather xrun; do DZ_TUNE_SPCONV_ENGINE=$e timeout 300 python tools/bench_spconv.py --batch 16 --reps 20 --math f16x2 2>&1 | tail -23 > $O/${TAG}_spconv_layers_$e.txt; tail -1 $O/${TAG}_spconv_layers_$e.txt; done
+fi
+if has xdiag; then
+  # k_spconv_x with in-kernel cycle counters / one effect removed at a time (-DDZ_SPCONV_DIAG build of sparse_conv_x.hip; DZ_TUNE_X_DIAG
+  # bits: 1 no MFMAs, 2 no fragment LDS reads, 4 no weight loads, 8 no window loads, 16 no barriers, 32 no epilogue, 512 cycle counters;
+  # results are garbage for all but 512, times are not).  XDIAG="512 1 2 ..." picks the list.
+  echo "==== x-run kernel: cycle accounting (diag build)"
+  cp detzero_amd/libdetzero_hip.so /tmp/libdz_orig.so
+  objs=$(ls detzero_amd/csrc/build/*.o | grep -v sparse_conv_x.o)
+  if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -DDZ_SPCONV_DIAG -c detzero_amd/csrc/sparse_conv_x.hip -o /tmp/spx_diag.o 2>/dev/null &&
+     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/spx_diag.o -o detzero_amd/libdetzero_hip.so 2>/dev/null; then
+    for d in ${XDIAG:-512}; do
+      echo "== DZ_TUNE_X_DIAG=$d"
+      DZ_TUNE_SPCONV_ENGINE=xrun DZ_TUNE_X_DIAG=$d timeout 200 python tools/bench_spconv.py --batch 16 --math f16x2 --reps 5 --only 32-32,64-64,128-128 > /tmp/xd.txt 2>&1
+      grep -E "^x" /tmp/xd.txt | grep -v "+res" | sort -u | cut -c1-30,95-125; grep x-dbg /tmp/xd.txt | sort -u
+    done 2>&1 | grep -v "steps/wave *per wave" | tee $O/${TAG}_xrun_cycles.txt
+  else echo "diag build failed"; fi
+  cp /tmp/libdz_orig.so detzero_amd/libdetzero_hip.so
+fi
+if has refine; then
+  echo "==== refiner"
+  for m in f32 f16x2; do timeout 300 python tools/bench_refine.py --math $m 2>/dev/null | tail -1 > $O/${TAG}_bench_refine_$m.json; cut -c1-500 $O/${TAG}_bench_refine_$m.json; done
+fi
+if has pdv; then
+  echo "==== two-stage detector (PDV second stage)"
+  for b in 1 8; do timeout 300 python tools/bench_pdv.py --math f16x2 --batch $b 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv_b$b.json; cat $O/${TAG}_bench_pdv_b$b.json; done
+  for b in 8 16; do timeout 300 python tools/bench_pdv.py --math f16x2 --batch $b --pipeline 2>/dev/null | tail -1 > $O/${TAG}_bench_pdv_pipeline_b$b.json; cat $O/${TAG}_bench_pdv_pipeline_b$b.json; done
+  timeout 300 python tools/bench_pdv.py --math f16x2 --batch 8 --reps 5 --phases > $O/${TAG}_pdv_phases_b8.json 2> $O/${TAG}_pdv_phases_b8.txt; tail -20 $O/${TAG}_pdv_phases_b8.txt
+  TRACE_HEAD=45 trace pdv_b8 python $ROOT/tools/bench_pdv.py --math f16x2 --batch 8 --reps 5 ${PDV_TRACE_ARGS}
+fi
+find $O -name "*.db" -delete
