@@ -34,6 +34,12 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const int grp = by / ntn;
     const int n0 = (by % ntn) * T::BC;
     const long row0 = (long)(lid / nty) * T::BP;
+    // phase groups (ConvTranspose2d with kernel == stride in one launch): group g = phase (g / out_sx, g % out_sx) of the output
+    // pixel block; all phases read the same input channels and share scale / shift.  The XCD-aware order above puts the phases
+    // of a pixel tile next to each other, so the input tile comes from HBM once and from that XCD's L2 for the other phases
+    const bool phases = p.phase_groups != 0;
+    const int ph_dy = phases ? grp / p.out_sx : 0, ph_dx = phases ? grp % p.out_sx : 0;
+    const int ssg = phases ? 0 : grp;                 // scale / shift / input-channel group
 
     for (int r = tid; r < T::BP; r += 256) {
         const long mrow = row0 + r;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
             const int y = (int)(t % p.ho);
             const int b = (int)(t / p.ho);
             ip = (b * p.in_hp + y * p.stride + p.in_off) * p.in_wp + x * p.stride + p.in_off;
-            op = (b * p.out_hp + y * p.out_sy + p.out_dy) * p.out_wp + x * p.out_sx + p.out_dx;
+            op = (b * p.out_hp + y * p.out_sy + p.out_dy + ph_dy) * p.out_wp + x * p.out_sx + p.out_dx + ph_dx;
         }
         in_pix[r] = ip;
         out_pix[r] = op;
@@ -52,8 +58,8 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     if constexpr (!OUT_F32) {
         for (int c = tid; c < T::BC; c += 256) {
             const bool in = n0 + c < p.g_cout[grp];
-            sc_s[c] = (in && p.scale) ? p.scale[grp * p.cout_pad + n0 + c] : 1.f;
-            sh_s[c] = (in && p.shift) ? p.shift[grp * p.cout_pad + n0 + c] : 0.f;
+            sc_s[c] = (in && p.scale) ? p.scale[ssg * p.cout_pad + n0 + c] : 1.f;
+            sh_s[c] = (in && p.shift) ? p.shift[ssg * p.cout_pad + n0 + c] : 0.f;
         }
     }
     __syncthreads();
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
     const int taps = p.kh * p.kw;
     const int kchunks = p.cin / T::KC;
     const int nchunks = taps * kchunks;
-    const long cbase = p.in_coff + (long)grp * p.cin;
+    const long cbase = p.in_coff + (long)ssg * p.cin;
 
     const srsrc_t prsrc = make_srsrc(p.in, in_bytes);
     const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
                         if (out_pix[lr] < 0 || col >= gcout) continue;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float sc = p.scale ? p.scale[grp * p.cout_pad + col + e] : 1.f;
-                            const float sh = p.shift ? p.shift[grp * p.cout_pad + col + e] : 0.f;
+                            const float sc = p.scale ? p.scale[ssg * p.cout_pad + col + e] : 1.f;
+                            const float sh = p.shift ? p.shift[ssg * p.cout_pad + col + e] : 0.f;
                             float a = acc[ct][pt][4 * j + e];
                             if (p.group_shift) a += p.group_shift[(size_t)grow * p.cout_pad + col + e];
                             a = fmaf(a, sc, sh);
@@ -189,8 +195,8 @@ __global__ __launch_bounds__(256) void k_conv2d_h(dz_conv2d_desc p, long m_total
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float sc = p.scale ? p.scale[grp * p.cout_pad + col + e] : 1.f;
-                    const float sh = p.shift ? p.shift[grp * p.cout_pad + col + e] : 0.f;
+                    const float sc = p.scale ? p.scale[ssg * p.cout_pad + col + e] : 1.f;
+                    const float sh = p.shift ? p.shift[ssg * p.cout_pad + col + e] : 0.f;
                     float a = acc[ct][pt][4 * j + e];
                     // per-row-group addend of the PointNet concat (linear layers: output pixel index = row)
                     if (p.group_shift) a += p.group_shift[(size_t)(op / p.group_rows) * p.cout_pad + col + e];
@@ -300,7 +306,10 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
     DZ_CHECK_ARG((d->ho - 1) * d->stride + d->in_off + d->kh - 1 < d->in_hp &&
                  (d->wo - 1) * d->stride + d->in_off + d->kw - 1 < d->in_wp && d->in_off >= 0,
                  "dz_conv2d_forward_split: taps leave the input image");
-    DZ_CHECK_ARG((d->ho - 1) * d->out_sy + d->out_dy < d->out_hp && (d->wo - 1) * d->out_sx + d->out_dx < d->out_wp,
+    DZ_CHECK_ARG(!d->phase_groups || (d->groups == d->out_sy * d->out_sx && d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->group_shift && !d->group_max),
+                 "dz_conv2d_forward_split: phase_groups needs groups == out_sy * out_sx (<= 8) and a 1x1 kernel");
+    const int ph_y = d->phase_groups ? d->out_sy - 1 : 0, ph_x = d->phase_groups ? d->out_sx - 1 : 0;
+    DZ_CHECK_ARG((d->ho - 1) * d->out_sy + d->out_dy + ph_y < d->out_hp && (d->wo - 1) * d->out_sx + d->out_dx + ph_x < d->out_wp,
                  "dz_conv2d_forward_split: output leaves the output image");
     if ((long)d->batch * d->ho * d->wo == 0) return DZ_OK;
     const size_t w_bytes = (size_t)d->groups * d->kh * d->kw * d->cout_pad * d->cin * sizeof(float);

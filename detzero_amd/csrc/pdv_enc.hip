@@ -198,7 +198,9 @@ struct EncBackArgs {
 };
 constexpr int VB_BO = 0, VB_G1 = 192, VB_BE1 = 384, VB_B1 = 576, VB_B2 = 704, VB_G2 = 896, VB_BE2 = 1088;
 
-template <class M>
+// OP16: the result as pair16 rows (the FC stack's operand) instead of fp32 - a template parameter, not a run-time branch: with both
+// store sequences in the code the six LayerNorm2 accumulators were spilled around the branch (r04: 400 bytes of scratch per lane)
+template <class M, bool OP16>
 __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_enc_back(EncBackArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     float *const vec = reinterpret_cast<float *>(sm + EN_OFF_VEC);
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- hidden = ReLU(W1 . x + b1)
+        asm volatile("" : "+v"(tid), "+v"(l31), "+v"(h));      // (per phase: the address temporaries of one phase must not stay live - spilled - through the next)
         v4u hh[8], hl[8];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             ring = ring + 1 == EN_RING ? 0 : ring + 1;
         }
         // ---- y = LayerNorm2(x + W2 . hidden + b2)
+        asm volatile("" : "+v"(tid), "+v"(l31), "+v"(h));
         v4u pa[4], pb[4];                                // pooled features of a fragment: two k-steps x two 16-byte loads (fp32)
         auto load_p = [&](v4u (&p)[4], int c) {
 #pragma unroll
@@ -378,6 +382,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         en_layernorm<6>(acc, vec + VB_G2, vec + VB_BE2, a.eps2, h);
         __builtin_amdgcn_sched_barrier(0);
         // ---- out = pooled + (skip ? pooled : y), fragment by fragment: the pooled rows arrive as operands (split here) one fragment ahead
+        asm volatile("" : "+v"(tid), "+v"(l31), "+v"(h));
         const bool sk = skip != 0u;
         const float pscale = sk ? 2.f : 1.f;
 #pragma unroll
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 en_split8<M>((c & 1) ? pb[2 * sl] : pa[2 * sl], (c & 1) ? pb[2 * sl + 1] : pa[2 * sl + 1], pscale, ph, pl);
                 d = en_add_rows<M>(d, en_identity<M>(sl, l31, h), ph, pl);
             }
-            if (a.out_pair16) {                          // (wave-uniform; four stores either way: the counted waits hold)
+            if constexpr (OP16) {                        // (four stores either way: the counted waits hold)
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = d[e];
@@ -656,8 +661,13 @@ int dz_pdv_encoder_back(const float *op, const float *src, const float *pooled, 
     if ((size_t)rows * EN_ROWB >= 0x80000000ull) { set_error("dz_pdv_encoder_back: %ld rows exceed the 2 GiB buffer-addressing limit", rows); return DZ_ERR_UNSUPPORTED; }
     const EncBackArgs a{op, src, pooled, row_skip, wo, w1, w2, bo, g1, be1, b1, b2, g2, be2, out, rows, eps1, eps2, out_pair16 ? 1 : 0};
     int rc;
-    if (math == DZ_MATH_F16X2) { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathF16>, a, rows, "dz_pdv_encoder_back", done, stream); }
-    else { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathBF16>, a, rows, "dz_pdv_encoder_back", done, stream); }
+    if (math == DZ_MATH_F16X2) {
+        if (a.out_pair16) { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathF16, true>, a, rows, "dz_pdv_encoder_back", done, stream); }
+        else { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathF16, false>, a, rows, "dz_pdv_encoder_back", done, stream); }
+    } else {
+        if (a.out_pair16) { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathBF16, true>, a, rows, "dz_pdv_encoder_back", done, stream); }
+        else { static PerDeviceFlags done; rc = en_launch(&k_enc_back<MathBF16, false>, a, rows, "dz_pdv_encoder_back", done, stream); }
+    }
     if (rc) return rc;
     DZ_LAUNCH_CHECK();
     return DZ_OK;

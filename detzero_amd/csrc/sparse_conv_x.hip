@@ -58,6 +58,7 @@ struct SpConvXArgs {
     unsigned long long *dbg;    // DIAG bit 9 builds: per-wave cycle sums (8 words per wave) or null
     const int *perm;            // output row of each (unit, position) when the table is in tap-set order, or null
     int *queue;                 // 10 words behind the windows: next ticket of each XCD's tile queue, workgroups done, single-unit queue
+    int xrun;                   // consecutive tiles per XCD run (8; DZ_TUNE_XRUN)
 };
 
 template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int nunits = (m + C::UR - 1) / C::UR;
     // tiles of two units while at least a unit per workgroup remains beyond them (a multiple of 64 = whole runs for all 8 queues), then
     // single units
-    const int nfull = (max(nunits - (int)gridDim.x, 0) / 2) / 64 * 64;
+    const int XRUN = a.xrun;
+    const int nfull = (max(nunits - (int)gridDim.x, 0) / 2) / (8 * XRUN) * (8 * XRUN);
     const int nk = a.cin / 16;
     const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes), crsrc = make_srsrc(a.w, a.w_bytes), nrsrc = make_srsrc(a.nbr, a.nbr_bytes);
     const unsigned int row_bytes = (unsigned int)a.cin * 4u, tap_bytes = (unsigned int)(COUT * a.cin * 4);
@@ -229,7 +231,6 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // resets the counters for the next launch.  Inside a tile: tz, 16-channel chunk.
     // (The returning atomic is a plain, compiler-tracked one: an asynchronous one from inline asm does not survive the register copies
     // the compiler inserts at loop edges - they read the destination before the value has landed.)
-    constexpr int XRUN = 8;
     const int xcd = blockIdx.x & 7;
     int *const tk_s = reinterpret_cast<int *>(smem + C::OFF_TK);
     // a ticket: q < nfull / 8 = the q-th full tile of my XCD's queue; past those, 2^30 + s = the s-th single unit of the common queue
@@ -743,6 +744,10 @@ using X128 = XCfg<128, 4, 2, 2, 3, 2, 640>;
 // short window
 using X32B = XCfg<32, 4, 1, 2, 3, 2, 448>;
 using X32C = XCfg<32, 4, 1, 2, 9, 1, 320>;
+static int x_run_len() {          // tiles per XCD run (development knob; a power of two in [1, 64])
+    static const int v = getenv("DZ_TUNE_XRUN") ? atoi(getenv("DZ_TUNE_XRUN")) : 8;
+    return v >= 1 && v <= 64 && (v & (v - 1)) == 0 ? v : 8;
+}
 static int x32_variant() {
     static const int v = getenv("DZ_TUNE_X32") ? atoi(getenv("DZ_TUNE_X32")) : 0;
     return v;
@@ -876,7 +881,7 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
                   (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr, perm,
-                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6};
+                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6, x_run_len()};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);
 }

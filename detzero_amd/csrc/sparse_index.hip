@@ -550,6 +550,150 @@ __global__ __launch_bounds__(256) void k_build_neighbors_rows(const int *__restr
     }
 }
 
+// k_build_neighbors_xwin: the PACKED submanifold table (k_build_neighbors_rows<3, 3, 3, true, true>) AND what the x-run convolution
+// needs on top of it (csrc/sparse_conv_x.hip: dz_spconv_x_windows) in ONE launch - the windows of every unit of `tile_rows` output
+// rows and, optionally, the unit's rows in tap-set order (perm + the re-ordered table).  Round 4 ran k_xwin as a second kernel that
+// read the whole table back (105 us per level and step at 32 frames); here a workgroup owns one 256-row block (one or two units),
+// every thread keeps the nine words of its row in registers, and the window bounds / the counting sort run on them.
+// Block order: XCD x takes the x-th contiguous eighth of the live blocks (the bitmap / prefix lines of a row's y and z neighbours
+// stay in one L2, as in k_build_neighbors_rows).
+__global__ __launch_bounds__(256) void k_build_neighbors_xwin(const int *__restrict__ coords_out, const int *__restrict__ d_m_out, int cap_out,
+                                                              const uint32_t *__restrict__ bitmap_in, const uint32_t *__restrict__ prefix_in,
+                                                              LevelGeom li, int *__restrict__ nbr, uint32_t *__restrict__ tile_masks, int mask_rows,
+                                                              uint32_t last_base, uint32_t index_bytes, uint32_t nbr_bytes, int tile_rows,
+                                                              int *__restrict__ win, int *__restrict__ nbr_sorted, int *__restrict__ perm) {
+    __shared__ int lo_s[2][3], hi_s[2][3];
+    __shared__ __attribute__((aligned(16))) unsigned int key_s[256];
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(nbr, 0, nbr_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bmr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(bitmap_in), 0, index_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pfr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(prefix_in), 0, index_bytes, 0x00020000);
+    const uint32_t row_bytes = (uint32_t)cap_out * 4u;
+    const int m = min(*d_m_out, cap_out);
+    const int tid = threadIdx.x;
+    const int nunits = (cap_out + tile_rows - 1) / tile_rows;
+    if (blockIdx.x == 0 && tid < 16) win[(size_t)nunits * 6 + tid] = 0;       // the tile queues of dz_spconv_forward_split_x
+    const int nblk = (m + 255) >> 8;                                          // live 256-row blocks
+    const int per = (nblk + 7) >> 3;
+    const int b_lo = (int)(blockIdx.x & 7u) * per, b_hi = min(nblk, b_lo + per);
+    const int upb = 256 / tile_rows;                                          // units per block: 1 or 2
+    const int su = tid / tile_rows, ui = tid - su * tile_rows;                // my unit of the block, my index in it
+    // mask words and windows past the live blocks: zero
+    for (int o = nblk * 256 + blockIdx.x * 256 + tid; o < mask_rows; o += gridDim.x * 256)
+        if ((tid & 31) == 0) tile_masks[o >> 5] = 0u;
+    for (int u = nblk * upb + blockIdx.x * 256 + tid; u < nunits; u += gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) win[(size_t)u * 6 + k] = 0;
+    }
+    for (int blk = b_lo + (int)(blockIdx.x >> 3); blk < b_hi; blk += (int)(gridDim.x >> 3)) {
+        const int o = blk * 256 + tid;
+        const bool mine = o < m;
+        if (tid < 6) { (&lo_s[0][0])[tid] = 0x7FFFFFFF; (&hi_s[0][0])[tid] = -1; }
+        int4 c = make_int4(0, 0, 0, 0);
+        if (mine) c = reinterpret_cast<const int4 *>(coords_out)[o];
+        const uint32_t voff = (uint32_t)o * 4u;
+        const int uxc = c.w;                                                  // centre cell (submanifold: the row's own x)
+        const bool lv = uxc > 0, rv = uxc + 1 < li.w;
+        const int uz0 = c.y - 1, uy0 = c.z - 1;
+        const uint32_t key00 = (uint32_t)(((c.x * li.d + uz0) * li.h + uy0) * li.w + uxc);
+        struct Slab { nbr_u3 word[3], pref[3]; uint32_t kc[3], base[3]; bool ok[3], edge; } sl[3];
+        auto fetch = [&](int tz, Slab &q) {
+            q.edge = false;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                q.ok[ty] = mine && (unsigned)(uz0 + tz) < (unsigned)li.d && (unsigned)(uy0 + ty) < (unsigned)li.h;
+                q.kc[ty] = q.ok[ty] ? key00 + (uint32_t)((tz * li.h + ty) * li.w) : 32u;
+                const uint32_t wc = q.kc[ty] >> 5;
+                q.edge |= wc - 1u > last_base;
+                q.base[ty] = min(wc > 0u ? wc - 1u : 0u, last_base);
+                q.word[ty] = __builtin_amdgcn_raw_buffer_load_b96(bmr, q.base[ty] * 4u, 0, 0);
+                q.pref[ty] = __builtin_amdgcn_raw_buffer_load_b96(pfr, q.base[ty] * 4u, 0, 0);
+            }
+        };
+        uint32_t words[9];
+        uint32_t bits = 0u;
+        fetch(0, sl[0]);
+#pragma unroll
+        for (int tz = 0; tz < 3; ++tz) {
+            if (tz + 1 < 3) fetch(tz + 1, sl[tz + 1]);
+            const Slab &q = sl[tz];
+            const bool any_edge = __any(q.edge);
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const int r = tz * 3 + ty;
+                const uint32_t bc = q.kc[ty] & 31u;
+                int vl, vc, vr;
+                if (any_edge) nbr_row3<true>(q.word[ty], q.pref[ty], (int)((q.kc[ty] >> 5) - q.base[ty]), bc, q.ok[ty], lv, rv, vl, vc, vr);
+                else nbr_row3<false>(q.word[ty], q.pref[ty], 1, bc, q.ok[ty], lv, rv, vl, vc, vr);
+                const uint32_t rr = vl >= 0 ? (uint32_t)vl + 1u : (vc >= 0 ? (uint32_t)vc : (vr >= 0 ? (uint32_t)vr : 0u));
+                const uint32_t e = rr | (vl >= 0 ? 1u << 29 : 0u) | (vc >= 0 ? 1u << 30 : 0u) | (vr >= 0 ? 1u << 31 : 0u);
+                words[r] = mine ? e : 0u;
+                if (mine) __builtin_amdgcn_raw_buffer_store_b32((int)e, tab, voff, (uint32_t)r * row_bytes, 0);
+                bits |= ((vl >= 0 ? 1u : 0u) | (vc >= 0 ? 2u : 0u) | (vr >= 0 ? 4u : 0u)) << (r * 3);
+            }
+        }
+        {
+            uint32_t gb = bits;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) gb |= (uint32_t)__shfl_xor((int)gb, d, 64);
+            if ((tid & 31) == 0 && o < mask_rows) tile_masks[o >> 5] = gb;
+        }
+        __syncthreads();                                                      // lo_s / hi_s initialised
+        // ---- windows of my unit: first / last referenced input row of every z slab (as k_xwin, sparse_conv_x.hip)
+#pragma unroll
+        for (int tz = 0; tz < 3; ++tz) {
+            int lo = 0x7FFFFFFF, hi = -1;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const uint32_t e = words[tz * 3 + ty];
+                if (!(e >> 29)) continue;
+                const int r = (int)(e & 0x1FFFFFFFu), l = (int)((e >> 29) & 1u), cc = (int)((e >> 30) & 1u), rt = (int)(e >> 31);
+                lo = min(lo, r - l);
+                hi = max(hi, rt ? r + cc : (cc ? r : r - 1));
+            }
+            // (a wavefront lies inside one unit: units are 128 or 256 rows)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                lo = min(lo, __shfl_xor(lo, d, 64));
+                hi = max(hi, __shfl_xor(hi, d, 64));
+            }
+            if ((tid & 63) == 0 && hi >= 0) { atomicMin(&lo_s[su][tz], lo); atomicMax(&hi_s[su][tz], hi); }
+        }
+        const int unit = blk * upb + su, row0 = unit * tile_rows;
+        unsigned int key = 0x8000000u;
+        if (perm) {
+            const unsigned int k27 = (unit & 1) ? (0x7FFFFFFu - (bits & 0x7FFFFFFu)) : (bits & 0x7FFFFFFu);      // odd units descending
+            key = mine ? k27 : 0x8000000u;
+            key_s[tid] = key;
+        }
+        __syncthreads();
+        if (ui < 3 && unit < nunits) {
+            const int tz = ui;
+            int lo = lo_s[su][tz], n = hi_s[su][tz] >= 0 ? hi_s[su][tz] - lo + 1 : 0;
+            if (n == 0) lo = 0;
+            if (tz == 1 && n == 0 && row0 < m) n = 1;        // a live unit always runs its centre slab
+            win[(size_t)unit * 6 + 2 * tz] = lo;
+            win[(size_t)unit * 6 + 2 * tz + 1] = n;
+        }
+        if (perm) {
+            // rank of my (tap set, row) key among my unit's keys by counting (broadcast LDS reads, no exchange stages)
+            int rank = 0;
+            const unsigned int *ks = key_s + su * tile_rows;
+            for (int j = 0; j < tile_rows; j += 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&ks[j]);
+                rank += (v.x < key || (v.x == key && j < ui)) + (v.y < key || (v.y == key && j + 1 < ui)) + (v.z < key || (v.z == key && j + 2 < ui)) +
+                        (v.w < key || (v.w == key && j + 3 < ui));
+            }
+            const int pos = row0 + rank;
+            if (pos < cap_out) {
+                perm[pos] = o;
+#pragma unroll
+                for (int g = 0; g < 9; ++g) nbr_sorted[(size_t)g * cap_out + pos] = (int)words[g];
+            }
+        }
+        __syncthreads();                                                      // key_s / lo_s are rewritten by the next block
+    }
+}
+
 // general form (brick key layout, other kernel widths / paddings): one thread per (o, tz, ty) row of kW taps; the tap masks are
 // collected with atomics into zero-filled words.
 __global__ __launch_bounds__(256) void k_build_neighbors(const int *__restrict__ coords_out,
@@ -798,6 +942,29 @@ int dz_build_neighbors_packed(const int *coords_out, const int *d_m_out, int cap
     hipLaunchKernelGGL((k_build_neighbors_rows<3, 3, 3, true, true>), grid, dim3(256), 0, stream, coords_out, d_m_out, cap_out, bitmap_in,
                        prefix_in, li, g, nbr, tile_masks, mask_rows, (uint32_t)(index_words - 3), (uint32_t)(index_words * 4),
                        (uint32_t)table_bytes);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_build_neighbors_packed_x(const int *coords, const int *d_m, int cap, const uint32_t *bitmap, const uint32_t *prefix, int b, int d, int h,
+                                int w, int *nbr, uint32_t *tile_masks, int tile_rows, int *windows, int *nbr_sorted, int *perm, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(coords && d_m && bitmap && prefix && nbr && tile_masks && windows, "dz_build_neighbors_packed_x: null argument");
+    DZ_CHECK_ARG(b >= 1 && d >= 1 && h >= 1 && w >= 1 && cap >= 0, "dz_build_neighbors_packed_x: bad grid");
+    DZ_CHECK_ARG(tile_rows == 128 || tile_rows == 256, "dz_build_neighbors_packed_x: tile_rows %d (128 or 256: dz_spconv_x_tile_rows)", tile_rows);
+    DZ_CHECK_ARG((nbr_sorted == nullptr) == (perm == nullptr), "dz_build_neighbors_packed_x: nbr_sorted and perm come together");
+    const size_t table_bytes = (size_t)9 * cap * sizeof(int);
+    if (table_bytes >= 0xFFFFFFFFull || cap >= (1 << 29)) {
+        set_error("dz_build_neighbors_packed_x: needs fewer than 2^29 rows");
+        return DZ_ERR_UNSUPPORTED;
+    }
+    if (cap == 0) return DZ_OK;
+    const LevelGeom li = make_level(b, d, h, w, DZ_LAYOUT_LINEAR);
+    const int mask_rows = tile_masks_words(cap) * 32;
+    const size_t index_words = dz_index_words(b, d, h, w, DZ_LAYOUT_LINEAR);
+    const dim3 grid((std::min(ceil_div(cap, 256), 2048) + 7) & ~7);
+    hipLaunchKernelGGL(k_build_neighbors_xwin, grid, dim3(256), 0, stream, coords, d_m, cap, bitmap, prefix, li, nbr, tile_masks, mask_rows,
+                       (uint32_t)(index_words - 3), (uint32_t)(index_words * 4), (uint32_t)table_bytes, tile_rows, windows, nbr_sorted, perm);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -377,7 +377,7 @@ class VoxelResBackBone8x(_Cached):
             if (xrun and src is dst and cout in xrun_couts and tuple(k) == (3, 3, 3) and dst.cap < (1 << 29)
                     and ops.L.load().dz_spconv_x_tile_rows(int(cout), int(cout)) != 0):
                 # submanifold table of a level the x-run kernel covers: packed words + the tiles' windows
-                nbr = ops.build_windows(src.neighbors_to(dst, k, s, p, packed=True), dst, cout)
+                nbr = ops.neighbors_xrun(dst, cout)          # (one launch: packed table + windows + tap-set order)
                 if getattr(nbr, 'xwin', None) is not None:
                     return nbr
             nbr = src.neighbors_to(dst, k, s, p, packed=pack and cout <= 32)
@@ -603,9 +603,12 @@ def _recode(img, enc, math):
     return ops.pair16_from_f32(plain, math=math) if math else plain
 
 
+FUSED_DEBLOCK_PHASES = os.environ.get('DZ_TUNE_DEBLOCK_PHASES', '1') != '0'     # development switch: 0 = one launch per phase (r01-r04)
+
+
 def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_cstride, in_coff=0, ksize=3,
                stride=1, in_off=0, out_cstride, out_coff=0, out_s=1, out_d=(0, 0), groups=1, cout_pad=None,
-               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False):
+               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False, phase_groups=False):
     """One dz_conv2d_forward[_split] call.  in_shape/out_shape = (Hp, Wp) of the (padded) images.
     math != 0: w is the pack_weight_split layout (..., cout_pad, cin)."""
     if cout_pad is None:
@@ -620,7 +623,7 @@ def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_
         out_sy=out_s, out_sx=out_s, out_dy=out_d[0], out_dx=out_d[1],
         groups=groups, cout_pad=cout_pad,
         g_cout=g_cout if g_cout is not None else [cout_pad], g_ooff=g_ooff if g_ooff is not None else [0],
-        relu=1 if relu else 0), math=math, out_f32=out_f32)
+        relu=1 if relu else 0, phase_groups=1 if phase_groups else 0), math=math, out_f32=out_f32)
 
 
 class BaseBEVBackbone(_Cached):
@@ -677,7 +680,9 @@ class BaseBEVBackbone(_Cached):
             s = de.stride[0]
             wt = de.weight.detach().float()                            # (Cin, Cout, s, s)
             phases = [[{'w': wt[:, :, dy, dx].contiguous().unsqueeze(0).contiguous()} for dx in range(s)] for dy in range(s)]
-            levels.append({'convs': convs, 'de': {'phases': phases, 'scale': scale, 'shift': shift, 's': s,
+            # (s*s, Cin, Cout): phase g = (dy, dx) = (g // s, g % s) - the group order of dz_conv2d_desc.phase_groups
+            w_phases = wt.permute(2, 3, 0, 1).reshape(s * s, wt.shape[0], wt.shape[1]).contiguous()
+            levels.append({'convs': convs, 'de': {'phases': phases, 'w_phases': w_phases, 'scale': scale, 'shift': shift, 's': s,
                                                   'cin': de.in_channels, 'cout': de.out_channels}})
         self._plan = levels
         return levels
@@ -711,6 +716,15 @@ class BaseBEVBackbone(_Cached):
             s = de['s']
             if xh * s != h or xw * s != w:
                 raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
+            if self.math and 1 < s * s <= 8 and FUSED_DEBLOCK_PHASES:
+                # the s x s phases of the ConvTranspose2d as the groups of ONE launch (dz_conv2d_desc.phase_groups): the phases of a
+                # pixel tile run next to each other on one XCD, the level's image is read from HBM once instead of s x s times
+                conv_layer(x, (xh + 2, xw + 2), self._w(de, 'w_phases'), de['scale'], de['shift'], True, concat,
+                           (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
+                           out_cstride=ctot, out_coff=coff, out_s=s, out_d=(1, 1), ho=xh, wo=xw, batch=batch, math=self.math,
+                           groups=s * s, g_cout=[de['cout']] * (s * s), g_ooff=[0] * (s * s), phase_groups=True)
+                coff += de['cout']
+                continue
             for dy in range(s):
                 for dx in range(s):
                     conv_layer(x, (xh + 2, xw + 2), self._w(de['phases'][dy][dx]), de['scale'], de['shift'], True, concat,

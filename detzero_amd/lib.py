@@ -39,7 +39,7 @@ class Conv2dDesc(ctypes.Structure):
         ('groups', c_int), ('cout_pad', c_int),
         ('g_cout', _I8), ('g_ooff', _I8),
         ('relu', c_int),
-        ('group_shift', c_void_p), ('group_rows', c_int), ('group_max', c_int),
+        ('group_shift', c_void_p), ('group_rows', c_int), ('group_max', c_int), ('phase_groups', c_int),
     ]
 
 
@@ -119,6 +119,8 @@ _SIGS = {
     'dz_spconv_x_window_rows': (c_int, [c_int, c_int]),
     'dz_spconv_x_windows_words': (c_size_t, [c_int, c_int]),
     'dz_spconv_x_windows': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dz_build_neighbors_packed_x': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     'dz_spconv_forward_split_x': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_x_variant': (ctypes.c_char_p, [c_int, c_int]),

@@ -251,6 +251,35 @@ class SparseLevel:
         return nbr
 
 
+FUSED_XWIN = os.environ.get('DZ_TUNE_FUSED_XWIN', '1') != '0'      # development switch: 0 = table and windows by two launches (r04)
+
+
+def neighbors_xrun(level, channels):
+    """Packed submanifold 3 x 3 x 3 table of `level` onto itself WITH the x-run windows (and, from XRUN_SORT_MIN_CHANNELS up, the
+    tap-set order) from one launch (dz_build_neighbors_packed_x) - what `build_windows(level.neighbors_to(level, ..., packed=True),
+    level, channels)` returns, bit for bit.  Levels / widths the engine does not cover come back as the plain packed / unpacked table."""
+    lib = L.load()
+    k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    tr = lib.dz_spconv_x_tile_rows(int(channels), int(channels))
+    cap = max(level.cap, 1)
+    if not FUSED_XWIN or tr == 0 or level.layout != LAYOUT_LINEAR or cap >= (1 << 29):
+        return build_windows(level.neighbors_to(level, k3, s1, p1, packed=True), level, channels)
+    dev = level.coords.device
+    masks = torch.empty((lib.dz_tile_masks_words(cap),), dtype=torch.int32, device=dev)
+    nbr = torch.empty((9, cap), dtype=torch.int32, device=dev)
+    win = torch.empty((lib.dz_spconv_x_windows_words(cap, tr),), dtype=torch.int32, device=dev)
+    sort = XRUN_SORT and channels >= XRUN_SORT_MIN_CHANNELS
+    nbr_sorted = torch.empty_like(nbr) if sort else None
+    perm = torch.empty((cap,), dtype=torch.int32, device=dev) if sort else None
+    rc = lib.dz_build_neighbors_packed_x(L.ptr(level.coords), L.ptr(level.d_m), level.cap, L.ptr(level.bitmap), L.ptr(level.prefix), level.batch,
+                                         *level.shape, L.ptr(nbr), L.ptr(masks), tr, L.ptr(win), L.ptr(nbr_sorted), L.ptr(perm), L.stream())
+    L.check(rc, 'dz_build_neighbors_packed_x')
+    nbr.tile_masks = masks
+    nbr.packed, nbr.kvol = True, 27
+    nbr.xwin = (win, tr, nbr_sorted, perm)
+    return nbr
+
+
 def unpack_table(nbr):
     """The (27, cap) form of a packed neighbour table (tests, statistics); other tables are returned as they are."""
     if not getattr(nbr, 'packed', False):
@@ -545,7 +574,7 @@ def conv2d(desc_kwargs, math=0, out_f32=False):
     taps = d.kh * d.kw
     cout = sum(d.g_cout[i] for i in range(d.groups))
     flops = 2.0 * m * taps * d.cin * cout
-    nbytes = 4.0 * (m * d.cin * d.groups + m * cout + taps * d.cin * d.cout_pad * d.groups)
+    nbytes = 4.0 * (m * d.cin * (1 if d.phase_groups else d.groups) + m * cout + taps * d.cin * d.cout_pad * d.groups)
     name = (lib.dz_conv2d_variant_split if math else lib.dz_conv2d_variant)(ctypes.byref(d)).decode()
     PROFILER.wrap(name, flops, nbytes, launch)
 

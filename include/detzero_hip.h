@@ -192,6 +192,11 @@ typedef struct dz_conv2d_desc {
     int group_rows;           /* row group = output row / group_rows (per-object bias of the PointNet concat)   */
     int group_max;            /* dz_linear_forward_split only: out = (row groups, out_cstride) fp32 pre-filled with -inf, the max over each
                                  group's rows is taken in the epilogue (no (rows, cout) result is written)          */
+    int phase_groups;         /* dz_conv2d_forward_split only, != 0: the `groups` are the out_sy x out_sx PHASES of a ConvTranspose2d with
+                                 kernel == stride (backbone2d.py:89-99) in ONE launch: every group reads the SAME cin input channels
+                                 (no per-group input offset), has its own weights w[g], shares scale / shift (cout_pad entries), and
+                                 writes output pixel (y*out_sy + out_dy + g / out_sx, x*out_sx + out_dx + g % out_sx); the phases of a
+                                 pixel tile are scheduled next to each other on one XCD, so the input image is fetched from HBM once */
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
@@ -277,6 +282,14 @@ int dz_spconv_x_window_rows(int cin, int cout);
 size_t dz_spconv_x_windows_words(int cap_out, int tile_rows);
 int dz_spconv_x_windows(const int *nbr_packed, int cap_out, const int *d_m_out, int tile_rows, int *windows, int *nbr_sorted, int *perm,
                         void *stream);
+/* dz_build_neighbors_packed (3 x 3 x 3 submanifold table of a level onto itself, linear keys) and dz_spconv_x_windows in ONE launch:
+ * the packed table, its per-32-row tap masks, the windows of every unit of tile_rows (128 | 256 = dz_spconv_x_tile_rows) rows and -
+ * optionally, both or neither - the table / row map in tap-set order.  Same outputs, bit for bit, as the two calls; a workgroup
+ * owns a 256-row block and keeps the nine words of a row in registers instead of reading the table back (round 5: the second
+ * launch cost 105 us per level and step at 32 frames).  (b, d, h, w) = the level's grid; coords / d_m / bitmap / prefix its index. */
+int dz_build_neighbors_packed_x(const int *coords, const int *d_m, int cap, const uint32_t *bitmap, const uint32_t *prefix, int b, int d,
+                                int h, int w, int *nbr_packed, uint32_t *tile_masks, int tile_rows, int *windows, int *nbr_sorted,
+                                int *perm, void *stream);
 /* nbr_sorted (9 x cap_out) / perm (cap_out), both or neither: the rows of every unit re-ordered by their tap set (ascending in even
  * units, descending in odd ones): perm[position] = output row, nbr_sorted = the packed table in that order.  Fragments of 32 rows
  * with similar tap sets let the kernel skip 11-13 % more (fragment, tap) pairs; pass both to dz_spconv_forward_split_x. */

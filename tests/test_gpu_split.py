@@ -206,6 +206,18 @@ def test_bev_backbone_and_head_goldens_split(device, golden_dir, name, mid):
     bb = bb.to(device).eval().set_math(name)
     out = bb({'spatial_features': _t(g['bev_in'], device)})['spatial_features_2d']
     torch.testing.assert_close(out.cpu(), torch.from_numpy(g['bev_out']), rtol=TOL[mid], atol=TOL[mid])
+    # the 2 x 2 phases of the ConvTranspose2d deblock as ONE launch (dz_conv2d_desc.phase_groups, the default) against one launch
+    # per phase: the same products in the same order -> the same bits, on a batch large enough for several pixel tiles per phase
+    from detzero_amd import det_modules
+    x = torch.randn((3, 32, 24, 40), generator=torch.Generator().manual_seed(7)).to(device)
+    assert det_modules.FUSED_DEBLOCK_PHASES
+    fused = bb({'spatial_features': x})['spatial_features_2d'].clone()
+    det_modules.FUSED_DEBLOCK_PHASES = False
+    try:
+        single = bb({'spatial_features': x})['spatial_features_2d']
+    finally:
+        det_modules.FUSED_DEBLOCK_PHASES = True
+    assert torch.equal(fused, single) and float(fused[:, 32:].abs().max()) > 0
 
     head = _golden_head(g, device).set_math(name)
     dd = head({'spatial_features_2d': _t(g['head_in'], device), 'batch_size': 2})

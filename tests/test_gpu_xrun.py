@@ -79,6 +79,37 @@ def test_windows_cover_the_rulebook_exactly(device, channels):
         assert (d <= 0).all() if u & 1 else (d >= 0).all(), u
 
 
+@pytest.mark.parametrize('channels', [32, 64, 128])
+def test_fused_table_and_windows_equal_the_two_launches(device, channels):
+    """dz_build_neighbors_packed_x (round 5: table, tap masks, windows and tap-set order from ONE launch, the detector's route)
+    against dz_build_neighbors_packed + dz_spconv_x_windows, bit for bit: levels with dense / nearly empty slabs, a capacity beyond
+    the live rows (dead units, a half-live last block), a single row, and the level-2 index of a 160k-point frame."""
+    from detzero_amd import ops
+    from detzero_amd.synth import POINT_CLOUD_RANGE, VOXEL_SIZE_01, synth_waymo_frame
+    rng = np.random.default_rng(7 * channels)
+    levels = [_level(rng, 2, [5, 40, 60], (0.02, 0.6, 0.1), device)[0], _level(rng, 1, [4, 48, 64], (0.01, 0.9, 0.02, 0.5), device, cap_extra=700)[0],
+              _level(rng, 1, [3, 9, 11], (0.004,), device, cap_extra=0)[0], _level(rng, 3, [3, 20, 33], (0.08,), device, cap_extra=300)[0]]
+    pts = torch.from_numpy(synth_waymo_frame(3, 160000)).to(device)
+    _, zyx, _, dn = ops.voxelize_hard_nosync(pts, POINT_CLOUD_RANGE, VOXEL_SIZE_01, 5, 200000, xy_range_mask=True)
+    n = int(dn.item())
+    c4 = torch.cat([zyx.new_zeros((n, 1)), zyx[:n]], 1).int().contiguous()
+    l1 = ops.SparseLevel(1, [41, 1504, 1504], n, device)
+    l1.build_from_coords(c4, want_rank=False)
+    levels.append(l1.downsample(K3, (2, 2, 2), P1))
+    assert ops.FUSED_XWIN
+    for lvl in levels:
+        two = ops.build_windows(lvl.neighbors_to(lvl, K3, S1, P1, packed=True), lvl, channels)
+        one = ops.neighbors_xrun(lvl, channels)
+        m = lvl.num_active()
+        assert one.packed and one.kvol == 27 and one.xwin[1] == two.xwin[1]
+        assert torch.equal(one[:, :m], two[:, :m]) and torch.equal(one.tile_masks, two.tile_masks)
+        assert torch.equal(one.xwin[0], two.xwin[0])
+        assert (one.xwin[2] is None) == (two.xwin[2] is None)
+        if one.xwin[2] is not None:
+            # (positions past the capacity's last whole unit are never written by either route)
+            assert torch.equal(one.xwin[3][:m], two.xwin[3][:m]) and torch.equal(one.xwin[2][:, :m], two.xwin[2][:, :m])
+
+
 def _run_case(device, rng, lvl, coords, channels, mid, with_res, relu, expect_gather=None):
     from detzero_amd import lib as L
     from detzero_amd import ops
