@@ -464,20 +464,27 @@ class FramePipeline:
         frames) is built once; a group is a contiguous slice of it."""
         m = self.model
         x, lvl = res['encoded']
-        bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
+        sparse = m.backbone3d.math != 0 and m.backbone2d.math == m.backbone3d.math and m.backbone2d.sparse_input_ok(x.shape[1], lvl.shape[0])
+        if sparse:
+            # HeightCompression without the image: 8 bytes of row indices per pixel; the first BEV convolution reads the rows
+            bev = ops.bev_row_index(lvl, x.shape[0], pad=1)
+            run2d = lambda g0, ng: m.backbone2d.run(None, ng, sparse_in=(x, bev[g0:g0 + ng]))          # noqa: E731
+        else:
+            bev = ops.sparse_to_bev(x, lvl, x.shape[1], pad=1, math=m.backbone3d.math)
+            run2d = lambda g0, ng: m.backbone2d.run(bev[g0:g0 + ng], ng)                               # noqa: E731
         # frames per group: the configured number, but never more than the largest activation image (the concatenation of the
         # upsampled maps, channel-last fp32-sized words, zero border included) allows inside the 2 GiB buffer window
-        per_frame = bev.shape[1] * bev.shape[2] * max(int(m.backbone2d.num_bev_features), int(bev.shape[3])) * 4
+        per_frame = bev.shape[1] * bev.shape[2] * max(int(m.backbone2d.num_bev_features), 2 * int(x.shape[1])) * 4
         group = max(1, min(self.dense_group if self.dense_group > 0 else nb, (2 ** 31 - 1) // per_frame))
         if nb <= group:
             with cp_modules.workspace(self._ws):
-                concat = m.backbone2d.run(bev, nb)
+                concat = run2d(0, nb)
                 return self.head.run_convs(concat, nb)
         out, h, w = None, 0, 0
         for g0 in range(0, nb, group):
             ng = min(group, nb - g0)
             with cp_modules.workspace(self._ws):
-                concat = m.backbone2d.run(bev[g0:g0 + ng], ng)
+                concat = run2d(g0, ng)
                 hd, h, w = self.head.run_convs(concat, ng)
             if out is None:
                 out = hd.new_empty((nb,) + tuple(hd.shape[1:]))

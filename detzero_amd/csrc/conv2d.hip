@@ -213,6 +213,7 @@ int dz_conv2d_forward(const dz_conv2d_desc *d, void *stream_) {
     DZ_CHECK_ARG(d && d->in && d->out && d->w, "dz_conv2d_forward: null pointer");
     DZ_CHECK_ARG(d->groups >= 1 && d->groups <= 8, "dz_conv2d_forward: groups %d not in [1,8]", d->groups);
     DZ_CHECK_ARG(!d->phase_groups, "dz_conv2d_forward: phase_groups is a dz_conv2d_forward_split feature (launch the phases one by one here)");
+    DZ_CHECK_ARG(!d->in_rowidx, "dz_conv2d_forward: in_rowidx (sparse input) is a dz_conv2d_forward_split feature");
     DZ_CHECK_ARG(!d->group_shift || (d->group_rows >= 1 && d->groups == 1), "dz_conv2d_forward: group_shift needs group_rows >= 1, groups == 1");
     DZ_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->cin >= 16, "dz_conv2d_forward: bad kernel/cin");
     DZ_CHECK_ARG(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0 && d->cout_pad % 16 == 0,

@@ -5,6 +5,8 @@
 // Reference: detection/detzero_det/models/centerpoint_modules/backbone2d.py:33-120, center_head.py:14-48, :81-102.
 // Input image and weights are pair16; the output image is pair16 (feeds the next layer) or plain fp32 (the
 // last head convolution, which feeds the decoder).
+#include <stdlib.h>
+
 #include "hgemm.h"
 
 namespace dz {
@@ -248,6 +250,9 @@ static ConvHVariant conv2d_h_select(const dz_conv2d_desc &p) {
     if (p.cin % 32 != 0) return CH_NONE;
     const long m_total = (long)p.batch * p.ho * p.wo;
     if (p.cout_pad % 64 != 0) return p.cout_pad % 32 == 0 ? CH_128_32 : CH_NONE;
+    // development knob: force a tile shape (1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 128, 4 = 64 x 64) for the layers it divides
+    static const int forced = getenv("DZ_TUNE_CONV2D_H") ? atoi(getenv("DZ_TUNE_CONV2D_H")) : 0;
+    if (forced >= 1 && forced <= 4 && p.cout_pad % (forced == 1 || forced == 3 ? 128 : 64) == 0 && m_total >= 4096) return (ConvHVariant)forced;
     // chip fill: two workgroups are resident per CU; prefer the largest tile that keeps >= ~90 % of the slots busy
     struct Cand { ConvHVariant v; int bp, bc; double eff; };
     static const Cand cands[4] = {{CH_128_128, 128, 128, 1.00}, {CH_128_64, 128, 64, 0.90}, {CH_64_128, 64, 128, 0.88}, {CH_64_64, 64, 64, 0.78}};
@@ -313,6 +318,14 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
                  "dz_conv2d_forward_split: output leaves the output image");
     if ((long)d->batch * d->ho * d->wo == 0) return DZ_OK;
     const size_t w_bytes = (size_t)d->groups * d->kh * d->kw * d->cout_pad * d->cin * sizeof(float);
+    if (d->in_rowidx) {
+        DZ_CHECK_ARG(d->in_row_channels >= 32 && d->in_rows >= 0, "dz_conv2d_forward_split: in_rowidx needs in_row_channels / in_rows");
+        if (!conv3x3_h_variant(*d) || out_f32) {
+            set_error("dz_conv2d_forward_split: in_rowidx (sparse input) is implemented for 3 x 3 stride-1 layers with 128-channel output tiles, "
+                      "two z slabs (cin == 2 * in_row_channels) and pair16 output");
+            return DZ_ERR_UNSUPPORTED;
+        }
+    }
     if (conv3x3_h_variant(*d)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);
     if (math == DZ_MATH_F16X2)
         return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);

@@ -24,6 +24,7 @@ constexpr int C3_TW = 32, C3_KC = 32;
 constexpr int C3_ROW_U4 = C3_KC / 4 + 1;                          // 144-byte LDS rows (conflict-free ds_read_b128)
 constexpr int C3_PXW = C3_TW + 2;
 constexpr int C3_NS = 3;                                          // weight stages in flight (9 taps % 3 == 0)
+using v2u = __attribute__((ext_vector_type(2))) unsigned int;
 
 // NT threads: 512 = 4 (pairs of image rows) x 2 (halves of BC) waves, one workgroup per CU; 256 = 4 x 1 waves, TWO workgroups
 // per CU whose barrier phases and epilogues interleave on the matrix pipe
@@ -57,7 +58,14 @@ struct C3Cfg {
 
 // DIAG (-DDZ_C3_DIAG builds only, timing experiments, results are garbage): bit 0 = no per-tap barriers, 1 = no weight LDS
 // stores, 2 = no fragment LDS reads, 3 = no global loads, 4 = no MFMAs, 5 = no epilogue
-template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0, int PT = 2>
+// SPARSE (dz_conv2d_desc.in_rowidx, round 5): the input image is never materialised.  `in` holds the rows of a sparse level
+// (in_row_channels pair16 channels each) and in_rowidx the row of every (pixel, z slab) of the zero-bordered image, -1 = empty:
+// input channel chunk kc of a pixel is chunk kc % (nk / 2) of the row of slab kc / (nk / 2).  A thread keeps the two row indices of
+// each of its PXPT pieces' pixels in registers (one 8-byte load per piece and TILE, issued behind the last input prefetch that
+// needs the current tile's indices, one channel chunk before the next tile's first prefetch reads them); everything downstream of
+// the input prefetch - LDS tile, fragments, MFMAs, epilogue - is the dense kernel.  This is HeightCompression
+// (height_compression.py:20-24) + the ZeroPad2d of the first BEV block (backbone2d.py:41-46) fused into that block's convolution.
+template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0, int PT = 2, bool SPARSE = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 : 1, PT == 2 ? 2 : 1))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
                                                           unsigned int w_bytes, int skew_ticks, int q_sa, int q_sb, float q_act) {
     using C = C3Cfg<BC, NT, PT>;
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         int ox, oy, ob;
         tile_origin(t, ox, oy, ob);
         TileGeo g;
-        g.base = (unsigned int)((((long)(ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off) * p.in_cstride + p.in_coff + grp * p.cin) * 4);
+        if constexpr (SPARSE) g.base = (unsigned int)((ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off);       // pixel index
+        else g.base = (unsigned int)((((long)(ob * p.in_hp + oy + p.in_off) * p.in_wp + ox + p.in_off) * p.in_cstride + p.in_coff + grp * p.cin) * 4);
         g.rows = p.in_hp - (oy + p.in_off);
         g.cols = p.in_wp - (ox + p.in_off);
         return g;
@@ -138,9 +147,56 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         for (int i = 0; i < WPT; ++i)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[i]) : "v"(cvoff[i] == OOB_OFFSET ? OOB_OFFSET : cvoff[i] + add), "s"(crsrc));
     };
+    // SPARSE: rows of my pieces' pixels (z slab 0 / 1) in the tile the next issue_px call reads.  The loads are inline asm: their
+    // results exist once a counted wait has covered them, so NOTHING may read ridx between issue_idx() and the own_idx() behind
+    // that wait - the validity of a piece (tile edge, stream end) therefore travels separately, as a bit mask, and is applied there
+    v2u ridx[SPARSE ? C3_PXPT : 1];
+    [[maybe_unused]] unsigned int ridx_ok = 0u;
+    [[maybe_unused]] const srsrc_t irsrc = make_srsrc(p.in_rowidx, SPARSE ? (unsigned int)((size_t)p.batch * p.in_hp * p.in_wp * 8) : 0u);
+    [[maybe_unused]] auto issue_idx = [&](const TileGeo &g, bool live) {
+        if constexpr (SPARSE) {
+            int pr = prow;
+            asm volatile("" : "+v"(pr));
+            unsigned int okm = 0u;
+#pragma unroll
+            for (int i = 0; i < C3_PXPT; ++i) {
+                const int r = pr + i * (C3_THREADS / (C3_KC / 4));
+                const int ry = r / C3_PXW, rx = r - ry * C3_PXW;
+                const bool ok = live && r < C3_PX_ROWS && ry < g.rows && rx < g.cols;
+                const unsigned int off = ok ? (g.base + (unsigned int)(ry * p.in_wp + rx)) * 8u : OOB_OFFSET;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(ridx[i]) : "v"(off), "s"(irsrc));
+                okm |= ok ? 1u << i : 0u;
+            }
+            ridx_ok = okm;
+        }
+    };
+    [[maybe_unused]] auto own_idx = [&]() {
+        if constexpr (SPARSE) {
+#pragma unroll
+            for (int i = 0; i < C3_PXPT; ++i) {
+                asm volatile("" : "+v"(ridx[i]));
+                if (!((ridx_ok >> i) & 1u)) ridx[i] = v2u{0xFFFFFFFFu, 0xFFFFFFFFu};       // (idempotent: own_idx runs once per channel chunk)
+            }
+        }
+    };
     auto issue_px = [&](int kc) {
         // input tile of channel chunk kc; kc == nk: chunk 0 of the next tile
         if constexpr (DIAG & 8) return;
+        if constexpr (SPARSE) {
+            const bool cur = kc < nk;
+            const bool any = cur || has_next;
+            const int kq = cur ? kc : 0, half = nk >> 1;
+            const bool z1 = kq >= half;
+            const unsigned int sbase = (unsigned int)((kq - (z1 ? half : 0)) * C3_KC * 4 + p.in_coff * 4);
+            const unsigned int rowb = (unsigned int)p.in_row_channels * 4u;
+#pragma unroll
+            for (int i = 0; i < C3_PXPT; ++i) {
+                const int ri = (int)(z1 ? ridx[i].y : ridx[i].x);
+                const unsigned int off = (any && ri >= 0) ? (unsigned int)ri * rowb + (unsigned int)(pq * 16) : OOB_OFFSET;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[i]) : "v"(off), "s"(prsrc), "s"(sbase));
+            }
+            return;
+        }
         const bool cur = kc < nk;
         const TileGeo g = cur ? geo : geo_next;
         const unsigned int sbase = g.base + (cur ? (unsigned int)(kc * C3_KC * 4) : 0u);
@@ -281,6 +337,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         sh_s[tid] = (in && p.shift) ? p.shift[grp * p.cout_pad + n0 + tid] : 0.f;
     }
     // ---- prologue: input tile of chunk 0 and weight slice of (chunk 0, tap 0) into LDS; taps 1..3 in flight
+    if constexpr (SPARSE) {
+        issue_idx(geo, true);
+        asm volatile("s_waitcnt vmcnt(0)");
+        own_idx();
+    }
     issue_px(0);
     issue_w(wst[0], 0);
     asm volatile("s_waitcnt vmcnt(0)");
@@ -308,8 +369,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             load_frag(f1, t, buf, 1);
             // loads younger than chunk c+1's: chunks c+2, c+3, plus this chunk's input prefetch while it is the youngest
             if constexpr (!(DIAG & 8)) {
-                if (t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2 + C3_PXPT));
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2));
+                if (t >= 1 && t <= 3) {
+                    // (SPARSE: in chunk nk - 2 the next tile's PXPT index loads are in flight too, younger than the input prefetch)
+                    if (SPARSE && kc == nk - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2 + 2 * C3_PXPT));
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2 + C3_PXPT));
+                } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW2));
+            }
+            if constexpr (SPARSE) {
+                if (t == 0) own_idx();           // (the indices issued a chunk ago are covered by the wait above)
             }
             own_w(wst[(t + 1) % 3]);
             store_w(wst[(t + 1) % 3], buf ^ 1);
@@ -328,7 +395,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             // ---- phase 2: fragments of chunk c+1, weights of chunk c+4 into the stage just freed, MFMAs of k-step 1
             load_frag(f0, (t + 1) % 9, buf ^ 1, 0);
             issue_w(wst[(t + 1) % 3], c + 4);
-            if (t == 0) issue_px(kc + 1);
+            if (t == 0) {
+                issue_px(kc + 1);
+                if constexpr (SPARSE) {
+                    // the current tile's indices have served their last prefetch: fetch the next tile's into the same registers
+                    if (kc == nk - 2) issue_idx(geo_next, has_next);
+                }
+            }
             mma(f1, 1);
             interleave_hint<0x100, M::TERMS == 1 ? (PT + CT) : 2 * (PT + CT), 1>();
         }
@@ -482,17 +555,22 @@ static int q16_sa() { static const int v = 127 + q16_env("DZ_TUNE_Q16_EW", -4); 
 static int q16_sb() { static const int v = 127 + q16_env("DZ_TUNE_Q16_EA", 2) - 11; return v; }           // activations the B operand; both correction terms carry 2^-11
 static float q16_act() { static const float v = ldexpf(1.f, -q16_env("DZ_TUNE_Q16_EA", 2)); return v; }
 
-template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0, int PT = 2>
+template <int BC, class M, bool OUT_F32, int NT, int DIAG = 0, int PT = 2, bool SPARSE = false>
 static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t stream) {
     using C = C3Cfg<BC, NT, PT>;
     const int tiles_x = ceil_div(p.wo, C3_TW), tiles_y = ceil_div(p.ho, C::TH);
-    const size_t in_bytes = (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
+    // (SPARSE: `in` is the level's rows - in_rows of them, in_row_channels channels each)
+    const size_t in_bytes = SPARSE ? (size_t)p.in_rows * p.in_row_channels * sizeof(float) : (size_t)p.batch * p.in_hp * p.in_wp * p.in_cstride * sizeof(float);
+    if (SPARSE && (size_t)p.batch * p.in_hp * p.in_wp * 8 >= 0x80000000ull) {
+        set_error("dz_conv2d_forward_split: row-index image exceeds the 2 GiB buffer-addressing limit");
+        return DZ_ERR_UNSUPPORTED;
+    }
     if (in_bytes >= 0x80000000ull || w_bytes >= 0x80000000ull) {
         set_error("dz_conv2d_forward_split: image of %zu bytes / weights of %zu bytes exceed the 2 GiB buffer-addressing limit", in_bytes, w_bytes);
         return DZ_ERR_UNSUPPORTED;
     }
     static PerDeviceFlags lds_done;
-    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), C::LDS_BYTES, lds_done, "dz_conv2d_forward_split")) return rc_;
+    if (int rc_ = reserve_lds(reinterpret_cast<const void *>(&k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT, SPARSE>), C::LDS_BYTES, lds_done, "dz_conv2d_forward_split")) return rc_;
     // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
     const int nty = p.cout_pad / BC * p.groups;
@@ -500,7 +578,7 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     if (per_xcd < nty) per_xcd = nty;
     const long grid = 8L * per_xcd;
     static const int skew = getenv("DZ_TUNE_C3_SKEW") ? atoi(getenv("DZ_TUNE_C3_SKEW")) : 0;     // 10 ns ticks
-    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
+    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT, SPARSE>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
                        tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew, q16_sa(), q16_sb(), q16_act());
     DZ_LAUNCH_CHECK();
     return DZ_OK;
@@ -546,6 +624,8 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
     if (off) return 0;
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.group_shift) return 0;
     if (p.cin % C3_KC != 0) return 0;
+    // sparse input (in_rowidx): two z slabs of in_row_channels channels each, 128 output channels per tile, pair16 out
+    if (p.in_rowidx && (p.groups != 1 || p.cout_pad % 128 != 0 || p.cin != 2 * p.in_row_channels || p.in_row_channels % C3_KC != 0 || p.in_coff != 0)) return 0;
     if (p.cout_pad == 32) {               // few output channels (per group): the 16 x 32-pixel tiles of the BC = 32 configuration
         const long t32 = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, 16) * p.groups;
         return t32 >= 384 ? 32 : 0;
@@ -559,7 +639,7 @@ int conv3x3_h_variant(const dz_conv2d_desc &p) {
     const int bc = (p.cout_pad % 128 == 0 && nt != 256) ? 128 : 64;
     // one 512-thread workgroup per CU: below ~1.5 waves of tiles the 4-wave kernels of conv2d_h.hip fill the chip better
     const long tiles = (long)p.batch * ceil_div(p.wo, C3_TW) * ceil_div(p.ho, 8) * (p.cout_pad / bc);
-    if (tiles < 384) return 0;
+    if (tiles < 384 && !p.in_rowidx) return 0;        // (the sparse-input form exists in this kernel only)
     return bc;
 }
 
@@ -570,6 +650,15 @@ int conv3x3_d_launch(const dz_conv2d_desc &p, int math, size_t w_bytes, hipStrea
 
 int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_bytes, hipStream_t stream) {
     const int bc = conv3x3_h_variant(p);
+    if (p.in_rowidx) {
+        if (bc != 128 || out_f32) {
+            set_error("dz_conv2d_forward_split: in_rowidx (sparse input) needs a 3 x 3 stride-1 layer, 128-channel output tiles, two z slabs, pair16 output");
+            return DZ_ERR_UNSUPPORTED;
+        }
+        if (math == DZ_MATH_F16X2) return launch_c3_nt<128, MathF16, false, 512, 0, 2, true>(p, w_bytes, stream);
+        if (math == DZ_MATH_F16) return launch_c3_nt<128, MathF16H, false, 512, 0, 2, true>(p, w_bytes, stream);
+        return launch_c3_nt<128, MathBF16, false, 512, 0, 2, true>(p, w_bytes, stream);
+    }
 #ifdef DZ_C3_DIAG
     if (bc == 128 && !out_f32 && conv3x3_d_eligible(p)) return conv3x3_d_launch(p, math, w_bytes, stream);
 #endif

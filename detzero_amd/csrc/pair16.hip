@@ -123,11 +123,46 @@ __global__ __launch_bounds__(256) void k_sparse_to_bev_split_dense2(const uint2 
     }
 }
 
+// Row-index image of a level with two z slabs: idx[b][y + pad][x + pad][z] = feature row of cell (b, z, y, x), -1 where the cell is
+// empty, the pixel is border, or the rank lies past the feature rows (a level that overflowed its calibrated capacity).  8 bytes
+// per pixel instead of the pixel's 2 x C channels: what the sparse-input convolution (conv3x3_h.hip, dz_conv2d_desc.in_rowidx)
+// reads in place of the dense BEV image.
+__global__ __launch_bounds__(256) void k_bev_row_index(const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ prefix, LevelGeom lg, int pad,
+                                                       int feat_rows, int2 *__restrict__ idx) {
+    const int hp = lg.h + 2 * pad, wp = lg.w + 2 * pad;
+    const long total = (long)lg.b * hp * wp;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(pix % wp), yp = (int)((pix / wp) % hp), b = (int)(pix / ((long)wp * hp));
+        const int x = xp - pad, y = yp - pad;
+        int r0 = -1, r1 = -1;
+        if ((unsigned)x < (unsigned)lg.w && (unsigned)y < (unsigned)lg.h) {
+            r0 = bitmap_find(bitmap, prefix, lg.key(b, 0, y, x));
+            r1 = bitmap_find(bitmap, prefix, lg.key(b, 1, y, x));
+            if (r0 >= feat_rows) r0 = -1;
+            if (r1 >= feat_rows) r1 = -1;
+        }
+        idx[pix] = make_int2(r0, r1);
+    }
+}
+
 }  // namespace dz
 
 using namespace dz;
 
 extern "C" {
+
+int dz_bev_row_index(const uint32_t *bitmap, const uint32_t *prefix, int batch, int d, int h, int w, int layout, int pad, int feat_rows, int *idx,
+                     void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(bitmap && prefix && idx && batch > 0 && h > 0 && w > 0 && pad >= 0 && feat_rows >= 0, "dz_bev_row_index: bad argument");
+    if (d != 2) { set_error("dz_bev_row_index: %d z slabs (the sparse-input convolution reads exactly 2)", d); return DZ_ERR_UNSUPPORTED; }
+    DZ_CHECK_ARG(layout == DZ_LAYOUT_LINEAR || layout == DZ_LAYOUT_BRICK, "dz_bev_row_index: bad layout %d", layout);
+    const LevelGeom lg = make_level(batch, d, h, w, layout);
+    const long total = (long)batch * (h + 2 * pad) * (w + 2 * pad);
+    hipLaunchKernelGGL(k_bev_row_index, dim3(stream_grid(total, 256)), dim3(256), 0, stream, bitmap, prefix, lg, pad, feat_rows, reinterpret_cast<int2 *>(idx));
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
 
 int dz_pair16_from_f32(const float *src, long rows, int c_src, int c_dst, int math, float *dst, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -603,12 +603,14 @@ def _recode(img, enc, math):
     return ops.pair16_from_f32(plain, math=math) if math else plain
 
 
+SPARSE_BEV_INPUT = os.environ.get('DZ_TUNE_SPARSE_BEV', '1') != '0'     # development switch: 0 = dense BEV image (r01-r04)
 FUSED_DEBLOCK_PHASES = os.environ.get('DZ_TUNE_DEBLOCK_PHASES', '1') != '0'     # development switch: 0 = one launch per phase (r01-r04)
 
 
 def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_cstride, in_coff=0, ksize=3,
                stride=1, in_off=0, out_cstride, out_coff=0, out_s=1, out_d=(0, 0), groups=1, cout_pad=None,
-               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False, phase_groups=False):
+               g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False, phase_groups=False, in_rowidx=None,
+               in_row_channels=0, in_rows=0):
     """One dz_conv2d_forward[_split] call.  in_shape/out_shape = (Hp, Wp) of the (padded) images.
     math != 0: w is the pack_weight_split layout (..., cout_pad, cin)."""
     if cout_pad is None:
@@ -623,7 +625,9 @@ def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_
         out_sy=out_s, out_sx=out_s, out_dy=out_d[0], out_dx=out_d[1],
         groups=groups, cout_pad=cout_pad,
         g_cout=g_cout if g_cout is not None else [cout_pad], g_ooff=g_ooff if g_ooff is not None else [0],
-        relu=1 if relu else 0, phase_groups=1 if phase_groups else 0), math=math, out_f32=out_f32)
+        relu=1 if relu else 0, phase_groups=1 if phase_groups else 0,
+        in_rowidx=in_rowidx.data_ptr() if in_rowidx is not None else None, in_row_channels=int(in_row_channels), in_rows=int(in_rows)),
+        math=math, out_f32=out_f32)
 
 
 class BaseBEVBackbone(_Cached):
@@ -674,6 +678,12 @@ class BaseBEVBackbone(_Cached):
                 scale, shift = fold_bn(bn, conv.bias)
                 convs.append({'w': _conv_weight_taps(conv.weight), 'scale': scale, 'shift': shift,
                               'stride': conv.stride[0], 'cin': conv.in_channels, 'cout': conv.out_channels})
+                if idx == 0 and len(convs) == 1 and conv.in_channels % 2 == 0:
+                    # HeightCompression's channel order is c * D + z (height_compression.py:22); the sparse-input convolution reads
+                    # the two slabs' rows one after the other (z * C + c): the same weights, input channels permuted
+                    wt_ = convs[0]['w']
+                    c_half = conv.in_channels // 2
+                    convs[0]['w_zmajor'] = wt_.view(wt_.shape[0], c_half, 2, wt_.shape[2]).permute(0, 2, 1, 3).reshape(wt_.shape).contiguous()
                 i += 3
             de, dbn = self.deblocks[idx][0], self.deblocks[idx][1]
             scale, shift = fold_bn(dbn, de.bias)
@@ -687,15 +697,29 @@ class BaseBEVBackbone(_Cached):
         self._plan = levels
         return levels
 
-    def run(self, bev, batch):
+    def sparse_input_ok(self, row_channels, slabs):
+        """The first block's convolution can read a two-slab sparse level directly (dz_conv2d_desc.in_rowidx) instead of the dense
+        BEV image: split math, 3 x 3 stride 1, 128-channel output tiles, input = 2 x row_channels."""
+        cv = self.plan()[0]['convs'][0]
+        return bool(self.math and SPARSE_BEV_INPUT and slabs == 2 and cv['stride'] == 1 and cv['cin'] == 2 * row_channels and
+                    row_channels % 32 == 0 and cv['cout'] % 128 == 0)
+
+    def run(self, bev, batch, sparse_in=None):
         """bev (B, H+2, W+2, Cin) zero-bordered channel-last -> concat (B, H+2, W+2, sum(upsample)) zero-bordered.
-        In a split math mode both images are pair16 (same shapes)."""
+        In a split math mode both images are pair16 (same shapes).
+        sparse_in = (rows (R, C) pair16, row index image (B, H+2, W+2, 2) int32) instead of `bev` (sparse_input_ok): the image is
+        never built - HeightCompression fused into the first convolution."""
         plan = self.plan()
-        dev = bev.device
-        h, w = bev.shape[1] - 2, bev.shape[2] - 2
+        if sparse_in is not None:
+            rows, ridx = sparse_in
+            dev = rows.device
+            h, w = ridx.shape[1] - 2, ridx.shape[2] - 2
+        else:
+            dev = bev.device
+            h, w = bev.shape[1] - 2, bev.shape[2] - 2
         ctot = self.num_bev_features
         concat = bordered_zeros('bev2d.concat', (batch, h + 2, w + 2, ctot), dev)
-        x, xh, xw, xc = bev, h, w, bev.shape[3]
+        x, xh, xw, xc = bev, h, w, (bev.shape[3] if sparse_in is None else 2 * rows.shape[1])
         coff = 0
         total_stride = 1
         for li, lvl in enumerate(plan):
@@ -706,6 +730,15 @@ class BaseBEVBackbone(_Cached):
                 if bufs is None or ci == 0:
                     bufs = [bordered_zeros('bev2d.l%d.%d' % (li, k), (batch, oh + 2, ow + 2, cv['cout']), dev) for k in range(2)]
                 y = bufs[ci % 2]
+                if sparse_in is not None and li == 0 and ci == 0:
+                    # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
+                    conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                               cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
+                               out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
+                               in_rows=rows.shape[0])
+                    x, xh, xw, xc = y, oh, ow, cv['cout']
+                    total_stride *= s
+                    continue
                 conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
                            out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math)

@@ -40,6 +40,7 @@ class Conv2dDesc(ctypes.Structure):
         ('g_cout', _I8), ('g_ooff', _I8),
         ('relu', c_int),
         ('group_shift', c_void_p), ('group_rows', c_int), ('group_max', c_int), ('phase_groups', c_int),
+        ('in_rowidx', c_void_p), ('in_row_channels', c_int), ('in_rows', c_int),
     ]
 
 
@@ -124,6 +125,7 @@ _SIGS = {
     'dz_spconv_forward_split_x': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_x_variant': (ctypes.c_char_p, [c_int, c_int]),
+    'dz_bev_row_index': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
     'dz_sparse_to_bev_split_dense': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

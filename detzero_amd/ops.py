@@ -444,6 +444,17 @@ def spconv_forward(feats, nbr, out_level, w_taps, scale, shift, residual=None, r
     return out
 
 
+def bev_row_index(level, feat_rows, pad=1):
+    """(B, H + 2 pad, W + 2 pad, 2) int32: the feature row of every (pixel, z slab) of a two-slab level, -1 = empty / border / past
+    `feat_rows` - the sparse-input form of HeightCompression (dz_conv2d_desc.in_rowidx)."""
+    lib = L.load()
+    d, h, w = level.shape
+    idx = torch.empty((level.batch, h + 2 * pad, w + 2 * pad, 2), dtype=torch.int32, device=level.coords.device)
+    rc = lib.dz_bev_row_index(L.ptr(level.bitmap), L.ptr(level.prefix), level.batch, d, h, w, level.layout, pad, int(feat_rows), L.ptr(idx), L.stream())
+    L.check(rc, 'dz_bev_row_index')
+    return idx
+
+
 BEV_DENSE = not os.environ.get('DZ_BEV_SCATTER')   # development switch: False = zero-fill + scatter (dz_sparse_to_bev_split) for two-slab levels too
 
 

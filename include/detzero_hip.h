@@ -197,6 +197,14 @@ typedef struct dz_conv2d_desc {
                                  (no per-group input offset), has its own weights w[g], shares scale / shift (cout_pad entries), and
                                  writes output pixel (y*out_sy + out_dy + g / out_sx, x*out_sx + out_dx + g % out_sx); the phases of a
                                  pixel tile are scheduled next to each other on one XCD, so the input image is fetched from HBM once */
+    const int *in_rowidx;     /* dz_conv2d_forward_split only, != NULL: SPARSE INPUT of a 3 x 3 stride-1 layer - the image is never built.
+                                 `in` = the rows of a sparse level with two z slabs (in_rows x in_row_channels pair16), in_rowidx =
+                                 (batch, in_hp, in_wp, 2) int32: the row of every (pixel, z slab) of the zero-bordered image, -1 = empty
+                                 (dz_bev_row_index).  Logical input channel j = z * in_row_channels + c (z-MAJOR: the layer's weights
+                                 are permuted accordingly - HeightCompression's own order is c * 2 + z); cin = 2 * in_row_channels;
+                                 in_cstride is ignored.  HeightCompression (height_compression.py:20-24) + the first block's ZeroPad2d
+                                 (backbone2d.py:41-46) fused into that block's convolution */
+    int in_row_channels, in_rows;
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
@@ -298,6 +306,12 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
                               const float *residual, int relu, float *out, int cout, int math, void *stream);
 /* (nbr_packed = the level's packed table and perm = NULL, or nbr_sorted and its perm) */
 const char *dz_spconv_x_variant(int cin, int cout);
+/* HeightCompression WITHOUT the dense image (round 5): idx (batch, h + 2 pad, w + 2 pad, 2) int32 = the feature row of every
+ * (pixel, z slab) of a two-slab level, -1 = empty cell / border / rank >= feat_rows (overflowed capacity).  The first block of
+ * BaseBEVBackbone reads the level's rows through it (dz_conv2d_desc.in_rowidx): height_compression.py:20-24 and the ZeroPad2d of
+ * backbone2d.py:41-46 never touch HBM.  DZ_ERR_UNSUPPORTED for d != 2. */
+int dz_bev_row_index(const uint32_t *bitmap, const uint32_t *prefix, int batch, int d, int h, int w, int layout, int pad, int feat_rows,
+                     int *idx, void *stream);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);

@@ -230,6 +230,49 @@ def test_bev_backbone_and_head_goldens_split(device, golden_dir, name, mid):
         assert abs(fb['pred_boxes'].shape[0] - ref_b.shape[0]) <= 1 and nm >= ref_b.shape[0] - 1, (nm, ref_b.shape[0], worst)
 
 
+@pytest.mark.parametrize('name,mid', MODES)
+def test_sparse_input_convolution_equals_the_dense_image(device, name, mid):
+    """HeightCompression fused into the first BEV convolution (dz_conv2d_desc.in_rowidx + dz_bev_row_index, round 5): the 3 x 3
+    convolution reading a two-slab level's rows through the row-index image against the same kernel on the materialised z-major
+    image - bit for bit (same products, same order); tiles at the image edge, empty tiles, a row capacity the level overflows."""
+    from detzero_amd import ops
+    from detzero_amd.det_modules import conv_layer
+    rng = np.random.default_rng(5 + mid)
+    b, shape, c, cout = 16, [2, 61, 90], 128, 128
+    cells = shape[0] * shape[1] * shape[2]
+    lin = np.unique(np.concatenate([i * cells + np.nonzero(rng.random(cells) < (0.3 if i % 3 else 0.02))[0] for i in range(b)]))
+    coords = np.stack([lin // cells, (lin % cells) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    n = coords.shape[0]
+    for cap in (n + 5, n - 300):                      # the second: an overflowed level - ranks past the rows read as empty cells
+        lvl = ops.SparseLevel(b, shape, cap, device)
+        lvl.build_from_coords(_t(coords, device), want_rank=False)
+        rows = ops.pair16_from_f32(_t(rng.standard_normal((cap, c)).astype(np.float32), device), c, mid)
+        idx = ops.bev_row_index(lvl, cap, pad=1)
+        assert tuple(idx.shape) == (b, shape[1] + 2, shape[2] + 2, 2)
+        # the index image against the coordinates themselves
+        want = np.full((b, shape[1] + 2, shape[2] + 2, 2), -1, np.int64)
+        keep = np.arange(n) < cap
+        want[coords[keep, 0], coords[keep, 2] + 1, coords[keep, 3] + 1, coords[keep, 1]] = np.arange(n)[keep]
+        assert np.array_equal(idx.cpu().numpy(), want)
+        # z-major dense image from the same rows (raw 32-bit words: a pair16 row is its channels' words)
+        img = torch.zeros((b, shape[1] + 2, shape[2] + 2, 2 * c), dtype=torch.float32, device=device).view(torch.int32)
+        ii = idx.long()
+        for z in range(2):
+            sel = ii[..., z] >= 0
+            img[..., z * c:(z + 1) * c][sel] = rows.view(torch.int32)[ii[..., z][sel]]
+        img = img.view(torch.float32)
+        w = ops.pack_weight_split(_t((rng.standard_normal((9, 2 * c, cout)) / 48).astype(np.float32), device), mid)
+        scale, shift = _t(rng.uniform(0.5, 1.5, cout).astype(np.float32), device), _t((rng.standard_normal(cout) * 0.1).astype(np.float32), device)
+        outs = []
+        for sparse in (False, True):
+            out = torch.zeros((b, shape[1] + 2, shape[2] + 2, cout), dtype=torch.float32, device=device)
+            conv_layer(rows if sparse else img, (shape[1] + 2, shape[2] + 2), w, scale, shift, True, out, (shape[1] + 2, shape[2] + 2), cin=2 * c,
+                       in_cstride=2 * c, ksize=3, stride=1, in_off=0, out_cstride=cout, out_d=(1, 1), ho=shape[1], wo=shape[2], batch=b, math=mid,
+                       in_rowidx=idx if sparse else None, in_row_channels=c, in_rows=cap)
+            outs.append(out)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)) and float(ops.pair16_to_f32(outs[1], mid).abs().max()) > 0.1
+
+
 @pytest.fixture(scope='module')
 def small(device):
     model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
