@@ -281,6 +281,9 @@ def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE
     return mode, rng
 
 
+GROUPED_DEEP_BLOCKS = os.environ.get('DZ_TUNE_GROUPED_DEEP', '1') != '0'       # development switch: 0 = every dense layer per frame group (r04)
+
+
 class _StackedFrames(list):
     """List view of a (B,N,C) tensor of equally long frames that remembers the backing tensor (no re-concatenation)."""
 
@@ -480,16 +483,22 @@ class FramePipeline:
             with cp_modules.workspace(self._ws):
                 concat = run2d(0, nb)
                 return self.head.run_convs(concat, nb)
-        out, h, w = None, 0, 0
-        for g0 in range(0, nb, group):
-            ng = min(group, nb - g0)
-            with cp_modules.workspace(self._ws):
-                concat = run2d(g0, ng)
-                hd, h, w = self.head.run_convs(concat, ng)
-            if out is None:
-                out = hd.new_empty((nb,) + tuple(hd.shape[1:]))
-            out[g0:g0 + ng].copy_(hd)          # (the activation images, the head map among them, are reused by the next group)
-        return out, h, w
+        st = {'out': None, 'h': 0, 'w': 0}
+
+        def head_of_group(concat, g0, ng):
+            hd, st['h'], st['w'] = self.head.run_convs(concat, ng)
+            if st['out'] is None:
+                st['out'] = hd.new_empty((nb,) + tuple(hd.shape[1:]))
+            st['out'][g0:g0 + ng].copy_(hd)          # (the activation images, the head map among them, are reused by the next group)
+        with cp_modules.workspace(self._ws):
+            if GROUPED_DEEP_BLOCKS:
+                # first block, deblocks and head in frame groups; the deeper (quarter-size) blocks over all frames at once
+                m.backbone2d.run_grouped(nb, group, head_of_group, bev=None if sparse else bev, sparse_in=(x, bev) if sparse else None)
+            else:
+                for g0 in range(0, nb, group):
+                    ng = min(group, nb - g0)
+                    head_of_group(run2d(g0, ng), g0, ng)
+        return st['out'], st['h'], st['w']
 
     @torch.no_grad()
     def post_stage(self, head, h, w):

@@ -704,6 +704,54 @@ class BaseBEVBackbone(_Cached):
         return bool(self.math and SPARSE_BEV_INPUT and slabs == 2 and cv['stride'] == 1 and cv['cin'] == 2 * row_channels and
                     row_channels % 32 == 0 and cv['cout'] % 128 == 0)
 
+    def _level_convs(self, li, lvl, x, xh, xw, xc, batch, dev, sparse_in=None, out_last=None):
+        """The 3 x 3 convolutions of block li over `batch` frames -> (activation, H, W, C).  out_last: where the block's LAST
+        convolution writes (a zero-bordered buffer of the right shape, e.g. a frame slice of a larger one) instead of a workspace image."""
+        convs = lvl['convs']
+        bufs = None
+        for ci, cv in enumerate(convs):
+            s = cv['stride']
+            oh, ow = (xh + 2 - 3) // s + 1, (xw + 2 - 3) // s + 1
+            if bufs is None:
+                bufs = [bordered_zeros('bev2d.l%d.%d' % (li, k), (batch, oh + 2, ow + 2, cv['cout']), dev) for k in range(2)]
+            y = out_last if (out_last is not None and ci == len(convs) - 1) else bufs[ci % 2]
+            if sparse_in is not None and li == 0 and ci == 0:
+                # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
+                rows, ridx = sparse_in
+                conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                           cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
+                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
+                           in_rows=rows.shape[0])
+            else:
+                conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                           cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
+                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math)
+            x, xh, xw, xc = y, oh, ow, cv['cout']
+        return x, xh, xw, xc
+
+    def _level_deblock(self, lvl, x, xh, xw, xc, concat, coff, h, w, batch):
+        """ConvTranspose2d (kernel == stride) + BN + ReLU of a block's output into channels [coff, coff + cout) of the concatenation."""
+        de = lvl['de']
+        s = de['s']
+        ctot = self.num_bev_features
+        if xh * s != h or xw * s != w:
+            raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
+        if self.math and 1 < s * s <= 8 and FUSED_DEBLOCK_PHASES:
+            # the s x s phases of the ConvTranspose2d as the groups of ONE launch (dz_conv2d_desc.phase_groups): the phases of a
+            # pixel tile run next to each other on one XCD, the level's image is read from HBM once instead of s x s times
+            conv_layer(x, (xh + 2, xw + 2), self._w(de, 'w_phases'), de['scale'], de['shift'], True, concat,
+                       (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
+                       out_cstride=ctot, out_coff=coff, out_s=s, out_d=(1, 1), ho=xh, wo=xw, batch=batch, math=self.math,
+                       groups=s * s, g_cout=[de['cout']] * (s * s), g_ooff=[0] * (s * s), phase_groups=True)
+            return coff + de['cout']
+        for dy in range(s):
+            for dx in range(s):
+                conv_layer(x, (xh + 2, xw + 2), self._w(de['phases'][dy][dx]), de['scale'], de['shift'], True, concat,
+                           (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
+                           out_cstride=ctot, out_coff=coff, out_s=s, out_d=(dy + 1, dx + 1), ho=xh, wo=xw,
+                           batch=batch, math=self.math)
+        return coff + de['cout']
+
     def run(self, bev, batch, sparse_in=None):
         """bev (B, H+2, W+2, Cin) zero-bordered channel-last -> concat (B, H+2, W+2, sum(upsample)) zero-bordered.
         In a split math mode both images are pair16 (same shapes).
@@ -717,55 +765,52 @@ class BaseBEVBackbone(_Cached):
         else:
             dev = bev.device
             h, w = bev.shape[1] - 2, bev.shape[2] - 2
-        ctot = self.num_bev_features
-        concat = bordered_zeros('bev2d.concat', (batch, h + 2, w + 2, ctot), dev)
+        concat = bordered_zeros('bev2d.concat', (batch, h + 2, w + 2, self.num_bev_features), dev)
         x, xh, xw, xc = bev, h, w, (bev.shape[3] if sparse_in is None else 2 * rows.shape[1])
         coff = 0
-        total_stride = 1
         for li, lvl in enumerate(plan):
-            bufs = None
-            for ci, cv in enumerate(lvl['convs']):
-                s = cv['stride']
-                oh, ow = (xh + 2 - 3) // s + 1, (xw + 2 - 3) // s + 1
-                if bufs is None or ci == 0:
-                    bufs = [bordered_zeros('bev2d.l%d.%d' % (li, k), (batch, oh + 2, ow + 2, cv['cout']), dev) for k in range(2)]
-                y = bufs[ci % 2]
-                if sparse_in is not None and li == 0 and ci == 0:
-                    # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
-                    conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
-                               cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
-                               out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
-                               in_rows=rows.shape[0])
-                    x, xh, xw, xc = y, oh, ow, cv['cout']
-                    total_stride *= s
-                    continue
-                conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
-                           cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
-                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math)
-                x, xh, xw, xc = y, oh, ow, cv['cout']
-                if ci == 0:
-                    total_stride *= s
-            de = lvl['de']
-            s = de['s']
-            if xh * s != h or xw * s != w:
-                raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
-            if self.math and 1 < s * s <= 8 and FUSED_DEBLOCK_PHASES:
-                # the s x s phases of the ConvTranspose2d as the groups of ONE launch (dz_conv2d_desc.phase_groups): the phases of a
-                # pixel tile run next to each other on one XCD, the level's image is read from HBM once instead of s x s times
-                conv_layer(x, (xh + 2, xw + 2), self._w(de, 'w_phases'), de['scale'], de['shift'], True, concat,
-                           (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
-                           out_cstride=ctot, out_coff=coff, out_s=s, out_d=(1, 1), ho=xh, wo=xw, batch=batch, math=self.math,
-                           groups=s * s, g_cout=[de['cout']] * (s * s), g_ooff=[0] * (s * s), phase_groups=True)
-                coff += de['cout']
-                continue
-            for dy in range(s):
-                for dx in range(s):
-                    conv_layer(x, (xh + 2, xw + 2), self._w(de['phases'][dy][dx]), de['scale'], de['shift'], True, concat,
-                               (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
-                               out_cstride=ctot, out_coff=coff, out_s=s, out_d=(dy + 1, dx + 1), ho=xh, wo=xw,
-                               batch=batch, math=self.math)
-            coff += de['cout']
+            x, xh, xw, xc = self._level_convs(li, lvl, x, xh, xw, xc, batch, dev, sparse_in=sparse_in if li == 0 else None)
+            coff = self._level_deblock(lvl, x, xh, xw, xc, concat, coff, h, w, batch)
         return concat
+
+    def run_grouped(self, nb, group, consume, bev=None, sparse_in=None):
+        """`run` for more frames than one concatenation image can hold (the kernels address an image through 32-bit offsets): the
+        FIRST block and the deblocks + `consume(concat, g0, ng)` run in frame groups, the DEEPER blocks over all nb frames at once.
+        Why not everything per group: at 16 frames the 94 x 94 layers of the Waymo config are 4.5 tiles per persistent workgroup -
+        every launch runs 5 rounds where 4.5 would do (90 % of the chip); over 32 frames they are exactly 9."""
+        plan = self.plan()
+        if sparse_in is not None:
+            rows, ridx = sparse_in
+            dev = rows.device
+            h, w = ridx.shape[1] - 2, ridx.shape[2] - 2
+            cin0 = 2 * rows.shape[1]
+        else:
+            dev = bev.device
+            h, w = bev.shape[1] - 2, bev.shape[2] - 2
+            cin0 = bev.shape[3]
+        l0 = plan[0]
+        s0 = l0['convs'][0]['stride']
+        h0, w0 = (h + 2 - 3) // s0 + 1, (w + 2 - 3) // s0 + 1
+        c0 = l0['convs'][-1]['cout']
+        if len(l0['convs']) < 2:
+            raise DetZeroHipError('BaseBEVBackbone.run_grouped: the first block needs at least two convolutions')
+        x0_all = bordered_zeros('bev2d.x0_all', (nb, h0 + 2, w0 + 2, c0), dev)
+        for g0 in range(0, nb, group):
+            ng = min(group, nb - g0)
+            sp = (rows, ridx[g0:g0 + ng]) if sparse_in is not None else None
+            self._level_convs(0, l0, None if sp is not None else bev[g0:g0 + ng], h, w, cin0, ng, dev, sparse_in=sp, out_last=x0_all[g0:g0 + ng])
+        outs = [(x0_all, h0, w0, c0)]
+        x, xh, xw, xc = outs[0]
+        for li in range(1, len(plan)):
+            x, xh, xw, xc = self._level_convs(li, plan[li], x, xh, xw, xc, nb, dev)
+            outs.append((x, xh, xw, xc))
+        for g0 in range(0, nb, group):
+            ng = min(group, nb - g0)
+            concat = bordered_zeros('bev2d.concat', (ng, h + 2, w + 2, self.num_bev_features), dev)
+            coff = 0
+            for lvl, (x, xh, xw, xc) in zip(plan, outs):
+                coff = self._level_deblock(lvl, x[g0:g0 + ng], xh, xw, xc, concat, coff, h, w, ng)
+            consume(concat, g0, ng)
 
     def forward(self, data_dict):
         _inference_only(self)
