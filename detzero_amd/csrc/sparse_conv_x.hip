@@ -59,6 +59,7 @@ struct SpConvXArgs {
     const int *perm;            // output row of each (unit, position) when the table is in tap-set order, or null
     int *queue;                 // 10 words behind the windows: next ticket of each XCD's tile queue, workgroups done, single-unit queue
     int xrun;                   // consecutive tiles per XCD run (8; DZ_TUNE_XRUN)
+    int steal, singles;         // tail: take whole tiles from other XCDs' queues before the single units; single units per workgroup (1)
 };
 
 template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // tiles of two units while at least a unit per workgroup remains beyond them (a multiple of 64 = whole runs for all 8 queues), then
     // single units
     const int XRUN = a.xrun;
-    const int nfull = (max(nunits - (int)gridDim.x, 0) / 2) / (8 * XRUN) * (8 * XRUN);
+    const int nfull = (max(nunits - a.singles * (int)gridDim.x, 0) / 2) / (8 * XRUN) * (8 * XRUN);
     const int nk = a.cin / 16;
     const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes), crsrc = make_srsrc(a.w, a.w_bytes), nrsrc = make_srsrc(a.nbr, a.nbr_bytes);
     const unsigned int row_bytes = (unsigned int)a.cin * 4u, tap_bytes = (unsigned int)(COUT * a.cin * 4);
@@ -234,10 +235,27 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int xcd = blockIdx.x & 7;
     int *const tk_s = reinterpret_cast<int *>(smem + C::OFF_TK);
     // a ticket: q < nfull / 8 = the q-th full tile of my XCD's queue; past those, 2^30 + s = the s-th single unit of the common queue
+    // When my XCD's queue is exhausted the other XCDs' are tried before the single units (round 5): without that, the workgroups of an
+    // XCD that finishes early eat the single units while a slower XCD still hands out whole tiles, and the launch ends on a whole
+    // tile - the slowest workgroup ran 8.6 % / 7 % behind the average at 128 / 64 channels and 32 frames per pass
+    // (profiles/r05_ab_notes.txt).  A stolen tile loses its L2 neighbourhood, but only the last few per launch are stolen.
+    // (thread 0 only; `steal_from` remembers where the last probe round ended: 8 = every queue is empty)
+    int steal_from = 1;
+    const int steal_on = a.steal;
     auto take_ticket = [&]() {
-        int t = atomicAdd(a.queue + xcd, 1);
-        if (t >= nfull / 8) t = 0x40000000 | atomicAdd(a.queue + 9, 1);
-        return t;
+        const int per = nfull / 8;
+        if (steal_from == 1) {
+            const int t = atomicAdd(a.queue + xcd, 1);
+            if (t < per) return t | (xcd << 20);
+            if (!steal_on) steal_from = 8;
+        }
+        while (steal_from < 8) {
+            const int x2 = (xcd + steal_from) & 7;
+            const int t = atomicAdd(a.queue + x2, 1);
+            if (t < per) return t | (x2 << 20);
+            ++steal_from;
+        }
+        return (int)(0x40000000 | atomicAdd(a.queue + 9, 1));
     };
     if (tid == 0) {
         tk_s[0] = take_ticket();
@@ -268,7 +286,8 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 g.half = true;
                 g.live = g.u0 < nunits;
             } else {
-                g.u0 = 2 * (((q / XRUN) * 8 + xcd) * XRUN + q % XRUN);
+                const int qx = q >> 20, qq = q & 0xFFFFF;           // the queue (XCD) the ticket came from, its number there
+                g.u0 = 2 * (((qq / XRUN) * 8 + qx) * XRUN + qq % XRUN);
                 g.half = false;
             }
             if (g.live) {
@@ -748,6 +767,11 @@ static int x_run_len() {          // tiles per XCD run (development knob; a powe
     static const int v = getenv("DZ_TUNE_XRUN") ? atoi(getenv("DZ_TUNE_XRUN")) : 8;
     return v >= 1 && v <= 64 && (v & (v - 1)) == 0 ? v : 8;
 }
+static int x_steal() { static const int v = getenv("DZ_TUNE_X_STEAL") ? atoi(getenv("DZ_TUNE_X_STEAL")) : 1; return v; }
+// single-unit tickets per workgroup at the end of a launch: 0 since round 5 (only the units that do not fill a whole run of tiles
+// are dealt singly; A/B 1063.8 vs 1059.6 frames/s: a single unit costs ~ 60 % of a tile for half its rows, which is more than the
+// imbalance it removes once whole tiles can be taken from every XCD's queue)
+static int x_singles() { static const int v = getenv("DZ_TUNE_X_SINGLES") ? atoi(getenv("DZ_TUNE_X_SINGLES")) : 0; return v >= 0 && v <= 8 ? v : 0; }
 static int x32_variant() {
     static const int v = getenv("DZ_TUNE_X32") ? atoi(getenv("DZ_TUNE_X32")) : 0;
     return v;
@@ -881,7 +905,7 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
                   (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr, perm,
-                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6, x_run_len()};
+                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6, x_run_len(), x_steal(), x_singles()};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);
 }
