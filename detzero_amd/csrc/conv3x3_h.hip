@@ -67,7 +67,7 @@ struct C3Cfg {
 // (height_compression.py:20-24) + the ZeroPad2d of the first BEV block (backbone2d.py:41-46) fused into that block's convolution.
 template <int BC, class M, bool OUT_F32, int NT = 512, int DIAG = 0, int PT = 2, bool SPARSE = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 : 1, PT == 2 ? 2 : 1))) void k_conv3x3_h(dz_conv2d_desc p, int tiles_x, int tiles_y, unsigned int in_bytes,
-                                                          unsigned int w_bytes, int skew_ticks, int q_sa, int q_sb, float q_act) {
+                                                          unsigned int w_bytes, int skew_ticks, int q_sa, int q_sb, float q_act, int pair0, int ny) {
     using C = C3Cfg<BC, NT, PT>;
     constexpr int CT = C::CT, WPT = C::WPT, C3_THREADS = NT, C3_PXPT = C::PXPT, WC = C::WC, C3_TH = C::TH, C3_PX_ROWS = C::PX_ROWS,
                   C3_PX_PIECES = C::PX_PIECES;
@@ -81,11 +81,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // contiguous eighth of the pixel tiles, its workgroups side by side (neighbouring tiles share halo rows in that L2).
     // A workgroup keeps ONE channel tile (its weight stream simply wraps around from tile to tile) and the load pipeline
     // never drains between tiles: the next tile's input is prefetched during the last channel chunk of the current one.
-    const int ntn = p.cout_pad / BC, nty = ntn * p.groups;       // channel tiles per group, in all
+    // this launch covers the (group, channel tile) pairs pair0 .. pair0 + ny - 1 of the layer's ntn * groups (all of them unless their
+    // number does not divide the 32 workgroups of an XCD: launch_c3_nt)
+    const int ntn = p.cout_pad / BC, nty = ny;                  // channel tiles per group; pairs of this launch
     const int npx = p.batch * tiles_x * tiles_y;                 // pixel tiles
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, nj = gridDim.x >> 3;      // gridDim.x is a multiple of 8
-    const int grp = (jloc % nty) / ntn;
-    const int n0 = ((jloc % nty) % ntn) * BC;
+    const int grp = (pair0 + jloc % nty) / ntn;
+    const int n0 = ((pair0 + jloc % nty) % ntn) * BC;
     const int per_xcd = (npx + 7) >> 3;
     const int band_lo = xcd * per_xcd, band_hi = min(npx, band_lo + per_xcd);
     const int tstep = nj / nty;                                   // workgroups of this XCD that share my channel tile
@@ -574,13 +576,27 @@ static int launch_c3_nt(const dz_conv2d_desc &p, size_t w_bytes, hipStream_t str
     // persistent: 512 / NT workgroups per CU, a multiple of 8 x channel tiles so that every XCD gets the same number of
     // workgroups of every channel tile
     const int nty = p.cout_pad / BC * p.groups;
-    int per_xcd = 32 * (PT == 2 ? 512 / NT : 1) / nty * nty;
-    if (per_xcd < nty) per_xcd = nty;
-    const long grid = 8L * per_xcd;
+    const int slots = 32 * (PT == 2 ? 512 / NT : 1);            // workgroups of an XCD
     static const int skew = getenv("DZ_TUNE_C3_SKEW") ? atoi(getenv("DZ_TUNE_C3_SKEW")) : 0;     // 10 ns ticks
-    hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT, SPARSE>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
-                       tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew, q16_sa(), q16_sb(), q16_act());
-    DZ_LAUNCH_CHECK();
+    static const int split = getenv("DZ_TUNE_C3_SPLIT") ? atoi(getenv("DZ_TUNE_C3_SPLIT")) : 1;  // development knob: 0 = one launch (r01-r04)
+    // A workgroup keeps ONE (group, channel tile) pair, so an XCD runs a multiple of their number: with 3 or 6 pairs (the head's
+    // 64 -> 384 layer and its grouped output layer) that is 30 of 32 workgroups - 16 CUs idle for the whole launch.  Such a layer runs
+    // as two launches over 2 + 1 / 4 + 2 of its pairs, each on all 256 CUs (round 5: 27 rounds of tiles instead of 28.8)
+    int parts[2][2] = {{0, nty}, {0, 0}};
+    if (split && slots % nty != 0 && nty < slots) {
+        int a = 1;
+        while (a * 2 <= nty) a *= 2;                            // largest power of two below nty
+        if (slots % a == 0 && slots % (nty - a) == 0) { parts[0][1] = a; parts[1][0] = a; parts[1][1] = nty - a; }
+    }
+    for (int k = 0; k < 2 && parts[k][1] > 0; ++k) {
+        const int ny = parts[k][1];
+        int per_xcd = slots / ny * ny;
+        if (per_xcd < ny) per_xcd = ny;
+        const long grid = 8L * per_xcd;
+        hipLaunchKernelGGL((k_conv3x3_h<BC, M, OUT_F32, NT, DIAG, PT, SPARSE>), dim3((unsigned int)grid), dim3(NT), C::LDS_BYTES, stream, p, tiles_x,
+                           tiles_y, (unsigned int)in_bytes, (unsigned int)w_bytes, skew, q16_sa(), q16_sb(), q16_act(), parts[k][0], ny);
+        DZ_LAUNCH_CHECK();
+    }
     return DZ_OK;
 }
 
