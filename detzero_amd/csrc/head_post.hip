@@ -50,7 +50,11 @@ __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__r
 // every lane evaluates ONE rotated IoU per step; __ballot packs the 64 verdicts into the mask word.
 // Pairs whose circumscribed circles are more than 5 cm apart cannot touch (the reference's corner
 // test has a 1 cm margin), so their IoU is exactly 0 and the polygon clipping is skipped.
-constexpr int NMS_ROWS_PER_WAVE = 2;     // 500 candidates -> ~1150 independent wavefronts
+// Round 5: the wave first runs the circle test for all of its NMS_ROWS_PER_WAVE x 64 pairs and COMPACTS the survivors (ballot +
+// prefix into an LDS list), then evaluates the rotated IoU of the list with all 64 lanes busy.  Before, every (row, 64 columns)
+// step ran the polygon clipping whenever ANY lane had survived - a few active lanes per step: 215 us per 32 frames, the largest
+// kernel of the post stage.  Same pairs, same rect_iou, same mask.
+constexpr int NMS_ROWS_PER_WAVE = 16;    // 500 candidates -> 32 x 8 (upper triangle: ~150) wavefronts per frame
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, const int *__restrict__ d_n, int n_cap,
                                                  float thr, unsigned long long *__restrict__ mask, int col_blocks) {
     // batch item = blockIdx.z: boxes (B,n_cap,7), d_n (B), mask (B,n_cap,col_blocks)
@@ -63,6 +67,8 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes
     if (row0 >= n) return;
     __shared__ P2 cp_s[16 * 64];
     __shared__ float ang_s[16 * 64];
+    __shared__ unsigned short pair_s[NMS_ROWS_PER_WAVE * 64];          // surviving pairs: local row << 6 | column lane
+    __shared__ unsigned long long bits_s[NMS_ROWS_PER_WAVE];
     const int t = threadIdx.x;
     const int rows = min(NMS_ROWS_PER_WAVE, n - row0);
     const int col = cb * 64 + t;
@@ -76,20 +82,40 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes
     for (int q = 0; q < 7; ++q) B[q] = col_ok ? boxes[col * 7 + q] : 0.f;
     const float rb2 = 0.25f * (B[3] * B[3] + B[4] * B[4]);          // squared half diagonal
     const float rbr = sqrtf(rb2);
+    if (t < NMS_ROWS_PER_WAVE) bits_s[t] = 0ull;
+    // ---- circle test of every pair, survivors appended in (row, column) order
+    int npairs = 0;
     for (int i = 0; i < rows; ++i) {
         const int row = row0 + i;
-        float A[7];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) A[q] = boxes[row * 7 + q];       // wave-uniform -> scalar loads
-        bool hit = false;
+        const float ax = boxes[row * 7], ay = boxes[row * 7 + 1], adx = boxes[row * 7 + 3], ady = boxes[row * 7 + 4];      // wave-uniform -> scalar loads
+        bool near = false;
         if (col_ok && col > row) {
-            const float dx = A[0] - B[0], dy = A[1] - B[1];
-            const float reach = sqrtf(0.25f * (A[3] * A[3] + A[4] * A[4])) + rbr + 0.05f;
-            if (dx * dx + dy * dy <= reach * reach) hit = rect_iou(A, B, cp_s + t, ang_s + t, 64) > thr;
+            const float dx = ax - B[0], dy = ay - B[1];
+            const float reach = sqrtf(0.25f * (adx * adx + ady * ady)) + rbr + 0.05f;
+            near = dx * dx + dy * dy <= reach * reach;
         }
-        const unsigned long long bits = __ballot(hit);
-        if (t == 0) mask[(size_t)row * col_blocks + cb] = bits;
+        const unsigned long long m = __ballot(near);
+        if (near) pair_s[npairs + __popcll(m & ((1ull << t) - 1ull))] = (unsigned short)((i << 6) | t);
+        npairs += __popcll(m);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- rotated IoU of the survivors, 64 at a time
+    for (int k0 = 0; k0 < npairs; k0 += 64) {
+        const int k = k0 + t;
+        if (k < npairs) {
+            const int pr = pair_s[k], i = pr >> 6, c = pr & 63;
+            float A[7], C[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { A[q] = boxes[(row0 + i) * 7 + q]; C[q] = boxes[(cb * 64 + c) * 7 + q]; }
+            if (rect_iou(A, C, cp_s + t, ang_s + t, 64) > thr) atomicOr(&bits_s[i], 1ull << c);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (t < rows) mask[(size_t)(row0 + t) * col_blocks + cb] = bits_s[t];
 }
 
 // sequential suppression, one workgroup: 64 mask rows at a time are staged in LDS, wave 0 sweeps.
