@@ -232,8 +232,23 @@ static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
     static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0), tw = tune("DZ_TUNE_SPCONV_W", 1);
     // small-channel levels: wave-private tiles with all weights resident in LDS (sparse_conv_w.h)
     if (tw && a.cout_pad == 32 && a.tile_masks && a.nbr_bytes) {
-        if (a.cin == 16 && a.cout == 16) return launch_spconv_w<16, 16, 4, M, 6, 3>(a, stream);
-        if (a.cin == 16 && a.cout == 32) return launch_spconv_w<16, 32, 3, M, 6, 3>(a, stream);
+        if (a.cin == 16 && a.cout == 16) {
+            // workgroup size (waves) x waves per SIMD: development knob.  Round 5: 4 waves per workgroup (three workgroups per CU)
+            // instead of 6 (two per CU): 238 vs 282 us per launch at 32 frames - the waves of a smaller workgroup drift apart less
+            // before the weights' LDS reads and share the CU with two independent neighbours
+            static const int w16 = tune("DZ_TUNE_W16", 2);
+            if (w16 == 0) return launch_spconv_w<16, 16, 4, M, 6, 3>(a, stream);
+            if (w16 == 1) return launch_spconv_w<16, 16, 4, M, 8, 4>(a, stream);
+            if (w16 == 6) return launch_spconv_w<16, 16, 4, M, 2, 3>(a, stream);
+            if (w16 == 7) return launch_spconv_w<16, 16, 4, M, 3, 3>(a, stream);
+            return launch_spconv_w<16, 16, 4, M, 4, 3>(a, stream);
+        }
+        if (a.cin == 16 && a.cout == 32) {
+            static const int w1632 = tune("DZ_TUNE_W1632", 0);
+            if (w1632 == 1) return launch_spconv_w<16, 32, 3, M, 4, 3>(a, stream);
+            if (w1632 == 2) return launch_spconv_w<16, 32, 3, M, 3, 3>(a, stream);
+            return launch_spconv_w<16, 32, 3, M, 6, 3>(a, stream);
+        }
         if (a.cin == 32 && a.cout == 32) return launch_spconv_w<32, 32, 2, M, 12, 3>(a, stream);
     }
     if (a.cin == 16 && a.cout_pad == 32) return launch_spconv_h<HTile<128, 32, 16, 4, 1>, M, 4, 3, 4, 5>(a, stream);

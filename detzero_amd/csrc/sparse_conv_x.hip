@@ -196,7 +196,9 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // tiles of two units while at least a unit per workgroup remains beyond them (a multiple of 64 = whole runs for all 8 queues), then
     // single units
     const int XRUN = a.xrun;
-    const int nfull = (max(nunits - a.singles * (int)gridDim.x, 0) / 2) / (8 * XRUN) * (8 * XRUN);
+    // single-unit tickets per workgroup at the end of the launch (0 unless forced: measured best at 8, 16 and 32 frames per pass)
+    const int singles = a.singles >= 0 ? a.singles : 0;
+    const int nfull = (max(nunits - singles * (int)gridDim.x, 0) / 2) / (8 * XRUN) * (8 * XRUN);
     const int nk = a.cin / 16;
     const srsrc_t prsrc = make_srsrc(a.in, a.in_bytes), crsrc = make_srsrc(a.w, a.w_bytes), nrsrc = make_srsrc(a.nbr, a.nbr_bytes);
     const unsigned int row_bytes = (unsigned int)a.cin * 4u, tap_bytes = (unsigned int)(COUT * a.cin * 4);
@@ -768,10 +770,9 @@ static int x_run_len() {          // tiles per XCD run (development knob; a powe
     return v >= 1 && v <= 64 && (v & (v - 1)) == 0 ? v : 8;
 }
 static int x_steal() { static const int v = getenv("DZ_TUNE_X_STEAL") ? atoi(getenv("DZ_TUNE_X_STEAL")) : 1; return v; }
-// single-unit tickets per workgroup at the end of a launch: 0 since round 5 (only the units that do not fill a whole run of tiles
-// are dealt singly; A/B 1063.8 vs 1059.6 frames/s: a single unit costs ~ 60 % of a tile for half its rows, which is more than the
-// imbalance it removes once whole tiles can be taken from every XCD's queue)
-static int x_singles() { static const int v = getenv("DZ_TUNE_X_SINGLES") ? atoi(getenv("DZ_TUNE_X_SINGLES")) : 0; return v >= 0 && v <= 8 ? v : 0; }
+// single-unit tickets per workgroup at the end of a launch: -1 = by the launch's size (k_spconv_x), else forced (development knob).
+// A/B at 32 frames per pass: 0 singles 1063.8 frames/s against 1059.6 with one per workgroup (round 4)
+static int x_singles() { static const int v = getenv("DZ_TUNE_X_SINGLES") ? atoi(getenv("DZ_TUNE_X_SINGLES")) : -1; return v >= -1 && v <= 8 ? v : -1; }
 static int x32_variant() {
     static const int v = getenv("DZ_TUNE_X32") ? atoi(getenv("DZ_TUNE_X32")) : 0;
     return v;
