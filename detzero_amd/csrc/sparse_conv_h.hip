@@ -229,7 +229,9 @@ static int launch_spconv_h(const SpConvHArgs &a, hipStream_t stream, bool ring_o
 // 4 register stages, 128 x 128 with 4 waves).
 template <class M>
 static int spconv_h_dispatch(const SpConvHArgs &a, hipStream_t stream) {
-    static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 0), tw = tune("DZ_TUNE_SPCONV_W", 1);
+    // (t128: 3 since round 5 - the 128-channel gather kernel now serves only the strided 64 -> 128 layer and conv_out, the x-run engine
+    // has the submanifold layers: 1079.8 / 1078.1 against 1074.4 / 1075.0 frames/s, profiles/r05_ab_notes.txt; 4 = the r03-r04 tile)
+    static const int t64 = tune("DZ_TUNE_SPCONV64", 0), t128 = tune("DZ_TUNE_SPCONV128", 3), tw = tune("DZ_TUNE_SPCONV_W", 1);
     // small-channel levels: wave-private tiles with all weights resident in LDS (sparse_conv_w.h)
     if (tw && a.cout_pad == 32 && a.tile_masks && a.nbr_bytes) {
         if (a.cin == 16 && a.cout == 16) {
@@ -373,7 +375,7 @@ const char *dz_spconv_variant_split(int cin, int cout) {
     if ((cin == 32 || cin == 64) && cout_pad == 64)
         return tune("DZ_TUNE_SPCONV64", 0) == 2 ? "k_spconv_h<128x64x32>" : "k_spconv_h<256x64x32>";
     if ((cin == 64 || cin == 128) && cout_pad == 128)
-        return tune("DZ_TUNE_SPCONV128", 0) == 3 ? "k_spconv_h<256x128x32>" : "k_spconv_h<128x128x32>";
+        return tune("DZ_TUNE_SPCONV128", 3) == 3 ? "k_spconv_h<256x128x32>" : "k_spconv_h<128x128x32>";
     return "none";
 }
 
