@@ -494,7 +494,8 @@ class VoxelResBackBone8x(_Cached):
         pool = self.__dict__.setdefault('_side_streams', {})
         k = (str(dev), key)
         if k not in pool:
-            pool[k] = torch.cuda.Stream(device=dev)
+            # (DZ_TUNE_SIDE_PRIORITY: development knob, -1 = high-priority queue for the index pyramid)
+            pool[k] = torch.cuda.Stream(device=dev, priority=int(os.environ.get('DZ_TUNE_SIDE_PRIORITY', '0')))
         return pool[k]
 
     def forward(self, batch_dict):
