@@ -14,8 +14,10 @@ def short(name):
     name = re.sub(r'TileCfg<(\d+), (\d+), (\d+), \d+, \d+>', r'\1x\2x\3', name)
     name = re.sub(r'<HTile<(\d+), (\d+), (\d+), \d+, \d+>, Math(\w+?)(, \w+)*>', r'<\1x\2x\3>[\4]', name)
     # resident-tile 3x3 kernel: <BC, Math, OUT_F32, threads, diag, rows per wave> -> <tile rows x 32 x BC>[Math] (16-row tiles at BC = 32)
-    name = re.sub(r'k_conv3x3_h<(\d+), Math(\w+?), \w+(, \d+)*>',
-                  lambda m: 'k_conv3x3_h<%sx32x%s>[%s]' % ('16' if m.group(1) == '32' else '8', m.group(1), m.group(2)), name)
+    # (round 5: a trailing `true` = the sparse-input form, dz_conv2d_desc.in_rowidx -> "|rows")
+    name = re.sub(r'k_conv3x3_h<(\d+), Math(\w+?), \w+((?:, \d+)*)(, (?:true|false))?>',
+                  lambda m: 'k_conv3x3_h<%sx32x%s%s>[%s]' % ('16' if m.group(1) == '32' else '8', m.group(1), '|rows' if (m.group(4) or '').endswith('true') else '',
+                                                          m.group(2)), name)
     return name[:90]
 
 
