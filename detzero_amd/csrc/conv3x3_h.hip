@@ -84,7 +84,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // this launch covers the (group, channel tile) pairs pair0 .. pair0 + ny - 1 of the layer's ntn * groups (all of them unless their
     // number does not divide the 32 workgroups of an XCD: launch_c3_nt)
     const int ntn = p.cout_pad / BC, nty = ny;                  // channel tiles per group; pairs of this launch
-    const int npx = p.batch * tiles_x * tiles_y;                 // pixel tiles
+    // pixel tiles: all of them, or - sparse input with a tile list (dz_bev_tile_list) - the occupied ones; the empty tiles' constant
+    // result is written by dz_bev_fill_empty_tiles
+    const int *const tlist = SPARSE ? p.in_tiles : nullptr;
+    const int npx = tlist ? tlist[0] : p.batch * tiles_x * tiles_y;
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, nj = gridDim.x >> 3;      // gridDim.x is a multiple of 8
     const int grp = (pair0 + jloc % nty) / ntn;
     const int n0 = ((pair0 + jloc % nty) % ntn) * BC;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
     int x0, y0, b;
     auto tile_origin = [&](int t, int &ox, int &oy, int &ob) {
+        if (tlist) t = __builtin_amdgcn_readfirstlane(tlist[2 + t]);         // (position in the list -> tile id)
         ox = (t % tiles_x) * C3_TW;
         oy = ((t / tiles_x) % tiles_y) * C3_TH;
         ob = t / (tiles_x * tiles_y);

@@ -145,11 +145,112 @@ __global__ __launch_bounds__(256) void k_bev_row_index(const uint32_t *__restric
     }
 }
 
+// ---- pixel tiles of the sparse-input convolution (8 x 32 output pixels, conv3x3_h.hip) whose 10 x 34 input halo holds no row at all:
+// the convolution of such a tile is ReLU(shift) in every pixel.  k_bev_tile_flags marks them (one wavefront per tile), k_bev_tile_compact
+// writes list[0] = n occupied, list[1] = n empty, then the occupied tile ids in ascending order, then the empty ones; the convolution
+// walks only the occupied ones, k_bev_fill_tiles writes the constant into the empty ones - the same bits the kernel would have produced
+// (acc = 0 -> fmaf(0, scale, shift) = shift -> ReLU -> the (hi, lo) split).
+__global__ __launch_bounds__(64) void k_bev_tile_flags(const int2 *__restrict__ idx, int batch, int hp, int wp, int ho, int wo, int tiles_y, int tiles_x,
+                                                       unsigned char *__restrict__ flags) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int y0 = ty * 8, x0 = tx * 32;                      // halo origin in the padded image = output origin (pad 1, in_off 0)
+    bool any = false;
+    for (int k = lane; k < 10 * 34; k += 64) {
+        const int ry = k / 34, rx = k - ry * 34;
+        const int y = y0 + ry, x = x0 + rx;
+        if (y < hp && x < wp) {
+            const int2 v = idx[((size_t)b * hp + y) * wp + x];
+            any |= v.x >= 0 || v.y >= 0;
+        }
+    }
+    const bool w = __ballot(any) != 0ull;
+    if (lane == 0) flags[t] = w ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void k_bev_tile_compact(const unsigned char *__restrict__ flags, int n, int *__restrict__ list) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += flags[i];
+    part[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                      // inclusive scan of the per-thread counts
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int total = part[1023];
+    int occ = part[tid] - c, emp = lo - occ;                 // occupied / empty tiles before my range
+    for (int i = lo; i < hi; ++i) {
+        if (flags[i]) list[2 + occ++] = i;
+        else list[2 + total + emp++] = i;
+    }
+    if (tid == 0) { list[0] = total; list[1] = n - total; }
+}
+
+template <class M>
+__global__ __launch_bounds__(256) void k_bev_fill_tiles(const int *__restrict__ list, int tiles_y, int tiles_x, int ho, int wo, const float *__restrict__ shift,
+                                                        int relu, int cout, float *__restrict__ out, int out_hp, int out_wp, int out_cstride, int out_coff) {
+    const int n_occ = list[0], n_emp = list[1];
+    if ((int)blockIdx.x >= n_emp) return;
+    const int t = list[2 + n_occ + blockIdx.x];
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int groups = cout / 8;
+    for (int k = threadIdx.x; k < 8 * 32 * groups; k += 256) {
+        const int g = k % groups, px = k / groups, r = px / 32, c = px % 32;
+        const int y = ty * 8 + r, x = tx * 32 + c;
+        if (y >= ho || x >= wo) continue;
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = shift ? shift[g * 8 + e] : 0.f, bb = shift ? shift[g * 8 + 4 + e] : 0.f;
+            v0[e] = relu ? fmaxf(a, 0.f) : a;
+            v1[e] = relu ? fmaxf(bb, 0.f) : bb;
+        }
+        uint2 h0, l0, h1, l1;
+        split4<M>(v0, h0, l0);
+        split4<M>(v1, h1, l1);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (((size_t)b * out_hp + y + 1) * out_wp + x + 1) * out_cstride + out_coff + g * 8);
+        dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
 }  // namespace dz
 
 using namespace dz;
 
 extern "C" {
+
+size_t dz_bev_tile_list_words(int batch, int ho, int wo) { return (size_t)batch * ceil_div(ho, 8) * ceil_div(wo, 32) + 2; }
+
+int dz_bev_tile_list(const int *idx, int batch, int hp, int wp, int ho, int wo, int *list, unsigned char *flags_ws, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(idx && list && flags_ws && batch > 0 && ho > 0 && wo > 0 && hp >= ho + 2 && wp >= wo + 2, "dz_bev_tile_list: bad argument");
+    const int ty = ceil_div(ho, 8), tx = ceil_div(wo, 32), n = batch * ty * tx;
+    hipLaunchKernelGGL(k_bev_tile_flags, dim3(n), dim3(64), 0, stream, reinterpret_cast<const int2 *>(idx), batch, hp, wp, ho, wo, ty, tx, flags_ws);
+    hipLaunchKernelGGL(k_bev_tile_compact, dim3(1), dim3(1024), 0, stream, flags_ws, n, list);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+int dz_bev_fill_empty_tiles(const int *list, int batch, int ho, int wo, const float *shift, int relu, int cout, float *out, int out_hp, int out_wp,
+                            int out_cstride, int out_coff, int math, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(list && out && batch > 0 && ho > 0 && wo > 0 && cout > 0 && cout % 8 == 0 && out_cstride % 8 == 0 && out_coff % 8 == 0 &&
+                 out_hp >= ho + 2 && out_wp >= wo + 2, "dz_bev_fill_empty_tiles: bad argument");
+    DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_bev_fill_empty_tiles: math %d is not a split mode", math);
+    const int ty = ceil_div(ho, 8), tx = ceil_div(wo, 32), n = batch * ty * tx;
+    if (math == DZ_MATH_BF16X2)
+        hipLaunchKernelGGL(k_bev_fill_tiles<MathBF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride, out_coff);
+    else
+        hipLaunchKernelGGL(k_bev_fill_tiles<MathF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride, out_coff);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
 
 int dz_bev_row_index(const uint32_t *bitmap, const uint32_t *prefix, int batch, int d, int h, int w, int layout, int pad, int feat_rows, int *idx,
                      void *stream_) {

@@ -604,6 +604,7 @@ def _recode(img, enc, math):
     return ops.pair16_from_f32(plain, math=math) if math else plain
 
 
+SKIP_EMPTY_TILES = os.environ.get('DZ_TUNE_SKIP_EMPTY_TILES', '1') != '0'  # development switch: 0 = the sparse-input convolution runs every pixel tile
 SPARSE_BEV_INPUT = os.environ.get('DZ_TUNE_SPARSE_BEV', '1') != '0'     # development switch: 0 = dense BEV image (r01-r04)
 FUSED_DEBLOCK_PHASES = os.environ.get('DZ_TUNE_DEBLOCK_PHASES', '1') != '0'     # development switch: 0 = one launch per phase (r01-r04)
 
@@ -611,7 +612,7 @@ FUSED_DEBLOCK_PHASES = os.environ.get('DZ_TUNE_DEBLOCK_PHASES', '1') != '0'     
 def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_cstride, in_coff=0, ksize=3,
                stride=1, in_off=0, out_cstride, out_coff=0, out_s=1, out_d=(0, 0), groups=1, cout_pad=None,
                g_cout=None, g_ooff=None, ho=None, wo=None, batch=1, math=0, out_f32=False, phase_groups=False, in_rowidx=None,
-               in_row_channels=0, in_rows=0):
+               in_row_channels=0, in_rows=0, in_tiles=None):
     """One dz_conv2d_forward[_split] call.  in_shape/out_shape = (Hp, Wp) of the (padded) images.
     math != 0: w is the pack_weight_split layout (..., cout_pad, cin)."""
     if cout_pad is None:
@@ -627,7 +628,8 @@ def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_
         groups=groups, cout_pad=cout_pad,
         g_cout=g_cout if g_cout is not None else [cout_pad], g_ooff=g_ooff if g_ooff is not None else [0],
         relu=1 if relu else 0, phase_groups=1 if phase_groups else 0,
-        in_rowidx=in_rowidx.data_ptr() if in_rowidx is not None else None, in_row_channels=int(in_row_channels), in_rows=int(in_rows)),
+        in_rowidx=in_rowidx.data_ptr() if in_rowidx is not None else None, in_row_channels=int(in_row_channels), in_rows=int(in_rows),
+        in_tiles=in_tiles.data_ptr() if in_tiles is not None else None),
         math=math, out_f32=out_f32)
 
 
@@ -719,10 +721,15 @@ class BaseBEVBackbone(_Cached):
             if sparse_in is not None and li == 0 and ci == 0:
                 # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
                 rows, ridx = sparse_in
+                # pixel tiles without any row in their halo (the corners of the BEV square beyond the sensor's range: 16-24 % of the
+                # tiles of a 160k-point frame) are left out of the launch and filled with their constant result
+                tiles = ops.bev_tile_list(ridx, oh, ow) if SKIP_EMPTY_TILES else None
                 conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
                            out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
-                           in_rows=rows.shape[0])
+                           in_rows=rows.shape[0], in_tiles=tiles)
+                if tiles is not None:
+                    ops.bev_fill_empty_tiles(tiles, batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math)
             else:
                 conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],

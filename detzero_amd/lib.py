@@ -40,7 +40,7 @@ class Conv2dDesc(ctypes.Structure):
         ('g_cout', _I8), ('g_ooff', _I8),
         ('relu', c_int),
         ('group_shift', c_void_p), ('group_rows', c_int), ('group_max', c_int), ('phase_groups', c_int),
-        ('in_rowidx', c_void_p), ('in_row_channels', c_int), ('in_rows', c_int),
+        ('in_rowidx', c_void_p), ('in_row_channels', c_int), ('in_rows', c_int), ('in_tiles', c_void_p),
     ]
 
 
@@ -125,6 +125,9 @@ _SIGS = {
     'dz_spconv_forward_split_x': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_x_variant': (ctypes.c_char_p, [c_int, c_int]),
+    'dz_bev_tile_list_words': (c_size_t, [c_int, c_int, c_int]),
+    'dz_bev_tile_list': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'dz_bev_fill_empty_tiles': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dz_bev_row_index': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),

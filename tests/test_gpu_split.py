@@ -240,7 +240,7 @@ def test_sparse_input_convolution_equals_the_dense_image(device, name, mid):
     rng = np.random.default_rng(5 + mid)
     b, shape, c, cout = 16, [2, 61, 90], 128, 128
     cells = shape[0] * shape[1] * shape[2]
-    lin = np.unique(np.concatenate([i * cells + np.nonzero(rng.random(cells) < (0.3 if i % 3 else 0.02))[0] for i in range(b)]))
+    lin = np.unique(np.concatenate([i * cells + np.nonzero(rng.random(cells) < (0.3 if i % 3 else 0.002))[0] for i in range(b)]))
     coords = np.stack([lin // cells, (lin % cells) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
     n = coords.shape[0]
     for cap in (n + 5, n - 300):                      # the second: an overflowed level - ranks past the rows read as empty cells
@@ -271,6 +271,20 @@ def test_sparse_input_convolution_equals_the_dense_image(device, name, mid):
                        in_rowidx=idx if sparse else None, in_row_channels=c, in_rows=cap)
             outs.append(out)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)) and float(ops.pair16_to_f32(outs[1], mid).abs().max()) > 0.1
+        # ... and with the empty pixel tiles left out of the launch and filled with their constant result (the detector's route)
+        tiles = ops.bev_tile_list(idx, shape[1], shape[2])
+        n_occ, n_emp = (int(v) for v in tiles[:2].tolist())
+        ntile = b * ((shape[1] + 7) // 8) * ((shape[2] + 31) // 32)
+        assert n_occ + n_emp == ntile and n_emp > ntile // 20 and n_occ > ntile // 2
+        ids = tiles[2:2 + ntile].cpu().numpy()
+        assert np.array_equal(np.sort(ids), np.arange(ntile)) and (np.diff(ids[:n_occ]) > 0).all() and (np.diff(ids[n_occ:]) > 0).all()
+        out = torch.full((b, shape[1] + 2, shape[2] + 2, cout), float('nan'), dtype=torch.float32, device=device)
+        out[:, 0], out[:, -1], out[:, :, 0], out[:, :, -1] = 0, 0, 0, 0
+        conv_layer(rows, (shape[1] + 2, shape[2] + 2), w, scale, shift, True, out, (shape[1] + 2, shape[2] + 2), cin=2 * c, in_cstride=2 * c, ksize=3,
+                   stride=1, in_off=0, out_cstride=cout, out_d=(1, 1), ho=shape[1], wo=shape[2], batch=b, math=mid, in_rowidx=idx, in_row_channels=c,
+                   in_rows=cap, in_tiles=tiles)
+        ops.bev_fill_empty_tiles(tiles, b, shape[1], shape[2], shift, True, cout, out, mid)
+        assert torch.equal(out.view(torch.int32), outs[1].view(torch.int32))
 
 
 @pytest.fixture(scope='module')
