@@ -84,9 +84,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // this launch covers the (group, channel tile) pairs pair0 .. pair0 + ny - 1 of the layer's ntn * groups (all of them unless their
     // number does not divide the 32 workgroups of an XCD: launch_c3_nt)
     const int ntn = p.cout_pad / BC, nty = ny;                  // channel tiles per group; pairs of this launch
-    // pixel tiles: all of them, or - sparse input with a tile list (dz_bev_tile_list) - the occupied ones; the empty tiles' constant
-    // result is written by dz_bev_fill_empty_tiles
-    const int *const tlist = SPARSE ? p.in_tiles : nullptr;
+    // pixel tiles: all of them, or - with a tile list (dz_bev_tile_list) - the tiles to run; the others' result (the layer's zero-input
+    // response) is written by dz_bev_fill_empty_tiles
+    const int *const tlist = p.in_tiles;
     const int npx = tlist ? tlist[0] : p.batch * tiles_x * tiles_y;
     const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, nj = gridDim.x >> 3;      // gridDim.x is a multiple of 8
     const int grp = (pair0 + jloc % nty) / ntn;

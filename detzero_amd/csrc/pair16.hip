@@ -150,30 +150,59 @@ __global__ __launch_bounds__(256) void k_bev_row_index(const uint32_t *__restric
 // writes list[0] = n occupied, list[1] = n empty, then the occupied tile ids in ascending order, then the empty ones; the convolution
 // walks only the occupied ones, k_bev_fill_tiles writes the constant into the empty ones - the same bits the kernel would have produced
 // (acc = 0 -> fmaf(0, scale, shift) = shift -> ReLU -> the (hi, lo) split).
-__global__ __launch_bounds__(64) void k_bev_tile_flags(const int2 *__restrict__ idx, int batch, int hp, int wp, int ho, int wo, int tiles_y, int tiles_x,
-                                                       unsigned char *__restrict__ flags) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+// Chebyshev distance (capped at DCAP) of every pixel to the nearest pixel that holds a row; outside the image there are none.
+// D >= l + 1 on all pixels of a tile <=> the tile's input halo at dense layer l (1 = the sparse-input layer) lies in the region where the
+// network's activations are its ZERO-INPUT RESPONSE: the tile's result is a copy of that response (dz_bev_fill_empty_tiles).
+constexpr int BEV_DCAP = 8;
+__global__ __launch_bounds__(256) void k_bev_tile_mind(const int2 *__restrict__ idx, int batch, int hp, int wp, int ho, int wo, int tiles_y, int tiles_x,
+                                                       unsigned char *__restrict__ mind) {
+    // one workgroup per tile: occupancy of the tile's pixels + BEV_DCAP pixels around them into LDS, then each of the 256 threads
+    // grows a square around its pixel
+    constexpr int R = BEV_DCAP - 1, SH = 8 + 2 * R, SW = 32 + 2 * R;
+    __shared__ unsigned char occ[SH][SW + 2];
+    __shared__ int tile_min;
+    const int t = blockIdx.x;
     const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-    const int y0 = ty * 8, x0 = tx * 32;                      // halo origin in the padded image = output origin (pad 1, in_off 0)
-    bool any = false;
-    for (int k = lane; k < 10 * 34; k += 64) {
-        const int ry = k / 34, rx = k - ry * 34;
+    const int y0 = ty * 8 - R, x0 = tx * 32 - R;             // image coordinates (unpadded) of the LDS window's origin
+    if (threadIdx.x == 0) tile_min = BEV_DCAP;
+    for (int k = threadIdx.x; k < SH * SW; k += 256) {
+        const int ry = k / SW, rx = k - ry * SW;
         const int y = y0 + ry, x = x0 + rx;
-        if (y < hp && x < wp) {
-            const int2 v = idx[((size_t)b * hp + y) * wp + x];
-            any |= v.x >= 0 || v.y >= 0;
+        unsigned char o = 0;
+        if ((unsigned)y < (unsigned)ho && (unsigned)x < (unsigned)wo) {
+            const int2 v = idx[((size_t)b * hp + y + 1) * wp + x + 1];
+            o = (v.x >= 0 || v.y >= 0) ? 1 : 0;
+        }
+        occ[ry][rx] = o;
+    }
+    __syncthreads();
+    const int py = threadIdx.x >> 5, px = threadIdx.x & 31;
+    int d = BEV_DCAP;
+    if (ty * 8 + py < ho && tx * 32 + px < wo) {
+        const int cy = py + R, cx = px + R;
+        if (occ[cy][cx]) d = 0;
+        else {
+            for (int r = 1; r <= R && d == BEV_DCAP; ++r) {
+                bool hit = false;
+                for (int k = -r; k <= r; ++k)
+                    hit |= occ[cy - r][cx + k] | occ[cy + r][cx + k] | occ[cy + k][cx - r] | occ[cy + k][cx + r];
+                if (hit) d = r;
+            }
         }
     }
-    const bool w = __ballot(any) != 0ull;
-    if (lane == 0) flags[t] = w ? 1 : 0;
+    atomicMin(&tile_min, d);
+    __syncthreads();
+    if (threadIdx.x == 0) mind[t] = (unsigned char)tile_min;
 }
 
-__global__ __launch_bounds__(1024) void k_bev_tile_compact(const unsigned char *__restrict__ flags, int n, int *__restrict__ list) {
+// list l (blockIdx.x = l - 1, l = 1 .. nlists): [n occupied, n skippable, ids of the tiles with min D < l + 1 ascending, the others], stride `stride` ints
+__global__ __launch_bounds__(1024) void k_bev_tile_compact(const unsigned char *__restrict__ mind, int n, int *__restrict__ lists, int stride) {
     __shared__ int part[1024];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, need = (int)blockIdx.x + 2;
+    int *const list = lists + (size_t)blockIdx.x * stride;
     const int per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
     int c = 0;
-    for (int i = lo; i < hi; ++i) c += flags[i];
+    for (int i = lo; i < hi; ++i) c += mind[i] < need;
     part[tid] = c;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                      // inclusive scan of the per-thread counts
@@ -183,9 +212,9 @@ __global__ __launch_bounds__(1024) void k_bev_tile_compact(const unsigned char *
         __syncthreads();
     }
     const int total = part[1023];
-    int occ = part[tid] - c, emp = lo - occ;                 // occupied / empty tiles before my range
+    int occ = part[tid] - c, emp = lo - occ;                 // occupied / skippable tiles before my range
     for (int i = lo; i < hi; ++i) {
-        if (flags[i]) list[2 + occ++] = i;
+        if (mind[i] < need) list[2 + occ++] = i;
         else list[2 + total + emp++] = i;
     }
     if (tid == 0) { list[0] = total; list[1] = n - total; }
@@ -193,7 +222,8 @@ __global__ __launch_bounds__(1024) void k_bev_tile_compact(const unsigned char *
 
 template <class M>
 __global__ __launch_bounds__(256) void k_bev_fill_tiles(const int *__restrict__ list, int tiles_y, int tiles_x, int ho, int wo, const float *__restrict__ shift,
-                                                        int relu, int cout, float *__restrict__ out, int out_hp, int out_wp, int out_cstride, int out_coff) {
+                                                        int relu, int cout, float *__restrict__ out, int out_hp, int out_wp, int out_cstride, int out_coff,
+                                                        const float *__restrict__ zero_resp) {
     const int n_occ = list[0], n_emp = list[1];
     if ((int)blockIdx.x >= n_emp) return;
     const int t = list[2 + n_occ + blockIdx.x];
@@ -203,6 +233,14 @@ __global__ __launch_bounds__(256) void k_bev_fill_tiles(const int *__restrict__ 
         const int g = k % groups, px = k / groups, r = px / 32, c = px % 32;
         const int y = ty * 8 + r, x = tx * 32 + c;
         if (y >= ho || x >= wo) continue;
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (((size_t)b * out_hp + y + 1) * out_wp + x + 1) * out_cstride + out_coff + g * 8);
+        if (zero_resp) {
+            // the layer's response to an all-zero input at this pixel: a (1, out_hp, out_wp, cout) pair16 image computed once per model
+            const uint4 *src = reinterpret_cast<const uint4 *>(zero_resp + (((size_t)(y + 1)) * out_wp + x + 1) * cout + g * 8);
+            dst[0] = src[0];
+            dst[1] = src[1];
+            continue;
+        }
         float v0[4], v1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -213,7 +251,6 @@ __global__ __launch_bounds__(256) void k_bev_fill_tiles(const int *__restrict__ 
         uint2 h0, l0, h1, l1;
         split4<M>(v0, h0, l0);
         split4<M>(v1, h1, l1);
-        uint4 *dst = reinterpret_cast<uint4 *>(out + (((size_t)b * out_hp + y + 1) * out_wp + x + 1) * out_cstride + out_coff + g * 8);
         dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
         dst[1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
@@ -227,27 +264,30 @@ extern "C" {
 
 size_t dz_bev_tile_list_words(int batch, int ho, int wo) { return (size_t)batch * ceil_div(ho, 8) * ceil_div(wo, 32) + 2; }
 
-int dz_bev_tile_list(const int *idx, int batch, int hp, int wp, int ho, int wo, int *list, unsigned char *flags_ws, void *stream_) {
+int dz_bev_tile_list(const int *idx, int batch, int hp, int wp, int ho, int wo, int nlists, int *lists, unsigned char *mind_ws, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DZ_CHECK_ARG(idx && list && flags_ws && batch > 0 && ho > 0 && wo > 0 && hp >= ho + 2 && wp >= wo + 2, "dz_bev_tile_list: bad argument");
+    DZ_CHECK_ARG(idx && lists && mind_ws && batch > 0 && ho > 0 && wo > 0 && hp >= ho + 2 && wp >= wo + 2 && nlists >= 1 && nlists < BEV_DCAP,
+                 "dz_bev_tile_list: bad argument (1 <= nlists <= %d)", BEV_DCAP - 1);
     const int ty = ceil_div(ho, 8), tx = ceil_div(wo, 32), n = batch * ty * tx;
-    hipLaunchKernelGGL(k_bev_tile_flags, dim3(n), dim3(64), 0, stream, reinterpret_cast<const int2 *>(idx), batch, hp, wp, ho, wo, ty, tx, flags_ws);
-    hipLaunchKernelGGL(k_bev_tile_compact, dim3(1), dim3(1024), 0, stream, flags_ws, n, list);
+    hipLaunchKernelGGL(k_bev_tile_mind, dim3(n), dim3(256), 0, stream, reinterpret_cast<const int2 *>(idx), batch, hp, wp, ho, wo, ty, tx, mind_ws);
+    hipLaunchKernelGGL(k_bev_tile_compact, dim3(nlists), dim3(1024), 0, stream, mind_ws, n, lists, (int)dz_bev_tile_list_words(batch, ho, wo));
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }
 
 int dz_bev_fill_empty_tiles(const int *list, int batch, int ho, int wo, const float *shift, int relu, int cout, float *out, int out_hp, int out_wp,
-                            int out_cstride, int out_coff, int math, void *stream_) {
+                            int out_cstride, int out_coff, const float *zero_resp, int math, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DZ_CHECK_ARG(list && out && batch > 0 && ho > 0 && wo > 0 && cout > 0 && cout % 8 == 0 && out_cstride % 8 == 0 && out_coff % 8 == 0 &&
                  out_hp >= ho + 2 && out_wp >= wo + 2, "dz_bev_fill_empty_tiles: bad argument");
     DZ_CHECK_ARG(math == DZ_MATH_F16X2 || math == DZ_MATH_BF16X2 || math == DZ_MATH_F16, "dz_bev_fill_empty_tiles: math %d is not a split mode", math);
     const int ty = ceil_div(ho, 8), tx = ceil_div(wo, 32), n = batch * ty * tx;
     if (math == DZ_MATH_BF16X2)
-        hipLaunchKernelGGL(k_bev_fill_tiles<MathBF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride, out_coff);
+        hipLaunchKernelGGL(k_bev_fill_tiles<MathBF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride,
+                           out_coff, zero_resp);
     else
-        hipLaunchKernelGGL(k_bev_fill_tiles<MathF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride, out_coff);
+        hipLaunchKernelGGL(k_bev_fill_tiles<MathF16>, dim3(n), dim3(256), 0, stream, list, ty, tx, ho, wo, shift, relu, cout, out, out_hp, out_wp, out_cstride,
+                           out_coff, zero_resp);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

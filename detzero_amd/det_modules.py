@@ -707,11 +707,46 @@ class BaseBEVBackbone(_Cached):
         return bool(self.math and SPARSE_BEV_INPUT and slabs == 2 and cv['stride'] == 1 and cv['cin'] == 2 * row_channels and
                     row_channels % 32 == 0 and cv['cout'] % 128 == 0)
 
+    def _zero_response(self, lvl, h, w, rows_c, dev, nb0):
+        """Outputs of the first block's layers on an ALL-ZERO input, one (1, H + 2, W + 2, C) pair16 image per layer - what every pixel far
+        enough from any data computes (dz_bev_tile_list).  Computed once per (shape, math, frames per launch) with the detector's own
+        kernels on nb0 all-zero frames: which kernel runs a layer depends on the launch's tile count, and the images must carry ITS bits."""
+        key = ('zero_resp', h, w, int(self.math), str(dev), int(nb0))
+        if key not in lvl:
+            ridx = torch.full((nb0, h + 2, w + 2, 2), -1, dtype=torch.int32, device=dev)
+            rows = torch.zeros((8, rows_c), dtype=torch.float32, device=dev)
+            outs = []
+            x, xh, xw, xc = None, h, w, 2 * rows_c
+            with workspace(None):
+                for ci, cv in enumerate(lvl['convs']):
+                    if cv['stride'] != 1:
+                        raise DetZeroHipError('BaseBEVBackbone: zero-response tiles need a stride-1 first block')
+                    y = torch.zeros((nb0, xh + 2, xw + 2, cv['cout']), dtype=torch.float32, device=dev)
+                    if ci == 0:
+                        conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (xh + 2, xw + 2), cin=cv['cin'],
+                                   in_cstride=xc, ksize=3, stride=1, in_off=0, out_cstride=cv['cout'], out_d=(1, 1), ho=xh, wo=xw, batch=nb0,
+                                   math=self.math, in_rowidx=ridx, in_row_channels=rows_c, in_rows=rows.shape[0])
+                    else:
+                        conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (xh + 2, xw + 2), cin=cv['cin'], in_cstride=xc,
+                                   ksize=3, stride=1, in_off=0, out_cstride=cv['cout'], out_d=(1, 1), ho=xh, wo=xw, batch=nb0, math=self.math)
+                    outs.append(y[:1].clone())
+                    x, xc = y, cv['cout']
+            lvl[key] = outs
+        return lvl[key]
+
     def _level_convs(self, li, lvl, x, xh, xw, xc, batch, dev, sparse_in=None, out_last=None):
         """The 3 x 3 convolutions of block li over `batch` frames -> (activation, H, W, C).  out_last: where the block's LAST
         convolution writes (a zero-bordered buffer of the right shape, e.g. a frame slice of a larger one) instead of a workspace image."""
         convs = lvl['convs']
         bufs = None
+        tiles = zero = None
+        if sparse_in is not None and li == 0 and SKIP_EMPTY_TILES:
+            # pixel tiles far enough from any data compute the network's zero-input response: they are left out of the launches of the
+            # block's layers (16-24 % of the tiles of a 160k-point frame at the first layer, 9-15 % at the sixth: the corners of the BEV
+            # square beyond the sensor's range) and receive a copy of that response
+            nl = min(len(convs), 6) if all(cv['stride'] == 1 for cv in convs) else 1
+            tiles = ops.bev_tile_list(sparse_in[1], xh, xw, nl)
+            zero = self._zero_response(lvl, xh, xw, sparse_in[0].shape[1], dev, batch) if nl > 1 else None
         for ci, cv in enumerate(convs):
             s = cv['stride']
             oh, ow = (xh + 2 - 3) // s + 1, (xw + 2 - 3) // s + 1
@@ -721,19 +756,19 @@ class BaseBEVBackbone(_Cached):
             if sparse_in is not None and li == 0 and ci == 0:
                 # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
                 rows, ridx = sparse_in
-                # pixel tiles without any row in their halo (the corners of the BEV square beyond the sensor's range: 16-24 % of the
-                # tiles of a 160k-point frame) are left out of the launch and filled with their constant result
-                tiles = ops.bev_tile_list(ridx, oh, ow) if SKIP_EMPTY_TILES else None
                 conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
                            out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
-                           in_rows=rows.shape[0], in_tiles=tiles)
+                           in_rows=rows.shape[0], in_tiles=tiles[0] if tiles is not None else None)
                 if tiles is not None:
-                    ops.bev_fill_empty_tiles(tiles, batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math)
+                    ops.bev_fill_empty_tiles(tiles[0], batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math)      # (ReLU(shift))
             else:
+                tl = tiles[ci] if (tiles is not None and ci < tiles.shape[0]) else None
                 conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
-                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math)
+                           out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_tiles=tl)
+                if tl is not None:
+                    ops.bev_fill_empty_tiles(tl, batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math, zero_resp=zero[ci])
             x, xh, xw, xc = y, oh, ow, cv['cout']
         return x, xh, xw, xc
 

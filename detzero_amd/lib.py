@@ -126,8 +126,8 @@ _SIGS = {
                                           c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dz_spconv_x_variant': (ctypes.c_char_p, [c_int, c_int]),
     'dz_bev_tile_list_words': (c_size_t, [c_int, c_int, c_int]),
-    'dz_bev_tile_list': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'dz_bev_fill_empty_tiles': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dz_bev_tile_list': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'dz_bev_fill_empty_tiles': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dz_bev_row_index': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dz_sparse_to_bev_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),

@@ -455,22 +455,24 @@ def bev_row_index(level, feat_rows, pad=1):
     return idx
 
 
-def bev_tile_list(ridx, ho, wo):
-    """[n occupied, n empty, occupied 8 x 32 pixel tiles ascending, empty ones] of a row-index image (dz_bev_tile_list)."""
+def bev_tile_list(ridx, ho, wo, nlists=1):
+    """(nlists, words) int32: list l - 1 = [n to run, n skippable, tiles to run ascending, skippable ones] for the l-th 3 x 3 layer of the
+    first BEV block over a row-index image (dz_bev_tile_list: 8 x 32 pixel tiles whose pixels are all at least l + 1 pixels away from any row)."""
     lib = L.load()
     b, hp, wp, _ = ridx.shape
     n = lib.dz_bev_tile_list_words(b, int(ho), int(wo))
-    lst = torch.empty((n,), dtype=torch.int32, device=ridx.device)
-    flags = torch.empty((n,), dtype=torch.uint8, device=ridx.device)
-    L.check(lib.dz_bev_tile_list(L.ptr(ridx), b, hp, wp, int(ho), int(wo), L.ptr(lst), L.ptr(flags), L.stream()), 'dz_bev_tile_list')
+    lst = torch.empty((int(nlists), n), dtype=torch.int32, device=ridx.device)
+    ws = torch.empty((n,), dtype=torch.uint8, device=ridx.device)
+    L.check(lib.dz_bev_tile_list(L.ptr(ridx), b, hp, wp, int(ho), int(wo), int(nlists), L.ptr(lst), L.ptr(ws), L.stream()), 'dz_bev_tile_list')
     return lst
 
 
-def bev_fill_empty_tiles(tiles, batch, ho, wo, shift, relu, cout, out, math):
-    """The constant result ReLU(shift) of the empty pixel tiles of `tiles` into the zero-bordered pair16 image `out` (B, ho + 2, wo + 2, C)."""
+def bev_fill_empty_tiles(tiles, batch, ho, wo, shift, relu, cout, out, math, zero_resp=None):
+    """The skippable pixel tiles of list `tiles` in the zero-bordered pair16 image `out` (B, ho + 2, wo + 2, C) get the layer's zero-input
+    response: the (1, ho + 2, wo + 2, C) image `zero_resp`, or - None: the first layer - the constant ReLU(shift)."""
     lib = L.load()
     L.check(lib.dz_bev_fill_empty_tiles(L.ptr(tiles), int(batch), int(ho), int(wo), L.ptr(shift), 1 if relu else 0, int(cout), L.ptr(out), out.shape[1],
-                                        out.shape[2], out.shape[3], 0, int(math), L.stream()), 'dz_bev_fill_empty_tiles')
+                                        out.shape[2], out.shape[3], 0, L.ptr(zero_resp), int(math), L.stream()), 'dz_bev_fill_empty_tiles')
 
 
 BEV_DENSE = not os.environ.get('DZ_BEV_SCATTER')   # development switch: False = zero-fill + scatter (dz_sparse_to_bev_split) for two-slab levels too

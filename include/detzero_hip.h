@@ -205,7 +205,7 @@ typedef struct dz_conv2d_desc {
                                  in_cstride is ignored.  HeightCompression (height_compression.py:20-24) + the first block's ZeroPad2d
                                  (backbone2d.py:41-46) fused into that block's convolution */
     int in_row_channels, in_rows;
-    const int *in_tiles;      /* with in_rowidx, optional: dz_bev_tile_list - the launch covers the occupied pixel tiles only            */
+    const int *in_tiles;      /* 3 x 3 stride-1 resident-tile layers, optional: a list of dz_bev_tile_list - the launch covers its tiles to run only */
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */
@@ -313,14 +313,19 @@ const char *dz_spconv_x_variant(int cin, int cout);
  * backbone2d.py:41-46 never touch HBM.  DZ_ERR_UNSUPPORTED for d != 2. */
 int dz_bev_row_index(const uint32_t *bitmap, const uint32_t *prefix, int batch, int d, int h, int w, int layout, int pad, int feat_rows,
                      int *idx, void *stream);
-/* Pixel tiles (8 x 32 output pixels) of the sparse-input convolution whose 10 x 34 input halo holds no row: their result is the constant
- * ReLU(shift).  dz_bev_tile_list: list (dz_bev_tile_list_words ints) = [n occupied, n empty, occupied tile ids ascending ..., empty ones ...]
- * (tile id = (b * tiles_y + ty) * tiles_x + tx); flags_ws = one byte per tile.  Pass `list` as dz_conv2d_desc.in_tiles: the convolution walks the
- * occupied tiles only; dz_bev_fill_empty_tiles writes the constant into the empty ones (same bits as the kernel's epilogue on a zero accumulator). */
+/* Pixel tiles (8 x 32 output pixels) of the first BEV block whose result is the network's ZERO-INPUT RESPONSE (round 5).  With D = the
+ * Chebyshev distance of a pixel to the nearest pixel holding a row (nothing outside the image), the 3 x 3 stride-1 layer number l of the
+ * block (l = 1: the sparse-input layer) sees, in a tile whose pixels all have D >= l + 1, exactly what it sees on an all-zero input - and
+ * produces what it produces there.  dz_bev_tile_list writes, for l = 1 .. nlists (< 8), list l at lists + (l - 1) * dz_bev_tile_list_words:
+ * [n to run, n skippable, ids of the tiles to run ascending ..., the skippable ones ...] (tile id = (b * tiles_y + ty) * tiles_x + tx);
+ * mind_ws = one byte per tile.  Pass list l as dz_conv2d_desc.in_tiles of layer l: the launch walks the tiles to run only;
+ * dz_bev_fill_empty_tiles gives the others their result: zero_resp = the layer's output on an all-zero input (1, out_hp, out_wp, cout)
+ * pair16, computed once per model by the same kernels - or NULL for layer 1, whose response is the constant ReLU(shift).  Bit-identical
+ * to running every tile (a pixel's result depends on its 3 x 3 input neighbourhood only). */
 size_t dz_bev_tile_list_words(int batch, int ho, int wo);
-int dz_bev_tile_list(const int *idx, int batch, int hp, int wp, int ho, int wo, int *list, unsigned char *flags_ws, void *stream);
+int dz_bev_tile_list(const int *idx, int batch, int hp, int wp, int ho, int wo, int nlists, int *lists, unsigned char *mind_ws, void *stream);
 int dz_bev_fill_empty_tiles(const int *list, int batch, int ho, int wo, const float *shift, int relu, int cout, float *out, int out_hp, int out_wp,
-                            int out_cstride, int out_coff, int math, void *stream);
+                            int out_cstride, int out_coff, const float *zero_resp, int math, void *stream);
 /* dz_sparse_to_bev on pair16 rows / images (the 16-bit halves are moved, no arithmetic) */
 int dz_sparse_to_bev_split(const float *feats, const int *coords, const int *d_m, int cap, int c, int d, int h,
                            int w, int pad, float *bev, void *stream);

@@ -353,3 +353,27 @@ def test_frame_without_points_in_range(small, device, math):
     empty_only, n_empty = pipe([far])
     assert int(n_both[1]) == int(n_empty[0])
     assert torch.isfinite(both[1]).all()
+
+
+def test_zero_response_tiles_do_not_change_a_bit(device):
+    """Round 5: pixel tiles of the first BEV block that are far enough from any data receive a copy of the network's zero-input response
+    instead of being computed (dz_bev_tile_list / dz_bev_fill_empty_tiles, six layers deep).  Same detections, bit for bit, as with
+    every tile computed - on full-size frames (0.1 m voxels, three frames: the resident-tile kernel's regime), f16x2."""
+    from detzero_amd import det_modules
+    from detzero_amd.centerpoint import FramePipeline
+    model, cfg, info = make_model(VOXEL_SIZE_01, seed=0)
+    model = model.to(device)
+    frames = [torch.from_numpy(masked_frame(30 + i, 160000)).to(device) for i in range(3)]
+    assert det_modules.SKIP_EMPTY_TILES
+    out1, n1 = FramePipeline(model, info, math='f16x2')(frames)
+    x1 = model.backbone2d  # (the zero-response images are cached on the plan: they exist now)
+    assert any(isinstance(k, tuple) and k[0] == 'zero_resp' for k in x1.plan()[0])
+    det_modules.SKIP_EMPTY_TILES = False
+    try:
+        out0, n0 = FramePipeline(model, info, math='f16x2')(frames)
+    finally:
+        det_modules.SKIP_EMPTY_TILES = True
+    assert torch.equal(n0, n1) and int(n0.min()) > 50
+    for i in range(3):
+        k = int(n0[i])
+        assert torch.equal(out0[i, :k], out1[i, :k])

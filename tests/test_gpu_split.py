@@ -272,7 +272,19 @@ def test_sparse_input_convolution_equals_the_dense_image(device, name, mid):
             outs.append(out)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)) and float(ops.pair16_to_f32(outs[1], mid).abs().max()) > 0.1
         # ... and with the empty pixel tiles left out of the launch and filled with their constant result (the detector's route)
-        tiles = ops.bev_tile_list(idx, shape[1], shape[2])
+        lists = ops.bev_tile_list(idx, shape[1], shape[2], 6)
+        # list l against the definition: a tile is skippable at layer l iff every one of its pixels is at least l + 1 pixels (Chebyshev)
+        # away from any pixel holding a row
+        from scipy.ndimage import distance_transform_cdt
+        occ = (idx.cpu().numpy()[:, 1:-1, 1:-1, :] >= 0).any(-1)
+        dist = np.stack([distance_transform_cdt(~o, metric='chessboard') if o.any() else np.full(o.shape, 99) for o in occ])
+        tyn, txn = (shape[1] + 7) // 8, (shape[2] + 31) // 32
+        for layer in range(1, 7):
+            lst = lists[layer - 1].cpu().numpy()
+            want_skip = np.array([dist[bb, ty * 8:ty * 8 + 8, tx * 32:tx * 32 + 32].min() >= layer + 1 for bb in range(b) for ty in range(tyn) for tx in range(txn)])
+            assert lst[0] == (~want_skip).sum() and lst[1] == want_skip.sum(), layer
+            assert np.array_equal(lst[2:2 + lst[0]], np.nonzero(~want_skip)[0]) and np.array_equal(lst[2 + lst[0]:2 + lst[0] + lst[1]], np.nonzero(want_skip)[0])
+        tiles = lists[0]
         n_occ, n_emp = (int(v) for v in tiles[:2].tolist())
         ntile = b * ((shape[1] + 7) // 8) * ((shape[2] + 31) // 32)
         assert n_occ + n_emp == ntile and n_emp > ntile // 20 and n_occ > ntile // 2
