@@ -745,6 +745,9 @@ class BaseBEVBackbone(_Cached):
             # block's layers (16-24 % of the tiles of a 160k-point frame at the first layer, 9-15 % at the sixth: the corners of the BEV
             # square beyond the sensor's range) and receive a copy of that response
             nl = min(len(convs), 6) if all(cv['stride'] == 1 for cv in convs) else 1
+            key = ('zero_resp', xh, xw, int(self.math), str(dev), int(batch))
+            if nl > 1 and key not in lvl and torch.cuda.is_current_stream_capturing():
+                nl = 1        # (the response images are computed by an eager pass: a capture without one before it skips at the first layer only)
             tiles = ops.bev_tile_list(sparse_in[1], xh, xw, nl)
             zero = self._zero_response(lvl, xh, xw, sparse_in[0].shape[1], dev, batch) if nl > 1 else None
         for ci, cv in enumerate(convs):
