@@ -630,7 +630,7 @@ def conv_layer(inp, in_shape, w, scale, shift, relu, out, out_shape, *, cin, in_
         relu=1 if relu else 0, phase_groups=1 if phase_groups else 0,
         in_rowidx=in_rowidx.data_ptr() if in_rowidx is not None else None, in_row_channels=int(in_row_channels), in_rows=int(in_rows),
         in_tiles=in_tiles.data_ptr() if in_tiles is not None else None),
-        math=math, out_f32=out_f32)
+        math=math, out_f32=out_f32, tiles=in_tiles)
 
 
 class BaseBEVBackbone(_Cached):

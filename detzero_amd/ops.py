@@ -579,9 +579,10 @@ def pair16_to_f32(x, math=1):
 # ------------------------------------------------------------------------------------------------
 # dense conv
 # ------------------------------------------------------------------------------------------------
-def conv2d(desc_kwargs, math=0, out_f32=False):
+def conv2d(desc_kwargs, math=0, out_f32=False, tiles=None):
     """One dense-conv launch from a dict of dz_conv2d_desc fields.  math != 0: pair16 input / weights
-    (pack_weight_split layout) and pair16 output unless out_f32."""
+    (pack_weight_split layout) and pair16 output unless out_f32.  tiles: the tensor behind `in_tiles` (profiling only: the work of
+    the launch is that of the tiles it runs)."""
     lib = L.load()
     d = L.Conv2dDesc()
     g_cout = desc_kwargs.pop('g_cout')
@@ -606,6 +607,13 @@ def conv2d(desc_kwargs, math=0, out_f32=False):
     cout = sum(d.g_cout[i] for i in range(d.groups))
     flops = 2.0 * m * taps * d.cin * cout
     nbytes = 4.0 * (m * d.cin * (1 if d.phase_groups else d.groups) + m * cout + taps * d.cin * d.cout_pad * d.groups)
+    if tiles is not None:
+        # zero-response tiles are not run: count the EXECUTED share of the layer (one host sync; profiling passes only), so that the
+        # roofline figures of the kernel describe the kernel, not the work it was spared
+        n_run, n_skip = (int(v) for v in tiles[:2].tolist())
+        share = n_run / float(max(n_run + n_skip, 1))
+        flops *= share
+        nbytes = 4.0 * (share * (m * d.cin + m * cout) + taps * d.cin * d.cout_pad * d.groups)
     name = (lib.dz_conv2d_variant_split if math else lib.dz_conv2d_variant)(ctypes.byref(d)).decode()
     PROFILER.wrap(name, flops, nbytes, launch)
 
