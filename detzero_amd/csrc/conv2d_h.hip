@@ -326,7 +326,10 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
             return DZ_ERR_UNSUPPORTED;
         }
     }
-    if (conv3x3_h_variant(*d)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);
+    {
+        const int bc3 = conv3x3_h_variant(*d);
+        if (bc3 && (!out_f32 || bc3 == 32)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);      // (fp32 output: 32-channel tiles only)
+    }
     if (math == DZ_MATH_F16X2)
         return out_f32 ? conv2d_h_dispatch<MathF16, true>(*d, w_bytes, stream) : conv2d_h_dispatch<MathF16, false>(*d, w_bytes, stream);
     if (math == DZ_MATH_F16)

@@ -687,7 +687,11 @@ int conv3x3_h_launch(const dz_conv2d_desc &p, int math, int out_f32, size_t w_by
     auto go = [&](auto bc_t, auto m_t) {
         constexpr int BCV = decltype(bc_t)::value;
         using MM = typename decltype(m_t)::type;
-        return out_f32 ? launch_c3<BCV, MM, true>(p, w_bytes, stream) : launch_c3<BCV, MM, false>(p, w_bytes, stream);
+        // fp32 output exists for the 32-channel configuration only (the head's grouped output layer - the one layer of the network that
+        // leaves the pair16 domain); the 64 / 128-channel instances were never launched and spilled (round-4 review): the caller
+        // (dz_conv2d_forward_split) sends such a layer to the generic kernel
+        if constexpr (BCV == 32) return out_f32 ? launch_c3<BCV, MM, true>(p, w_bytes, stream) : launch_c3<BCV, MM, false>(p, w_bytes, stream);
+        else return launch_c3<BCV, MM, false>(p, w_bytes, stream);
     };
     auto by_math = [&](auto bc_t) {
         if (math == DZ_MATH_F16X2) return go(bc_t, TypeTag<MathF16>{});
