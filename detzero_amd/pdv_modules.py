@@ -465,12 +465,15 @@ class PDVHead(_Cached):
                 level = ops.SparseLevel(x_conv.batch_size, x_conv.spatial_shape, max(x_conv.indices.shape[0], 1), points.device)
                 level.build_from_coords(x_conv.indices.int().contiguous(), want_rank=False)
             rows = index_lookup(coords, level)
-            feats = x_conv.features
+            n_rows = x_conv.indices.shape[0]
             # (ranks at or beyond the feature rows exist only when a calibrated level overflowed its capacity - FramePipeline.two_stage
             # refuses such a pass; the mask keeps the gather inside the tensor for any other caller)
-            sel = torch.nonzero((rows >= 0) & (rows < feats.shape[0])).flatten()
+            sel = torch.nonzero((rows >= 0) & (rows < n_rows)).flatten()
             point_coords[loc] = cen[sel][:, :4].contiguous()
-            point_features[loc] = feats[rows[sel].long()].contiguous()
+            if hasattr(x_conv, 'feature_rows'):          # (our tensors: gather first, decode the gathered rows only)
+                point_features[loc] = x_conv.feature_rows(rows[sel].long()).contiguous()
+            else:
+                point_features[loc] = x_conv.features[rows[sel].long()].contiguous()
             self._point_index[loc] = (coords[sel].contiguous(), dims, vs)
         return point_features, point_coords
 
