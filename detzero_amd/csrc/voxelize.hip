@@ -224,7 +224,8 @@ __global__ void k_level_emit_mean(const float *__restrict__ pts, int c, const in
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum[e] = 0.f;
         int cnt = 0;
-        for (int q = 0; q < max_points; ++q) {
+        // (a group of channel padding - every group behind the first at 5 point features - is zeros: it reads nothing)
+        for (int q = 0; q < (gq * 8 < c ? max_points : 0); ++q) {
             const int pi = mins[(size_t)q * cap + v];
             if (pi != 0x7f7f7f7f) {
                 ++cnt;
