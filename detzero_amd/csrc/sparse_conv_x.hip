@@ -60,6 +60,7 @@ struct SpConvXArgs {
     int *queue;                 // 10 words behind the windows: next ticket of each XCD's tile queue, workgroups done, single-unit queue
     int xrun;                   // consecutive tiles per XCD run (8; DZ_TUNE_XRUN)
     int steal, singles;         // tail: take whole tiles from other XCDs' queues before the single units; single units per workgroup (1)
+    int sload;                  // window words through scalar loads (1; DZ_TUNE_X_SLOAD)
 };
 
 template <int COUT_, int WP_, int WC_, int PT_, int TAPS_, int D_, int RCAP_>
@@ -294,14 +295,34 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
             if (g.live) {
                 // windows of the tile's unit(s): per z slab the union of the two units' ranges
+                // The twelve words come through the SCALAR cache in three s_load_dwordx4 with one lgkmcnt wait.  As plain loads the
+                // compiler issued six global_load_dwordx2 ONE AFTER THE OTHER, each behind an `s_waitcnt vmcnt(0)` - six memory round
+                // trips per tile, and each wait also drained the window / weight prefetches in flight: ~9.7 k of a tile's ~230 k cycles
+                // at 128 channels, 3-6 % of the x-run kernels (in-kernel counter `gen`, profiles/r05b_xrun_cycles.txt).  (The table is
+                // written by an earlier launch: the scalar cache cannot hold stale lines of it.  A single unit's second half is the
+                // next unit's words - inside the buffer, not used.)
                 const int *wq = a.win + (size_t)g.u0 * 6;
+                typedef int v4i_t __attribute__((ext_vector_type(4)));
+                v4i_t w0, w1, w2;
+                if (a.sload) {
+                    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(wq) : "memory");
+                } else {            // (development knob DZ_TUNE_X_SLOAD=0: the round-4 loads)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w0[q] = __builtin_amdgcn_readfirstlane(wq[q]);
+                        w1[q] = __builtin_amdgcn_readfirstlane(wq[4 + q]);
+                        w2[q] = __builtin_amdgcn_readfirstlane(wq[8 + q]);
+                    }
+                }
+                const int ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
                 int lo[3], n[3];
 #pragma unroll
                 for (int z = 0; z < 3; ++z) {
-                    lo[z] = __builtin_amdgcn_readfirstlane(wq[2 * z]);
-                    n[z] = __builtin_amdgcn_readfirstlane(wq[2 * z + 1]);
+                    lo[z] = ww[2 * z];
+                    n[z] = ww[2 * z + 1];
                     if (!g.half) {
-                        const int lb = __builtin_amdgcn_readfirstlane(wq[6 + 2 * z]), nb = __builtin_amdgcn_readfirstlane(wq[6 + 2 * z + 1]);
+                        const int lb = ww[6 + 2 * z], nb = ww[6 + 2 * z + 1];
                         if (n[z] == 0) { lo[z] = lb; n[z] = nb; }
                         else if (nb > 0) { const int hi = max(lo[z] + n[z], lb + nb); lo[z] = min(lo[z], lb); n[z] = hi - lo[z]; }
                     }
@@ -773,6 +794,7 @@ static int x_steal() { static const int v = getenv("DZ_TUNE_X_STEAL") ? atoi(get
 // single-unit tickets per workgroup at the end of a launch: -1 = by the launch's size (k_spconv_x), else forced (development knob).
 // A/B at 32 frames per pass: 0 singles 1063.8 frames/s against 1059.6 with one per workgroup (round 4)
 static int x_singles() { static const int v = getenv("DZ_TUNE_X_SINGLES") ? atoi(getenv("DZ_TUNE_X_SINGLES")) : -1; return v >= -1 && v <= 8 ? v : -1; }
+static int x_sload() { static const int v = getenv("DZ_TUNE_X_SLOAD") ? atoi(getenv("DZ_TUNE_X_SLOAD")) : 1; return v; }
 static int x32_variant() {
     static const int v = getenv("DZ_TUNE_X32") ? atoi(getenv("DZ_TUNE_X32")) : 0;
     return v;
@@ -906,7 +928,7 @@ int dz_spconv_forward_split_x(const float *in, int in_rows, int cin, const int *
     }
     SpConvXArgs a{in, nbr_packed, windows, d_m_out, w, scale, shift, residual, out, cin, cout, cap_out, relu,
                   (unsigned int)in_bytes, (unsigned int)w_bytes, (unsigned int)nbr_bytes, nullptr, perm,
-                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6, x_run_len(), x_steal(), x_singles()};
+                  windows + (size_t)ceil_div(cap_out, tile_rows) * 6, x_run_len(), x_steal(), x_singles(), x_sload()};
     if (math == DZ_MATH_F16) return x_dispatch<MathF16H>(a, stream);
     return math == DZ_MATH_F16X2 ? x_dispatch<MathF16>(a, stream) : x_dispatch<MathBF16>(a, stream);
 }
