@@ -627,16 +627,10 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     while (cur.live) {
         const bool tile_last = !nxt.live || nxt.tile_first;
         if (tile_last) {
-            // the tile's last stage: the rows of my epilogue items, through the row map when the table is in tap-set order - requested
-            // now, used after this stage's MFMAs.  (Extra loads in flight only make the counted waits below stricter.)
-            const int nu = cur.half ? 1 : 2;
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pos = (cur.u0 + pt) * C::UR + wp * 32 + (lane >> 2) + 16 * i;
-                    orow[pt][i] = (pt < nu && pos < m) ? (a.perm ? a.perm[pos] : pos) : -1;
-                }
+            // (round 5: the rows of the epilogue items - through the row map when the table is in tap-set order - are fetched at the START OF
+            // THE EPILOGUE, not here: as plain loads in front of the stage the compiler's wait-count pass, which does not see the asm loads
+            // of the stream, put an `s_waitcnt vmcnt(0)` before them and emptied the prefetch queue at the start of every tile's last
+            // stage; as asm loads their results crossed the stage in registers the compiler is free to copy before they land)
         }
         step(std::integral_constant<int, 0>{});
         if constexpr (SPS == 3) {
@@ -656,6 +650,16 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             tap_block(fp, [](auto) {});
             fp.any = 0u;
             __syncthreads();
+            {
+                const int nu = cur.half ? 1 : 2;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int pos = (cur.u0 + pt) * C::UR + wp * 32 + (lane >> 2) + 16 * i;
+                        orow[pt][i] = (pt < nu && pos < m) ? (a.perm ? a.perm[pos] : pos) : -1;
+                    }
+            }
             int next_ticket = 0;            // the ticket of the tile after next (thread 0; read at the end of the epilogue)
             if (tid == 0) next_ticket = take_ticket();
             if constexpr (DIAG & 32) {
