@@ -104,8 +104,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     const srsrc_t prsrc = make_srsrc(p.in, in_bytes);
     const srsrc_t crsrc = make_srsrc(p.w, w_bytes);
     int x0, y0, b;
-    auto tile_origin = [&](int t, int &ox, int &oy, int &ob) {
-        if (tlist) t = __builtin_amdgcn_readfirstlane(tlist[2 + t]);         // (position in the list -> tile id)
+    // position in the launch's tile sequence -> tile id.  With a tile list the id comes through the SCALAR cache (one s_load_dword + an
+    // lgkmcnt wait): a plain load here is a vector load guarded by `s_waitcnt vmcnt(0)` - it would empty the weight / input prefetch
+    // queue twice per tile (tile_geo of the next tile, tile_origin of the epilogue)
+    auto tile_id = [&](int t) {
+        if (!tlist) return t;
+        const int *ptr = tlist + 2 + t;
+        int id;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(id) : "s"(ptr) : "memory");
+        return id;
+    };
+    auto tile_origin = [&](int t, int &ox, int &oy, int &ob) {          // t = a tile ID
         ox = (t % tiles_x) * C3_TW;
         oy = ((t / tiles_x) % tiles_y) * C3_TH;
         ob = t / (tiles_x * tiles_y);
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
         g.cols = p.in_wp - (ox + p.in_off);
         return g;
     };
-    TileGeo geo = tile_geo(tile), geo_next = geo;
+    int id_cur = tile_id(tile), id_next = id_cur;
+    TileGeo geo = tile_geo(id_cur), geo_next = geo;
     const int prow = tid / (C3_KC / 4), pq = tid % (C3_KC / 4);
     bool has_next = tile + tstep < band_hi;
     unsigned int cvoff[WPT];
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
 
     int kcg = 0;                                                 // channel chunks done so far, over all tiles (LDS buffer parity)
     for (;;) {
-    if (has_next) geo_next = tile_geo(tile + tstep);
+    if (has_next) { id_next = tile_id(tile + tstep); geo_next = tile_geo(id_next); }
     for (int kc = 0; kc < nk; ++kc, ++kcg) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
             interleave_hint<0x100, M::TERMS == 1 ? (PT + CT) : 2 * (PT + CT), 1>();
         }
     }
-    tile_origin(tile, x0, y0, b);
+    tile_origin(id_cur, x0, y0, b);
 
     // ---- epilogue: 32x32 accumulator: pixel column = lane & 31, channel = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
     if constexpr (DIAG & 32) {                                   // no epilogue: the accumulators only have to stay alive
@@ -542,6 +552,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PT == 2 ? 2 
     // ---- next tile: its first input chunk is already in LDS, its first weight slices are in flight
     if (!has_next) break;
     tile += tstep;
+    id_cur = id_next;
     geo = geo_next;
     has_next = tile + tstep < band_hi;
 #pragma unroll
