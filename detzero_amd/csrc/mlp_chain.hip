@@ -50,6 +50,7 @@ struct ChainArgs {
     long rows;
     int group_rows, ldg;
     unsigned int x_bytes;
+    int direct;                              // result rows straight from the accumulator layout (0 = through the wave's LDS window)
 };
 
 __device__ __forceinline__ void mc_load16_lds(unsigned int lds_base, unsigned int voff, srsrc_t rsrc) {
@@ -197,7 +198,18 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // 32 finished channels x 32 rows -> global fp32 rows through the wave's window: lane (row = lane >> 1, half) stores 64 contiguous bytes.
     // Buffer stores with a 32-bit offset (rows past the end carry the out-of-range offset: dropped by the hardware, no branches)
     unsigned char *const win = smem_raw + MC_OFF_WIN + wid * MC_WIN;
-    auto store_f32 = [&](const float (&v)[16], __amdgpu_buffer_rsrc_t rs, unsigned int off) {
+    auto store_f32 = [&](const float (&v)[16], __amdgpu_buffer_rsrc_t rs, unsigned int off, unsigned int doff) {
+        if (a.direct) {
+            // lane (row l31, half h) holds channels 8 q + 4 h .. + 3 of its row: four 16-byte stores; lanes h = 0 / 1 write adjacent pieces
+            // and the four q complete the row's 128 bytes (one L2 line) back to back - as many store instructions as the window route,
+            // none of its 8 LDS accesses and 2 wave barriers per fragment
+            if (DZ_CHAIN_DIAG & 64) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3])},
+                                                       rs, (int)doff + q * 32, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(win + l31 * MC_WIN_ROW + (q * 8 + h * 4) * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         // fp32 output rows: lane (row0 + lane / 2, 64-byte half lane & 1); out of range = dropped (outputs are < 2 GiB, host-checked)
         const unsigned int rowoff = (live && row0 + (lane >> 1) < a.rows) ? (unsigned int)((row0 + (lane >> 1)) * (MC_C2 * 4)) + (unsigned int)((lane & 1) * 64) : OOB_OFFSET;
+        const unsigned int rowoff_d = rok ? (unsigned int)(row * (MC_C2 * 4)) + (unsigned int)(h * 16) : OOB_OFFSET;
         // the tile's row of per-object addends (512 floats) rides into the wave's window (idle until the result stores): read from
         // global inside the slice stream, every load of it would make the compiler wait for the weight slices in flight behind it
         const bool has_gs = a.gshift != nullptr;
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int ct = 0; ct < 8; ++ct) {
             float v[16];
             finish(accB[ct], sB + ct * 32, bB + ct * 32, nullptr, true, v);
-            store_f32(v, rsMem, rowoff + ct * 128);
+            store_f32(v, rsMem, rowoff + ct * 128, rowoff_d + ct * 128);
             if (KV) to_operands(v, mh[2 * ct], ml[2 * ct], mh[2 * ct + 1], ml[2 * ct + 1]);
         }
         if constexpr (KV) {
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(MC_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 for (int ct = 0; ct < 8; ++ct) {
                     float v[16];
                     finish(acc[ct], nullptr, (pj ? bV : bK) + ct * 32, nullptr, false, v);
-                    store_f32(v, rsOut, rowoff + ct * 128);
+                    store_f32(v, rsOut, rowoff + ct * 128, rowoff_d + ct * 128);
                 }
             }
         }
@@ -417,7 +430,8 @@ int dz_mlp_chain_forward(const float *x, long rows, const float *wa, const float
     DZ_CHECK_ARG(!group_shift || rows % group_rows == 0, "dz_mlp_chain_forward: rows not a multiple of group_rows");
     const size_t x_bytes = (size_t)rows * MC_CIN * 4;
     if ((size_t)rows * MC_C2 * 4 >= 0x80000000ull) { set_error("dz_mlp_chain_forward: %ld rows exceed the 2 GiB buffer-addressing limit of an output", rows); return DZ_ERR_UNSUPPORTED; }
-    const ChainArgs a{x, wa, wb, wk, wv, sa, ba, sb, bb, bk, bv, group_shift, mem, k, v, rows, group_rows, ldg, (unsigned int)x_bytes};
+    static const int direct = [] { const char *e = getenv("DZ_TUNE_CHAIN_DIRECT"); return e ? atoi(e) : 1; }();
+    const ChainArgs a{x, wa, wb, wk, wv, sa, ba, sb, bb, bk, bv, group_shift, mem, k, v, rows, group_rows, ldg, (unsigned int)x_bytes, direct};
     const int rc = math == DZ_MATH_F16X2 ? launch_chain<MathF16>(a, kv, stream) : launch_chain<MathBF16>(a, kv, stream);
     if (rc) return rc;
     DZ_LAUNCH_CHECK();
