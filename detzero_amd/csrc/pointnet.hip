@@ -30,6 +30,10 @@
 #define DZ_PN_DIAG 0           // timing experiments only (results are garbage): 1 = no workgroup barriers, 2 = no W3 loads, 4 = no layer-3 epilogue,
 #endif                          // 8 = no vmcnt waits in the slice loop, 16 = weight fragments from registers, 32 = no hidden-layer epilogues
 
+#ifndef PN_PREFETCH_X
+#define PN_PREFETCH_X 1        // 0: the input rows of a tile are loaded at its top (the form up to r05h; timing comparisons)
+#endif
+
 namespace dz {
 
 constexpr int PN_THREADS = 512, PN_WAVES = 8, PN_HID = 128, PN_CIN = 32;
@@ -142,14 +146,41 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
 
+    // operand registers of a layer's input: k-step s -> (hi, lo) of channels 16 s + 8 h .. + 7 of my row
+    v4u xh[2], xl[2];
+    v4u hh[8], hl[8];
+    // The input rows of a tile are requested a whole tile ahead, as soon as layer 1 has consumed the registers they land in (with the
+    // loads at the top of the tile every wave of the workgroup - they run in step, a barrier per W3 slice - sat out the HBM round trip
+    // once per tile).  pair16 rows: 128 bytes = 4 groups of (16 hi | 16 lo), k-step s takes groups 2 s + h.  fp32 rows: k-step s takes
+    // channels 16 s + 8 h .. + 7 = 32 contiguous bytes, which wait in xh / xl as they are and are split at the top of their tile (the
+    // same bits dz_pair16_from_f32 would have written); a 16-column input has no second k-step (out-of-range offset: zeros)
+    auto issue_x = [&](long tile_n) {
+        const long row_n = tile_n * 32 + l31;
+        const bool ok = tile_n < ntiles && row_n < a.rows;
+        if (a.x_cols_f32 == 0) {
+            const unsigned int off = ok ? (unsigned int)(row_n * (PN_CIN * 4)) + (unsigned int)(h * 32) : OOB_OFFSET;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(xh[s]) : "v"(off + (unsigned int)(s * 64)), "s"(xrsrc));
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(xl[s]) : "v"(off + (unsigned int)(s * 64)), "s"(xrsrc));
+            }
+        } else {
+            const unsigned int rb = (unsigned int)a.x_cols_f32 * 4u;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned int off = (ok && s * 16 + h * 8 < a.x_cols_f32) ? (unsigned int)row_n * rb + (unsigned int)((s * 16 + h * 8) * 4) : OOB_OFFSET;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(xh[s]) : "v"(off), "s"(xrsrc));
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(xl[s]) : "v"(off), "s"(xrsrc));
+            }
+        }
+    };
+
     __syncthreads();
+    issue_x(t_begin);
     w3_issue(0, 0);
     w3_issue(nsl > 1 ? 1 : 0, 1);
     int ring = 0;                                        // buffer of the slice about to be consumed (wave-uniform)
 
-    // operand registers of a layer's input: k-step s -> (hi, lo) of channels 16 s + 8 h .. + 7 of my row
-    v4u xh[2], xl[2];
-    v4u hh[8], hl[8];
     for (long it = 0; it < per; ++it) {
         const long tile = t_begin + it;
         const long row = tile * 32 + l31;
@@ -157,34 +188,17 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool rok = live && row < a.rows;
         const long group = live ? (tile * 32) / a.group_rows : -1;
         if (group != cur_group) { flush(); cur_group = group; }
-        // ---- input rows: 128 bytes = 4 groups of (16 hi | 16 lo); k-step s takes groups 2 s + h
-        if (a.x_cols_f32 == 0) {
-            const unsigned int off = rok ? (unsigned int)(row * (PN_CIN * 4)) + (unsigned int)(h * 32) : OOB_OFFSET;
+        // ---- my input rows: requested before the two W3 slices now in flight (2 loads per thread each; loads return in order), so
+        // "at most four outstanding" covers them without draining the slices
+        if (PN_PREFETCH_X) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else { issue_x(tile); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+        if (a.x_cols_f32 != 0) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(xh[s]) : "v"(off + (unsigned int)(s * 64)), "s"(xrsrc));
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(xl[s]) : "v"(off + (unsigned int)(s * 64)), "s"(xrsrc));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
-        } else {
-            // fp32 rows: k-step s takes channels 16 s + 8 h .. + 7 = 32 contiguous bytes, split here (the same bits dz_pair16_from_f32
-            // would have written); a 16-column input has no second k-step (reads past the row come back as zeros: out-of-range offset)
-            const unsigned int rb = (unsigned int)a.x_cols_f32 * 4u;
-            v4u lo4[2], hi4[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned int off = (rok && s * 16 + h * 8 < a.x_cols_f32) ? (unsigned int)row * rb + (unsigned int)((s * 16 + h * 8) * 4) : OOB_OFFSET;
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(lo4[s]) : "v"(off), "s"(xrsrc));
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(hi4[s]) : "v"(off), "s"(xrsrc));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                asm volatile("" : "+v"(lo4[s]), "+v"(hi4[s]));
-                const float f0[4] = {__uint_as_float(lo4[s].x), __uint_as_float(lo4[s].y), __uint_as_float(lo4[s].z), __uint_as_float(lo4[s].w)};
-                const float f1[4] = {__uint_as_float(hi4[s].x), __uint_as_float(hi4[s].y), __uint_as_float(hi4[s].z), __uint_as_float(hi4[s].w)};
+                const float f0[4] = {__uint_as_float(xh[s].x), __uint_as_float(xh[s].y), __uint_as_float(xh[s].z), __uint_as_float(xh[s].w)};
+                const float f1[4] = {__uint_as_float(xl[s].x), __uint_as_float(xl[s].y), __uint_as_float(xl[s].z), __uint_as_float(xl[s].w)};
                 uint2 h0, l0, h1, l1;
                 split4<M>(f0, h0, l0);
                 split4<M>(f1, h1, l1);
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         };
         hidden_layer(PN_OFF_W1, std::integral_constant<int, 2>{}, xh, xl, ss, ss + PN_HID);
+        if (PN_PREFETCH_X) issue_x(tile + 1);              // (past the wave's range: another wave's rows or out of range - never used)
         {
             v4u ih[8], il[8];
 #pragma unroll
