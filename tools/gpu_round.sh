@@ -82,6 +82,7 @@ fi
 if has refine; then
   echo "==== refiner"
   for m in f32 f16x2; do timeout 300 python tools/bench_refine.py --math $m 2>/dev/null | tail -1 > $O/${TAG}_bench_refine_$m.json; cut -c1-500 $O/${TAG}_bench_refine_$m.json; done
+  TRACE_HEAD=36 trace refine_f16x2 python $ROOT/tools/bench_refine.py --math f16x2 --steps 2
 fi
 if has pdv; then
   echo "==== two-stage detector (PDV second stage)"
