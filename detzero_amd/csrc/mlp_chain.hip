@@ -17,7 +17,9 @@
 //     (every workgroup of the launch walks the same 1.3 MB of weights in step: with one slice of look-ahead a third of the time went
 //     into waiting for L2), loaded with `buffer_load_dwordx4 ... lds` (no staging registers) into an XOR-swizzled layout that is
 //     conflict-free for the fragment reads; 40 slices per 128 rows (24 without K / V), one workgroup barrier per slice = per 48 MFMAs;
-//   * fp32 results leave through a wave-private LDS window (a lane stores 64 contiguous bytes of a row).
+//   * fp32 results leave straight from the accumulator layout: lane (row, half) stores the 16 bytes it holds of each 8-channel group, the
+//     two half-wave lanes write adjacent pieces and four stores complete a 128-byte line (round 5; DZ_TUNE_CHAIN_DIRECT=0 = the earlier
+//     transposition through a wave-private LDS window, 4 % slower).  The window still carries the tile's per-object addends.
 // HBM traffic: the tap rows in (512 B each), memory / K / V rows out (1 KB each) - nothing else.
 #include <stdlib.h>
 
