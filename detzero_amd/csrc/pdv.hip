@@ -290,6 +290,130 @@ __global__ __launch_bounds__(256) void k_part_counts(const float *__restrict__ p
     }
 }
 
+// The same counts with the boxes binned on a coarse BEV grid first (round 5).  k_part_counts tests every point against every RoI of its
+// frame (320k points x 487 RoIs x 8 frames = 1.2e9 circle tests, ~0.5 ms per pass); a point lies in a handful of boxes at most.  Here
+//   k_part_cells   per frame: the staged box table (the 10 floats of k_part_counts' LDS rows) and, per cell of a PC_G x PC_G grid over
+//                  the bounding square of the frame's box circles, the ids (ascending) of the boxes whose circle reaches the cell -
+//                  one 64-byte line per cell: [count | ids x 15], count -1 = more than 15 (the point kernel then walks all boxes);
+//   k_part_counts_binned   one thread per point: its cell's line, then exactly the tests of k_part_counts on the listed boxes.
+// The cell of a coordinate is trunc(clamp((v - lo) * inv, 0, G - 1)) for points and box bounds alike: float subtraction, multiplication,
+// clamp and truncation are monotone, and a point that passes the circle test of box k has |p - c_k| < R_k (R_k = the test's radius
+// with 0.2 % + 1 mm of slack for its rounding), so its cell lies inside the box's cell range; points outside the grid fall into the
+// edge cells, which the clamped box ranges include.  Every box that could pass is therefore listed, in box order: bit-identical counts.
+constexpr int PC_G = 64, PC_LINE = 16, PC_HDR = 16;               // cells per axis; ints per cell line; floats of the frame header
+
+__device__ __forceinline__ int pc_cell(float v, float lo, float inv) {
+    const float t = fminf(fmaxf(__fmul_rn(__fsub_rn(v, lo), inv), 0.f), (float)(PC_G - 1));     // (NaN -> 0)
+    return (int)t;
+}
+
+__device__ __forceinline__ size_t pc_frame_floats(int o) { return (size_t)PC_HDR + (size_t)PC_G * PC_G * PC_LINE + (((size_t)o * 10 + 15) & ~(size_t)15); }
+
+__global__ __launch_bounds__(256) void k_part_cells(const float *__restrict__ rois, int o, float *__restrict__ ws) {
+    extern __shared__ float sb[];                                    // [o][4]: centre x, y, bin radius, -
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *bx = rois + (size_t)b * o * 7;
+    float *frame = ws + (size_t)b * pc_frame_floats(o);
+    int *cells = reinterpret_cast<int *>(frame + PC_HDR);
+    float *table = frame + PC_HDR + (size_t)PC_G * PC_G * PC_LINE;
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int k = tid; k < o; k += 256) {
+        const float *qb = bx + (size_t)k * 7;
+        const float rr = 0.5f * (fabsf(qb[3]) + fabsf(qb[4])) + 1e-2f;      // (k_part_counts' radius)
+        const float rb = rr * 1.002f + 1e-3f;
+        sb[k * 4] = qb[0]; sb[k * 4 + 1] = qb[1]; sb[k * 4 + 2] = rb;
+        if (qb[0] - rb < x0) x0 = qb[0] - rb;                               // (comparisons, not fmin: a NaN box joins no bound)
+        if (qb[0] + rb > x1) x1 = qb[0] + rb;
+        if (qb[1] - rb < y0) y0 = qb[1] - rb;
+        if (qb[1] + rb > y1) y1 = qb[1] + rb;
+        if (blockIdx.y == 0) {
+            float *d = table + (size_t)k * 10;
+            for (int j = 0; j < 7; ++j) d[j] = qb[j];
+            d[7] = cosf(-qb[6]);
+            d[8] = sinf(-qb[6]);
+            d[9] = rr * rr * 1.001f;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+        y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
+    }
+    if (lane == 0) { red[w][0] = x0; red[w][1] = x1; red[w][2] = y0; red[w][3] = y1; }
+    __syncthreads();
+    x0 = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+    x1 = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+    y0 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+    y1 = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+    // (no finite box: one cell row / column, every list holds every box that compares at all - the clamps make any inv safe)
+    const float invx = (x1 > x0 && x1 - x0 < INFINITY) ? (float)PC_G / (x1 - x0) : 0.f, invy = (y1 > y0 && y1 - y0 < INFINITY) ? (float)PC_G / (y1 - y0) : 0.f;
+    const float lox = (x0 > -INFINITY && x0 < INFINITY) ? x0 : 0.f, loy = (y0 > -INFINITY && y0 < INFINITY) ? y0 : 0.f;
+    if (blockIdx.y == 0 && tid == 0) { frame[0] = lox; frame[1] = loy; frame[2] = invx; frame[3] = invy; }
+    const int cell = blockIdx.y * 256 + tid, cy = cell / PC_G, cx = cell % PC_G;
+    int *line = cells + (size_t)cell * PC_LINE;
+    int cnt = 0;
+    for (int k = 0; k < o; ++k) {
+        const float bxc = sb[k * 4], byc = sb[k * 4 + 1], rb = sb[k * 4 + 2];
+        // (a box with a NaN centre or radius can contain no point: its comparisons all fail in k_part_counts)
+        if (!(bxc == bxc) || !(byc == byc) || !(rb == rb)) continue;
+        if (cx < pc_cell(bxc - rb, lox, invx) || cx > pc_cell(bxc + rb, lox, invx) || cy < pc_cell(byc - rb, loy, invy) || cy > pc_cell(byc + rb, loy, invy)) continue;
+        if (cnt < PC_LINE - 1) line[1 + cnt] = k;
+        ++cnt;
+    }
+    line[0] = cnt < PC_LINE ? cnt : -1;
+}
+
+__global__ __launch_bounds__(256) void k_part_counts_binned(const float *__restrict__ pts, int n, int stride, const float *__restrict__ ws, int batch,
+                                                            int o, int gsz, int max_boxes, int *__restrict__ counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * stride;
+    const int b = (int)p[0];
+    if (b < 0 || b >= batch) return;
+    const float x = p[1], y = p[2], z = p[3];
+    const float *frame = ws + (size_t)b * pc_frame_floats(o);
+    const int *cells = reinterpret_cast<const int *>(frame + PC_HDR);
+    const float *table = frame + PC_HDR + (size_t)PC_G * PC_G * PC_LINE;
+    const int cell = pc_cell(y, frame[1], frame[3]) * PC_G + pc_cell(x, frame[0], frame[2]);
+    int line[PC_LINE];
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(cells + (size_t)cell * PC_LINE);
+#pragma unroll
+        for (int j = 0; j < PC_LINE / 4; ++j) { const int4 v = src[j]; line[4 * j] = v.x; line[4 * j + 1] = v.y; line[4 * j + 2] = v.z; line[4 * j + 3] = v.w; }
+    }
+    const bool all = line[0] < 0;
+    const int ncand = all ? o : line[0];
+    int found = 0;
+    for (int c = 0; c < ncand && found < max_boxes; ++c) {
+        int k = c;
+        if (!all) {
+            // (a run-time index into the register copy of the line would become a scratch array: select)
+            k = line[1];
+#pragma unroll
+            for (int j = 2; j < PC_LINE; ++j) k = (c == j - 1) ? line[j] : k;
+        }
+        const float *qb = table + (size_t)k * 10;
+        const float sx = x - qb[0], sy = y - qb[1];
+        if (sx * sx + sy * sy > qb[9]) continue;
+        if ((double)fabsf(z - qb[2]) > (double)qb[5] / 2.0) continue;           // check_pt_in_box3d
+        const float lx = sx * qb[7] + sy * (-qb[8]);
+        const float ly = sx * qb[8] + sy * qb[7];
+        if (!(((double)fabsf(lx) < (double)qb[3] / 2.0 + (double)1e-5f) && ((double)fabsf(ly) < (double)qb[4] / 2.0 + (double)1e-5f))) continue;
+        ++found;
+        const float loc[3] = {lx, ly, z - qb[2]};
+        int cellp[3];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float corner = __fadd_rn(loc[a], __fdiv_rn(qb[3 + a], 2.f));
+            const float gq = __fdiv_rn(corner, __fdiv_rn(qb[3 + a], (float)gsz));
+            ok = ok && !(gq < 0.f) && !(gq >= (float)gsz) && (gq == gq);
+            cellp[a] = (int)gq;
+        }
+        if (ok) atomicAdd(&counts[((((size_t)b * o + k) * gsz + cellp[0]) * gsz + cellp[1]) * gsz + cellp[2]], 1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ single-head attention, wide head
 // out[r] = softmax(q[r] k[r]^T * scale + mask) v[r] for R independent sequences of L <= 256 tokens with E <= 256 channels (the PDV
 // encoder layer: L = 216 grid points, E = 192, one head - dz_mha_core serves the refiner's 32-channel heads).  A workgroup = 8 query
@@ -503,6 +627,30 @@ int dz_pdv_part_counts(const float *points_b, int n, int stride, const float *ro
     if (n == 0) return DZ_OK;
     hipLaunchKernelGGL(k_part_counts, dim3(ceil_div(n, 256), batch), dim3(256), 64 * 10 * sizeof(float), stream, points_b, n, stride, rois, batch, o, grid,
                        max_boxes, counts);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+}
+
+size_t dz_pdv_part_counts_ws_bytes(int batch, int o) {
+    if (batch < 1 || o < 0) return 0;
+    return (size_t)batch * ((size_t)PC_HDR + (size_t)PC_G * PC_G * PC_LINE + (((size_t)o * 10 + 15) & ~(size_t)15)) * sizeof(float);
+}
+
+int dz_pdv_part_counts_binned(const float *points_b, int n, int stride, const float *rois, int batch, int o, int grid, int max_boxes, int *counts,
+                              void *ws, size_t ws_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DZ_CHECK_ARG(n >= 0 && stride >= 4 && batch >= 1 && o >= 0 && grid >= 1 && max_boxes >= 1, "dz_pdv_part_counts_binned: bad sizes");
+    if (o == 0) return DZ_OK;
+    DZ_CHECK_ARG(rois && counts && (points_b || n == 0), "dz_pdv_part_counts_binned: null pointer");
+    DZ_CHECK_ARG(ws && ws_bytes >= dz_pdv_part_counts_ws_bytes(batch, o) && ((uintptr_t)ws & 63) == 0,
+                 "dz_pdv_part_counts_binned: workspace of %zu bytes, 64-byte aligned (dz_pdv_part_counts_ws_bytes)", dz_pdv_part_counts_ws_bytes(batch, o));
+    if ((size_t)o * 16 > 64 * 1024) return dz_pdv_part_counts(points_b, n, stride, rois, batch, o, grid, max_boxes, counts, stream_);     // (box circles staged in LDS)
+    const int rc = fill_u32(counts, 0u, (size_t)batch * o * grid * grid * grid, stream);
+    if (rc) return rc;
+    if (n == 0) return DZ_OK;
+    hipLaunchKernelGGL(k_part_cells, dim3(batch, PC_G * PC_G / 256), dim3(256), (size_t)o * 16, stream, rois, o, (float *)ws);
+    hipLaunchKernelGGL(k_part_counts_binned, dim3(ceil_div(n, 256)), dim3(256), 0, stream, points_b, n, stride, (const float *)ws, batch, o, grid, max_boxes,
+                       counts);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
 }

@@ -179,6 +179,8 @@ _SIGS = {
     'dz_pdv_group_features': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                       c_void_p, c_int, c_void_p]),
     'dz_pdv_part_counts': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dz_pdv_part_counts_ws_bytes': (ctypes.c_size_t, [c_int, c_int]),
+    'dz_pdv_part_counts_binned': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     'dz_attention_single_head': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'dz_points_in_boxes_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dz_points_in_boxes_v2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -20,6 +20,7 @@ Data flow of ``PDVHead.forward`` (eval):
 Training paths (proposal target layer, losses) are out of scope, like everywhere in this backend.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -250,14 +251,26 @@ def sa_pool_split(new_xyz, per_batch, xyz, feats, level, idx, cnt, stack, math, 
     return out
 
 
+PART_COUNTS_BINNED = os.environ.get('DZ_TUNE_PART_BINNED', '1') != '0'      # 0: every point against every RoI of its frame (dz_pdv_part_counts)
+
+
 def part_counts(points_b, rois, grid_size, max_num_boxes):
     """density_utils.find_num_points_per_part_multi -> (B, O, G, G, G) int32."""
     b, o = rois.shape[0], rois.shape[1]
     counts = torch.empty((b, o, grid_size, grid_size, grid_size), dtype=torch.int32, device=rois.device)
     r7 = rois[..., :7].float().contiguous()
+    lib = L.load()
     with torch.cuda.device(rois.device):
-        rc = L.load().dz_pdv_part_counts(L.ptr(points_b), points_b.shape[0], points_b.shape[1], L.ptr(r7), b, o, grid_size, max_num_boxes, L.ptr(counts), L.stream())
-    L.check(rc, 'dz_pdv_part_counts')
+        if PART_COUNTS_BINNED and o > 0:
+            # RoIs binned on a BEV grid first (dz_pdv_part_counts_binned: the same counts, bit for bit)
+            nb = int(lib.dz_pdv_part_counts_ws_bytes(b, o))
+            ws = torch.empty((nb,), dtype=torch.uint8, device=rois.device)
+            rc = lib.dz_pdv_part_counts_binned(L.ptr(points_b), points_b.shape[0], points_b.shape[1], L.ptr(r7), b, o, grid_size, max_num_boxes, L.ptr(counts),
+                                               L.ptr(ws), nb, L.stream())
+            L.check(rc, 'dz_pdv_part_counts_binned')
+        else:
+            rc = lib.dz_pdv_part_counts(L.ptr(points_b), points_b.shape[0], points_b.shape[1], L.ptr(r7), b, o, grid_size, max_num_boxes, L.ptr(counts), L.stream())
+            L.check(rc, 'dz_pdv_part_counts')
     return counts
 
 

@@ -627,6 +627,13 @@ int dz_pdv_sa_pool_split(const float *new_xyz, int mq, int per_batch, const floa
  * counting for the first max_boxes RoIs (in RoI order) that contain it. */
 int dz_pdv_part_counts(const float *points_b, int n, int stride, const float *rois, int batch, int o, int grid, int max_boxes,
                        int *counts, void *stream);
+/* The same counts, bit for bit, with the RoIs binned on a 64 x 64 BEV grid first (a point then tests the handful of boxes whose
+ * footprint circle reaches its cell instead of all o of its frame: ~0.5 ms -> tens of microseconds per 8 frames of 320k points).
+ * ws: dz_pdv_part_counts_ws_bytes(batch, o) bytes of device scratch, 64-byte aligned (per frame: grid origin / scale, one 64-byte
+ * line of box ids per cell, the staged box table).  More than 4096 RoIs per frame: runs dz_pdv_part_counts. */
+size_t dz_pdv_part_counts_ws_bytes(int batch, int o);
+int dz_pdv_part_counts_binned(const float *points_b, int n, int stride, const float *rois, int batch, int o, int grid, int max_boxes,
+                              int *counts, void *ws, size_t ws_bytes, void *stream);
 /* softmax(q k^T * scale + key padding mask) v for r independent sequences of l <= 256 tokens, one head of e <= 256 channels
  * (nn.MultiheadAttention core of attention_utils.TransformerEncoder; q, k, v, out (r, l, e) f32; mask (r, l) bytes or NULL). */
 int dz_attention_single_head(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask, int r, int l,

@@ -545,3 +545,47 @@ def test_encoder_row_chains(device, mode, mid, tol, rows):
     # the same result as pair16 rows (the operand of the FC stack that follows): the fp32 result rounded to the pair format
     outp = ops.pair16_to_f32(pm.encoder_back(opp, srcp, dev(pooled), dev(skip.to(torch.uint8)), bw, mid, out_pair16=True), mid).cpu().double()
     assert float((outp - out).abs().max()) <= (4e-6 if mid == 1 else 2e-4) * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('o, n, max_boxes', [(487, 200000, 20), (37, 5000, 2), (1, 300, 1), (600, 30000, 3)])
+def test_part_counts_binned_equals_every_box(device, o, n, max_boxes):
+    """dz_pdv_part_counts_binned (RoIs binned on a BEV grid, a point tests its cell's boxes) against dz_pdv_part_counts (every point
+    against every RoI of its frame), bit for bit: crowded cells (more than 15 boxes: the overflow line), degenerate / NaN / far-away
+    boxes, points outside the boxes' bounding square, NaN / inf points, batch indices out of range, the max_boxes cut in box order."""
+    from detzero_amd import pdv_modules as pm
+    g = torch.Generator().manual_seed(o)
+    b = 3
+    rois = torch.zeros(b, o, 7)
+    rois[..., 0:2] = (torch.rand(b, o, 2, generator=g) - 0.5) * 150
+    rois[..., 2] = torch.rand(b, o, generator=g) * 4 - 2
+    rois[..., 3:6] = torch.rand(b, o, 3, generator=g) * torch.tensor([8., 3., 3.]) + 0.3
+    rois[..., 6] = (torch.rand(b, o, generator=g) - 0.5) * 6.3
+    crowd = min(o, 40)
+    rois[1, :crowd, 0:2] = torch.tensor([10., -5.]) + torch.rand(crowd, 2, generator=g)
+    if o > 5:
+        rois[0, 3, 3:6] = 0
+        rois[0, 4, 0] = float('nan')
+        rois[2, 5, 0] = 1e6
+    pts = torch.zeros(n, 5)
+    pts[:, 0] = torch.randint(0, b, (n,), generator=g).float()
+    k = torch.randint(0, o, (n,), generator=g)
+    centre = rois[pts[:, 0].long(), k, :3]
+    near = centre + (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([6., 3., 3.])
+    far = (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([400., 400., 10.])
+    pts[:, 1:4] = torch.where((torch.rand(n, generator=g) < 0.6)[:, None], near, far)
+    pts[0, 1] = float('nan')
+    pts[1, 2] = float('inf')
+    pts[2, 0] = 7
+    pts[3, 0] = -1
+    pts, rois = pts.to(device), rois.to(device)
+    saved = pm.PART_COUNTS_BINNED
+    try:
+        pm.PART_COUNTS_BINNED = False
+        every = pm.part_counts(pts, rois, 6, max_boxes)
+        pm.PART_COUNTS_BINNED = True
+        binned = pm.part_counts(pts, rois, 6, max_boxes)
+    finally:
+        pm.PART_COUNTS_BINNED = saved
+    assert int(every.sum()) > n // 50
+    assert torch.equal(every, binned)
