@@ -34,25 +34,42 @@ struct CentroidGeom {
 };
 
 // voxel_aggregation_utils.py:29-39: index = (p - lo) / vs in float32; outside iff index < 0 or index >= grid; then .long()
+// (round 5: one atomicOr per point was 0.29 ms per 8 two-sweep frames - the stride-4 / stride-8 cells hold dozens of points each and
+// their atomics queue up on one address.  The lanes of a run of equal bitmap words OR their bits in registers, the run's last lane
+// reads the word first and skips the atomic when its bits are there already - a stale read only costs a redundant atomic.)
 __global__ void k_cen_keys(const float *__restrict__ pts, int n, int stride, CentroidGeom g, int batch, uint32_t *__restrict__ keys,
                            uint32_t *__restrict__ bitmap) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float *p = pts + (size_t)i * stride;
-        const int b = (int)p[0];
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
         uint32_t key = KEY_INVALID;
-        float q[3];
-        bool ok = (unsigned)b < (unsigned)batch;
+        if (i < n) {
+            const float *p = pts + (size_t)i * stride;
+            const int b = (int)p[0];
+            float q[3];
+            bool ok = (unsigned)b < (unsigned)batch;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            q[a] = __fdiv_rn(__fsub_rn(p[1 + a], g.lo[a]), g.vs[a]);
-            ok = ok && !(q[a] < 0.f) && !(q[a] >= (float)g.g[a]);
+            for (int a = 0; a < 3; ++a) {
+                q[a] = __fdiv_rn(__fsub_rn(p[1 + a], g.lo[a]), g.vs[a]);
+                ok = ok && !(q[a] < 0.f) && !(q[a] >= (float)g.g[a]);
+            }
+            if (ok) {
+                const int cx = (int)q[0], cy = (int)q[1], cz = (int)q[2];
+                key = (uint32_t)(((b * g.g[2] + cz) * g.g[1] + cy) * g.g[0] + cx);
+            }
+            keys[i] = key;
         }
-        if (ok) {
-            const int cx = (int)q[0], cy = (int)q[1], cz = (int)q[2];
-            key = (uint32_t)(((b * g.g[2] + cz) * g.g[1] + cy) * g.g[0] + cx);
-            atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+        const uint32_t w = key == KEY_INVALID ? KEY_INVALID : key >> 5;
+        uint32_t bits = key == KEY_INVALID ? 0u : 1u << (key & 31u);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t wp = (uint32_t)__shfl_up((int)w, d, 64), bp = (uint32_t)__shfl_up((int)bits, d, 64);
+            if (lane >= d && wp == w) bits |= bp;
         }
-        keys[i] = key;
+        const uint32_t wn = (uint32_t)__shfl_down((int)w, 1, 64);
+        if (bits && (lane == 63 || wn != w)) {
+            if ((__builtin_nontemporal_load(&bitmap[w]) & bits) != bits) atomicOr(&bitmap[w], bits);
+        }
     }
 }
 
