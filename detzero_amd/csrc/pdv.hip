@@ -366,14 +366,26 @@ __global__ __launch_bounds__(256) void k_part_cells(const float *__restrict__ ro
     const float invx = (x1 > x0 && x1 - x0 < INFINITY) ? (float)PC_G / (x1 - x0) : 0.f, invy = (y1 > y0 && y1 - y0 < INFINITY) ? (float)PC_G / (y1 - y0) : 0.f;
     const float lox = (x0 > -INFINITY && x0 < INFINITY) ? x0 : 0.f, loy = (y0 > -INFINITY && y0 < INFINITY) ? y0 : 0.f;
     if (blockIdx.y == 0 && tid == 0) { frame[0] = lox; frame[1] = loy; frame[2] = invx; frame[3] = invy; }
-    const int cell = blockIdx.y * 256 + tid, cy = cell / PC_G, cx = cell % PC_G;
+    // cell range of every box, once per workgroup: x0 | x1 << 8 | y0 << 16 | y1 << 24 (PC_G <= 256), an empty range for a box with a NaN
+    // centre or radius (it can contain no point: its comparisons all fail in k_part_counts)
+    static_assert(PC_G <= 256, "packed cell ranges");
+    unsigned int *rng = reinterpret_cast<unsigned int *>(sb);
+    for (int k = tid; k < o; k += 256) {
+        const float bxc = sb[k * 4], byc = sb[k * 4 + 1], rb = sb[k * 4 + 2];
+        unsigned int r = 1u;                                                // x0 = 1 > x1 = 0
+        if (bxc == bxc && byc == byc && rb == rb)
+            r = (unsigned int)pc_cell(bxc - rb, lox, invx) | (unsigned int)pc_cell(bxc + rb, lox, invx) << 8 | (unsigned int)pc_cell(byc - rb, loy, invy) << 16 |
+                (unsigned int)pc_cell(byc + rb, loy, invy) << 24;
+        rng[k * 4 + 3] = r;
+    }
+    __syncthreads();
+    const int cell = blockIdx.y * 256 + tid;
+    const unsigned int cy = (unsigned int)(cell / PC_G), cx = (unsigned int)(cell % PC_G);
     int *line = cells + (size_t)cell * PC_LINE;
     int cnt = 0;
     for (int k = 0; k < o; ++k) {
-        const float bxc = sb[k * 4], byc = sb[k * 4 + 1], rb = sb[k * 4 + 2];
-        // (a box with a NaN centre or radius can contain no point: its comparisons all fail in k_part_counts)
-        if (!(bxc == bxc) || !(byc == byc) || !(rb == rb)) continue;
-        if (cx < pc_cell(bxc - rb, lox, invx) || cx > pc_cell(bxc + rb, lox, invx) || cy < pc_cell(byc - rb, loy, invy) || cy > pc_cell(byc + rb, loy, invy)) continue;
+        const unsigned int r = rng[k * 4 + 3];
+        if (cx < (r & 255u) || cx > ((r >> 8) & 255u) || cy < ((r >> 16) & 255u) || cy > (r >> 24)) continue;
         if (cnt < PC_LINE - 1) line[1 + cnt] = k;
         ++cnt;
     }
