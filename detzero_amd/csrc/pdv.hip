@@ -185,15 +185,29 @@ __global__ __launch_bounds__(256) void k_ball_query(const float *__restrict__ ne
     int cnt = 0, first = 0;
     for (int cz = lo[2]; cz <= hi[2] && cnt < nsample; ++cz)
         for (int cy = lo[1]; cy <= hi[1] && cnt < nsample; ++cy) {
+            // the x cells of a (z, y) row are consecutive keys: whole bitmap words, masked to the row's span, and only their SET bits
+            // are visited - ascending bit = ascending x, the order of the cell-by-cell probe (round 5: most cells of a ball's box are
+            // empty, each cost a word load and a test)
             const uint32_t line = batch_key + (uint32_t)((cz * g.H + cy) * g.W);
-            for (int cx = lo[0]; cx <= hi[0] && cnt < nsample; ++cx) {
-                const int v = bitmap_find(bitmap, prefix, line + (uint32_t)cx);
-                if (v < 0) continue;
-                const float dx = __fsub_rn(qx, xyz[(size_t)v * 3]), dy = __fsub_rn(qy, xyz[(size_t)v * 3 + 1]), dz = __fsub_rn(qz, xyz[(size_t)v * 3 + 2]);
-                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                if (d2 < r2) {
-                    if (cnt == 0) first = v - batch_start;
-                    row[cnt++] = v - batch_start;
+            if (hi[0] < lo[0]) continue;
+            const uint32_t k0 = line + (uint32_t)lo[0], k1 = line + (uint32_t)hi[0];
+            for (uint32_t w = k0 >> 5; w <= (k1 >> 5) && cnt < nsample; ++w) {
+                const uint32_t full = bitmap[w];
+                uint32_t word = full;
+                if (w == (k0 >> 5)) word &= ~0u << (k0 & 31u);
+                if (w == (k1 >> 5) && (k1 & 31u) != 31u) word &= (1u << ((k1 & 31u) + 1u)) - 1u;
+                if (!word) continue;
+                const uint32_t base = prefix[w];
+                while (word && cnt < nsample) {
+                    const int bit = __ffs((int)word) - 1;
+                    word &= word - 1u;
+                    const int v = (int)(base + __popc(full & ((1u << bit) - 1u)));
+                    const float dx = __fsub_rn(qx, xyz[(size_t)v * 3]), dy = __fsub_rn(qy, xyz[(size_t)v * 3 + 1]), dz = __fsub_rn(qz, xyz[(size_t)v * 3 + 2]);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    if (d2 < r2) {
+                        if (cnt == 0) first = v - batch_start;
+                        row[cnt++] = v - batch_start;
+                    }
                 }
             }
         }
