@@ -193,3 +193,9 @@ def test_capability_queries_answer_without_a_gpu():
     assert lib.dz_pdv_sa_pool_supported(128, 144, 64, 64, 32, 1, 1) == 0
     assert lib.dz_pdv_sa_pool_supported(128, 144, 64, 64, 16, 1, 0) == 0
     assert lib.dz_pdv_sa_pool_supported(126, 144, 64, 64, 16, 1, 1) == 0
+    # PDV part counts on a BEV grid of RoI lists: per frame a 64-byte header, 64 x 64 lines of 16 ints, the staged box table (10 floats
+    # per RoI, padded to whole lines)
+    assert lib.dz_pdv_part_counts_ws_bytes(8, 487) == 8 * (16 + 64 * 64 * 16 + 4880) * 4
+    assert lib.dz_pdv_part_counts_ws_bytes(1, 0) == (16 + 64 * 64 * 16) * 4
+    assert lib.dz_pdv_part_counts_ws_bytes(0, 5) == 0
+    assert lib.dz_pdv_part_counts_ws_bytes(2, 3) % 64 == 0
