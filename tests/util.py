@@ -11,10 +11,11 @@ POST = {'SCORE_THRESH': 0.03, 'POST_CENTER_LIMIT_RANGE': [-80, -80, -10.0, 80, 8
         'NMS_THRESH': 0.7, 'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}
 
 
-def make_model(voxel_size, seed=0, sweeps=1):
-    """Seeded random-init CenterPoint (reference architecture) - see detzero_amd.centerpoint.synth_detector."""
+def make_model(voxel_size, seed=0, sweeps=1, gain='preserve', second_stage=False):
+    """Seeded random-init CenterPoint (reference architecture) - see detzero_amd.centerpoint.synth_detector.  gain='preserve' (default):
+    the variance-preserving weight set whose boxes depend on the frame; 'default': the rounds 1-5 set (frame-independent border boxes)."""
     from detzero_amd.centerpoint import synth_detector
-    return synth_detector(voxel_size, seed, sweeps)
+    return synth_detector(voxel_size, seed, sweeps, gain=gain, second_stage=second_stage)
 
 
 def cpu_state_dict(model):
