@@ -717,8 +717,10 @@ def variance_preserving_init(model, seed=0, ring=0.15, branch=0.5, down=0.4, up2
         too), Cin for the deblocks (the 2 x 2 upsampling one, which spreads a coarse cell over four fine ones, at `up2` of that);
         the first layer's input columns are scaled to O(1) (x, y in units of 40 m);
       * the second convolution of a residual block carries `branch`, a strided convolution `down`, so that the sparse stages stay O(1);
-      * the output layers keep their default draw, scaled: centre offsets 0.5 +- 0.2 of a cell, log-sizes around a car, heat map x `hm_gain`
-        with its bias placed `hm_floor` below zero for a cell far from any data (`uniform_field_response`) - sigmoid(-4) = 0.018 is under
+      * the output layers keep their default draw, scaled so that the decode is as well-conditioned as a trained head's: centre offsets
+        0.5 +- 0.2 of a cell, log-sizes 0.25 around a car's (exp() of a log-size of 4 would turn a 1e-4 error into 5e-3 m), the (cos, sin)
+        pair 0.3 around a unit vector (atan2 of a pair of norm 0.05 turns 1e-4 into 2e-3 rad; a trained head's pair has norm ~ 1), heat map
+        x `hm_gain` with its bias placed `hm_floor` below zero for a cell far from any data (`uniform_field_response`) - sigmoid(-4) = 0.018 is under
         SCORE_THRESH, so a box exists only where the frame's points raised the heat map.
     BatchNorm statistics / affine terms are left to the caller (synth_detector randomises them BEFORE calling this)."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -748,7 +750,8 @@ def variance_preserving_init(model, seed=0, ring=0.15, branch=0.5, down=0.4, up2
             std = math.sqrt(2.0 / (m.weight.shape[1] * float(taps.pow(2).sum())))
             m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std * taps)
     for hl in model.dense_head.heads_list:
-        for head, gain, bias in (('center', 0.15, [0.5, 0.5]), ('center_z', 0.5, [1.0]), ('dim', 0.25, [1.2, 0.6, 0.4]), ('iou', 0.5, [0.6])):
+        for head, gain, bias in (('center', 0.15, [0.5, 0.5]), ('center_z', 0.5, [1.0]), ('dim', 0.12, [1.2, 0.6, 0.4]), ('rot', 0.3, [0.8, 0.6]),
+                                 ('iou', 0.5, [0.6])):
             if hasattr(hl, head):
                 out = getattr(hl, head)[1]
                 out.weight.mul_(gain)

@@ -3,9 +3,13 @@ grid 1504 x 1504 x 40, the full network - per stage and end to end, in every mat
 ``FramePipeline`` (the stacked ``dz_voxelize_to_level`` chain that ``bench.py`` times, and the ragged per-frame route), plus
 the multi-sweep configuration of configs[4] (two merged sweeps, 320k points, 6 features, DynamicMeanVFE).
 
-The CPU oracle needs ~3 s per 160k frame, so it runs once per module.  Tolerances: active sets / coordinates bit-exact;
-sparse features 2e-3; dense maps 2e-3 (5e-3 in bf16x2, whose pairs carry 16 bits); final boxes and scores within the north
-star's 1e-3.  Reference: backbone3d.py:289-338, backbone2d.py:89-120, center_head.py:315-368,440-488.
+The CPU oracle needs ~3 s per 160k frame, so it runs once per module.  The detector is the round-6 weight set (`gain='preserve'`):
+activations are O(1) in every stage and the boxes depend on the frame (tests/test_oracle_data_dependence.py), so an error is measured
+against a signal.  Tolerances: active sets / coordinates bit-exact; every feature tensor max |error| <= REL x the stage's own standard
+deviation (the data-dependent amplitude: between two frames the maps differ by about their own spread); final boxes and scores
+within the north star's 1e-3 in f32 and f16x2.  bf16x2 (16-bit pairs) does NOT meet 1e-3 on data-dependent boxes - it is checked
+at 1e-2 and is an opt-in mode only (select_math no longer falls back to it).
+Reference: backbone3d.py:289-338, backbone2d.py:89-120, center_head.py:315-368,440-488.
 """
 import numpy as np
 import pytest
@@ -16,17 +20,19 @@ from tests.util import canon_order, canon_tensor, cpu_state_dict, make_model, ma
 
 pytestmark = pytest.mark.gpu
 MATHS = ['f32', 'f16x2', 'bf16x2']
-# Tolerances = ~10x the largest error OBSERVED on the MI355X (r03, printed by _close for every stage and math mode; the achieved
-# values are in profiles/r03*_gputests.txt), not one flat bound: f32 / f16x2 sit at fp32 summation-order noise (x_conv1 carries the
-# largest activations, |x| ~ 30), bf16x2 at its 16-bit pairs.
-TOL = {             # stage: (f32, f16x2, bf16x2)
-    'x_conv1': (1.5e-4, 1.5e-4, 3.5e-3), 'x_conv2': (5e-5, 1e-4, 2e-3), 'x_conv3': (2e-5, 5e-5, 3e-4), 'x_conv4': (1e-5, 2e-5, 2e-4),
-    'encoded': (6e-6, 1e-5, 1e-4), 'spatial_features': (6e-6, 1e-5, 1e-4), 'spatial_features_2d': (2e-6, 4e-6, 6e-5), 'head': (6e-6, 8e-6, 6e-5)}
+# REL = max |error| / std(reference stage), ~10x the largest value OBSERVED on the MI355X (r06, printed by _close for every stage and
+# math mode; the achieved values are in profiles/r06*_gputests.txt).  f32 / f16x2 sit at fp32 summation-order noise (the oracle sums
+# tap by tap, the kernels in MFMA order), bf16x2 at its 16-bit pairs.
+REL = {             # stage: (f32, f16x2, bf16x2)
+    'x_conv1': (2e-4, 3e-4, 3e-3), 'x_conv2': (4e-4, 4e-4, 5e-3), 'x_conv3': (4e-4, 4e-4, 5e-3), 'x_conv4': (4e-4, 5e-4, 5e-3),
+    'encoded': (5e-4, 8e-4, 5e-3), 'spatial_features': (5e-4, 8e-4, 5e-3), 'spatial_features_2d': (1e-3, 1e-3, 1e-2), 'head': (1e-3, 1e-3, 1e-2)}
+BOX_TOL = {'f32': 1e-3, 'f16x2': 1e-3, 'bf16x2': 1e-2}       # the north star's 1e-3 for the two fp32-class engines
 _MI = {'f32': 0, 'f16x2': 1, 'bf16x2': 2}
 
 
 def _tol(name, math):
-    return TOL['head' if name.startswith('head/') else name][_MI[math]]
+    name = name[3:] if name.startswith('ms/') else name
+    return REL['head' if name.startswith('head/') else name][_MI[math]]
 N_FULL = 160000
 
 
@@ -43,22 +49,24 @@ def full(device):
 SEEN = {}            # (stage, math) -> largest max-abs error observed in this run (printed at the end of the module)
 
 
-def _close(name, math, got, ref, tol=None):
-    """max |got - ref| <= tol, with the achieved error printed and collected (a regression by two decimal digits would otherwise
-    hide under a flat tolerance)."""
-    tol = _tol(name, math) if tol is None else tol
+def _close(name, math, got, ref, rel=None):
+    """max |got - ref| <= rel x std(ref), with the achieved error printed and collected (a regression by two decimal digits would
+    otherwise hide under a flat tolerance)."""
+    rel = _tol(name, math) if rel is None else rel
+    amp = float(ref.float().std()) if ref.numel() > 1 else 1.0
     err = float((got.float() - ref.float()).abs().max()) if got.numel() else 0.0
-    SEEN[(name, math)] = max(SEEN.get((name, math), 0.0), err)
-    print('  parity %-22s [%-6s] max abs err %.3e (tolerance %.1e)' % (name, math, err, tol))
-    assert err <= tol, '%s [%s]: max abs error %.3e above %.1e' % (name, math, err, tol)
+    SEEN[(name, math)] = max(SEEN.get((name, math), 0.0), err / amp)
+    print('  parity %-24s [%-6s] max abs err %.3e = %.2e of the stage std %.3g (tolerance %.1e of it)' % (name, math, err, err / amp, amp, rel))
+    assert err <= rel * amp, '%s [%s]: max abs error %.3e = %.2e of std %.3g, above %.1e' % (name, math, err, err / amp, amp, rel)
     return err
 
 
-def _flip_is_on_a_threshold(box, score, others, others_scores, post_thresh=0.03, nms_thresh=0.7):
+def _flip_is_on_a_threshold(box, score, others, others_scores, post_thresh=0.03, nms_thresh=0.7, cut=None):
     """A box that one side reports and the other does not is acceptable only when it sits ON a decision threshold: its score
-    within 1e-4 of SCORE_THRESH, or its BEV IoU with a higher-scored box within 1e-3 of the NMS threshold."""
+    within 1e-4 of SCORE_THRESH or of the K-th candidate's score (`cut`: MAX_OBJ_PER_SAMPLE keeps the 500 best cells, centernet_utils.py:
+    138-165 - the lowest score that survived on either side), or its BEV IoU with a higher-scored box within 1e-3 of the NMS threshold."""
     from oracle import cref
-    if abs(float(score) - post_thresh) <= 1e-4:
+    if abs(float(score) - post_thresh) <= 1e-4 or (cut is not None and abs(float(score) - cut) <= 1e-4):
         return True
     hi = others[others_scores > score]
     if hi.shape[0] == 0:
@@ -67,22 +75,24 @@ def _flip_is_on_a_threshold(box, score, others, others_scores, post_thresh=0.03,
     return bool(np.any(np.abs(iou - nms_thresh) <= 1e-3))
 
 
-def _check_boxes(ref_final, boxes9, n, tag):
+def _check_boxes(ref_final, boxes9, n, tag, tol=1e-3):
     rb = ref_final[0]
     n_ref = rb['pred_boxes'].shape[0]
     assert n_ref > 50, (tag, n_ref)
     got = boxes9[:n].cpu().numpy()
-    nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), got[:, :7], got[:, 7], tol=1e-3)
+    nm, worst = match_boxes(rb['pred_boxes'].numpy(), rb['pred_scores'].numpy(), got[:, :7], got[:, 7], tol=tol)
+    print('  boxes %-36s %d reference / %d ours, %d matched within %.0e (worst %.2e)' % (tag, n_ref, n, nm, tol, worst))
     # a candidate sitting exactly on SCORE_THRESH / the NMS threshold may flip; everything else matches within 1e-3 - and every
     # box that did flip is shown to sit on one of the two thresholds
     assert abs(n - n_ref) <= 2 and nm >= n_ref - 2, (tag, n, n_ref, nm, worst)
     if nm < n_ref or nm < n:
         rbx, rsc = rb['pred_boxes'].numpy(), rb['pred_scores'].numpy()
         d = np.abs(rbx[:, None, :3] - got[None, :, :3]).max(-1)
-        for i in np.nonzero(d.min(axis=1) > 1e-3)[0]:                    # reference boxes without a partner
-            assert _flip_is_on_a_threshold(rbx[i], rsc[i], rbx, rsc), (tag, 'reference box without partner', rbx[i], rsc[i])
-        for j in np.nonzero(d.min(axis=0) > 1e-3)[0]:                    # our boxes without a partner
-            assert _flip_is_on_a_threshold(got[j, :7], got[j, 7], got[:, :7], got[:, 7]), (tag, 'box without partner', got[j])
+        cut = float(min(rsc.min(), got[:, 7].min()))
+        for i in np.nonzero(d.min(axis=1) > tol)[0]:                    # reference boxes without a partner
+            assert _flip_is_on_a_threshold(rbx[i], rsc[i], rbx, rsc, cut=cut), (tag, 'reference box without partner', rbx[i], rsc[i])
+        for j in np.nonzero(d.min(axis=0) > tol)[0]:                    # our boxes without a partner
+            assert _flip_is_on_a_threshold(got[j, :7], got[j, 7], got[:, :7], got[:, 7], cut=cut), (tag, 'box without partner', got[j])
     lab = {tuple(np.round(b[:3], 2)): int(l) for b, l in zip(rb['pred_boxes'].numpy(), rb['pred_labels'].numpy())}
     hits = sum(1 for g in got if lab.get(tuple(np.round(g[:3], 2)), int(g[8])) == int(g[8]))
     assert hits >= n - 2, (tag, hits, n)
@@ -144,7 +154,7 @@ def test_modules_stage_by_stage_160k(full, device, math):
         _close('head/' + k, math, pred[k].cpu(), v)
     got = bd['final_box_dicts'][0]
     b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
-    _check_boxes(ref['final'], b9, b9.shape[0], 'modules/' + math)
+    _check_boxes(ref['final'], b9, b9.shape[0], 'modules/' + math, BOX_TOL[math])
     set_math(model, 'f32')
 
 
@@ -208,8 +218,8 @@ def test_frame_pipeline_routes_160k(full, device, math, route):
     for i in range(2):
         _check_sparse(res, refs[i], math, model, frame=i, nb=2)
     out, cnt = pipe(inp)
-    worst = [_check_boxes(refs[i]['final'], out[i], int(cnt[i].item()), '%s/%s/frame%d' % (route, math, i)) for i in range(2)]
-    assert max(worst) <= 1e-3
+    worst = [_check_boxes(refs[i]['final'], out[i], int(cnt[i].item()), '%s/%s/frame%d' % (route, math, i), BOX_TOL[math]) for i in range(2)]
+    assert max(worst) <= BOX_TOL[math]
     from detzero_amd.centerpoint import set_math
     set_math(model, 'f32')
 
@@ -274,14 +284,14 @@ def test_multisweep_320k_dynamic_vfe(multisweep, device, math):
         rf, rc, rs = ref['backbone'][name]
         ti, tf = canon_tensor(t)
         assert np.array_equal(ti, rc), name
-        _close('ms/' + name, math, tf, rf, 5.0 * _tol(name, math))      # (another model and input: 5x the single-sweep table, achieved value printed)
+        _close('ms/' + name, math, tf, rf)
     for mod in (model.map_to_bev, model.backbone2d, model.dense_head):
         bd = mod(bd)
-    _close('ms/spatial_features_2d', math, bd['spatial_features_2d'].cpu(), ref['f2d'], 5.0 * _tol('spatial_features_2d', math))
+    _close('ms/spatial_features_2d', math, bd['spatial_features_2d'].cpu(), ref['f2d'])
     got = bd['final_box_dicts'][0]
     b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
-    _check_boxes(ref['final'], b9, b9.shape[0], 'multisweep-modules/' + math)
+    _check_boxes(ref['final'], b9, b9.shape[0], 'multisweep-modules/' + math, BOX_TOL[math])
     pipe = FramePipeline(model, info, dynamic=True, math=math)
     out, d_n = pipe(torch.from_numpy(merged).to(device))
-    _check_boxes(ref['final'], out, int(d_n.item()), 'multisweep-pipeline/' + math)
+    _check_boxes(ref['final'], out, int(d_n.item()), 'multisweep-pipeline/' + math, BOX_TOL[math])
     set_math(model, 'f32')

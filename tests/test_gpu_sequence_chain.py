@@ -36,7 +36,7 @@ def test_sequence_detect_track_input_refine(device):
     pipe = FramePipeline(model.to(device), info, dynamic=True, math='f16x2')
     host = []
     for i in range(N_FRAMES):
-        m = merge_two_sweeps(synth_waymo_frame(100 + i, 10000), synth_waymo_frame(101 + i, 10000))
+        m = merge_two_sweeps(synth_waymo_frame(100 + i, 40000), synth_waymo_frame(101 + i, 40000))     # (enough points for > 10 confident boxes per frame)
         host.append(m[mask_points_by_range(m, info.point_cloud_range)])
     frames = [torch.from_numpy(f).to(device) for f in host]
     metas = [{'sequence_name': 'seq-a', 'frame_id': i, 'pose': _pose(i)} for i in range(N_FRAMES)]
@@ -50,6 +50,7 @@ def test_sequence_detect_track_input_refine(device):
     # anchor: frame 3 against the CPU oracle (DynamicMeanVFE path), boxes within the north star's 1e-3
     ref = oracle_detect(sd, host[3], info, dynamic=True)['final'][0]
     nm, worst = match_boxes(ref['pred_boxes'].numpy(), ref['pred_scores'].numpy(), annos[3]['boxes_lidar'], annos[3]['score'], tol=1e-3)
+    print('sequence anchor: %d reference boxes, %d matched within 1e-3 (worst %.2e)' % (ref['pred_boxes'].shape[0], nm, worst))
     assert ref['pred_boxes'].shape[0] > 10 and nm >= ref['pred_boxes'].shape[0] - 2, (nm, ref['pred_boxes'].shape[0], worst)
     # tracker input (config-named queue; overlap filter on dz_boxes_overlap_bev)
     cfgs = [AttrDict({'NAME': 'heading_process'}), AttrDict({'NAME': 'low_confidence_box_filter', 'THRESHOLD': 0.1}),
