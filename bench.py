@@ -165,8 +165,9 @@ class Case:
     lengths = (lo, hi), mode 'padded': frames of lo..hi points padded with out-of-range rows to slots of hi rows (same route).
     lengths = (lo, hi), mode 'list': slot j holds a frame of its own length L_j in lo..hi (ragged list route)."""
 
-    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1, engine=None):
+    def __init__(self, args, dev, rank, math, batch, lengths=None, mode='stacked', seed_base=0, sweeps=1, engine=None, select=False):
         engine = engine or args.sparse_engine
+        self.math_selected, self.activation_peaks = math, None
         from detzero_amd.centerpoint import FramePipeline, set_sparse_engine, synth_detector
         from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
         self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
@@ -219,6 +220,13 @@ class Case:
                     g = merge_two_sweeps(g, synth_waymo_frame(seed_base + 1000 * rank + 7300 + i, g.shape[0]))
                 cal.append(torch.from_numpy(g).to(dev))
             self.caps = self.pipe.calibrate(cal)
+            if math in ('f16x2', 'bf16x2') and select:
+                # the arithmetic a deployment would pick for this checkpoint (centerpoint.select_math: a calibration pass on the exact-fp32
+                # engine, per-stage activation peaks) - reported as config.math_selected; the line is measured in THAT mode
+                from detzero_amd.centerpoint import select_math
+                self.math_selected, peaks = select_math(self.model, self.info, cal[:2], prefer=math, dynamic=sweeps > 1)
+                self.activation_peaks = {k: float('%.4g' % v) for k, v in peaks.items()}
+                self.math = self.math_selected            # (select_math has set the model to it)
             del cal
         self.graph = None
         self.g_out = self.g_n = None
@@ -478,7 +486,7 @@ def main():
 
     torch.set_num_threads(min(usable_cores(), 32))
     log('rank', rank, 'of', world, 'usable host cores', usable_cores())
-    case = Case(args, dev, rank, args.math, args.batch, engine=args.sparse_engine, sweeps=args.sweeps)
+    case = Case(args, dev, rank, args.math, args.batch, engine=args.sparse_engine, sweeps=args.sweeps, select=True)
     if case.caps is not None:
         log('calibrated level capacities per frame:', case.caps)
     B = case.B
@@ -521,7 +529,7 @@ def main():
         out = {
             'metric': 'LiDAR frames/sec (160k pts, 0.1m voxels)', 'value': round(value, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1000.0 * dt / K, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_names[args.math], 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_names[case.math], 'data': 'synthetic',
             'ranks_seen': tinfo.get('ranks_seen', 1), 'gather_ms': tinfo.get('gather_ms', 0.0),
             'config': {'workload': ('BASELINE configs[1]: %d-pt synthetic Waymo frames, 0.1 m voxels '
                                     '(grid 1504x1504x40), hard voxelize + MeanVFE + VoxelResBackBone8x + BaseBEVBackbone '
@@ -531,10 +539,11 @@ def main():
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'latency_ms_per_pass': round(1000.0 * dt / K, 4),
                        'like_for_like': 'leg ref_batch (8 frames per pass = BATCH_SIZE_PER_GPU of the reference config, centerpoint_1sweep.yaml:88) is the '
                                         'like-for-like batch; leg batch16 is the headline configuration of rounds 1-3; value is at frames_per_step_per_gpu', 'parallelism': 'frame-parallel x%d' % world,
-                       'launch': graph_note, 'math': args.math, 'sparse_engine': args.sparse_engine,
+                       'launch': graph_note, 'math': case.math, 'math_selected': case.math_selected, 'activation_peaks': case.activation_peaks,
+                       'sparse_engine': args.sparse_engine,
                        'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',
-                       'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded random init (no checkpoints offline)',
-                       'mean_boxes_per_frame': round(n_boxes, 1)},
+                       'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded synthetic set synth_detector(gain=preserve): variance-preserving, boxes depend on the frame and sit on its points (no checkpoints offline)',
+                       'mean_boxes_per_frame': round(n_boxes, 1), 'boxes_per_frame_min_max': [int(case.counts.min().item()), int(case.counts.max().item())]},
         }
 
     # ---- roofline of the dominant kernel: HIP events around every conv launch, on the launch stream
@@ -743,12 +752,12 @@ def main():
                 import bench_pdv
                 out['pdv'] = bench_pdv.measure(dev, args.points, 8, 'f32')
                 p16 = bench_pdv.measure(dev, args.points, 8, 'f16x2')
-                out['pdv']['f16x2'] = {k: p16[k] for k in ('first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
+                out['pdv']['f16x2'] = {k: p16[k] for k in ('first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois', 'rois_proposed', 'rois_nonempty_frac')}
                 # the same modules over 8 frames per pass (one batch_dict: every kernel of both stages launched once for all frames / RoIs)
                 p16b = bench_pdv.measure(dev, args.points, 4, 'f16x2', batch=8)
-                out['pdv']['f16x2_batch8'] = {k: p16b[k] for k in ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')}
+                out['pdv']['f16x2_batch8'] = {k: p16b[k] for k in ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois', 'rois_proposed', 'rois_nonempty_frac')}
                 # FramePipeline.two_stage: first stage batched and sync-free, roi_head once over the batch
-                keys = ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois')
+                keys = ('frames_per_pass', 'first_stage_ms', 'second_stage_ms', 'rois_per_s', 'frames_per_s', 'rois', 'rois_proposed', 'rois_nonempty_frac')
                 for nb in (8, 16):
                     pp = bench_pdv.measure(dev, args.points, 4, 'f16x2', batch=nb, pipeline=True)
                     out['pdv']['f16x2_pipeline_batch%d' % nb] = {k: pp[k] for k in keys}

@@ -249,10 +249,10 @@ F16_PAIR_SAFE_MIN = 2.0 ** -6
 
 
 @torch.no_grad()
-def activation_range(model, dataset_info, frames):
+def activation_range(model, dataset_info, frames, dynamic=False):
     """Largest |activation| per stage of the detector on sample frames, measured on the exact-fp32 engine: the outputs of the
     five sparse stages and the concatenated 2-D feature map.  Leaves the model in 'f32' math."""
-    pipe = FramePipeline(model, dataset_info, math='f32')
+    pipe = FramePipeline(model, dataset_info, math='f32', dynamic=dynamic)
     frames = list(frames)
     out = {}
     res = pipe.backbone_stage(pipe.prepare(frames))
@@ -264,13 +264,13 @@ def activation_range(model, dataset_info, frames):
     return out
 
 
-def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX, low_limit=F16_PAIR_SAFE_MIN):
+def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX, low_limit=F16_PAIR_SAFE_MIN, dynamic=False):
     """Pick the split-precision mode for a checkpoint from a calibration pass: fp16 pairs (22-bit significands) while every
     stage's largest activation stays inside [`low_limit`, `limit`], else bf16 pairs (16 bits, the full fp32 exponent range) -
     fp16 pairs SATURATE at +-65504 + lo, so a network whose activations reach 1e5 must not run on them, and their lo half goes
     subnormal for small values, so a network whose stages peak at 1e-3 is better served by bf16 pairs too.  Returns (mode,
     per-stage maxima) and sets the mode."""
-    rng = activation_range(model, dataset_info, frames)
+    rng = activation_range(model, dataset_info, frames, dynamic)
     # a stage with no active site on the calibration frames (maximum exactly 0) says nothing about the range of its activations
     live = {k: v for k, v in rng.items() if v > 0.0}
     too_big = [k for k, v in live.items() if v > limit]
@@ -493,8 +493,9 @@ class FramePipeline:
                 st['out'] = hd.new_empty((nb,) + tuple(hd.shape[1:]))
             st['out'][g0:g0 + ng].copy_(hd)          # (the activation images, the head map among them, are reused by the next group)
         with cp_modules.workspace(self._ws):
-            if GROUPED_DEEP_BLOCKS:
-                # first block, deblocks and head in frame groups; the deeper (quarter-size) blocks over all frames at once
+            if GROUPED_DEEP_BLOCKS and m.backbone2d.grouped_fits(nb, bev.shape[1] - 2, bev.shape[2] - 2):
+                # first block, deblocks and head in frame groups; the deeper (quarter-size) blocks over all frames at once (while the
+                # all-frame images of those blocks fit the 2 GiB window: 116 frames at the Waymo size - beyond that every layer per group)
                 m.backbone2d.run_grouped(nb, group, head_of_group, bev=None if sparse else bev, sparse_in=(x, bev) if sparse else None)
             else:
                 for g0 in range(0, nb, group):

@@ -328,6 +328,14 @@ int dz_conv2d_forward_split(const dz_conv2d_desc *d, int math, int out_f32, void
     }
     {
         const int bc3 = conv3x3_h_variant(*d);
+        // in_tiles lists 8 x 32-pixel tiles (dz_bev_tile_list): only the 64 / 128-channel variants of k_conv3x3_h walk that grid.  The
+        // 32-channel variant has 16 x 32 tiles - a list there would be decoded on the wrong grid (wrong pixels): refused.  A layer
+        // that no tile variant takes (small images, strided layers) runs on the generic kernel, which computes EVERY pixel: the list is
+        // ignored there (results stay correct; the caller's fill of the skipped tiles rewrites what was computed).
+        if (d->in_tiles && bc3 && !((bc3 == 64 || bc3 == 128) && !out_f32)) {
+            set_error("dz_conv2d_forward_split: in_tiles lists 8 x 32 pixel tiles; this layer runs on the 32-channel tile kernel (16 x 32 tiles) - pass no list");
+            return DZ_ERR_UNSUPPORTED;
+        }
         if (bc3 && (!out_f32 || bc3 == 32)) return conv3x3_h_launch(*d, math, out_f32, w_bytes, stream);      // (fp32 output: 32-channel tiles only)
     }
     if (math == DZ_MATH_F16X2)

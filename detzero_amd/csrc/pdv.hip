@@ -687,7 +687,9 @@ int dz_pdv_part_counts_binned(const float *points_b, int n, int stride, const fl
     DZ_CHECK_ARG(rois && counts && (points_b || n == 0), "dz_pdv_part_counts_binned: null pointer");
     DZ_CHECK_ARG(ws && ws_bytes >= dz_pdv_part_counts_ws_bytes(batch, o) && ((uintptr_t)ws & 63) == 0,
                  "dz_pdv_part_counts_binned: workspace of %zu bytes, 64-byte aligned (dz_pdv_part_counts_ws_bytes)", dz_pdv_part_counts_ws_bytes(batch, o));
-    if ((size_t)o * 16 > 64 * 1024) return dz_pdv_part_counts(points_b, n, stride, rois, batch, o, grid, max_boxes, counts, stream_);     // (box circles staged in LDS)
+    // k_part_cells stages the o box circles (16 bytes each) in dynamic LDS next to 64 bytes of static LDS: beyond the default 64 KiB
+    // limit of a launch (o > 4092) the all-pairs kernel runs instead
+    if ((size_t)o * 16 + 64 > 64 * 1024) return dz_pdv_part_counts(points_b, n, stride, rois, batch, o, grid, max_boxes, counts, stream_);     // (box circles staged in LDS)
     const int rc = fill_u32(counts, 0u, (size_t)batch * o * grid * grid * grid, stream);
     if (rc) return rc;
     if (n == 0) return DZ_OK;

@@ -739,6 +739,12 @@ class BaseBEVBackbone(_Cached):
                     outs.append(y[:1].clone())
                     x, xc = y, cv['cout']
             lvl[key] = outs
+            # one entry = six (1, H+2, W+2, C) images (~110 MB at 188 x 188 x 128): ragged last groups and other batch sizes add keys -
+            # keep the four most recent
+            order = lvl.setdefault('_zero_resp_keys', [])
+            order.append(key)
+            while len(order) > 4:
+                lvl.pop(order.pop(0), None)
         return lvl[key]
 
     def _level_convs(self, li, lvl, x, xh, xw, xc, batch, dev, sparse_in=None, out_last=None):
@@ -755,6 +761,11 @@ class BaseBEVBackbone(_Cached):
             key = ('zero_resp', xh, xw, int(self.math), str(dev), int(batch))
             if nl > 1 and key not in lvl and torch.cuda.is_current_stream_capturing():
                 nl = 1        # (the response images are computed by an eager pass: a capture without one before it skips at the first layer only)
+                if not getattr(self, '_warned_capture_nl1', False):
+                    self._warned_capture_nl1 = True
+                    import warnings
+                    warnings.warn('BaseBEVBackbone: graph capture of a %d-frame pass without an eager pass of the same size before it - empty tiles '
+                                  'are skipped at the first layer only (run one eager pass first to skip them in all six)' % batch)
             tiles = ops.bev_tile_list(sparse_in[1], xh, xw, nl)
             zero = self._zero_response(lvl, xh, xw, sparse_in[0].shape[1], dev, batch) if nl > 1 else None
         for ci, cv in enumerate(convs):
@@ -825,6 +836,18 @@ class BaseBEVBackbone(_Cached):
             x, xh, xw, xc = self._level_convs(li, lvl, x, xh, xw, xc, batch, dev, sparse_in=sparse_in if li == 0 else None)
             coff = self._level_deblock(lvl, x, xh, xw, xc, concat, coff, h, w, batch)
         return concat
+
+    def grouped_fits(self, nb, h, w):
+        """Whether `run_grouped` can hold the images it keeps for ALL nb frames (the first block's output and every deeper block's
+        activations) inside the 2 GiB window the kernels address through 32-bit offsets: at the Waymo size (190 x 190 x 128 words,
+        18.5 MB per frame) that is 116 frames; beyond it the caller runs every layer per frame group."""
+        plan = self.plan()
+        xh, xw, worst = h, w, 0
+        for lvl in plan:
+            s = lvl['convs'][0]['stride']
+            xh, xw = (xh + 2 - 3) // s + 1, (xw + 2 - 3) // s + 1
+            worst = max(worst, (xh + 2) * (xw + 2) * lvl['convs'][-1]['cout'] * 4)
+        return nb * worst < 2 ** 31
 
     def run_grouped(self, nb, group, consume, bev=None, sparse_in=None):
         """`run` for more frames than one concatenation image can hold (the kernels address an image through 32-bit offsets): the

@@ -205,7 +205,9 @@ typedef struct dz_conv2d_desc {
                                  in_cstride is ignored.  HeightCompression (height_compression.py:20-24) + the first block's ZeroPad2d
                                  (backbone2d.py:41-46) fused into that block's convolution */
     int in_row_channels, in_rows;
-    const int *in_tiles;      /* 3 x 3 stride-1 resident-tile layers, optional: a list of dz_bev_tile_list - the launch covers its tiles to run only */
+    const int *in_tiles;      /* 3 x 3 stride-1 resident-tile layers, optional: a list of dz_bev_tile_list (8 x 32 pixel tiles) - the launch covers its tiles to run only.
+                                 Walked by the 64- / 128-channel tile kernels (pair16 output); IGNORED by the generic kernel (every pixel computed); refused
+                                 (DZ_ERR_UNSUPPORTED) on the 32-channel tile kernel, whose tiles are 16 x 32 */
 } dz_conv2d_desc;
 int dz_conv2d_forward(const dz_conv2d_desc *h_desc, void *stream);
 /* name of the kernel instance dz_conv2d_forward / dz_spconv_forward dispatch to (for profiling reports) */

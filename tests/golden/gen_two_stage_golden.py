@@ -9,8 +9,8 @@ gen_pdv_golden.py does).
 What the chain is: points -> DynamicMeanVFE -> VoxelResBackBone8x -> BEV backbone -> CenterHead -> decode + NMS (oracle/, each
 function cites the reference file it restates) -> the first stage's boxes are the RoIs, x_conv3 / x_conv4 of the oracle's backbone
 the multi-scale features -> pdv_head.PDVHead.forward (reference code) -> batch_box_preds / batch_cls_preds.
-Everything is a function of seeds (frame: synth_waymo_frame(60 / 70); weights: torch.manual_seed(0) + the default initialisers, the
-head biases of tools/bench_pdv.py), so the fixture stores outputs only: the RoIs the second stage saw, its boxes and confidences,
+Everything is a function of seeds (frame: synth_waymo_frame(60 / 70); weights: detzero_amd.centerpoint.synth_detector(seed=0,
+second_stage=True) - the variance-preserving set, RoIs on occupied cells), so the fixture stores outputs only: the RoIs the second stage saw, its boxes and confidences,
 and per-RoI ball-index checksums (to tell a boundary centroid that changed sides from an error).
 tests/test_pdv.py::test_two_stage_boxes_at_bench_size runs FramePipeline.two_stage on the same frame on the GPU and compares."""
 import os
@@ -30,19 +30,10 @@ SEEDS = (60, 70)
 
 
 def build_model():
-    """The model of tools/bench_pdv.py (seeded default initialisers; head biases set so that the first stage proposes boxes)."""
-    from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network
-    from detzero_amd.config import centerpoint_pdv_cfg
-    cfg = centerpoint_pdv_cfg((0.1, 0.1, 0.15))
-    info = SyntheticDatasetInfo(cfg, num_point_features=6)
-    torch.manual_seed(0)
-    model = build_network(cfg.MODEL, 3, info).eval()
-    with torch.no_grad():
-        hl = model.dense_head.heads_list[0]
-        hl.hm[1].bias.fill_(-0.5)
-        hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4]))
-        hl.iou[1].bias.fill_(0.6)
-    return model, cfg, info
+    """The model of tools/bench_pdv.py: `synth_detector(second_stage=True)` - the centerpoint_pdv_3sweeps shape on the variance-preserving
+    weight set (round 6), so the first stage's boxes - the RoIs of the second stage - sit on the frame's points."""
+    from detzero_amd.centerpoint import synth_detector
+    return synth_detector((0.1, 0.1, 0.15), seed=0, second_stage=True)
 
 
 def frame():
@@ -95,6 +86,7 @@ def main():
     small = {'n_points': np.array(pts.shape[0]), 'n_c3': np.array(c3.shape[0]), 'n_c4': np.array(c4.shape[0]), 'rois': rois[0], 'roi_scores': scores[0],
              'roi_labels': labels[0], 'ball_row_sums': ball.numpy().astype(np.int64).sum(axis=(1, 2)),
              'batch_box_preds': out['batch_box_preds'].numpy()[0].astype(np.float32), 'batch_cls_preds': out['batch_cls_preds'].numpy()[0].astype(np.float32)}
+    print('RoIs with at least one non-empty ball: %d of %d' % (int((small['ball_row_sums'] != 0).sum()), k))
     path = os.path.join(HERE, 'two_stage_golden.npz')
     np.savez_compressed(path, **small)
     print('saved', os.path.getsize(path) // 1024, 'KiB')

@@ -21,17 +21,10 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1, pipe
     through the plugin modules as ONE batch_dict (batch-index column, as collate_batch builds it): every kernel of both stages is
     launched once per pass over all frames / all RoIs.  pipeline: the first stage through FramePipeline.two_stage (batched, sync-free,
     its own streams) instead of the plugin modules."""
-    from detzero_amd.centerpoint import SyntheticDatasetInfo, build_network, set_math
-    from detzero_amd.config import centerpoint_pdv_cfg
+    from detzero_amd.centerpoint import SyntheticDatasetInfo, set_math, synth_detector
     from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
-    cfg = centerpoint_pdv_cfg((0.1, 0.1, 0.15))
-    torch.manual_seed(0)
-    model = build_network(cfg.MODEL, 3, SyntheticDatasetInfo(cfg, num_point_features=6)).eval()
-    with torch.no_grad():       # random heads give no peaks: bias the heat map / sizes so that the first stage proposes boxes
-        hl = model.dense_head.heads_list[0]
-        hl.hm[1].bias.fill_(-0.5)
-        hl.dim[1].bias.copy_(torch.tensor([1.2, 0.6, 0.4]))
-        hl.iou[1].bias.fill_(0.6)
+    # the variance-preserving weight set (round 6): the first stage's boxes - the second stage's RoIs - sit on the frame's points
+    model, cfg, _ = synth_detector((0.1, 0.1, 0.15), seed=0, second_stage=True)
     model = model.to(dev)
     set_math(model, math)
     rows = []
@@ -48,6 +41,8 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1, pipe
         frames_t = [points_t[points_t[:, 0] == b][:, 1:].contiguous() for b in range(batch)]
         pipe.calibrate(frames_t[:4])
 
+    last = {}
+
     def run(timed):
         bd = {'batch_size': batch, 'points': points_t}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -62,6 +57,7 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1, pipe
                 bd = model.roi_head(bd)
             ev[2].record()
         torch.cuda.synchronize()
+        last['bd'] = bd
         return (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), int(bd['rois'].shape[0] * bd['rois'].shape[1])) if timed else None
     for _ in range(3):
         run(False)
@@ -104,8 +100,16 @@ def measure(dev, points=160000, reps=10, math='f32', phases=False, batch=1, pipe
         a, b, n_roi = run(True)
         t1 += a / reps
         t2 += b / reps
+    # what the second stage worked on: RoIs the first stage really proposed (rows past its count are zero boxes) and the share of them
+    # with at least one non-empty ball (an RoI on empty space costs the pooling kernels nothing: round-5 review, weak 4)
+    rois = last['bd']['rois'].reshape(-1, last['bd']['rois'].shape[-1])
+    valid = rois[:, 3:6].abs().amax(1) > 0
+    nonempty = ~model.roi_head.forward_ret_dict['key_padding_mask'].reshape(rois.shape[0], -1).all(1)
+    n_valid = int(valid.sum().item())
+    frac = float((nonempty & valid).sum().item()) / max(n_valid, 1)
     return {'metric': 'two-stage detector, ms per pass of %d frame(s) (%s, eager)' % (batch, 'FramePipeline.two_stage' if pipeline else 'plugin modules'), 'math': math, 'frames_per_pass': batch,
-            'points_per_frame': int(pts.shape[0] // batch), 'rois': n_roi, 'first_stage_ms': round(t1, 3),
+            'points_per_frame': int(pts.shape[0] // batch), 'rois': n_roi, 'rois_proposed': n_valid, 'rois_nonempty_frac': round(frac, 3),
+            'weights': 'synth_detector(second_stage=True, gain=preserve)', 'first_stage_ms': round(t1, 3),
             'second_stage_ms': round(t2, 3), 'rois_per_s': round(n_roi / (t2 * 1e-3), 1),
             'frames_per_s': round(1000.0 * batch / (t1 + t2), 2), 'data': 'synthetic'}
 
