@@ -241,11 +241,30 @@ def set_sparse_engine(model, engine):
 # development switch: DZ_TUNE_EAGER_PYRAMID=1 builds the whole index pyramid before the first convolution (the r01c-r03f schedule)
 STAGGERED_PYRAMID = not os.environ.get('DZ_TUNE_EAGER_PYRAMID')
 
-F16_PAIR_SAFE_MAX = 3.0e4      # |activation| up to which fp16 pairs are used (fp16 saturates at 65504; interior layers get 2x headroom)
-# ... and the stage PEAK below which they are not: the lo half of an fp16 pair is subnormal below |x| ~ 0.06 (absolute quantum 2^-24), so a
-# value x carries max(2^-22, 2^-25 / |x|) relative error - worse than a bf16 pair's 2^-16 once |x| < 2^-9.  A stage whose largest
-# activation is under 2^-6 has its bulk (peak / 10 and below) in that regime
-F16_PAIR_SAFE_MIN = 2.0 ** -6
+F16_PAIR_TARGET_PEAK = 2.0 ** 11    # where select_math places a stage's largest |activation|: 32x of headroom under fp16's 65504 for frames
+# that run hotter than the calibration samples, and 14 binades (down to 2^-3) in which the lo half of the pair is a NORMAL fp16, i.e.
+# the pair carries its full 22 bits; below that the absolute quantum 2^-25 applies (1.5e-11 of the peak)
+PRESCALE_STAGES = ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'encoded', 'spatial_features_2d')
+
+
+def set_prescale(model, exps):
+    """Install (or clear, exps=None) the per-stage power-of-two pre-scale of the fp16-pair tensors on the detector's three convolution
+    modules: exps = {stage: e} for PRESCALE_STAGES - a stage's tensors are stored as value * 2^e, the factors folded exactly into the
+    layers' folded-BN scale / shift (det_modules._Cached._p).  Has no effect in 'f32' and 'bf16x2' math (their exponent range is fp32's)."""
+    for name in ('backbone3d', 'backbone2d', 'dense_head'):
+        mod = getattr(model, name, None)
+        if mod is not None and hasattr(mod, 'set_prescale'):
+            mod.set_prescale(exps)
+    return model
+
+
+def prescale_exponents(peaks, target=F16_PAIR_TARGET_PEAK):
+    """{stage: floor(log2(target / peak))} from per-stage activation peaks; a stage without active rows (peak 0) gets 0."""
+    out = {}
+    for k in PRESCALE_STAGES:
+        v = float(peaks.get(k, 0.0))
+        out[k] = int(max(-100, min(100, math.floor(math.log2(target / v))))) if v > 0.0 and math.isfinite(v) else 0
+    return out
 
 
 @torch.no_grad()
@@ -264,23 +283,20 @@ def activation_range(model, dataset_info, frames, dynamic=False):
     return out
 
 
-def select_math(model, dataset_info, frames, prefer='f16x2', limit=F16_PAIR_SAFE_MAX, low_limit=F16_PAIR_SAFE_MIN, dynamic=False):
-    """Pick the split-precision mode for a checkpoint from a calibration pass: fp16 pairs (22-bit significands) while every
-    stage's largest activation stays inside [`low_limit`, `limit`], else bf16 pairs (16 bits, the full fp32 exponent range) -
-    fp16 pairs SATURATE at +-65504 + lo, so a network whose activations reach 1e5 must not run on them, and their lo half goes
-    subnormal for small values, so a network whose stages peak at 1e-3 is better served by bf16 pairs too.  Returns (mode,
-    per-stage maxima) and sets the mode."""
+def select_math(model, dataset_info, frames, prefer='f16x2', dynamic=False, target=F16_PAIR_TARGET_PEAK):
+    """Fit the split-precision arithmetic to a checkpoint from a calibration pass on the exact-fp32 engine: the per-stage activation
+    peaks give per-stage power-of-two exponents (`prescale_exponents`) that put every stage's tensors where fp16 pairs carry 22 bits,
+    whatever the checkpoint's own scale is - activations of 1e6 (fp16 saturates at 65504) as well as of 1e-4 (the lo half of an
+    unscaled pair would be subnormal).  The factors are exact (powers of two folded into scale / shift), so the result is that of
+    the same network at O(1000) activations.  Rounds 2-5 fell back to bf16 pairs (16 bits) outside [2^-6, 3e4]; round 6 measured
+    bf16 pairs at up to 5e-3 on data-dependent boxes - outside the north star's 1e-3 - so they are an opt-in mode only.
+    Returns (mode, per-stage maxima); sets the mode and the pre-scale (model.prescale = the exponents)."""
     rng = activation_range(model, dataset_info, frames, dynamic)
-    # a stage with no active site on the calibration frames (maximum exactly 0) says nothing about the range of its activations
-    live = {k: v for k, v in rng.items() if v > 0.0}
-    too_big = [k for k, v in live.items() if v > limit]
-    too_small = [k for k, v in live.items() if v < low_limit]
-    mode = prefer if not (too_big or too_small) else 'bf16x2'
-    if mode != prefer:
-        import warnings
-        warnings.warn('select_math: %s -> bf16x2 (stages above %g: %s; stages peaking below %g: %s)' % (prefer, limit, too_big, low_limit, too_small))
-    set_math(model, mode)
-    return mode, rng
+    exps = prescale_exponents(rng, target)
+    set_prescale(model, exps if ops.storage_math(ops.math_id(prefer)) == 1 else None)
+    model.prescale = exps
+    set_math(model, prefer)
+    return prefer, rng
 
 
 GROUPED_DEEP_BLOCKS = os.environ.get('DZ_TUNE_GROUPED_DEEP', '1') != '0'       # development switch: 0 = every dense layer per frame group (r04)

@@ -47,12 +47,16 @@ def fold_bn(bn, conv_bias=None):
     return scale.float().contiguous(), shift.float().contiguous()
 
 
+_FROM_ENTRY = object()
+
+
 class _Cached(nn.Module):
     """Modules that cache kernel-layout parameters; the cache is dropped when weights change."""
 
     def __init__(self):
         super().__init__()
         self._plan = None
+        self.act_exp = None
         self.math = 0       # ops.MATH_MODES: 0 = fp32 MFMA, 1 = fp16-pair split, 2 = bf16-pair split, 3 = fp16 pairs with one product (csrc/hgemm.h)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
@@ -62,6 +66,55 @@ class _Cached(nn.Module):
     def set_math(self, mode):
         self.math = ops.math_id(mode)
         return self
+
+    def set_prescale(self, exps):
+        """Per-stage power-of-two pre-scale of the activations kept as fp16 pairs: exps = {stage name: e} (centerpoint.select_prescale)
+        or None.  A tensor of stage g is stored as value * 2^e_g; the factor is folded, exactly, into the folded-BN scale / shift of
+        the layer that writes it (`_p`), so fp16 pairs keep their 22 bits whatever the checkpoint's activation range is."""
+        self.act_exp = {k: int(v) for k, v in exps.items()} if exps else None
+        return self
+
+    def _e(self, name):
+        """Exponent of stage `name` in the active math mode (0 unless the tensors are fp16 pairs and a pre-scale is set)."""
+        if getattr(self, 'act_exp', None) is None or ops.storage_math(self.math) != 1:
+            return 0
+        return int(self.act_exp.get(name, 0))
+
+    def _p(self, entry, e_in=0, e_out=0, key='w', scale=_FROM_ENTRY, shift=_FROM_ENTRY):
+        """(weights, scale, shift) of a plan entry as the kernels of the active math mode take them.  fp32: the plan's own tensors.
+        Split modes: weights packed as pairs (cached); for fp16 pairs with the per-output-channel pre-scale of ops.weight_prescale, and
+        scale' = scale * 2^(e_out - e_in) / 2^e_c, shift' = shift * 2^e_out for an input stored at 2^e_in and an output at 2^e_out -
+        all exact (powers of two).  scale=None in the plan (a layer without BatchNorm) becomes the vector of those factors."""
+        scale = entry.get('scale') if scale is _FROM_ENTRY else scale
+        shift = entry.get('shift') if shift is _FROM_ENTRY else shift
+        if not self.math:
+            return entry[key], scale, shift
+        sm = ops.storage_math(self.math)
+        if sm != 1:
+            return self._w(entry, key), scale, shift
+        cache = entry.setdefault('_pre', {})
+        ck = (key, int(e_in), int(e_out), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr())
+        if ck not in cache:
+            wk = (key, 'w')
+            if wk not in cache:
+                ws, inv = ops.weight_prescale(entry[key])
+                cache[wk] = (ops.pack_weight_split(ws, sm), inv)
+            wp, inv = cache[wk]
+            k = inv * (2.0 ** (int(e_out) - int(e_in)))
+            ref = scale if scale is not None else shift
+            if ref is not None and k.numel() != ref.numel():
+                # per-group channel padding of the vectors (the head's output layer: 6 groups x 16 columns padded to 32)
+                g = k.shape[0] if k.dim() > 1 else 1
+                kk = k.reshape(g, -1)
+                pad = ref.numel() // g - kk.shape[1]
+                if pad < 0:
+                    raise DetZeroHipError('_p: %d weight columns per group but %d scale / shift entries' % (kk.shape[1], ref.numel() // g))
+                k = torch.cat([kk, kk.new_ones(g, pad)], dim=1)
+            k = k.reshape(-1).contiguous()
+            sc = (scale * k if scale is not None else k).contiguous()
+            sh = None if shift is None else ((shift * (2.0 ** int(e_out))).contiguous() if e_out else shift)
+            cache[ck] = (wp, sc, sh)
+        return cache[ck]
 
     def _w(self, entry, key='w'):
         """Weights of a plan entry in the layout of the active math mode (split layouts packed once, cached)."""
@@ -92,12 +145,13 @@ class SparseConvTensor:
         self._level = level
         self._padded = padded      # (capacity-sized feature matrix, SparseLevel) for the fast path
         self._math = math          # encoding of the padded matrix (0 = fp32, else pair16); .features is always fp32
+        # (the padded rows may carry the level's power-of-two pre-scale, SparseLevel.act_exp: removed on decoding)
 
     @property
     def features(self):
         if self._features is None:
             rows = self._padded[0][:self.indices.shape[0]]
-            self._features = ops.pair16_to_f32(rows, self._math) if self._math else rows
+            self._features = ops.level_rows_f32(rows, self._padded[1], self._math)
         return self._features
 
     @features.setter
@@ -109,7 +163,7 @@ class SparseConvTensor:
         the gathered rows are converted (the PDV head reads ~60 k of a level's ~1.7 M rows per 8 frames; round 4 decoded the level)."""
         if self._features is not None or self._padded is None or not self._math:
             return self.features[rows]
-        return ops.pair16_to_f32(self._padded[0][rows].contiguous(), self._math)
+        return ops.level_rows_f32(self._padded[0][rows].contiguous(), self._padded[1], self._math)
 
     def replace_feature(self, new_features):
         return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._level)
@@ -327,10 +381,11 @@ class VoxelResBackBone8x(_Cached):
         return p
 
     # ---- execution ------------------------------------------------------------------------------
-    def _res_block(self, x, nbr, level, params):
+    def _res_block(self, x, nbr, level, params, e=0):
+        """(all tensors of a level - block inputs, hidden activations, the residual - share the level's exponent e)"""
         c1, c2 = params
-        y = ops.spconv_forward(x, nbr, level, self._w(c1), c1['scale'], c1['shift'], None, True, math=self.math)
-        return ops.spconv_forward(y, nbr, level, self._w(c2), c2['scale'], c2['shift'], x, True, math=self.math)
+        y = ops.spconv_forward(x, nbr, level, *self._p(c1, e, e), None, True, math=self.math)
+        return ops.spconv_forward(y, nbr, level, *self._p(c2, e, e), x, True, math=self.math)
 
     def build_pyramid(self, voxel_features, voxel_coords, batch_size, d_n=None, overlap=True, side_key=0, caps=None, level1=None,
                       staggered=False, exact=False):
@@ -469,9 +524,11 @@ class VoxelResBackBone8x(_Cached):
         _, nbr, lvl1, ev = steps[0]
         ready(ev)
         ci = p['conv_input']
-        x = ops.spconv_forward(x, nbr, lvl1, self._w(ci), ci['scale'], ci['shift'], None, True, math=mm)
+        e = self._e('x_conv1')                                # (the voxel features themselves are stored unscaled)
+        x = ops.spconv_forward(x, nbr, lvl1, *self._p(ci, 0, e), None, True, math=mm)
         for bp in p['conv1']:
-            x = self._res_block(x, nbr, lvl1, bp)
+            x = self._res_block(x, nbr, lvl1, bp, e)
+        lvl1.act_exp = e
         out = {'x_conv1': (x, lvl1)}
         level = lvl1
         for i, name in enumerate(('conv2', 'conv3', 'conv4')):
@@ -480,15 +537,19 @@ class VoxelResBackBone8x(_Cached):
             dp = p[name]['down']
             nbr_d, nbr, nxt, ev = steps[i + 1]
             ready(ev)
-            x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
+            e_prev, e = e, self._e('x_conv%d' % (i + 2))
+            x = ops.spconv_forward(x, nbr_d, nxt, *self._p(dp, e_prev, e), None, True, in_level=level, math=mm)
             for bp in p[name]['blocks']:
-                x = self._res_block(x, nbr, nxt, bp)
+                x = self._res_block(x, nbr, nxt, bp, e)
+            nxt.act_exp = e
             out['x_conv%d' % (i + 2)] = (x, nxt)
             level = nxt
         dp = p['conv_out']
         nbr_d, _, nxt, ev = steps[4]
         ready(ev)
-        x = ops.spconv_forward(x, nbr_d, nxt, self._w(dp), dp['scale'], dp['shift'], None, True, in_level=level, math=mm)
+        e_prev, e = e, self._e('encoded')
+        x = ops.spconv_forward(x, nbr_d, nxt, *self._p(dp, e_prev, e), None, True, in_level=level, math=mm)
+        nxt.act_exp = e
         out['encoded'] = (x, nxt)
         return out
 
@@ -540,9 +601,13 @@ class HeightCompression(nn.Module):
         math = t._math if t._padded is not None else 0
         c = feats.shape[1]
         bev = ops.sparse_to_bev(feats, level, c, pad=1, math=math)      # (B, H+2, W+2, C*D)
+        e = int(getattr(level, 'act_exp', 0) or 0) if t._padded is not None else 0
         batch_dict['_nhwc_spatial_features'] = bev
         batch_dict['_nhwc_math'] = math                                 # encoding of the private channel-last images
+        batch_dict['_nhwc_exp'] = e                                     # ... and their power-of-two pre-scale (values * 2^e)
         plain = ops.pair16_to_f32(bev, math) if math else bev
+        if e:
+            plain = plain * (2.0 ** -e)
         batch_dict['spatial_features'] = plain[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)   # NCHW view
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict
@@ -603,11 +668,14 @@ def nchw_to_padded_nhwc(x, pad=1):
     return out
 
 
-def _recode(img, enc, math):
-    """Channel-last image from encoding `enc` (0 = fp32, else pair16 of that mode) to the encoding of `math`."""
-    if ops.storage_math(enc) == ops.storage_math(math):
+def _recode(img, enc, math, e_src=0, e_dst=0):
+    """Channel-last image from encoding `enc` (0 = fp32, else pair16 of that mode) at pre-scale 2^e_src to the encoding of `math` at
+    2^e_dst."""
+    if ops.storage_math(enc) == ops.storage_math(math) and e_src == e_dst:
         return img
     plain = ops.pair16_to_f32(img, enc) if enc else img
+    if e_src != e_dst:
+        plain = plain * (2.0 ** (e_dst - e_src))
     return ops.pair16_from_f32(plain, math=math) if math else plain
 
 
@@ -718,7 +786,8 @@ class BaseBEVBackbone(_Cached):
         """Outputs of the first block's layers on an ALL-ZERO input, one (1, H + 2, W + 2, C) pair16 image per layer - what every pixel far
         enough from any data computes (dz_bev_tile_list).  Computed once per (shape, math, frames per launch) with the detector's own
         kernels on nb0 all-zero frames: which kernel runs a layer depends on the launch's tile count, and the images must carry ITS bits."""
-        key = ('zero_resp', h, w, int(self.math), str(dev), int(nb0))
+        e_in, e_mid = self._e('encoded'), self._e('spatial_features_2d')
+        key = ('zero_resp', h, w, int(self.math), str(dev), int(nb0), e_in, e_mid)
         if key not in lvl:
             ridx = torch.full((nb0, h + 2, w + 2, 2), -1, dtype=torch.int32, device=dev)
             rows = torch.zeros((8, rows_c), dtype=torch.float32, device=dev)
@@ -730,11 +799,11 @@ class BaseBEVBackbone(_Cached):
                         raise DetZeroHipError('BaseBEVBackbone: zero-response tiles need a stride-1 first block')
                     y = torch.zeros((nb0, xh + 2, xw + 2, cv['cout']), dtype=torch.float32, device=dev)
                     if ci == 0:
-                        conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (xh + 2, xw + 2), cin=cv['cin'],
+                        conv_layer(rows, (xh + 2, xw + 2), *self._p(cv, e_in, e_mid, key='w_zmajor'), True, y, (xh + 2, xw + 2), cin=cv['cin'],
                                    in_cstride=xc, ksize=3, stride=1, in_off=0, out_cstride=cv['cout'], out_d=(1, 1), ho=xh, wo=xw, batch=nb0,
                                    math=self.math, in_rowidx=ridx, in_row_channels=rows_c, in_rows=rows.shape[0])
                     else:
-                        conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (xh + 2, xw + 2), cin=cv['cin'], in_cstride=xc,
+                        conv_layer(x, (xh + 2, xw + 2), *self._p(cv, e_mid, e_mid), True, y, (xh + 2, xw + 2), cin=cv['cin'], in_cstride=xc,
                                    ksize=3, stride=1, in_off=0, out_cstride=cv['cout'], out_d=(1, 1), ho=xh, wo=xw, batch=nb0, math=self.math)
                     outs.append(y[:1].clone())
                     x, xc = y, cv['cout']
@@ -753,12 +822,13 @@ class BaseBEVBackbone(_Cached):
         convs = lvl['convs']
         bufs = None
         tiles = zero = None
+        e_in, e_mid = self._e('encoded'), self._e('spatial_features_2d')     # exponents of the BEV input and of every tensor of this module
         if sparse_in is not None and li == 0 and SKIP_EMPTY_TILES:
             # pixel tiles far enough from any data compute the network's zero-input response: they are left out of the launches of the
             # block's layers (16-24 % of the tiles of a 160k-point frame at the first layer, 9-15 % at the sixth: the corners of the BEV
             # square beyond the sensor's range) and receive a copy of that response
             nl = min(len(convs), 6) if all(cv['stride'] == 1 for cv in convs) else 1
-            key = ('zero_resp', xh, xw, int(self.math), str(dev), int(batch))
+            key = ('zero_resp', xh, xw, int(self.math), str(dev), int(batch), e_in, e_mid)
             if nl > 1 and key not in lvl and torch.cuda.is_current_stream_capturing():
                 nl = 1        # (the response images are computed by an eager pass: a capture without one before it skips at the first layer only)
                 if not getattr(self, '_warned_capture_nl1', False):
@@ -777,19 +847,21 @@ class BaseBEVBackbone(_Cached):
             if sparse_in is not None and li == 0 and ci == 0:
                 # (weights with the input channels in z-major order: the rows of slab 0, then of slab 1)
                 rows, ridx = sparse_in
-                conv_layer(rows, (xh + 2, xw + 2), self._w(cv, 'w_zmajor'), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                wz, scz, shz = self._p(cv, e_in, e_mid, key='w_zmajor')
+                conv_layer(rows, (xh + 2, xw + 2), wz, scz, shz, True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
                            out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_rowidx=ridx, in_row_channels=rows.shape[1],
                            in_rows=rows.shape[0], in_tiles=tiles[0] if tiles is not None else None)
                 if tiles is not None:
-                    ops.bev_fill_empty_tiles(tiles[0], batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math)      # (ReLU(shift))
+                    ops.bev_fill_empty_tiles(tiles[0], batch, oh, ow, shz, True, cv['cout'], y, self.math)      # (ReLU(shift))
             else:
                 tl = tiles[ci] if (tiles is not None and ci < tiles.shape[0]) else None
-                conv_layer(x, (xh + 2, xw + 2), self._w(cv), cv['scale'], cv['shift'], True, y, (oh + 2, ow + 2),
+                wc, scc, shc = self._p(cv, e_in if (li == 0 and ci == 0) else e_mid, e_mid)
+                conv_layer(x, (xh + 2, xw + 2), wc, scc, shc, True, y, (oh + 2, ow + 2),
                            cin=cv['cin'], in_cstride=xc, ksize=3, stride=s, in_off=0, out_cstride=cv['cout'],
                            out_d=(1, 1), ho=oh, wo=ow, batch=batch, math=self.math, in_tiles=tl)
                 if tl is not None:
-                    ops.bev_fill_empty_tiles(tl, batch, oh, ow, cv['shift'], True, cv['cout'], y, self.math, zero_resp=zero[ci])
+                    ops.bev_fill_empty_tiles(tl, batch, oh, ow, shc, True, cv['cout'], y, self.math, zero_resp=zero[ci])
             x, xh, xw, xc = y, oh, ow, cv['cout']
         return x, xh, xw, xc
 
@@ -798,19 +870,20 @@ class BaseBEVBackbone(_Cached):
         de = lvl['de']
         s = de['s']
         ctot = self.num_bev_features
+        e_mid = self._e('spatial_features_2d')
         if xh * s != h or xw * s != w:
             raise DetZeroHipError('BaseBEVBackbone: deblock output %dx%d does not match %dx%d' % (xh * s, xw * s, h, w))
         if self.math and 1 < s * s <= 8 and FUSED_DEBLOCK_PHASES:
             # the s x s phases of the ConvTranspose2d as the groups of ONE launch (dz_conv2d_desc.phase_groups): the phases of a
             # pixel tile run next to each other on one XCD, the level's image is read from HBM once instead of s x s times
-            conv_layer(x, (xh + 2, xw + 2), self._w(de, 'w_phases'), de['scale'], de['shift'], True, concat,
+            conv_layer(x, (xh + 2, xw + 2), *self._p(de, e_mid, e_mid, key='w_phases'), True, concat,
                        (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
                        out_cstride=ctot, out_coff=coff, out_s=s, out_d=(1, 1), ho=xh, wo=xw, batch=batch, math=self.math,
                        groups=s * s, g_cout=[de['cout']] * (s * s), g_ooff=[0] * (s * s), phase_groups=True)
             return coff + de['cout']
         for dy in range(s):
             for dx in range(s):
-                conv_layer(x, (xh + 2, xw + 2), self._w(de['phases'][dy][dx]), de['scale'], de['shift'], True, concat,
+                conv_layer(x, (xh + 2, xw + 2), *self._p(de['phases'][dy][dx], e_mid, e_mid, scale=de['scale'], shift=de['shift']), True, concat,
                            (h + 2, w + 2), cin=de['cin'], in_cstride=xc, ksize=1, stride=1, in_off=1,
                            out_cstride=ctot, out_coff=coff, out_s=s, out_d=(dy + 1, dx + 1), ho=xh, wo=xw,
                            batch=batch, math=self.math)
@@ -893,13 +966,19 @@ class BaseBEVBackbone(_Cached):
         with torch.no_grad():
             bev = data_dict.get('_nhwc_spatial_features', None)
             enc = data_dict.get('_nhwc_math', 0)
+            e_src = int(data_dict.get('_nhwc_exp', 0) or 0)
             if bev is None:
                 bev, enc = nchw_to_padded_nhwc(data_dict['spatial_features'].float()), 0
-            bev = _recode(bev, enc, self.math)
+                e_src = 0
+            bev = _recode(bev, enc, self.math, e_src, self._e('encoded'))
             concat = self.run(bev, bev.shape[0])
+        e_out = self._e('spatial_features_2d')
         data_dict['_nhwc_spatial_features_2d'] = concat
         data_dict['_nhwc_math'] = self.math
+        data_dict['_nhwc_exp'] = e_out
         plain = ops.pair16_to_f32(concat, self.math) if self.math else concat
+        if e_out:
+            plain = plain * (2.0 ** -e_out)
         data_dict['spatial_features_2d'] = plain[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
         return data_dict
 
@@ -1025,7 +1104,8 @@ class CenterHead(_Cached):
         hp, wp = concat.shape[1], concat.shape[2]
         c = p['c']
         shared = bordered_zeros('head.shared', (batch, hp, wp, c), concat.device)
-        conv_layer(concat, (hp, wp), self._w(p['shared']), p['shared']['scale'], p['shared']['shift'], True, shared, (hp, wp),
+        e = self._e('spatial_features_2d')                    # (the head's hidden maps share the exponent of its input)
+        conv_layer(concat, (hp, wp), *self._p(p['shared'], e, e), True, shared, (hp, wp),
                    cin=p['shared']['cin'], in_cstride=concat.shape[3], out_cstride=c, out_d=(1, 1), ho=hp - 2, wo=wp - 2, batch=batch,
                    math=self.math)
         return shared
@@ -1041,10 +1121,12 @@ class CenterHead(_Cached):
         c = p['c']
         mm = self.math
         hidden = bordered_zeros('head.hidden', (batch, hp, wp, 6 * c), dev)
-        conv_layer(shared, (hp, wp), self._w(hp_['hidden']), hp_['hidden']['scale'], hp_['hidden']['shift'], True, hidden, (hp, wp),
+        e = self._e('spatial_features_2d')
+        conv_layer(shared, (hp, wp), *self._p(hp_['hidden'], e, e), True, hidden, (hp, wp),
                    cin=c, in_cstride=c, out_cstride=6 * c, out_d=(1, 1), ho=h, wo=w, batch=batch, math=mm)
         head = torch.empty((batch, h * w, 12), dtype=torch.float32, device=dev)
-        conv_layer(hidden, (hp, wp), self._w(hp_['final']), None, hp_['final']['shift32' if mm else 'shift'], False, head, (h, w),
+        # (output layer: no BatchNorm - the plan holds no scale; fp32 output at exponent 0)
+        conv_layer(hidden, (hp, wp), *self._p(hp_['final'], e, 0, scale=None, shift=hp_['final']['shift32' if mm else 'shift']), False, head, (h, w),
                    cin=c, in_cstride=6 * c, out_cstride=12, out_d=(0, 0), groups=6, cout_pad=32 if mm else 16,
                    g_cout=hp_['final']['g_cout'], g_ooff=hp_['final']['g_ooff'], ho=h, wo=w, batch=batch, math=mm, out_f32=True)
         return head, h, w
@@ -1101,9 +1183,11 @@ class CenterHead(_Cached):
         with torch.no_grad():
             concat = data_dict.get('_nhwc_spatial_features_2d', None)
             enc = data_dict.get('_nhwc_math', 0)
+            e_src = int(data_dict.get('_nhwc_exp', 0) or 0)
             if concat is None:
                 concat, enc = nchw_to_padded_nhwc(data_dict['spatial_features_2d'].float()), 0
-            concat = _recode(concat, enc, self.math)
+                e_src = 0
+            concat = _recode(concat, enc, self.math, e_src, self._e('spatial_features_2d'))
             shared = self.run_shared(concat, concat.shape[0])
             heads, preds = [], []
             for index, names in enumerate(self.class_names_each_head):

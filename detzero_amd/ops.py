@@ -185,6 +185,8 @@ class SparseLevel:
         # True for levels written by dz_voxelize_to_level: prefix[] is valid only at words that hold a bit, so only ACTIVE cells may
         # be ranked (csrc/common.h: bitmap_rank contract); build_from_coords / downsample write the full prefix
         self.prefix_partial = False
+        # power-of-two pre-scale of the feature rows stored on this level (det_modules._Cached.set_prescale): rows hold value * 2^act_exp
+        self.act_exp = 0
 
     def num_active(self):
         """Host copy of the active-site count (one sync; cached)."""
@@ -551,6 +553,33 @@ def pack_weight_split(w, math, cout_mult=32):
     if cp > co:
         wt = torch.cat([wt, wt.new_zeros(*wt.shape[:-2], cp - co, wt.shape[-1])], dim=-2)
     return pair16_pack(wt.contiguous(), math)
+
+
+F16_PAIR_WEIGHT_TOP = 2.0 ** 14      # where the largest |weight| of an output channel is placed before the fp16-pair split
+
+
+def weight_prescale(w):
+    """Exact per-output-channel power-of-two scaling of conv / linear weights (..., cin, cout) for fp16-pair storage.
+    An fp16 pair carries 22 significant bits only while its lo half is a NORMAL fp16 (|value| >= 2^-3); checkpoint weights are
+    O(1e-2) and would keep ~18.  Every output channel is multiplied by 2^e_c so that its largest |weight| lands in [2^13, 2^15)
+    (fp16 tops out at 65504; the products are accumulated in fp32, where a power of two changes nothing), and 2^-e_c goes into the
+    layer's per-channel epilogue scale.  Returns (scaled weights, inverse factors (..., cout))."""
+    red = (-3, -2) if w.dim() >= 3 else (-2,)
+    amax = w.detach().abs().float().amax(dim=red)
+    e = torch.floor(torch.log2(F16_PAIR_WEIGHT_TOP / amax.clamp_min(1e-30))).clamp_(-40.0, 40.0)
+    e = torch.where(amax > 0, e, torch.zeros_like(e)).to(torch.int32)
+    one = torch.ones_like(amax)
+    up, down = torch.ldexp(one, e), torch.ldexp(one, -e)
+    for _ in red:
+        up = up.unsqueeze(-2)
+    return w.float() * up, down
+
+
+def level_rows_f32(rows, level, math=0):
+    """Feature rows of a level as plain fp32 values: pair16 decoded, the level's power-of-two pre-scale (SparseLevel.act_exp) removed."""
+    plain = pair16_to_f32(rows, math) if math else rows
+    e = int(getattr(level, 'act_exp', 0) or 0)
+    return plain * (2.0 ** -e) if e else plain
 
 
 def pair16_from_f32(x, c_dst=None, math=1):

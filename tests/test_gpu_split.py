@@ -418,11 +418,28 @@ def test_full_size_batch_split_equals_f32_pipeline(device):
 
 
 # ------------------------------------------------------------------------------------------------ range safety of the fp16 pairs
-def _scaled_model(device, gain):
+def _scaled_model(device, gain, homogeneous=False):
     """Seed-0 detector whose first BatchNorm gain is multiplied by `gain`: every later layer is positively homogeneous up to
-    its shifts, so all activations scale by ~gain (real checkpoints are not normalised to O(1) like the random-init ones)."""
+    its shifts, so all activations scale by ~gain (real checkpoints are not normalised to O(1) like the synthetic ones).
+    homogeneous: every BatchNorm shift and hidden conv bias zeroed (the network is then EXACTLY homogeneous: all hidden activations are
+    gain x those of the gain-1 network) and the output layers' weights divided by gain - the boxes stay those of the gain-1 network,
+    so a detection can be compared at any activation scale."""
     model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
     with torch.no_grad():
+        if homogeneous:
+            for mod in model.modules():
+                if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    mod.bias.zero_()
+                    mod.running_mean.zero_()
+            for name, mod in model.named_modules():
+                if getattr(mod, 'bias', None) is not None and not isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    out_layer = name.startswith('dense_head.heads_list') and name.split('.')[-1] == '1'
+                    if not out_layer:
+                        mod.bias.zero_()
+            for hl in model.dense_head.heads_list:
+                for head in ('center', 'center_z', 'dim', 'rot', 'iou', 'hm'):
+                    getattr(hl, head)[1].weight.div_(gain)
+                hl.hm[1].bias.fill_(-4.0)            # (no shifts: the far field of the dense stage is zero, the bias alone is the floor)
         model.backbone3d.conv_input[1].weight.mul_(gain)
         model.backbone3d.conv_input[1].bias.mul_(gain)
     return model.to(device), info
@@ -437,59 +454,82 @@ def _stage_features(model, info, pts, math):
     out = {}
     for name, (feats, lvl) in res.items():
         m = lvl.num_active()
-        out[name] = (ops.pair16_to_f32(feats[:m], mid) if mid else feats[:m]).clone()
+        out[name] = ops.level_rows_f32(feats[:m], lvl, mid).clone()        # (pair16 decoded, the level's power-of-two pre-scale removed)
     return out
 
 
-@pytest.mark.parametrize('gain,expect', [(300.0, 'f16x2'), (3.0e4, 'bf16x2')])
-def test_math_mode_selection_by_activation_range(device, gain, expect):
-    """Activations of 1e3..1e4 stay on fp16 pairs and keep ~1e-6 relative accuracy; activations beyond the fp16 range make
-    select_math fall over to bf16 pairs, which still track the fp32 engine to 2e-3 relative - while fp16 pairs there are
-    demonstrably wrong (saturated), which is exactly what the selection prevents."""
-    from detzero_amd.centerpoint import activation_range, select_math
+def _boxes(model, info, pts, math):
+    from detzero_amd.centerpoint import FramePipeline
+    o, n = FramePipeline(model, info, math=math)(pts)
+    return o[:int(n.item())].cpu().numpy()
+
+
+@pytest.mark.parametrize('gain', [1.0, 3.0e4, 1.0e6, 2.0 ** -10, 2.0 ** -20], ids=['1', '3e4', '1e6', '2^-10', '2^-20'])
+def test_select_math_keeps_fp16_pairs_at_any_activation_scale(device, gain):
+    """Round-5 review, item 2a: instead of falling back to bf16 pairs (16 bits) when a checkpoint's activations leave [2^-6, 3e4],
+    select_math installs an exact per-stage power-of-two pre-scale.  On a detector whose hidden activations are `gain` x those of the
+    gain-1 detector (and whose boxes are the same): f16x2 is retained, every sparse stage stays within 2e-5 of its peak of the exact-fp32
+    engine, and the final boxes within the north star's 1e-3 - at activations of 1e8 (fp16 tops out at 65504) as at 1e-6."""
+    from detzero_amd.centerpoint import F16_PAIR_TARGET_PEAK, select_math, set_math
+    model, info = _scaled_model(device, gain, homogeneous=True)
+    pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
+    mode, rng = select_math(model, info, [pts])
+    assert mode == 'f16x2', (mode, rng)
+    for k, e in model.prescale.items():
+        assert F16_PAIR_TARGET_PEAK / 2 < rng[k] * 2.0 ** e <= F16_PAIR_TARGET_PEAK, (k, rng[k], e)
+    ref = _stage_features(model, info, pts, 'f32')
+    got = _stage_features(model, info, pts, 'f16x2')
+    worst = 0.0
+    for name in ref:
+        scale = float(ref[name].abs().max())
+        err = float((got[name] - ref[name]).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-5, (name, err, scale)
+    a, b = _boxes(model, info, pts, 'f32'), _boxes(model, info, pts, 'f16x2')
+    nm, wbox = match_boxes(a[:, :7], a[:, 7], b[:, :7], b[:, 7], tol=1e-3)
+    print('gain %.3g: peaks %s -> exponents %s; stages within %.2e of their peak; %d / %d boxes of the f32 engine matched within 1e-3 (worst %.2e)'
+          % (gain, {k: float('%.3g' % v) for k, v in rng.items()}, model.prescale, worst, nm, a.shape[0], wbox))
+    assert a.shape[0] > 50 and abs(a.shape[0] - b.shape[0]) <= 2 and nm >= a.shape[0] - 2, (a.shape, b.shape, nm, wbox)
+    set_math(model, 'f32')
+
+
+@pytest.mark.parametrize('gain', [3.0e4, 2.0 ** -20], ids=['3e4', '2^-20'])
+def test_unscaled_fp16_pairs_fail_where_the_prescale_holds(device, gain):
+    """What the pre-scale prevents: the same detectors on fp16 pairs WITHOUT it - saturated at gain 3e4 (stage errors of the order of the
+    activations themselves), and at gain 2^-20 far less accurate than with it (the lo halves are subnormal: an absolute quantum of 2^-24
+    against activations of 1e-5)."""
+    from detzero_amd.centerpoint import select_math, set_math, set_prescale
+    model, info = _scaled_model(device, gain, homogeneous=True)
+    pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
+    select_math(model, info, [pts])
+    ref = _stage_features(model, info, pts, 'f32')
+    good = _stage_features(model, info, pts, 'f16x2')
+    set_prescale(model, None)
+    bad = _stage_features(model, info, pts, 'f16x2')
+    rel = lambda t: max(float((t[n] - ref[n]).abs().max()) / float(ref[n].abs().max()) for n in ref)      # noqa: E731
+    print('gain %.3g: worst stage error relative to its peak: %.2e with the pre-scale, %.2e without' % (gain, rel(good), rel(bad)))
+    assert rel(good) < 2e-5 and rel(bad) > 50.0 * rel(good)
+    if gain > 1:
+        assert rel(bad) > 1e-2
+    set_math(model, 'f32')
+
+
+@pytest.mark.parametrize('gain', [300.0, 3.0e4])
+def test_prescale_on_a_network_with_shifts(device, gain):
+    """The gain on the first BatchNorm only, every shift in place (not homogeneous: the later stages grow by less than `gain`, each
+    stage gets its own exponent): stage features of f16x2 + pre-scale within 2e-5 of each stage's peak of the fp32 engine."""
+    from detzero_amd.centerpoint import select_math, set_math
     model, info = _scaled_model(device, gain)
     pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
     mode, rng = select_math(model, info, [pts])
-    assert mode == expect, (mode, rng)
-    peak = max(rng.values())
-    assert (1e3 < peak < 3e4) if expect == 'f16x2' else peak > 65504, rng
+    assert mode == 'f16x2' and max(rng.values()) > 1e3
     ref = _stage_features(model, info, pts, 'f32')
     got = _stage_features(model, info, pts, mode)
     for name in ref:
         scale = float(ref[name].abs().max())
         err = float((got[name] - ref[name]).abs().max()) / scale
-        assert err < (2e-5 if mode == 'f16x2' else 2e-3), (name, err, scale)
-    if expect == 'bf16x2':
-        bad = _stage_features(model, info, pts, 'f16x2')
-        worst = max(float((bad[n] - ref[n]).abs().max()) / float(ref[n].abs().max()) for n in ref)
-        assert worst > 1e-2, worst
-
-
-def test_math_mode_selection_guards_small_activations(device):
-    """A detector whose activations are scaled DOWN until its stages peak far below 2^-6: the lo halves of fp16 pairs are
-    subnormal there (absolute quantum 2^-24, i.e. fewer than 22 significant bits), so select_math must fall over to bf16 pairs -
-    which keep their 16 bits at any magnitude and track the fp32 engine to 2e-3 relative."""
-    from detzero_amd.centerpoint import F16_PAIR_SAFE_MIN, select_math
-    model, info = _scaled_model(device, 1.0e-5)
-    with torch.no_grad():           # (no shifts: the later layers then scale with the first one - a uniformly small network)
-        for mod in model.backbone3d.modules():
-            if isinstance(mod, torch.nn.BatchNorm1d):
-                mod.bias.zero_()
-                mod.running_mean.zero_()
-    pts = torch.from_numpy(masked_frame(0, 20000)).to(device)
-    mode, rng = select_math(model, info, [pts])
-    assert min(rng.values()) < F16_PAIR_SAFE_MIN and mode == 'bf16x2', (mode, rng)
-    ref = _stage_features(model, info, pts, 'f32')
-    got = _stage_features(model, info, pts, 'bf16x2')
-    pairs = _stage_features(model, info, pts, 'f16x2')
-    for name in ref:
-        scale = float(ref[name].abs().max())
-        if scale == 0.0:
-            continue
-        err = float((got[name] - ref[name]).abs().max()) / scale
-        err16 = float((pairs[name] - ref[name]).abs().max()) / scale
-        print('%s: peak %.3g  bf16x2 %.2e  f16x2 %.2e (relative to the peak)' % (name, scale, err, err16))
-        assert err < 2e-3, (name, err, scale)
+        assert err < 2e-5, (name, err, scale)
+    set_math(model, 'f32')
 
 
 @pytest.mark.parametrize('name,mid', MODES)
