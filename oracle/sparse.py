@@ -93,7 +93,7 @@ def weight_to_taps(w):
 def sparse_conv(feats, rulebook, w_taps, m_out, bias=None):
     """out[o] = bias + sum_t feats[i] @ W[t] over rulebook triples; fp32 torch CPU; taps ascending."""
     i, o, t = rulebook
-    out = torch.zeros((m_out, w_taps.shape[2]), dtype=torch.float32)
+    out = torch.zeros((m_out, w_taps.shape[2]), dtype=feats.dtype)
     for tap in range(w_taps.shape[0]):
         sel = np.nonzero(t == tap)[0]
         if sel.size == 0:
@@ -117,14 +117,16 @@ class Level:
         self.shape = list(shape)
 
 
-def backbone_forward(sd, voxel_features, voxel_coords, sparse_shape, prefix='backbone3d.', last_pad=0):
+def backbone_forward(sd, voxel_features, voxel_coords, sparse_shape, prefix='backbone3d.', last_pad=0, dtype=torch.float32):
     """VoxelResBackBone8x.forward (backbone3d.py:289-338) with BN in eval mode (eps 1e-3, :239).
     voxel_coords (M,4) int32 [b,z,y,x] in ANY order; internally re-ordered canonically.
-    Returns dict with per-stage (features, coords, shape) and rulebooks for parity checks."""
+    Returns dict with per-stage (features, coords, shape) and rulebooks for parity checks.
+    dtype: torch.float32 = the reference's arithmetic; torch.float64 (with a float64 state dict) = the error-budget yardstick of
+    tests/test_gpu_full_parity.py - the same fp32 weights and voxel features evaluated without rounding noise."""
     eps = 1e-3
     order = canonical_order(voxel_coords, sparse_shape)
     coords = voxel_coords[order]
-    x = torch.from_numpy(np.ascontiguousarray(voxel_features[order])).float()
+    x = torch.from_numpy(np.ascontiguousarray(voxel_features[order])).to(dtype)
     out = {'rulebooks': {}}
     K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
 
@@ -173,7 +175,7 @@ def to_bev(feats, coords, shape, batch_size):
     """HeightCompression (height_compression.py:20-24): dense (B,C,D,H,W) -> (B, C*D, H, W)."""
     d, h, w = shape
     c = feats.shape[1]
-    dense = torch.zeros((batch_size, c, d, h, w), dtype=torch.float32)
+    dense = torch.zeros((batch_size, c, d, h, w), dtype=feats.dtype)
     cc = torch.from_numpy(coords.astype(np.int64))
     dense[cc[:, 0], :, cc[:, 1], cc[:, 2], cc[:, 3]] = feats
     return dense.reshape(batch_size, c * d, h, w)

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from detzero_amd.synth import VOXEL_SIZE_01, merge_two_sweeps, synth_waymo_frame
-from tests.util import canon_order, canon_tensor, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect
+from tests.util import canon_order, canon_tensor, cpu_state_dict, make_model, masked_frame, match_boxes, oracle_detect, oracle_features_f64
 
 pytestmark = pytest.mark.gpu
 MATHS = ['f32', 'f16x2', 'bf16x2']
@@ -156,6 +156,57 @@ def test_modules_stage_by_stage_160k(full, device, math):
     b9 = torch.cat([got['pred_boxes'], got['pred_scores'][:, None], got['pred_labels'][:, None].float()], 1)
     _check_boxes(ref['final'], b9, b9.shape[0], 'modules/' + math, BOX_TOL[math])
     set_math(model, 'f32')
+
+
+def _module_stages(model, cfg, info, frame, device, math):
+    """Stage tensors of the plugin modules on one frame in `math`, rows in canonical order, as float64 CPU tensors."""
+    from detzero_amd.centerpoint import set_math
+    from tests.test_gpu_e2e import _batch_dict
+    set_math(model, math)
+    bd = _batch_dict(model, cfg, info, frame, device)
+    bd = model.backbone3d(model.vfe(bd))
+    out = {}
+    for name in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'):
+        out[name] = canon_tensor(bd['multi_scale_3d_features'][name])[1].double()
+    out['encoded'] = canon_tensor(bd['encoded_spconv_tensor'])[1].double()
+    bd = model.backbone2d(model.map_to_bev(bd))
+    out['spatial_features_2d'] = bd['spatial_features_2d'].cpu().double()
+    bd = model.dense_head(bd)
+    for k, v in model.dense_head.forward_ret_dict['pred_dicts'][0].items():
+        out['head/' + k] = v.cpu().double()
+    set_math(model, 'f32')
+    return out
+
+
+def test_error_budget_against_float64(full, device):
+    """Round-5 review, item 2b: what licenses the 22-bit arithmetic as the headline.  The yardstick is the network evaluated in
+    FLOAT64 (same fp32 weights, same voxel features: tests/util.oracle_features_f64); against it every fp32-class evaluation has its own
+    rounding noise - the CPU oracle (torch fp32), the exact-fp32 HIP engine, and fp16 pairs.  Per stage, on data-dependent O(1)
+    activations at the headline size: the fp16-pair engine's error must not exceed TWICE the fp32 engine's; bf16 pairs are listed next
+    to them (an opt-in mode: 10-30x).  The table is printed (profiles/r06*_gputests.txt)."""
+    model, cfg, info, frames, refs = full
+    r64 = oracle_features_f64(cpu_state_dict(model), frames[0], info)
+    yard = {k: r64['backbone'][k][0] for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'encoded')}
+    yard['spatial_features_2d'] = r64['f2d']
+    for k, v in r64['pred'].items():
+        yard['head/' + k] = v
+    ora = {k: refs[0]['backbone'][k][0].double() for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'encoded')}
+    ora['spatial_features_2d'] = refs[0]['f2d'].double()
+    for k, v in refs[0]['pred'].items():
+        ora['head/' + k] = v.double()
+    got = {m: _module_stages(model, cfg, info, frames[0], device, m) for m in MATHS}
+    err = lambda t, k: float((t[k] - yard[k]).abs().max()) / float(yard[k].std())      # noqa: E731
+    print('\n  max |error| against float64, in units of the stage standard deviation')
+    print('  %-22s %12s %12s %12s %12s %10s' % ('stage', 'CPU oracle', 'f32 engine', 'f16x2', 'bf16x2', 'f16x2/f32'))
+    worst = 0.0
+    for k in yard:
+        e = {m: err(got[m], k) for m in MATHS}
+        ratio = e['f16x2'] / max(e['f32'], 1e-12)
+        worst = max(worst, ratio)
+        print('  %-22s %12.2e %12.2e %12.2e %12.2e %10.2f' % (k, err(ora, k), e['f32'], e['f16x2'], e['bf16x2'], ratio))
+        assert e['f16x2'] <= 2.0 * e['f32'], (k, e)
+        assert e['f32'] < 2e-4 and e['bf16x2'] < 1e-2, (k, e)
+    print('  worst f16x2 / f32-engine ratio %.2f' % worst)
 
 
 @pytest.mark.experimental

@@ -63,6 +63,28 @@ def oracle_detect(sd, points, info, post=POST, dynamic=False, times=None):
             'f2d': f2d, 'pred': pred, 'final': final}
 
 
+def oracle_features_f64(sd, points, info, dynamic=False):
+    """The feature path of `oracle_detect` (backbone -> BEV -> 2-D backbone -> head maps) in FLOAT64 on the same fp32 weights and the
+    same fp32 voxel features: the yardstick of the error-budget test (an fp32 evaluation's own rounding noise is what the HIP
+    engines are allowed; against float64 it can be measured for each of them separately)."""
+    from oracle import dense, sparse as osp, voxelize as ov
+    if dynamic:
+        pb = np.concatenate([np.zeros((points.shape[0], 1), np.float32), points], 1)
+        feats, coords = ov.dynamic_mean_vfe(pb, info.point_cloud_range, info.voxel_size)
+    else:
+        vox, czyx, nump = ov.hard_voxelize(points, info.point_cloud_range, info.voxel_size, 5, info.max_voxels['test'])
+        feats = ov.mean_vfe(vox, nump)
+        coords = np.concatenate([np.zeros((czyx.shape[0], 1), np.int32), czyx], 1)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    grid = info.grid_size
+    res = osp.backbone_forward(sd64, feats, coords, [int(grid[2]) + 1, int(grid[1]), int(grid[0])], dtype=torch.float64)
+    x, oc, shape = res['encoded']
+    bev = osp.to_bev(x, oc, shape, 1)
+    f2d = dense.bev_backbone_forward(sd64, bev)
+    pred = dense.center_head_forward(sd64, f2d)
+    return {'backbone': res, 'bev': bev, 'f2d': f2d, 'pred': pred}
+
+
 def match_boxes(a_boxes, a_scores, b_boxes, b_scores, tol=1e-3):
     """Greedy one-to-one match by centre distance; returns (n_matched, max_abs_diff over matched)."""
     a_boxes, b_boxes = np.asarray(a_boxes), np.asarray(b_boxes)
