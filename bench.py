@@ -126,7 +126,7 @@ def parse():
     ap.add_argument('--profile-frames', type=int, default=3, help='eager passes timed per launch for the roofline')
     ap.add_argument('--no-aux', action='store_true', help='skip the auxiliary legs (fp32, ref_batch, ragged, f16, multisweep, with_h2d, stages)')
     ap.add_argument('--aux-seconds', type=float, default=2.5, help='timed GPU seconds per auxiliary leg')
-    ap.add_argument('--fp32-batch', type=int, default=8, help='frames per step of the exact-fp32 leg')
+    ap.add_argument('--fp32-batch', type=int, default=0, help='frames per step of the exact-fp32 leg (0 = the headline batch)')
     ap.add_argument('--tiles-leg', action='store_true', help='also time the opt-in tile-resident engine of round 3 (slower)')
     ap.add_argument('--sparse-engine', default='xrun', choices=['gather', 'xrun', 'tiles'], help='sparse-backbone engine of the headline run')
     ap.add_argument('--sweeps', type=int, default=1, choices=[1, 2],
@@ -636,7 +636,7 @@ def main():
                    'math': math, 'dtype': dtype_names[math], 'launch': c.graph_note, 'mean_points_per_frame': round(c.mean_points), 'note': note}
             log('%s %.1f frames/s' % (name, fps))
             return c, rec
-        c, rec = leg('fp32', 'f32', args.fp32_batch, note='every convolution on v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation')
+        c, rec = leg('fp32', 'f32', args.fp32_batch or B, note='every convolution on v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation; same frames per pass as the headline unless --fp32-batch')
         if args.profile_frames > 0:
             kern, roof, _ = c.kernel_profile(args.profile_frames)
             rec['roofline'] = roof
@@ -645,6 +645,16 @@ def main():
         # the precision-equivalent figure next to `value` (whose arithmetic carries 22 significant bits): promoted to top-level keys
         out['value_fp32'] = rec['value']
         out['roofline_fp32'] = rec.get('roofline')
+        # ... and INSIDE `roofline`, the object the driver's record keeps: the reference-precision figure (exact fp32 on the fp32 matrix
+        # cores, the reference's own arithmetic) at the same frames per pass, with the roofline fraction of ITS dominant kernel
+        if isinstance(out.get('roofline'), dict):
+            r32 = rec.get('roofline') or {}
+            out['roofline'].update({'fp32_frames_per_s': rec['value'], 'fp32_frames_per_step': rec['frames_per_step'], 'fp32_ms_per_step': rec['ms_per_step'],
+                                    'fp32_frac': r32.get('frac'), 'fp32_kernel': r32.get('kernel'), 'fp32_achieved': r32.get('achieved'),
+                                    'fp32_peak': r32.get('peak'), 'fp32_unit': r32.get('unit'),
+                                    'precision_note': 'value is measured in fp16 pairs (22-bit significand; per stage within 1.6x of the exact-fp32 engine\'s own '
+                                                      'rounding error against float64, tests/test_gpu_full_parity.py::test_error_budget_against_float64); '
+                                                      'fp32_frames_per_s is the same workload in exact fp32'})
         del c
         c, out['ref_batch'] = leg('ref_batch', args.math, REF_BATCH, note='BATCH_SIZE_PER_GPU of centerpoint_1sweep.yaml:88')
         del c
@@ -660,7 +670,7 @@ def main():
         out['ragged'] = {'padded': padded, 'list': lst}
         if args.math == 'f16x2':
             c, rec = leg('f16', 'f16', B, note='opt-in fast mode on the same tensors: ONE fp16 MFMA per product (hi halves only) - plain-fp16 inputs, '
-                                             'fp32 accumulation; not fp32-class (boxes within 2.5e-3 of the oracle on this workload, '
+                                             'fp32 accumulation; not fp32-class (boxes within 3e-2 of the oracle on this workload, '
                                              'tests/test_gpu_f16.py) and never the headline value')
             if args.profile_frames > 0:
                 kern, roof, _ = c.kernel_profile(args.profile_frames)

@@ -681,6 +681,7 @@ def _recode(img, enc, math, e_src=0, e_dst=0):
 
 SKIP_EMPTY_TILES = os.environ.get('DZ_TUNE_SKIP_EMPTY_TILES', '1') != '0'  # development switch: 0 = the sparse-input convolution runs every pixel tile
 SPARSE_BEV_INPUT = os.environ.get('DZ_TUNE_SPARSE_BEV', '1') != '0'     # development switch: 0 = dense BEV image (r01-r04)
+FIRST_BLOCK_WIDE_GROUPS = os.environ.get('DZ_TUNE_FIRST_BLOCK_WIDE', '1') != '0'     # development switch: 0 = the first BEV block in the concatenation's frame groups (r05)
 FUSED_DEBLOCK_PHASES = os.environ.get('DZ_TUNE_DEBLOCK_PHASES', '1') != '0'     # development switch: 0 = one launch per phase (r01-r04)
 
 
@@ -944,8 +945,12 @@ class BaseBEVBackbone(_Cached):
         if len(l0['convs']) < 2:
             raise DetZeroHipError('BaseBEVBackbone.run_grouped: the first block needs at least two convolutions')
         x0_all = bordered_zeros('bev2d.x0_all', (nb, h0 + 2, w0 + 2, c0), dev)
-        for g0 in range(0, nb, group):
-            ng = min(group, nb - g0)
+        # the first block's own images are a quarter of the concatenation's channels: it runs in groups as large as ITS widest image
+        # allows (all 32 frames of the default pass: 6 launches instead of 12, half the launch ramps and tails)
+        widest = max([cin0] + [cv['cout'] for cv in l0['convs']])
+        group1 = max(group, min(nb, (2 ** 31 - 1) // ((h + 2) * (w + 2) * widest * 4))) if FIRST_BLOCK_WIDE_GROUPS else group
+        for g0 in range(0, nb, group1):
+            ng = min(group1, nb - g0)
             sp = (rows, ridx[g0:g0 + ng]) if sparse_in is not None else None
             self._level_convs(0, l0, None if sp is not None else bev[g0:g0 + ng], h, w, cin0, ng, dev, sparse_in=sp, out_last=x0_all[g0:g0 + ng])
         outs = [(x0_all, h0, w0, c0)]

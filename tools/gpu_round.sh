@@ -4,10 +4,10 @@
 # command, HBM-side PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes - never together with a trace domain) and the SQ matrix-pipe
 # counters of the same command, the per-layer sparse benchmark of both engines, the x-run kernel's in-kernel cycle accounting
 # (diag build), the refiner and two-stage (PDV) benches with their traces.
-# usage: tools/gpu_round.sh <tag> [sections]     tag = r05a ...; sections = any of: tests bench trace pmc sq layers xdiag refine pdv
+# usage: tools/gpu_round.sh <tag> [sections]     tag = r05a ...; sections = any of: tests bench trace pmc sq clk layers xdiag refine pdv
 #        (default: all).  Outputs -> gpurun_out/<round>/<tag>_*  (copy what is to be judged into profiles/).
 TAG=${1:-r05a}
-SECT=${2:-tests bench trace pmc sq layers xdiag refine pdv}
+SECT=${2:-tests bench trace pmc sq clk layers xdiag refine pdv}
 cd "$(dirname "$0")/.."
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
@@ -57,6 +57,16 @@ if has sq; then
   echo "==== rocprofv3 pmc SQ (matrix pipe)"
   rm -rf $O/pmc_sq; ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/pmc_sq -o bench -- python $ROOT/bench.py $PARGS > $O/pmc_sq_stdout.txt 2>&1 )
   python tools/rocpd_summary.py $O/pmc_sq/bench_results.db | sed -n '/PMC/,$p' > $O/${TAG}_pmc_SQ_bench_eager3.txt; grep -E "MFMA_BUSY" $O/${TAG}_pmc_SQ_bench_eager3.txt | head -10
+fi
+if has clk; then
+  # idle CUs or clock (round-5 review, item 4): GRBM_GUI_ACTIVE next to SQ_BUSY_CU_CYCLES in ONE pass of the same eager command, and an
+  # amd-smi / rocm-smi clock sample taken while the un-profiled bench runs
+  echo "==== rocprofv3 pmc GRBM_GUI_ACTIVE + SQ_BUSY_CU_CYCLES (effective clock, busy CUs)"
+  rm -rf $O/pmc_clk; ( cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $O/pmc_clk -o bench -- python $ROOT/bench.py $PARGS > $O/pmc_clk_stdout.txt 2>&1 )
+  python tools/clock_table.py $O/pmc_clk/bench_results.db > $O/${TAG}_clock_table.txt 2>&1; head -16 $O/${TAG}_clock_table.txt
+  ( timeout 60 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --profile-frames 0 --no-aux --no-refine --no-pdv > /dev/null 2>&1 & 
+    sleep 25; for i in 1 2 3 4 5; do (rocm-smi --showclocks 2>/dev/null | grep -i -E "sclk|mclk|fclk" | head -3; rocm-smi --showpower 2>/dev/null | grep -i -E "power" | head -2) ; sleep 1; done; wait ) > $O/${TAG}_smi_clock_sample.txt 2>&1
+  tail -12 $O/${TAG}_smi_clock_sample.txt
 fi
 if has layers; then
   echo "==== per-layer sparse benchmark, both engines"
