@@ -256,12 +256,13 @@ class Case:
         torch.cuda.synchronize()
         if use_graph:
             try:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self.g_out, self.g_n = self.pipe(self.static_in)
+                # (FramePipeline.capture: one graph; a batch run as concurrent sub-passes = parallel branches of it)
+                self.graph = self.pipe.capture(self.static_in)
+                self.g_out, self.g_n = self.graph.boxes, self.graph.counts
                 self.graph.replay()
                 torch.cuda.synchronize()
-                self.graph_note = 'hipGraph replay'
+                self.graph_note = 'hipGraph replay' + (' (%d parallel branches: concurrent sub-passes of %d frames)' % (self.graph.branches, B // self.graph.branches)
+                                                       if self.graph.branches > 1 else '')
             except Exception as e:  # capture is an optimisation, not a requirement
                 self.graph = None
                 self.graph_note = 'eager launches (graph capture failed: %s)' % str(e).split('\n')[0][:120]
@@ -307,7 +308,8 @@ class Case:
         from detzero_amd import ops
         prof = ops.LaunchProfiler()
         ops.PROFILER = prof
-        try:
+        ways, self.pipe.ways = self.pipe.ways, 1       # one pass of B frames: every launch timed ALONE (the timed region runs the batch as
+        try:                                           # `ways` concurrent sub-passes, whose launches share the chip)
             for i in range(passes):
                 self.load_inputs(i)
                 self.pipe(self.static_in)
@@ -323,6 +325,7 @@ class Case:
                                                                                            flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9))
         finally:
             ops.PROFILER = None
+            self.pipe.ways = ways
         kern = []
         for name, a in agg.items():
             per = a['ms'] / a['launches']
@@ -539,6 +542,7 @@ def main():
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'latency_ms_per_pass': round(1000.0 * dt / K, 4),
                        'like_for_like': 'leg ref_batch (8 frames per pass = BATCH_SIZE_PER_GPU of the reference config, centerpoint_1sweep.yaml:88) is the '
                                         'like-for-like batch; leg batch16 is the headline configuration of rounds 1-3; value is at frames_per_step_per_gpu', 'parallelism': 'frame-parallel x%d' % world,
+                       'concurrent_sub_passes': case.pipe.ways if B >= 2 * case.pipe.ways else 1,
                        'launch': graph_note, 'math': case.math, 'math_selected': case.math_selected, 'activation_peaks': case.activation_peaks,
                        'sparse_engine': args.sparse_engine,
                        'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',

@@ -321,10 +321,19 @@ class FramePipeline:
     [0,count) are ``[x,y,z,dx,dy,dz,heading,score,label(1-based)]`` after NMS.
     """
 
-    def __init__(self, model, dataset_info, mode='test', dynamic=False, math=None):
+    def __init__(self, model, dataset_info, mode='test', dynamic=False, math=None, ways=None):
         self.model = model.eval()
         if math is not None:
             set_math(model, math)
+        # ways: a batch is split into this many sub-passes that run CONCURRENTLY on their own streams (`_call_split`): every launch of
+        # the persistent kernels leaves CUs idle while it ramps up and while its last tiles finish (busy CUs 0.84-0.96,
+        # profiles/r06a_clock_table.txt) - an independent second pass fills them: +2.6 % frames/s at 32 frames per batch, +5 % at 16,
+        # +1.6 % at 8; three or four ways, or two ways of 32 frames, give nothing (profiles/r06_ab_notes.txt).  None = DZ_TUNE_WAYS or 2
+        self.ways = int(os.environ.get('DZ_TUNE_WAYS', '2')) if ways is None else int(ways)
+        self._subs = None
+        self._way_streams = None
+        self.side_key = 0
+        self.fork_ok = True           # False while this pipeline is a branch of somebody's graph capture: no forks of its own
         self.info = dataset_info
         self.mode = mode
         self.dynamic = dynamic
@@ -367,8 +376,9 @@ class FramePipeline:
         feats = torch.empty((nb * cap, c), dtype=torch.float32, device=dev)
         coords = torch.full((nb * cap, 4), -1, dtype=torch.int32, device=dev)
         d_ns = torch.zeros((nb,), dtype=torch.int32, device=dev)
-        streams = [main]
-        if nb > 1:
+        streams = [main] * nb
+        fork = nb > 1 and self.fork_ok
+        if fork:
             streams = self._streams.setdefault(cid, [])
             if len(streams) < nb:
                 streams += [torch.cuda.Stream(device=dev) for _ in range(nb - len(streams))]
@@ -381,7 +391,7 @@ class FramePipeline:
                 ops.voxelize_hard_mean_into(p, rng, info.voxel_size, info.max_points_per_voxel, info.max_voxels[self.mode], i,
                                             feats[i * cap:(i + 1) * cap], coords[i * cap:(i + 1) * cap], d_ns[i:i + 1],
                                             xy_range_mask=True)
-        if nb > 1:
+        if fork:
             for st in streams[:nb]:                # join
                 main.wait_stream(st)
         return feats, coords, None
@@ -410,10 +420,11 @@ class FramePipeline:
         stage before it (VoxelResBackBone8x.build_pyramid)."""
         caps = None if self.level_caps is None else [c * nb for c in self.level_caps]
         bb = self.model.backbone3d
+        # (side_key: the index pyramid's side stream - a concurrent sub-pass (`_call_split`) has its own)
         if vox[0] == 'level':
-            pyr = bb.build_pyramid(vox[2], None, nb, None, overlap=overlap, caps=caps, level1=vox[1], staggered=staggered)
+            pyr = bb.build_pyramid(vox[2], None, nb, None, overlap=overlap, side_key=self.side_key, caps=caps, level1=vox[1], staggered=staggered)
         else:
-            pyr = bb.build_pyramid(vox[1], vox[2], nb, vox[3], overlap=overlap, caps=caps, staggered=staggered)
+            pyr = bb.build_pyramid(vox[1], vox[2], nb, vox[3], overlap=overlap, side_key=self.side_key, caps=caps, staggered=staggered)
         pyr['nb'] = nb
         return pyr
 
@@ -439,16 +450,30 @@ class FramePipeline:
         self.level_caps = [int(margin * b) + 4096 for b in best]
         if self._overflow_acc is None and frames:
             self._overflow_acc = torch.zeros((), dtype=torch.int32, device=frames[0].device)
+        if self.ways > 1 and frames:                 # (the sub-passes' counters too: nothing is allocated inside a capture)
+            for sub in self._make_subs(frames[0].device):
+                if sub._overflow_acc is None:
+                    sub._overflow_acc = torch.zeros((), dtype=torch.int32, device=frames[0].device)
         return self.level_caps
+
+    def _make_subs(self, dev):
+        if self._subs is None:
+            self._subs = [FramePipeline(self.model, self.info, self.mode, self.dynamic, ways=1) for _ in range(self.ways)]
+            for k, sub in enumerate(self._subs):
+                sub.side_key = 1 + k
+            self._way_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ways)]
+        return self._subs
 
     def overflow_seen(self, clear=True):
         """Host-side read (one sync) of the STICKY overflow counter: True when any pass since the last read (eager or replayed from
         a graph - the OR into the counter is a kernel of the pass) lost sparse sites to a calibrated capacity."""
-        if self._overflow_acc is None:
+        accs = [a for a in [self._overflow_acc] + [sub._overflow_acc for sub in (self._subs or [])] if a is not None]
+        if not accs:
             return False
-        seen = bool(self._overflow_acc.item())
+        seen = bool(torch.stack([a.reshape(()) for a in accs]).sum().item())
         if clear:
-            self._overflow_acc.zero_()
+            for a in accs:
+                a.zero_()
         return seen
 
     def check_overflow(self):
@@ -580,8 +605,71 @@ class FramePipeline:
             frames = _StackedFrames(points.contiguous())
         else:
             frames = points if isinstance(points, _StackedFrames) else list(points)
+        if self.ways > 1 and len(frames) >= 2 * self.ways:
+            return self._call_split(frames)
         out, d_nk = self.infer(self.prepare(frames, staggered=STAGGERED_PYRAMID))
         return (out[0], d_nk) if single else (out, d_nk)
+
+    def _split_parts(self, frames):
+        nb, w = len(frames), self.ways
+        bounds = [(k * nb) // w for k in range(w + 1)]
+        return [(_StackedFrames(frames.tensor[a:b]) if isinstance(frames, _StackedFrames) else list(frames[a:b]), a, b)
+                for a, b in zip(bounds[:-1], bounds[1:])]
+
+    def _call_split(self, frames):
+        """The batch as `ways` concurrent sub-passes: frames [k * nb / ways, (k + 1) * nb / ways) through their own FramePipeline (own
+        activation images, same model / capacities, own overflow counter) on their own stream, forked from and joined to the caller's
+        stream.  Frames are independent, so the results are those of the single pass bit for bit (tests/test_gpu_e2e.py).
+        Inside a graph capture the sub-passes are parallel branches of the graph and must not fork again (hipStreamEndCapture of
+        ROCm 7.2 crashes on a fork nested inside a forked branch, tools/dbg_nested_capture.py): they then build their index pyramids and voxelize
+        ragged frames on their own stream."""
+        dev = frames[0].device
+        self._make_subs(dev)
+        main = torch.cuda.current_stream(dev)
+        nested_ok = not torch.cuda.is_current_stream_capturing()
+        outs = []
+        for (part, _, _), sub, st in zip(self._split_parts(frames), self._subs, self._way_streams):
+            sub.level_caps, sub.dense_group = self.level_caps, self.dense_group       # (every sub-pass keeps its OWN sticky overflow counter:
+            sub.fork_ok = nested_ok                                                    # two streams OR-ing into one word would race)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(sub.infer(sub.prepare(part, overlap=nested_ok, staggered=nested_ok and STAGGERED_PYRAMID)))
+        for st in self._way_streams:
+            main.wait_stream(st)
+        for o, n in outs:
+            o.record_stream(main)
+            n.record_stream(main)
+        flags = [sub.last_overflow for sub in self._subs if sub.last_overflow is not None]
+        self.last_overflow = None if not flags else (flags[0] if len(flags) == 1 else torch.stack([f.reshape(()) for f in flags]).any())
+        return torch.cat([o for o, _ in outs], dim=0), torch.cat([n for _, n in outs], dim=0)
+
+    def capture(self, static_points):
+        """hipGraph(s) of this pipeline over a STATIC input -> CapturedPass (replay(); results in .boxes (B, K, 9) / .counts (B,)).  Run
+        calibrate() and one eager pass before (allocations, kernel-layout weights, zero-response images)."""
+        return CapturedPass(self, static_points)
+
+
+class CapturedPass:
+    """FramePipeline over a static input as ONE captured graph; with ways > 1 the concurrent sub-passes are parallel branches of it
+    (each on its own stream, without forks of its own: see `_call_split`).  Measured on one box against ways = 1 (profiles/
+    r06_ab_notes.txt): +1.0 % frames/s at 32 frames per pass, +3.0 % at 16, +-0 at 8.  One graph PER sub-pass, replayed side by side
+    (which keeps the sub-passes' inner forks) was built first and is slower than no split at all in bench.py: -2.7 % / -4.5 % / -13 %."""
+
+    def __init__(self, pipe, static_points):
+        self.pipe = pipe
+        nb = static_points.shape[0] if torch.is_tensor(static_points) else len(static_points)
+        dev = static_points.device if torch.is_tensor(static_points) else static_points[0].device
+        self.boxes = torch.zeros((nb, pipe.post_max, 9), dtype=torch.float32, device=dev)
+        self.counts = torch.zeros((nb,), dtype=torch.int32, device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            o, n = pipe(static_points)
+            self.boxes.copy_(o.view(self.boxes.shape))
+            self.counts.copy_(n.view(-1))
+        self.branches = pipe.ways if (pipe.ways > 1 and nb >= 2 * pipe.ways) else 1
+
+    def replay(self):
+        self.graph.replay()
 
 
 class StreamingDetector:

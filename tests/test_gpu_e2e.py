@@ -333,6 +333,55 @@ def test_stacked_equal_length_batch_equals_single_frames(device, math):
     set_math(model, 'f32')
 
 
+@pytest.mark.parametrize('route', ['stacked', 'list'])
+def test_concurrent_sub_passes_equal_the_single_pass(device, route):
+    """FramePipeline(ways=2) runs a batch as two concurrent sub-passes on their own streams (round 6: an independent pass fills the
+    CUs every persistent launch leaves idle while it ramps up and tails off): frames are independent, so boxes and counts equal the
+    single pass (ways=1) BIT FOR BIT - eagerly, replayed from a captured graph (parallel branches), with an odd number of frames, and
+    the overflow flag of either sub-pass reaches check_overflow()."""
+    from detzero_amd.centerpoint import FramePipeline, set_math
+    from detzero_amd.lib import DetZeroHipError
+    from detzero_amd.synth import synth_waymo_frame
+    model, cfg, info = make_model(VOXEL_SIZE_02, seed=0)
+    model = model.to(device)
+    lens = [20000] * 5 if route == 'stacked' else [20000, 18000, 19000, 17000, 20000]
+    frames = [torch.from_numpy(synth_waymo_frame(80 + i, n)).to(device) for i, n in enumerate(lens)]
+    inp = torch.stack(frames) if route == 'stacked' else frames
+    one = FramePipeline(model, info, math='f16x2', ways=1)
+    two = FramePipeline(model, info, math='f16x2', ways=2)
+    o1, n1 = one(inp)
+    o2, n2 = two(inp)
+    assert two._subs is not None and len(two._subs) == 2 and int(n1.sum().item()) > 100
+    assert torch.equal(n1, n2) and torch.equal(o1, o2)
+    small = inp[:3] if route == 'stacked' else frames[:3]           # fewer than 2 x ways frames: not split
+    assert torch.equal(two(small)[0], one(small)[0])
+    # captured: the sub-passes are parallel branches of ONE graph
+    two.calibrate(frames[:2])
+    static = inp.clone() if route == 'stacked' else [f.clone() for f in frames]
+    for _ in range(2):
+        two(static)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        go, gn = two(static)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gn, n1) and torch.equal(go, o1)
+    # capture(): the same as a CapturedPass with static result tensors
+    cp = two.capture(static)
+    assert cp.branches == 2
+    cp.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cp.counts, n1) and torch.equal(cp.boxes, o1)
+    assert not two.overflow_seen()
+    # capacities far too small: the flag of a sub-pass is seen by the parent
+    two.level_caps = [64, 64, 64, 64]
+    two(inp)
+    with pytest.raises(DetZeroHipError):
+        two.check_overflow()
+    set_math(model, 'f32')
+
+
 @pytest.mark.parametrize('math', ['f32', 'f16x2'])
 def test_frame_without_points_in_range(small, device, math):
     """A frame whose points all fall outside the range (an empty frame after the reference's range mask) next to a normal one:
