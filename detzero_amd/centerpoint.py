@@ -627,11 +627,22 @@ class FramePipeline:
         self._make_subs(dev)
         main = torch.cuda.current_stream(dev)
         nested_ok = not torch.cuda.is_current_stream_capturing()
+        parts = self._split_parts(frames)
+        # first pass of a cache generation (new weights / math mode / pre-scale / sub-pass shapes): the modules build their kernel-layout
+        # weights, packed pairs and zero-response images lazily ON THE STREAM THAT ASKS FIRST - the sub-passes then run one after the
+        # other, so that whatever the first one builds is complete before the second one reads it from another stream
+        sig = (cp_modules.CACHE_GEN[0], tuple((len(p), tuple(p[0].shape)) for p, _, _ in parts), str(dev))
+        serial = sig != getattr(self, '_split_sig', None)
+        self._split_sig = sig
         outs = []
-        for (part, _, _), sub, st in zip(self._split_parts(frames), self._subs, self._way_streams):
+        prev = None
+        for (part, _, _), sub, st in zip(parts, self._subs, self._way_streams):
             sub.level_caps, sub.dense_group = self.level_caps, self.dense_group       # (every sub-pass keeps its OWN sticky overflow counter:
             sub.fork_ok = nested_ok                                                    # two streams OR-ing into one word would race)
             st.wait_stream(main)
+            if serial and prev is not None:
+                st.wait_stream(prev)
+            prev = st
             with torch.cuda.stream(st):
                 outs.append(sub.infer(sub.prepare(part, overlap=nested_ok, staggered=nested_ok and STAGGERED_PYRAMID)))
         for st in self._way_streams:

@@ -48,6 +48,10 @@ def fold_bn(bn, conv_bias=None):
 
 
 _FROM_ENTRY = object()
+# bumped whenever a module's lazily built device-side caches (kernel-layout weights, packed pairs, zero-response images) may be rebuilt by
+# the next pass: concurrent sub-passes (centerpoint.FramePipeline._call_split) run ONE AFTER THE OTHER on the first pass of a generation,
+# so that a cache one of them builds on its stream is complete before the other reads it on another stream
+CACHE_GEN = [0]
 
 
 class _Cached(nn.Module):
@@ -62,8 +66,11 @@ class _Cached(nn.Module):
 
     def invalidate(self):
         self._plan = None
+        CACHE_GEN[0] += 1
 
     def set_math(self, mode):
+        if ops.math_id(mode) != self.math:
+            CACHE_GEN[0] += 1
         self.math = ops.math_id(mode)
         return self
 
@@ -72,6 +79,7 @@ class _Cached(nn.Module):
         or None.  A tensor of stage g is stored as value * 2^e_g; the factor is folded, exactly, into the folded-BN scale / shift of
         the layer that writes it (`_p`), so fp16 pairs keep their 22 bits whatever the checkpoint's activation range is."""
         self.act_exp = {k: int(v) for k, v in exps.items()} if exps else None
+        CACHE_GEN[0] += 1
         return self
 
     def _e(self, name):
@@ -127,6 +135,7 @@ class _Cached(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         self._plan = None
+        CACHE_GEN[0] += 1
         return super()._apply(fn, *a, **kw)
 
 

@@ -353,6 +353,13 @@ def test_concurrent_sub_passes_equal_the_single_pass(device, route):
     o2, n2 = two(inp)
     assert two._subs is not None and len(two._subs) == 2 and int(n1.sum().item()) > 100
     assert torch.equal(n1, n2) and torch.equal(o1, o2)
+    # the FIRST pass of a fresh model is a split one with equally sized sub-passes: both need the same lazily built caches (packed
+    # weights, zero-response images) - the first split pass of a cache generation runs its sub-passes one after the other
+    model_b = make_model(VOXEL_SIZE_02, seed=0)[0].to(device)
+    four = inp[:4] if route == 'stacked' else frames[:4]
+    of, nf = FramePipeline(model_b, info, math='f16x2', ways=2)(four)
+    og, ng = one(four)
+    assert torch.equal(nf, ng) and torch.equal(of, og)
     small = inp[:3] if route == 'stacked' else frames[:3]           # fewer than 2 x ways frames: not split
     assert torch.equal(two(small)[0], one(small)[0])
     # captured: the sub-passes are parallel branches of ONE graph
