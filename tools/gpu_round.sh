@@ -24,6 +24,10 @@ trace() {   # name, command...
 }
 if has tests; then
   echo "==== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider 2>&1 | tail -4 | tee $O/${TAG}_gputests.txt
+  # the achieved errors the parity tests print (per stage and math mode, boxes, the float64 error budget, the pre-scale runs, the two-stage pins)
+  timeout 900 python -m pytest tests/test_gpu_full_parity.py tests/test_gpu_split.py tests/test_gpu_f16.py tests/test_pdv.py tests/test_gpu_sequence_chain.py -m gpu -q -s --timeout=600 -p no:cacheprovider 2>&1 |
+    grep -E "parity |boxes |max \|error\||^  stage|^  x_conv|^  encoded|^  spatial|^  head/|worst f16x2|^gain|gain [0-9.e+-]+:|two-stage at|two_stage vs|full-size|f16 \(single|f16x2 on the same|sequence anchor|passed|failed" | cut -c1-400 > $O/${TAG}_gputests_parity.txt
+  tail -3 $O/${TAG}_gputests_parity.txt
   echo "==== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $O/${TAG}_smoke.txt
 fi
 if has bench; then
