@@ -464,6 +464,97 @@ def test_frame_pipeline_two_stage_equals_the_plugin_path(device, mode, sparse_be
 
 
 @pytest.mark.gpu
+def test_prescale_through_the_plugin_path_and_the_second_stage(device):
+    """select_math installs per-stage power-of-two pre-scales on the fp16-pair tensors.  Everything that leaves the engine
+    must come out unscaled: the fp32 views of the plugin surface (`spatial_features`, `spatial_features_2d`, `multi_scale_3d_features[*]
+    .features`), the feature rows the PDV head gathers, the boxes.  A detector whose activations are 2^12 x the synthetic set's (so the
+    exponents are far from 0), with and without the pre-scale machinery in the way (an unscaled f16x2 run of the gain-1 twin), through the
+    plugin modules and through FramePipeline.two_stage."""
+    from detzero_amd.centerpoint import FramePipeline, select_math, set_math, set_prescale, synth_detector
+    from detzero_amd.synth import merge_two_sweeps, synth_waymo_frame
+    gain = 2.0 ** 12
+
+    def build(g):
+        model, cfg, info = synth_detector((0.2, 0.2, 0.15), seed=0, second_stage=True)
+        with torch.no_grad():
+            # homogeneous twin (tests/test_gpu_split.py::_scaled_model): shifts zeroed, first BatchNorm x g, output layers / g - the
+            # hidden activations are g x the gain-1 network's, the first stage's boxes are the same
+            for name, mod in model.named_modules():
+                if name.startswith('roi_head'):
+                    continue
+                if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    mod.bias.zero_(); mod.running_mean.zero_()
+                elif getattr(mod, 'bias', None) is not None and not (name.startswith('dense_head.heads_list') and name.split('.')[-1] == '1'):
+                    mod.bias.zero_()
+            for hl in model.dense_head.heads_list:
+                for head in ('center', 'center_z', 'dim', 'rot', 'iou', 'hm'):
+                    getattr(hl, head)[1].weight.div_(g)
+                hl.hm[1].bias.fill_(-4.0)
+            model.backbone3d.conv_input[1].weight.mul_(g)
+        return model.to(device), cfg, info
+    frames = [merge_two_sweeps(synth_waymo_frame(60 + i, 40000), synth_waymo_frame(70 + i, 40000)) for i in range(2)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), i, np.float32), f], 1) for i, f in enumerate(frames)])
+    dev_frames = [torch.from_numpy(f).to(device) for f in frames]
+
+    def plugin(model):
+        bd = {'batch_size': 2, 'points': torch.from_numpy(pts).to(device)}
+        with torch.no_grad():
+            for mod in model.module_list:
+                bd = mod(bd)
+        return bd
+    base, cfg, info = build(1.0)
+    set_math(base, 'f16x2')
+    ref = plugin(base)
+    ref_x3 = ref['multi_scale_3d_features']['x_conv3'].features.clone()
+    big, _, _ = build(gain)
+    mode, peaks = select_math(big, info, dev_frames[:1], dynamic=True)
+    assert mode == 'f16x2' and min(big.prescale.values()) <= -6, big.prescale          # (peaks ~ 2^12 x O(100): exponents around -8)
+    got = plugin(big)
+    # hidden stages: gain x the reference's, after unscaling
+    x3 = got['multi_scale_3d_features']['x_conv3'].features
+    assert x3.shape == ref_x3.shape
+    torch.testing.assert_close(x3 / gain, ref_x3, rtol=2e-4, atol=2e-4 * float(ref_x3.abs().max()))
+    torch.testing.assert_close(got['spatial_features'] / gain, ref['spatial_features'], rtol=2e-4, atol=2e-4 * float(ref['spatial_features'].abs().max()))
+    torch.testing.assert_close(got['spatial_features_2d'] / gain, ref['spatial_features_2d'], rtol=5e-4, atol=5e-4 * float(ref['spatial_features_2d'].abs().max()))
+    # first-stage boxes are the gain-1 network's
+    for f in range(2):
+        a, b = ref['final_box_dicts'][f], got['final_box_dicts'][f]
+        assert a['pred_boxes'].shape[0] > 20 and abs(a['pred_boxes'].shape[0] - b['pred_boxes'].shape[0]) <= 2
+        d = (a['pred_boxes'][:, None, :3] - b['pred_boxes'][None, :, :3]).abs().amax(-1)
+        j = d.argmin(1)
+        close = (a['pred_boxes'] - b['pred_boxes'][j]).abs().amax(-1) <= 1e-3
+        assert int(close.sum()) >= a['pred_boxes'].shape[0] - 2, (f, int(close.sum()), a['pred_boxes'].shape[0])
+    # (the second stage of `big` sees gain x the features with uncompensated weights: not comparable.)  The second stage is checked on
+    # the gain-1 detector with its peaks placed at 2^15 instead of 2^11 (exponents +7 .. +10): exact powers of two, so what the
+    # head reads through `feature_rows` / the fp32 views must be what it reads without any pre-scale
+    mode, peaks = select_math(base, info, dev_frames[:1], dynamic=True, target=2.0 ** 15)
+    assert mode == 'f16x2' and min(base.prescale.values()) >= 6, base.prescale
+    got = plugin(base)
+    torch.testing.assert_close(got['multi_scale_3d_features']['x_conv3'].features, ref_x3, rtol=2e-4, atol=2e-4 * float(ref_x3.abs().max()))
+    torch.testing.assert_close(got['spatial_features_2d'], ref['spatial_features_2d'], rtol=5e-4, atol=5e-4 * float(ref['spatial_features_2d'].abs().max()))
+    pipe = FramePipeline(base, info, dynamic=True)
+    out = pipe.two_stage(dev_frames)
+    for name, res in (('plugin', got), ('two_stage', out)):
+        for f in range(2):
+            va = res['rois'][f].abs().amax(-1) > 0
+            vb = ref['rois'][f].abs().amax(-1) > 0
+            assert abs(int(va.sum()) - int(vb.sum())) <= 2 and int(vb.sum()) > 20
+            d = (ref['rois'][f][vb][:, None, :3] - res['rois'][f][va][None, :, :3]).abs().amax(-1)
+            j = d.argmin(1)
+            close = (ref['rois'][f][vb] - res['rois'][f][va][j]).abs().amax(-1) <= 1e-3
+            assert int(close.sum()) >= int(vb.sum()) - 3, (name, f, int(close.sum()), int(vb.sum()))
+            pa, pb = res['batch_box_preds'][f][va][j][close], ref['batch_box_preds'][f][vb][close]
+            ca, cb = res['batch_cls_preds'][f][va][j][close], ref['batch_cls_preds'][f][vb][close]
+            assert torch.isfinite(pa).all()
+            # (an RoI with a centroid on a ball's surface may pick another sample set: bounded share, loose bound - as in the tests above)
+            tight = ((pa - pb).abs().amax(-1) <= 2e-3) & ((ca - cb).abs().amax(-1) <= 2e-3)
+            assert float(tight.float().mean()) > 0.95 and float((pa - pb).abs().max()) <= 5e-2, (name, f, float(tight.float().mean()), float((pa - pb).abs().max()))
+    set_prescale(base, None)
+    set_prescale(big, None)
+    set_math(big, 'f32'); set_math(base, 'f32')
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['f32', 'f16x2'])
 def test_two_stage_boxes_at_bench_size(device, golden_dir, mode):
     """The WHOLE two-stage detector at bench size - one merged 2-sweep frame of 320 000 points, 0.1 m voxels, the model of
