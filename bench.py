@@ -542,7 +542,7 @@ def main():
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'latency_ms_per_pass': round(1000.0 * dt / K, 4),
                        'like_for_like': 'leg ref_batch (8 frames per pass = BATCH_SIZE_PER_GPU of the reference config, centerpoint_1sweep.yaml:88) is the '
                                         'like-for-like batch; leg batch16 is the headline configuration of rounds 1-3; value is at frames_per_step_per_gpu', 'parallelism': 'frame-parallel x%d' % world,
-                       'concurrent_sub_passes': case.pipe.ways if B >= 2 * case.pipe.ways else 1,
+                       'concurrent_sub_passes': case.pipe.ways if case.pipe.splits(B) else 1,
                        'launch': graph_note, 'math': case.math, 'math_selected': case.math_selected, 'activation_peaks': case.activation_peaks,
                        'sparse_engine': args.sparse_engine,
                        'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',

@@ -326,9 +326,11 @@ class FramePipeline:
             set_math(model, math)
         # ways: a batch is split into this many sub-passes that run CONCURRENTLY on their own streams (`_call_split`): every launch of
         # the persistent kernels leaves CUs idle while it ramps up and while its last tiles finish (busy CUs 0.84-0.96,
-        # profiles/r06a_clock_table.txt) - an independent second pass fills them: +2.6 % frames/s at 32 frames per batch, +5 % at 16,
-        # +1.6 % at 8; three or four ways, or two ways of 32 frames, give nothing (profiles/r06_ab_notes.txt).  None = DZ_TUNE_WAYS or 2
+        # profiles/r06a_clock_table.txt) - an independent second pass fills them: +1.0 % frames/s at 32 frames per batch, +3.0 % at 16,
+        # +-0 at 8 (batches under `split_min` frames are not split); three or four ways, or two ways of 32 frames, give nothing
+        # (profiles/r06_ab_notes.txt).  None = DZ_TUNE_WAYS or 2
         self.ways = int(os.environ.get('DZ_TUNE_WAYS', '2')) if ways is None else int(ways)
+        self.split_min = int(os.environ.get('DZ_TUNE_SPLIT_MIN', '12'))     # smallest batch that is split (8 frames: +-0, sometimes a loss)
         self._subs = None
         self._way_streams = None
         self.side_key = 0
@@ -604,10 +606,14 @@ class FramePipeline:
             frames = _StackedFrames(points.contiguous())
         else:
             frames = points if isinstance(points, _StackedFrames) else list(points)
-        if self.ways > 1 and len(frames) >= 2 * self.ways:
+        if self.splits(len(frames)):
             return self._call_split(frames)
         out, d_nk = self.infer(self.prepare(frames, staggered=STAGGERED_PYRAMID))
         return (out[0], d_nk) if single else (out, d_nk)
+
+    def splits(self, nb):
+        """Whether a batch of nb frames runs as concurrent sub-passes."""
+        return self.ways > 1 and nb >= max(2 * self.ways, self.split_min)
 
     def _split_parts(self, frames):
         nb, w = len(frames), self.ways
@@ -676,7 +682,7 @@ class CapturedPass:
             o, n = pipe(static_points)
             self.boxes.copy_(o.view(self.boxes.shape))
             self.counts.copy_(n.view(-1))
-        self.branches = pipe.ways if (pipe.ways > 1 and nb >= 2 * pipe.ways) else 1
+        self.branches = pipe.ways if pipe.splits(nb) else 1
 
     def replay(self):
         self.graph.replay()

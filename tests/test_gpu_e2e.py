@@ -349,6 +349,7 @@ def test_concurrent_sub_passes_equal_the_single_pass(device, route):
     inp = torch.stack(frames) if route == 'stacked' else frames
     one = FramePipeline(model, info, math='f16x2', ways=1)
     two = FramePipeline(model, info, math='f16x2', ways=2)
+    two.split_min = 4                       # (the default splits batches of 12 frames and more; the test's batches are 4 and 5)
     o1, n1 = one(inp)
     o2, n2 = two(inp)
     assert two._subs is not None and len(two._subs) == 2 and int(n1.sum().item()) > 100
@@ -357,7 +358,10 @@ def test_concurrent_sub_passes_equal_the_single_pass(device, route):
     # weights, zero-response images) - the first split pass of a cache generation runs its sub-passes one after the other
     model_b = make_model(VOXEL_SIZE_02, seed=0)[0].to(device)
     four = inp[:4] if route == 'stacked' else frames[:4]
-    of, nf = FramePipeline(model_b, info, math='f16x2', ways=2)(four)
+    fresh = FramePipeline(model_b, info, math='f16x2', ways=2)
+    fresh.split_min = 4
+    of, nf = fresh(four)
+    assert fresh._subs is not None
     og, ng = one(four)
     assert torch.equal(nf, ng) and torch.equal(of, og)
     small = inp[:3] if route == 'stacked' else frames[:3]           # fewer than 2 x ways frames: not split
