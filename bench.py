@@ -120,6 +120,9 @@ def parse():
                          'one graph per step; +0.8 .. +1.4 %% on MI355X (r03e build, A/B on one box), not the default')
     ap.add_argument('--no-calibrate', action='store_true', help='keep worst-case level capacities (limits the batch to ~4 frames)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a HIP graph')
+    ap.add_argument('--weights', default='preserve', choices=['preserve', 'default'],
+                    help="synthetic weight set: 'preserve' (round 6: boxes depend on the frame) or 'default' (rounds 1-5: the default initialisers - "
+                         'frame-independent border boxes, near-constant activations; for continuity with the earlier lines only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--dump-launches', default=None, help='file: every conv launch of one eager pass in launch order (us, GFLOP, MB)')
@@ -173,7 +176,7 @@ class Case:
         self.args, self.dev, self.math, self.B, self.mode = args, dev, math, max(1, batch), mode
         # sweeps = 2: BASELINE configs[4] shape - two sweeps merged into one 6-feature frame (time-offset column), the
         # centerpoint_3sweeps model with DynamicMeanVFE
-        self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0, sweeps=3 if sweeps > 1 else 1)
+        self.model, self.cfg, self.info = synth_detector(VOXEL_SIZE_01, seed=0, sweeps=3 if sweeps > 1 else 1, gain=getattr(args, 'weights', 'preserve'))
         self.model = self.model.to(dev)
         set_sparse_engine(self.model, engine)
         self.engine = engine
@@ -546,7 +549,8 @@ def main():
                        'launch': graph_note, 'math': case.math, 'math_selected': case.math_selected, 'activation_peaks': case.activation_peaks,
                        'sparse_engine': args.sparse_engine,
                        'calibration': 'level capacities fitted (x1.5) on 4 frames of other seeds than the timed ones; overflow flag checked after the timed region',
-                       'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': 'seeded synthetic set synth_detector(gain=preserve): variance-preserving, boxes depend on the frame and sit on its points (no checkpoints offline)',
+                       'overlap': 'stage A (voxelize + index pyramid) of batch i+1 under stage B (convs, head, NMS) of batch i' if streamer is not None else 'none', 'weights': ('seeded synthetic set synth_detector(gain=preserve): variance-preserving, boxes depend on the frame and sit on its points (no checkpoints offline)'
+                                   if args.weights == 'preserve' else 'NOT the headline weights (--weights default): the default initialisers of rounds 1-5, frame-independent boxes'),
                        'mean_boxes_per_frame': round(n_boxes, 1), 'boxes_per_frame_min_max': [int(case.counts.min().item()), int(case.counts.max().item())]},
         }
 
