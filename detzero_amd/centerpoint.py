@@ -639,6 +639,10 @@ class FramePipeline:
         sig = (cp_modules.CACHE_GEN[0], tuple((len(p), tuple(p[0].shape)) for p, _, _ in parts), str(dev))
         serial = sig != getattr(self, '_split_sig', None)
         self._split_sig = sig
+        if serial and not nested_ok:
+            import warnings
+            warnings.warn('FramePipeline: graph capture of a split pass without an eager pass of the same shapes before it - the sub-passes '
+                          'are recorded ONE AFTER THE OTHER (correct, but without their overlap); run one eager pass first')
         outs = []
         prev = None
         for (part, _, _), sub, st in zip(parts, self._subs, self._way_streams):
