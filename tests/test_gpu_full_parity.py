@@ -183,7 +183,7 @@ def test_error_budget_against_float64(full, device):
     FLOAT64 (same fp32 weights, same voxel features: tests/util.oracle_features_f64); against it every fp32-class evaluation has its own
     rounding noise - the CPU oracle (torch fp32), the exact-fp32 HIP engine, and fp16 pairs.  Per stage, on data-dependent O(1)
     activations at the headline size: the fp16-pair engine's error must not exceed TWICE the fp32 engine's; bf16 pairs are listed next
-    to them (an opt-in mode: 10-30x).  The table is printed (profiles/r06*_gputests.txt)."""
+    to them (an opt-in mode: 10-30x).  The table is printed (profiles/r06e_gputests_parity.txt)."""
     model, cfg, info, frames, refs = full
     r64 = oracle_features_f64(cpu_state_dict(model), frames[0], info)
     yard = {k: r64['backbone'][k][0] for k in ('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'encoded')}
