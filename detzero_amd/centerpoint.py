@@ -606,10 +606,29 @@ class FramePipeline:
             frames = _StackedFrames(points.contiguous())
         else:
             frames = points if isinstance(points, _StackedFrames) else list(points)
-        if self.splits(len(frames)):
+        nb = len(frames)
+        if nb > self.max_pass_frames():
+            # more frames than one pass can key: the voxel keys are 32 bits wide (batch x grid cells: 46 frames of the 1504 x 1504 x 41
+            # Waymo grid) - the batch runs as consecutive chunks, each of them a pass (or two concurrent sub-passes) of its own
+            step = self.max_pass_frames()
+            outs = []
+            for a in range(0, nb, step):
+                part = _StackedFrames(frames.tensor[a:a + step]) if isinstance(frames, _StackedFrames) else list(frames[a:a + step])
+                outs.append(self(part))
+            return torch.cat([o for o, _ in outs], dim=0), torch.cat([n.view(-1) for _, n in outs], dim=0)
+        if self.splits(nb):
             return self._call_split(frames)
         out, d_nk = self.infer(self.prepare(frames, staggered=STAGGERED_PYRAMID))
         return (out[0], d_nk) if single else (out, d_nk)
+
+    def max_pass_frames(self):
+        """Largest batch ONE call runs as one pass or one set of concurrent sub-passes: every (sub-)pass must key its frames' voxels in
+        32 bits (csrc/voxelize.hip: batch x D x H x W < 2^32 - 1); 32 frames per (sub-)pass is also where the dense stage's images and the
+        x-run tiles are sized best (bench.py's sweep), so that is the chunk."""
+        g = self.info.grid_size
+        cells = (int(g[2]) + 1) * int(g[1]) * int(g[0])
+        per_pass = max(1, min(32, (2 ** 32 - 2) // cells))
+        return per_pass * (self.ways if self.ways > 1 else 1)
 
     def splits(self, nb):
         """Whether a batch of nb frames runs as concurrent sub-passes."""
