@@ -106,12 +106,13 @@ _T0 = time.perf_counter()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300, help='timed steps (default: ~10 s of GPU time at 32 frames per step)')
+    ap.add_argument('--steps', type=int, default=160, help='timed steps (default: ~9 s of GPU time at 64 frames per step)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=160000)
-    ap.add_argument('--batch', type=int, default=32, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU = 8, leg ref_batch; 16 was the default of '
-                    'rounds 1-3, leg batch16; chosen by the sweep of DESIGN.md section 4: 8 / 16 / 24 / 32 -> 940 / 1031 / 1029 / 1051 frames/s; 48 does not fit '
-                    'the 32-bit voxel keys)')
+    ap.add_argument('--batch', type=int, default=64, help='frames per step per GPU (reference eval: BATCH_SIZE_PER_GPU = 8, leg ref_batch; 16 was the default of '
+                    'rounds 1-3, leg batch16; 32 of rounds 4-6, leg batch32; a step of 64 runs as two concurrent sub-passes of 32 frames - the size '
+                    'one pass is best at, DESIGN.md section 4: 32 / 48 / 64 -> 1088 / 1107 / 1113 frames/s on one box; DetZero labels sequences '
+                    'offline: throughput, not latency, is the metric)')
     ap.add_argument('--math', default='f16x2', choices=['f32', 'f16x2', 'bf16x2', 'f16'],
                     help='conv arithmetic: f32 = fp32 MFMA; f16x2 / bf16x2 = split-precision pairs on the 16-bit matrix cores; '
                          'f16 = one fp16 MFMA per product on the same tensors (fast mode, not fp32-class)')
@@ -231,6 +232,9 @@ class Case:
                 self.activation_peaks = {k: float('%.4g' % v) for k, v in peaks.items()}
                 self.math = self.math_selected            # (select_math has set the model to it)
             del cal
+        # the instrumented passes (kernel_profile, stage_profile) run ONE pass, every launch alone on the chip: of the whole batch while it
+        # fits one pass (<= 32 frames: the voxel keys of a pass are 32 bits), else of one sub-pass's share of it
+        self.PB = B if (B <= 32 or not self.pipe.splits(B)) else B // self.pipe.ways
         self.graph = None
         self.g_out = self.g_n = None
         self.graph_note = 'eager launches'
@@ -315,13 +319,13 @@ class Case:
         try:                                           # `ways` concurrent sub-passes, whose launches share the chip)
             for i in range(passes):
                 self.load_inputs(i)
-                self.pipe(self.static_in)
+                self.pipe(self.static_in[:self.PB])
             agg = prof.summary()
             if getattr(self.args, 'dump_launches', None):
                 # every launch of the LAST eager pass, in launch order (the per-layer view the aggregated `kernels` list hides)
                 per_pass = len(prof.records) // max(passes, 1)
                 with open(self.args.dump_launches, 'w') as f:
-                    f.write('# launch order of one eager pass (%d frames): kernel, us, algorithmic GFLOP, algorithmic MB, TF/s, GB/s\n' % self.B)
+                    f.write('# launch order of one eager pass (%d frames): kernel, us, algorithmic GFLOP, algorithmic MB, TF/s, GB/s\n' % self.PB)
                     for name, flops, nbytes, e0, e1 in prof.records[-per_pass:]:
                         ms = e0.elapsed_time(e1)
                         f.write('%-34s %9.1f us %9.2f GF %9.1f MB %8.1f TF/s %8.1f GB/s\n' % (name, 1000.0 * ms, flops / 1e9, nbytes / 1e6,
@@ -367,8 +371,8 @@ class Case:
         """Each stage of the step captured as its own hipGraph (index pyramid on the main stream, i.e. serial) and replayed in
         order with HIP events in between.  Returns a list of {stage, ms_per_step, algorithmic_bytes, hbm_gbs, frac_of_hbm_peak}."""
         from detzero_amd.centerpoint import _StackedFrames
-        pipe, B = self.pipe, self.B
-        frames = _StackedFrames(self.static_in) if torch.is_tensor(self.static_in) else self.static_in
+        pipe, B = self.pipe, self.PB                      # (one pass: see PB)
+        frames = _StackedFrames(self.static_in[:B]) if torch.is_tensor(self.static_in) else self.static_in[:B]
         self.load_inputs(0)
         torch.cuda.synchronize()
         graphs = []
@@ -435,7 +439,7 @@ class Case:
         algo = {'voxelize': vox_bytes, 'index': idx_bytes, 'sparse_backbone': conv_bytes}
         out = []
         for nme, t in zip(names, ms):
-            rec = {'stage': nme, 'ms_per_step': round(t, 4), 'ms_per_frame': round(t / B, 4)}
+            rec = {'stage': nme, 'frames': B, 'ms_per_step': round(t, 4), 'ms_per_frame': round(t / B, 4)}        # (ms_per_step: per pass of `frames` frames)
             if nme in algo:
                 gbs = algo[nme] / (t * 1e-3) / 1e9
                 rec.update({'algorithmic_bytes': round(algo[nme]), 'hbm_gbs': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)})
@@ -544,7 +548,7 @@ def main():
                                     'DynamicMeanVFE + 3-sweep model' % args.points),
                        'frames_per_step_per_gpu': B, 'ms_per_frame': round(1000.0 * dt / (K * B), 4), 'latency_ms_per_pass': round(1000.0 * dt / K, 4),
                        'like_for_like': 'leg ref_batch (8 frames per pass = BATCH_SIZE_PER_GPU of the reference config, centerpoint_1sweep.yaml:88) is the '
-                                        'like-for-like batch; leg batch16 is the headline configuration of rounds 1-3; value is at frames_per_step_per_gpu', 'parallelism': 'frame-parallel x%d' % world,
+                                        'like-for-like batch; legs batch16 / batch32 are the headline configurations of rounds 1-3 / 4-6; value is at frames_per_step_per_gpu', 'parallelism': 'frame-parallel x%d' % world,
                        'concurrent_sub_passes': case.pipe.ways if case.pipe.splits(B) else 1,
                        'launch': graph_note, 'math': case.math, 'math_selected': case.math_selected, 'activation_peaks': case.activation_peaks,
                        'sparse_engine': args.sparse_engine,
@@ -561,7 +565,8 @@ def main():
             out['roofline'] = roof
         out['kernels'] = kern
         log('per-kernel profile done')
-        out['conv_ms_per_frame'] = round(sum(r['ms_per_step'] for r in kern) / B, 4)
+        out['conv_ms_per_frame'] = round(sum(r['ms_per_step'] for r in kern) / case.PB, 4)        # (`kernels`: one pass of case.PB frames)
+        out['profiled_pass_frames'] = case.PB
 
     # ---- auxiliary legs (single GPU only): what the headline does not show
     if rank == 0 and world == 1 and not args.no_aux and streamer is None:
@@ -593,7 +598,7 @@ def main():
                         roof['hbm_%s_%s' % (nme, k)] = hbm[nme][k]
                 roof['dense_ms'] = st['dense']['ms_per_step']
                 roof['post_ms'] = st['post']['ms_per_step']
-                roof['frames_per_step'] = B
+                roof['frames_per_step'] = case.PB           # frames of the profiled pass (`kernels`, `stages`, the hbm_* entries): one sub-pass of the step
                 for k, v in old.items():
                     roof.setdefault(k, v)
                 out['roofline'] = roof
@@ -668,6 +673,9 @@ def main():
         del c
         if B != 16:
             c, out['batch16'] = leg('batch16', args.math, 16, note='16 frames per pass: the headline configuration of rounds 1-3 (round-over-round comparison)')
+            del c
+        if B != 32:
+            c, out['batch32'] = leg('batch32', args.math, 32, note='32 frames per step: the headline configuration of rounds 4-6 (round-over-round comparison)')
             del c
         c, padded = leg('ragged/padded', args.math, B, (150000, 180000), 'padded',
                         note='frames of 150k-180k points padded with out-of-range rows to 180k-row slots: stacked dz_voxelize_to_level route')
