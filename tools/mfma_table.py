@@ -30,6 +30,8 @@ def main():
     # passes of the detector inside a PMC run: from a kernel whose launches per pass are known - the 128-channel x-run kernel runs 4 times
     # per pass and per concurrent sub-pass (the PMC command runs the bench's default: config.concurrent_sub_passes)
     ways = int(bench['config'].get('concurrent_sub_passes', 1) or 1)
+    # `kernels` describes ONE profiled pass of profiled_pass_frames frames; a step of the PMC command covers frames_per_step_per_gpu
+    scale = float(bench['config'].get('frames_per_step_per_gpu', 1)) / float(bench.get('profiled_pass_frames', bench['config'].get('frames_per_step_per_gpu', 1)))
     def passes_of(table, field):
         k = find(table, 'k_spconv_x<128>')
         if not k:
@@ -42,8 +44,8 @@ def main():
     print('%-26s %14s %8s %7s %9s %9s %8s' % ('kernel', 'launches x us', 'useful', 'busy', 'use/issue', 'HBM frac', 'traffic'))
     for k in bench['kernels']:
         name = k['kernel']
-        flops_step = k['tflops'] * 1e12 * k['ms_per_step'] * 1e-3
-        bytes_step = k['algorithmic_gbs'] * 1e9 * k['ms_per_step'] * 1e-3
+        flops_step = scale * k['tflops'] * 1e12 * k['ms_per_step'] * 1e-3
+        bytes_step = scale * k['algorithmic_gbs'] * 1e9 * k['ms_per_step'] * 1e-3
         row = '%-26s %6.0f x %5.0f %8.3f' % (name, k['launches_per_step'], k['avg_us'], k['tflops'] / 838.9)
         s = find(sq, name)
         busy = ui = float('nan')
