@@ -553,7 +553,14 @@ class FramePipeline:
 
     def infer(self, prep):
         """Stage B: the 21 sparse convolutions, BEV backbone, head, top-K decode, NMS -> (boxes9 (B,K,9), counts (B,))."""
-        return self.post_stage(*self.dense_stage(self.backbone_stage(prep), prep['nb']))
+        try:
+            return self.post_stage(*self.dense_stage(self.backbone_stage(prep), prep['nb']))
+        except DetZeroHipError as e:
+            if '2 GiB' in str(e) and self.level_caps is None:
+                raise DetZeroHipError('%s\n(FramePipeline: %d frames per pass with WORST-CASE row capacities for the strided sparse levels - call '
+                                      'pipe.calibrate(sample_frames) first: it sizes them to 1.5 x the measured counts, a device-side flag and '
+                                      'check_overflow() guard denser frames)' % (e, prep['nb'])) from None
+            raise
 
     @torch.no_grad()
     def two_stage(self, points, before_second=None):
