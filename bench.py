@@ -562,6 +562,7 @@ def main():
     if rank == 0 and args.profile_frames > 0:
         kern, roof, _ = case.kernel_profile(args.profile_frames)
         if roof:
+            roof['frames_per_step'] = case.PB               # frames of the profiled pass (one sub-pass of the step)
             out['roofline'] = roof
         out['kernels'] = kern
         log('per-kernel profile done')
