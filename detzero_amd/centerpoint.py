@@ -298,6 +298,7 @@ def select_math(model, dataset_info, frames, prefer='f16x2', dynamic=False, targ
     return prefer, rng
 
 
+PAD_RAGGED = os.environ.get('DZ_TUNE_PAD_RAGGED', '1') != '0'      # development switch: 0 = ragged lists through one fused voxelizer chain per frame (r01-r05)
 GROUPED_DEEP_BLOCKS = os.environ.get('DZ_TUNE_GROUPED_DEEP', '1') != '0'       # development switch: 0 = every dense layer per frame group (r04)
 
 
@@ -405,6 +406,20 @@ class FramePipeline:
         nb = len(frames)
         bb = self.model.backbone3d
         n0 = frames[0].shape[0]
+        if (PAD_RAGGED and not self.dynamic and nb > 1 and not isinstance(frames, _StackedFrames) and any(p.shape[0] != n0 for p in frames)):
+            # frames of different lengths (what real sweeps are): padded on the device to the longest with rows OUTSIDE the point-cloud
+            # range - the xy mask of data_processor.py:24-37 inside the kernels drops them - and voxelized as ONE stacked batch straight
+            # into the level-1 index, instead of one fused-voxelizer chain per frame: nb small copies buy the batched route (round 6:
+            # the `ragged/list` leg of bench.py)
+            nmax = max(p.shape[0] for p in frames)
+            if nmax <= self.info.max_voxels[self.mode]:
+                c = frames[0].shape[1]
+                buf = frames[0].new_zeros((nb, nmax, c))
+                buf[:, :, 0] = 1.0e6
+                for i, p in enumerate(frames):
+                    buf[i, :p.shape[0]].copy_(p)
+                frames = _StackedFrames(buf)
+                n0 = nmax
         if (not self.dynamic and nb > 1 and n0 <= self.info.max_voxels[self.mode] and all(p.shape[0] == n0 for p in frames)):
             c = frames[0].shape[1]
             pts = frames.tensor.reshape(-1, c) if isinstance(frames, _StackedFrames) else torch.cat(list(frames), dim=0)
