@@ -695,7 +695,7 @@ def main():
                 rec['kernels'] = kern[:6]
             out['f16'] = rec
             del c
-        c, out['multisweep'] = leg('multisweep', args.math, REF_BATCH, sweeps=2,
+        c, out['multisweep'] = leg('multisweep', args.math, min(B, 32), sweeps=2,          # (r02-r06e: 8 frames per step; 8 / 16 / 32 -> 686 / 752 / 778 frames/s)
                                    note='BASELINE configs[4] shape: two merged sweeps per frame (2 x %d points, 6 features incl. the time '
                                         'offset), DynamicMeanVFE + centerpoint_3sweeps backbone and head' % args.points)
         del c

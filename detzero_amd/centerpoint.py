@@ -650,6 +650,10 @@ class FramePipeline:
         g = self.info.grid_size
         cells = (int(g[2]) + 1) * int(g[1]) * int(g[0])
         per_pass = max(1, min(32, (2 ** 32 - 2) // cells))
+        if self.dynamic:
+            # DynamicMeanVFE merges on int32 keys, as the reference does (vfe.py:128-131: "overflows for b >= 24" on the Waymo grid)
+            lim = (2 ** 31 - 1) // cells
+            per_pass = max(1, min(per_pass, lim if lim < 8 else lim // 8 * 8))
         return per_pass * (self.ways if self.ways > 1 else 1)
 
     def splits(self, nb):
